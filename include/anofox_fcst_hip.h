@@ -1,0 +1,217 @@
+/*
+ * anofox_fcst_hip.h -- C ABI of the MI355X batch-forecasting backend.
+ *
+ * This is the drop-in boundary for the `ts_forecast_by` hot path of
+ * DataZooDE/anofox-forecast.  The first block mirrors, byte for byte, the part
+ * of the reference's cbindgen header that the path touches; the second block is
+ * this backend's additive batch / device-resident interface.
+ *
+ * Reference interfaces replaced (file:line in /root/reference):
+ *   ErrorCode            src/include/anofox_fcst_ffi.h:72-84
+ *   AnofoxError          src/include/anofox_fcst_ffi.h:269-272
+ *   ForecastOptions      src/include/anofox_fcst_ffi.h:1036-1095   (184 bytes)
+ *   ForecastResult       src/include/anofox_fcst_ffi.h:1100-1145   (144 bytes)
+ *   anofox_ts_forecast   src/include/anofox_fcst_ffi.h:2332-2337
+ *                        (Rust body crates/anofox-fcst-ffi/src/lib.rs:3344-3550)
+ *   anofox_free_forecast_result  anofox_fcst_ffi.h:2886 (lib.rs:5900-5930)
+ *   anofox_fcst_version  anofox_fcst_ffi.h:3058
+ *
+ * Plain C, SysV x86-64, no torch / HIP types in any signature: a device stream
+ * is passed as an opaque `void *` (a hipStream_t), device buffers as `void *`.
+ */
+#ifndef ANOFOX_FCST_HIP_H
+#define ANOFOX_FCST_HIP_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------- */
+/* Block 1: the reference's ABI for this path (layout-identical)              */
+/* ------------------------------------------------------------------------- */
+
+#ifndef ANOFOX_FCST_FFI_H /* the reference header defines the same names */
+
+typedef enum ErrorCode {
+    SUCCESS = 0,
+    NULL_POINTER = 1,
+    INVALID_INPUT = 2,
+    COMPUTATION_ERROR = 3,
+    ALLOCATION_ERROR = 4,
+    INVALID_MODEL = 5,
+    INSUFFICIENT_DATA = 6,
+    INVALID_DATE_FORMAT = 7,
+    INVALID_FREQUENCY = 8,
+    PANIC_CAUGHT = 9,
+    INTERNAL_ERROR = 10,
+} ErrorCode;
+
+typedef struct AnofoxError {
+    enum ErrorCode code;
+    char message[256]; /* NUL-terminated, truncated at 255 */
+} AnofoxError;
+
+typedef struct ForecastOptions {
+    char model[32];                 /* method name, exact or alias            */
+    char ets_model[8];              /* "AAA", "MNM", "AAdA"...; "" = no spec   */
+    int horizon;
+    double confidence_level;
+    int seasonal_period;            /* 0 = not given                          */
+    bool auto_detect_seasonality;
+    bool include_fitted;
+    bool include_residuals;
+    int window;                     /* SMA window, 0 = default                */
+    char seasonal_periods_str[64];  /* "[24, 168]"; multi-seasonal models only */
+    char model_pool[32];            /* AutoETS pool; "" = complete            */
+    char laplace_variant[16];       /* unused by this backend                 */
+    bool laplace_seasonal_batch_init;
+} ForecastOptions;
+
+typedef struct ForecastResult {
+    double *point_forecasts;        /* malloc'd, n_forecasts                  */
+    double *lower_bounds;
+    double *upper_bounds;
+    double *fitted_values;          /* malloc'd, n_fitted, or NULL            */
+    double *residuals;
+    size_t n_forecasts;
+    size_t n_fitted;
+    char model_name[64];
+    double aic;                     /* always NaN on this path                */
+    double bic;
+    double mse;                     /* NaN unless fitted values requested     */
+} ForecastResult;
+
+/*
+ * Fit + forecast ONE series.  `values[length]` is sorted by date by the caller;
+ * `validity` is a DuckDB bitmask (bit i%64 of word i/64, 1 = valid) or NULL.
+ * Returns false and fills `out_error` (may be NULL) on failure; on success the
+ * callee malloc()s the result arrays, released by anofox_free_forecast_result.
+ * Runs on the GPU as a batch of one; there is no CPU fallback.
+ */
+bool anofox_ts_forecast(const double *values,
+                        const uint64_t *validity,
+                        size_t length,
+                        const struct ForecastOptions *options,
+                        struct ForecastResult *out_result,
+                        struct AnofoxError *out_error);
+
+void anofox_free_forecast_result(struct ForecastResult *result);
+
+const char *anofox_fcst_version(void);
+
+#endif /* ANOFOX_FCST_FFI_H */
+
+/* ------------------------------------------------------------------------- */
+/* Block 2: batch entry (host buffers) -- additive, same per-series semantics */
+/* ------------------------------------------------------------------------- */
+
+/*
+ * Fit + forecast `n_series` independent series with ONE shared option block in
+ * one GPU pass.  Replaces the serial per-group loop of the reference binding
+ * (src/table_functions/ts_forecast_native.cpp:586-740, one anofox_ts_forecast
+ * call per group).  `horizons` may be NULL (= options->horizon for all) or give
+ * a per-series horizon (cross-validation folds, ts_cv_forecast_native.cpp:676).
+ * Per-series failures land in out_errors[i] with out_results[i] zeroed; the
+ * return value is false only for batch-level failures (NULL pointers, no GPU).
+ * INVALID_MODEL / INVALID_INPUT are uniform across the batch and are also
+ * reported through `out_batch_error` (may be NULL).
+ */
+bool anofox_ts_forecast_batch(const double *const *values,
+                              const uint64_t *const *validity,
+                              const size_t *lengths,
+                              size_t n_series,
+                              const struct ForecastOptions *options,
+                              const int *horizons,
+                              struct ForecastResult *out_results,
+                              struct AnofoxError *out_errors,
+                              struct AnofoxError *out_batch_error);
+
+/* ------------------------------------------------------------------------- */
+/* Block 3: device-resident batch (series block already in HBM)               */
+/* ------------------------------------------------------------------------- */
+
+typedef struct AnofoxHipBatch AnofoxHipBatch; /* opaque plan + HBM workspace */
+
+/* Per-run measurements, filled by anofox_hip_batch_run. */
+typedef struct AnofoxHipStats {
+    uint64_t n_series;
+    uint64_t t_max;
+    uint64_t n_problems;        /* (series, candidate spec) optimiser problems */
+    uint64_t total_passes;      /* streamed passes over a series (sum over problems) */
+    uint64_t max_passes;        /* max over series of its summed passes          */
+    uint64_t total_evals;       /* objective evaluations (>= passes)             */
+    uint64_t algorithmic_bytes; /* sum_s 8*T_s*(P_s+1) + 24*h, SURVEY.md 8(d)    */
+    double   fit_kernel_ms;     /* HIP-event time of the dominant (fit) kernel(s) */
+    double   total_device_ms;   /* HIP-event time of the whole run on its stream  */
+    uint32_t fit_kernel_launches;
+    uint32_t reserved;
+} AnofoxHipStats;
+
+/* Device selection; returns number of visible devices or -1. */
+int anofox_hip_device_count(void);
+int anofox_hip_set_device(int device);
+
+/*
+ * Create a plan for `n_series` series of at most `t_max` observations.
+ * Validates the option block exactly like anofox_ts_forecast would (model name,
+ * ETS notation, pool, seasonal_period compatibility).  The packed layout is the
+ * time-major block Y[t * ld + s] (fp64), ld = n_series rounded up to 64.
+ */
+bool anofox_hip_batch_create(size_t n_series, size_t t_max,
+                             const struct ForecastOptions *options,
+                             AnofoxHipBatch **out_batch,
+                             struct AnofoxError *out_error);
+void anofox_hip_batch_destroy(AnofoxHipBatch *batch);
+
+size_t anofox_hip_batch_ld(const AnofoxHipBatch *batch);
+
+/* Host series -> HBM block (NULL interpolation, imputation.rs:61-114, then pack + H2D). */
+bool anofox_hip_batch_pack_host(AnofoxHipBatch *batch,
+                                const double *const *values,
+                                const uint64_t *const *validity,
+                                const size_t *lengths,
+                                struct AnofoxError *out_error);
+
+/*
+ * Adopt a block that is already in HBM: `d_y` is [t_max x ld] fp64 time-major,
+ * `d_len` is int32[n_series].  No copy; the caller keeps both alive.
+ */
+bool anofox_hip_batch_set_device_block(AnofoxHipBatch *batch,
+                                       const void *d_y, size_t ld,
+                                       const void *d_len,
+                                       struct AnofoxError *out_error);
+
+/* Asynchronous fit + forecast on `stream` (a hipStream_t, may be NULL). */
+bool anofox_hip_batch_run(AnofoxHipBatch *batch, void *stream,
+                          struct AnofoxError *out_error);
+
+/* Waits for the run, then fills `out_stats`. */
+bool anofox_hip_batch_stats(AnofoxHipBatch *batch, AnofoxHipStats *out_stats);
+
+/*
+ * Device result pointers (valid until destroy): yhat/lower/upper are
+ * [n_series x horizon] fp64 row-major; model_code int32[n_series] (see
+ * anofox_hip_model_name); status int32[n_series] (ErrorCode per series).
+ */
+bool anofox_hip_batch_device_results(AnofoxHipBatch *batch,
+                                     void **d_yhat, void **d_lower, void **d_upper,
+                                     void **d_model_code, void **d_status);
+
+/* D2H + per-series malloc'd results with reference ownership rules. */
+bool anofox_hip_batch_fetch(AnofoxHipBatch *batch,
+                            struct ForecastResult *out_results,
+                            struct AnofoxError *out_errors);
+
+/* Render a device model_code to the reference's model_name text (<= 63 chars). */
+void anofox_hip_model_name(const struct ForecastOptions *options, int32_t model_code,
+                           char out_name[64]);
+
+#ifdef __cplusplus
+} /* extern "C" */
+#endif
+
+#endif /* ANOFOX_FCST_HIP_H */

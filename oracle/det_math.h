@@ -1,0 +1,127 @@
+/*
+ * det_math.h -- TEST INFRASTRUCTURE (oracle).  Not part of the product.
+ *
+ * Deterministic log / exp / pow used by the oracle's ETS likelihood.  The HIP
+ * kernels state the same formulas independently (csrc/det_math.hpp); both sides
+ * are compiled with -ffp-contract=off, so every operation below is one
+ * correctly-rounded IEEE-754 binary64 operation and the two implementations
+ * agree bit for bit.  libm's log()/exp() are NOT used on the parity path because
+ * glibc and ROCm's ocml differ in the last ulp, which is enough to flip a
+ * Nelder-Mead comparison.
+ *
+ * The reductions are the classic public-domain fdlibm ones
+ * (log: x = 2^k (1+f), s = f/(2+f), minimax R(s^2); exp: x = k ln2 + r,
+ * Remez c(r)); accuracy < 1 ulp.  No reference file corresponds to this: the
+ * reference delegates to Rust's f64::ln / f64::exp inside the un-vendored
+ * anofox-forecast 0.15.3 crate (finding 1).
+ */
+#ifndef ORACLE_DET_MATH_H
+#define ORACLE_DET_MATH_H
+
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+static inline uint64_t det_bits(double x) { uint64_t u; memcpy(&u, &x, 8); return u; }
+static inline double det_from_bits(uint64_t u) { double x; memcpy(&x, &u, 8); return x; }
+
+static inline double det_log(double x)
+{
+    static const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+                        Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
+                        Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
+                        Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                        Lg7 = 1.479819860511658591e-01;
+    uint64_t u = det_bits(x);
+    uint32_t hx = (uint32_t)(u >> 32);
+    int k = 0;
+    if (x != x) return x;                              /* NaN */
+    if (hx < 0x00100000u || (hx >> 31)) {
+        if ((u << 1) == 0) return -INFINITY;           /* log(+-0) */
+        if (hx >> 31) return NAN;                      /* log(x<0) */
+        k -= 54;                                       /* subnormal: scale up */
+        x *= 18014398509481984.0;                      /* 2^54 */
+        u = det_bits(x);
+        hx = (uint32_t)(u >> 32);
+    } else if (hx >= 0x7ff00000u) {
+        return x;                                      /* +inf */
+    } else if (hx == 0x3ff00000u && (u << 32) == 0) {
+        return 0.0;                                    /* log(1) */
+    }
+    /* reduce x into [sqrt(2)/2, sqrt(2)) */
+    hx += 0x3ff00000u - 0x3fe6a09eu;
+    k += (int)(hx >> 20) - 0x3ff;
+    hx = (hx & 0x000fffffu) + 0x3fe6a09eu;
+    u = ((uint64_t)hx << 32) | (u & 0xffffffffu);
+    x = det_from_bits(u);
+
+    double f = x - 1.0;
+    double hfsq = 0.5 * f * f;
+    double s = f / (2.0 + f);
+    double z = s * s;
+    double w = z * z;
+    double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+    double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    double R = t2 + t1;
+    double dk = (double)k;
+    return s * (hfsq + R) + dk * ln2_lo - hfsq + f + dk * ln2_hi;
+}
+
+/* x * 2^n by exponent arithmetic only (no libm), n in a safe range. */
+static inline double det_scalbn(double x, int n)
+{
+    if (n > 1023) {
+        x *= 8.98846567431157953865e307; /* 2^1023 */
+        n -= 1023;
+        if (n > 1023) {
+            x *= 8.98846567431157953865e307;
+            n -= 1023;
+            if (n > 1023) n = 1023;
+        }
+    } else if (n < -1022) {
+        x *= 2.004168360008972778e-292;  /* 2^-1022 * 2^53 */
+        n += 1022 - 53;
+        if (n < -1022) {
+            x *= 2.004168360008972778e-292;
+            n += 1022 - 53;
+            if (n < -1022) n = -1022;
+        }
+    }
+    return x * det_from_bits((uint64_t)(0x3ff + n) << 52);
+}
+
+static inline double det_exp(double x)
+{
+    static const double ln2hi = 6.93147180369123816490e-01, ln2lo = 1.90821492927058770002e-10,
+                        invln2 = 1.44269504088896338700e+00,
+                        P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03,
+                        P3 = 6.61375632143793436117e-05, P4 = -1.65339022054652515390e-06,
+                        P5 = 4.13813679705723846039e-08;
+    if (x != x) return x;
+    if (x > 709.782712893383973096) return INFINITY;
+    if (x < -745.13321910194110842) return 0.0;
+    double ax = x < 0 ? -x : x;
+    int k = 0;
+    double hi, lo;
+    if (ax > 0.34657359027997264) {            /* |x| > 0.5 ln2 */
+        k = (int)(invln2 * x + (x < 0 ? -0.5 : 0.5));
+        hi = x - (double)k * ln2hi;
+        lo = (double)k * ln2lo;
+        x = hi - lo;
+    } else if (ax > 3.725290298461914e-09) {   /* |x| > 2^-28 */
+        hi = x;
+        lo = 0.0;
+    } else {
+        return 1.0 + x;
+    }
+    double xx = x * x;
+    double c = x - xx * (P1 + xx * (P2 + xx * (P3 + xx * (P4 + xx * P5))));
+    double y = 1.0 + (x * c / (2.0 - c) - lo + hi);
+    if (k == 0) return y;
+    return det_scalbn(y, k);
+}
+
+/* pow for a positive base (ETS multiplicative trend, b^phi): exp(y * log(x)). */
+static inline double det_pow_pos(double x, double y) { return det_exp(y * det_log(x)); }
+
+#endif /* ORACLE_DET_MATH_H */
