@@ -1,0 +1,353 @@
+"""Host-side mirror of the reference's `ts_forecast_by` operator for the MI355X backend.
+
+The reference's binding is a DuckDB C++ extension (no DuckDB headers exist in this image), so
+the operator is restated here over columnar numpy inputs, with the same names, argument meaning
+and error behaviour:
+
+  * macro surface          src/macros/ts_macros.cpp:575-594
+  * bind-time validation   src/table_functions/ts_forecast_native.cpp:312-399
+  * per-row MAP parsing    src/scalar_functions/ts_forecast_scalar.cpp:85-158
+  * collect / sort / mask  src/table_functions/ts_forecast_native.cpp:476-610
+  * forecast timestamps    src/scalar_functions/ts_forecast_scalar.cpp:250-292
+  * frequency strings      src/table_functions/ts_fill_gaps_native.cpp:21-102
+  * error policy           ts_forecast_native.cpp:666-672 (INVALID_MODEL / INVALID_INPUT abort the
+                           statement, any other per-series failure drops that group's rows)
+
+All numeric work goes through the C-ABI of libanofox_fcst_hip.so (one batch call replacing the
+reference's serial per-group loop); nothing here computes a forecast.
+"""
+from __future__ import annotations
+
+import calendar
+import ctypes as C
+import re
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import lib as _lib
+
+VALID_PARAM_KEYS = ("model", "seasonal_period", "seasonal_periods", "confidence_level", "window", "model_pool",
+                    "laplace_variant", "laplace_seasonal_batch_init")
+MULTI_SEASONAL = ("MFLES", "AutoMFLES", "MSTL", "AutoMSTL", "TBATS", "AutoTBATS")
+
+
+class InvalidInputException(Exception):
+    """The reference throws duckdb::InvalidInputException for statement-level failures."""
+
+
+# --------------------------------------------------------------------------------------------
+# frequency parsing (ParseFrequencyWithType)
+# --------------------------------------------------------------------------------------------
+@dataclass
+class ParsedFrequency:
+    seconds: int
+    is_raw: bool
+    type: str  # FIXED | MONTHLY | QUARTERLY | YEARLY
+
+
+def parse_frequency(freq) -> ParsedFrequency:
+    s = str(freq).strip().upper()
+    m = re.fullmatch(r"([0-9]+)(D|H|M|MIN|W|MO|Q|Y)", s)
+    if m:
+        c, u = int(m.group(1)), m.group(2).lower()
+        if u == "d": return ParsedFrequency(c * 86400, False, "FIXED")
+        if u == "h": return ParsedFrequency(c * 3600, False, "FIXED")
+        if u in ("m", "min"): return ParsedFrequency(c * 60, False, "FIXED")
+        if u == "w": return ParsedFrequency(c * 86400 * 7, False, "FIXED")
+        if u == "mo": return ParsedFrequency(c, False, "MONTHLY")
+        if u == "q": return ParsedFrequency(c, False, "QUARTERLY")
+        if u == "y": return ParsedFrequency(c, False, "YEARLY")
+    m = re.fullmatch(r"([0-9]+)\s*(DAY|DAYS|HOUR|HOURS|MINUTE|MINUTES|WEEK|WEEKS|MONTH|MONTHS|QUARTER|QUARTERS|YEAR|YEARS)", s)
+    if m:
+        c, u = int(m.group(1)), m.group(2).lower().rstrip("s")
+        if u == "day": return ParsedFrequency(c * 86400, False, "FIXED")
+        if u == "hour": return ParsedFrequency(c * 3600, False, "FIXED")
+        if u == "minute": return ParsedFrequency(c * 60, False, "FIXED")
+        if u == "week": return ParsedFrequency(c * 86400 * 7, False, "FIXED")
+        if u == "month": return ParsedFrequency(c, False, "MONTHLY")
+        if u == "quarter": return ParsedFrequency(c, False, "QUARTERLY")
+        if u == "year": return ParsedFrequency(c, False, "YEARLY")
+    if re.fullmatch(r"[0-9]+", s):
+        return ParsedFrequency(int(s), True, "FIXED")
+    raise InvalidInputException(
+        f"Invalid frequency '{freq}'. Valid formats:\n"
+        "  Polars-style: '1d', '1h', '30m', '1w', '1mo', '1q', '1y'\n"
+        "  DuckDB INTERVAL: '1 day', '1 hour', '1 minute', '1 week', '1 month', '1 quarter', '1 year'\n"
+        "  Raw integer: '86400' (for integer date columns)")
+
+
+_US_PER_DAY = 86400 * 1000000
+
+
+def _date_kind(dates: np.ndarray) -> str:
+    if np.issubdtype(dates.dtype, np.datetime64):
+        unit = np.datetime_data(dates.dtype)[0]
+        return "DATE" if unit == "D" else "TIMESTAMP"
+    if dates.dtype == np.int32:
+        return "INTEGER"
+    if np.issubdtype(dates.dtype, np.integer):
+        return "BIGINT"
+    raise InvalidInputException(f"Date column must be DATE, TIMESTAMP, INTEGER, or BIGINT, got: {dates.dtype}")
+
+
+def _to_micros(dates: np.ndarray, kind: str) -> np.ndarray:
+    if kind == "DATE":
+        return dates.astype("datetime64[D]").astype(np.int64) * _US_PER_DAY
+    if kind == "TIMESTAMP":
+        return dates.astype("datetime64[us]").astype(np.int64)
+    return dates.astype(np.int64)
+
+
+def _from_micros(us: np.ndarray, kind: str, dtype) -> np.ndarray:
+    if kind == "DATE":
+        return (us // _US_PER_DAY).astype("datetime64[D]")
+    if kind == "TIMESTAMP":
+        return us.astype("datetime64[us]")
+    return us.astype(dtype)
+
+
+def compute_forecast_date(last_us: int, step: int, f: ParsedFrequency, kind: str) -> int:
+    """ts_forecast_scalar.cpp:250-292."""
+    if f.type in ("MONTHLY", "QUARTERLY", "YEARLY"):
+        days = int(last_us // _US_PER_DAY)
+        d = np.datetime64(days, "D").astype(object)
+        months = step * f.seconds * (3 if f.type == "QUARTERLY" else 12 if f.type == "YEARLY" else 1)
+        total = d.year * 12 + (d.month - 1) + months
+        ny, nm = total // 12, total % 12 + 1
+        nd = min(d.day, calendar.monthrange(ny, nm)[1])
+        nd64 = np.datetime64(f"{ny:04d}-{nm:02d}-{nd:02d}", "D")
+        return int(nd64.astype(np.int64)) * _US_PER_DAY
+    if kind in ("INTEGER", "BIGINT"):
+        freq = f.seconds
+    else:
+        freq = f.seconds * _US_PER_DAY if f.is_raw else f.seconds * 1000000
+    return int(last_us) + freq * step
+
+
+# --------------------------------------------------------------------------------------------
+# parameters (MAP or STRUCT -> bind data)
+# --------------------------------------------------------------------------------------------
+@dataclass
+class BindData:
+    horizon: int
+    frequency: ParsedFrequency
+    method: str = "AutoETS"
+    model_spec: str = ""
+    seasonal_period: int = 0
+    confidence_level: float = 0.90
+    window: int = 0
+    seasonal_periods_str: str = ""
+    model_pool: str = ""
+
+
+def bind(method, horizon, frequency, params) -> BindData:
+    """Union of route B's bind-time validation and route A's per-row tolerance."""
+    b = BindData(horizon=int(horizon), frequency=parse_frequency(frequency))
+    if method is not None:
+        b.method = str(method)
+    params = params or {}
+    unknown = [k for k in params if k not in VALID_PARAM_KEYS]
+    if unknown:
+        raise InvalidInputException(
+            "Unknown parameter(s): " + ", ".join(f"'{k}'" for k in unknown) +
+            ". Valid parameters are: model, seasonal_period, seasonal_periods, confidence_level, window, model_pool, "
+            "laplace_variant, laplace_seasonal_batch_init")
+
+    def as_int(key, default):
+        v = params.get(key)
+        if v is None:
+            return default
+        try:
+            return int(str(v))
+        except ValueError:
+            return default
+
+    def as_float(key, default):
+        v = params.get(key)
+        if v is None:
+            return default
+        try:
+            return float(str(v))
+        except ValueError:
+            return default
+
+    b.model_spec = str(params.get("model") or "")
+    b.seasonal_period = as_int("seasonal_period", 0)
+    b.confidence_level = as_float("confidence_level", 0.90)
+    b.window = as_int("window", 0)
+    b.seasonal_periods_str = str(params.get("seasonal_periods") or "")
+    b.model_pool = str(params.get("model_pool") or "")
+    if params:
+        if b.confidence_level <= 0.0 or b.confidence_level >= 1.0:
+            raise InvalidInputException(
+                f"Invalid confidence_level: {b.confidence_level:.2f}. Must be between 0.0 and 1.0 (exclusive). "
+                "Common values: 0.80 (80%), 0.90 (90%), 0.95 (95%), 0.99 (99%)")
+        if b.model_spec and b.method != "ETS":
+            raise InvalidInputException(
+                f"Parameter 'model' (value: '{b.model_spec}') is only valid when method='ETS'. "
+                f"Current method is '{b.method}'. Remove the 'model' parameter or change method to 'ETS'.")
+        if b.window != 0:
+            if b.method != "SMA":
+                raise InvalidInputException(
+                    f"Parameter 'window' is only valid when method='SMA'. Current method is '{b.method}'. "
+                    "Remove the 'window' parameter or change method to 'SMA'.")
+            if b.window < 1:
+                raise InvalidInputException(f"Parameter 'window' must be a positive integer. Got {b.window}.")
+        if b.seasonal_periods_str and b.method not in MULTI_SEASONAL:
+            raise InvalidInputException(
+                "Parameter 'seasonal_periods' is only valid for multi-seasonal models "
+                f"(MFLES, AutoMFLES, MSTL, AutoMSTL, TBATS, AutoTBATS). Current method is '{b.method}'.")
+    return b
+
+
+def options_from_bind(b: BindData) -> _lib.ForecastOptions:
+    return _lib.make_options(b.method, b.horizon, ets_model=b.model_spec, seasonal_period=b.seasonal_period,
+                             confidence_level=b.confidence_level, window=b.window, model_pool=b.model_pool,
+                             seasonal_periods_str=b.seasonal_periods_str)
+
+
+# --------------------------------------------------------------------------------------------
+# C-ABI calls
+# --------------------------------------------------------------------------------------------
+def validity_mask(valid) -> np.ndarray:
+    valid = np.asarray(valid, dtype=bool)
+    words = np.zeros((len(valid) + 63) // 64, dtype=np.uint64)
+    idx = np.nonzero(valid)[0]
+    np.bitwise_or.at(words, idx // 64, np.uint64(1) << (idx % 64).astype(np.uint64))
+    return words
+
+
+def _result_dict(res: _lib.ForecastResult, n_values: int) -> dict:
+    h = res.n_forecasts
+    out = {
+        "point": np.array(res.point_forecasts[:h], dtype=np.float64),
+        "lower": np.array(res.lower_bounds[:h], dtype=np.float64),
+        "upper": np.array(res.upper_bounds[:h], dtype=np.float64),
+        "model_name": res.model_name.decode(),
+        "aic": res.aic, "bic": res.bic, "mse": res.mse, "n_fitted": res.n_fitted,
+    }
+    if res.fitted_values:
+        out["fitted"] = np.array(res.fitted_values[:res.n_fitted])
+    if res.residuals:
+        out["residuals"] = np.array(res.residuals[:n_values])
+    return out
+
+
+def forecast_series(values, opts, valid=None) -> dict:
+    """anofox_ts_forecast: one series (runs on the GPU as a batch of one)."""
+    L = _lib.load()
+    y = np.ascontiguousarray(values, dtype=np.float64)
+    res = _lib.ForecastResult()
+    C.memset(C.byref(res), 0, C.sizeof(res))
+    err = _lib.AnofoxError()
+    mask = validity_mask(valid) if valid is not None else None
+    ok = L.anofox_ts_forecast(y.ctypes.data if len(y) else None, mask.ctypes.data if mask is not None else None, len(y),
+                              C.byref(opts), C.byref(res), C.byref(err))
+    out = {"ok": bool(ok), "code": int(err.code), "message": err.message.decode(errors="replace")}
+    if ok:
+        out.update(_result_dict(res, len(y)))
+        L.anofox_free_forecast_result(C.byref(res))
+    return out
+
+
+def forecast_batch(series, opts, valids=None, horizons=None):
+    """anofox_ts_forecast_batch over host buffers. Returns (results, batch_error)."""
+    L = _lib.load()
+    n = len(series)
+    arrs = [np.ascontiguousarray(s, dtype=np.float64) for s in series]
+    masks = [validity_mask(v) if v is not None else None for v in valids] if valids is not None else None
+    vptr = (C.c_void_p * n)(*[a.ctypes.data if len(a) else C.addressof(C.c_double()) for a in arrs])
+    mptr = None
+    if masks is not None:
+        mptr = (C.c_void_p * n)(*[m.ctypes.data if m is not None and len(m) else None for m in masks])
+    lens = (C.c_size_t * n)(*[len(a) for a in arrs])
+    hz = None
+    if horizons is not None:
+        hz = (C.c_int * n)(*[int(x) for x in horizons])
+    results = (_lib.ForecastResult * n)()
+    errors = (_lib.AnofoxError * n)()
+    berr = _lib.AnofoxError()
+    ok = L.anofox_ts_forecast_batch(vptr, mptr, lens, n, C.byref(opts), hz, results, errors, C.byref(berr))
+    out = []
+    for i in range(n):
+        d = {"ok": bool(ok) and errors[i].code == 0, "code": int(errors[i].code) if ok else int(berr.code),
+             "message": (errors[i].message if ok else berr.message).decode(errors="replace")}
+        if d["ok"]:
+            d.update(_result_dict(results[i], len(arrs[i])))
+            L.anofox_free_forecast_result(C.byref(results[i]))
+        out.append(d)
+    return out, {"ok": bool(ok), "code": int(berr.code), "message": berr.message.decode(errors="replace")}
+
+
+# --------------------------------------------------------------------------------------------
+# the operator
+# --------------------------------------------------------------------------------------------
+def ts_forecast_by(group, date, target, method, horizon, frequency, params=None,
+                   group_name="id", date_name="ds"):
+    """ts_forecast_by(source, group_col, date_col, target_col, method, horizon, frequency, params := MAP{}).
+
+    `group`, `date`, `target` are equal-length columns (target may contain None / NaN-free NULLs as
+    masked entries: pass a numpy masked array or an object array with None).  Returns a dict of
+    columns: <group_name>, forecast_step, <date_name>, yhat, yhat_lower, yhat_upper, model_name.
+    Rows of a group come in step order; groups in first-appearance order (ts_forecast_native.cpp:586).
+    """
+    b = bind(method, horizon, frequency, params)
+    dates = np.asarray(date)
+    kind = _date_kind(dates)
+    us = _to_micros(dates, kind)
+    grp = np.asarray(group, dtype=object)
+    tgt = np.ma.masked_invalid(np.ma.array([np.nan if v is None else v for v in np.asarray(target, dtype=object)],
+                                           dtype=np.float64)) if np.asarray(target).dtype == object \
+        else np.ma.array(np.asarray(target, dtype=np.float64), mask=np.ma.getmaskarray(target) if np.ma.isMaskedArray(target) else False)
+    null_date = np.isnat(dates) if np.issubdtype(dates.dtype, np.datetime64) else np.zeros(len(dates), bool)
+
+    order, members = [], {}
+    for i in range(len(grp)):
+        if null_date[i]:
+            continue                      # rows with NULL dates are dropped (ts_forecast_native.cpp:505)
+        k = "__NULL__" if grp[i] is None else grp[i]
+        if k not in members:
+            members[k] = []
+            order.append(k)
+        members[k].append(i)
+
+    series, valids, last_dates, keys = [], [], [], []
+    tvals, tmask = np.ma.getdata(tgt), np.ma.getmaskarray(tgt)
+    for k in order:
+        idx = np.array(members[k])
+        o = np.argsort(us[idx], kind="stable")
+        idx = idx[o]
+        v = np.where(tmask[idx], 0.0, tvals[idx])
+        series.append(v)
+        valids.append(~tmask[idx])
+        last_dates.append(int(us[idx][-1]))
+        keys.append(k)
+
+    opts = options_from_bind(b)
+    results, berr = forecast_batch(series, opts, valids)
+    if not berr["ok"]:
+        raise InvalidInputException(berr["message"])
+
+    out = {group_name: [], "forecast_step": [], date_name: [], "yhat": [], "yhat_lower": [], "yhat_upper": [], "model_name": []}
+    for k, last, r in zip(keys, last_dates, results):
+        if not r["ok"]:
+            if r["code"] in (_lib.INVALID_MODEL, _lib.INVALID_INPUT):
+                raise InvalidInputException(r["message"])
+            continue                      # any other failure: the group yields no rows
+        for i in range(len(r["point"])):
+            out[group_name].append(None if k == "__NULL__" else k)
+            out["forecast_step"].append(i + 1)
+            out[date_name].append(compute_forecast_date(last, i + 1, b.frequency, kind))
+            out["yhat"].append(r["point"][i])
+            out["yhat_lower"].append(r["lower"][i])
+            out["yhat_upper"].append(r["upper"][i])
+            out["model_name"].append(r["model_name"])
+    out["forecast_step"] = np.array(out["forecast_step"], dtype=np.int32)
+    out[date_name] = _from_micros(np.array(out[date_name], dtype=np.int64), kind, dates.dtype)
+    for c in ("yhat", "yhat_lower", "yhat_upper"):
+        out[c] = np.array(out[c], dtype=np.float64)
+    return out
+
+
+anofox_fcst_ts_forecast_by = ts_forecast_by  # alias registered by the reference (ts_macros.cpp:2191-2194)

@@ -1,0 +1,166 @@
+// classic_device.hpp -- SES / Holt / additive Holt-Winters / SeasonalES passes (SSE objective).
+//
+// These are the models the reference reaches through SimpleExponentialSmoothing::{new,auto},
+// HoltLinearTrend::auto, HoltWinters::auto(p, Additive) and SeasonalES::{new,optimized}
+// (crates/anofox-fcst-core/src/forecast.rs:1102-1144, 1206-1232) and the fallback chain of
+// ETS-without-spec / failed AutoETS (forecast.rs:1327-1336, 1631-1640).  Formulations are the
+// ones that reproduce the reference KATs (test/sql/ts_model_distinctness.test:116,141):
+//   SES            l0 = y0 ; l += alpha (y - l), t >= 1
+//   Holt           l0 = y0, b0 = y1 - y0 ; l' = (l+b) + alpha e ; b += beta ((l'-l) - b)
+//   Holt-Winters   l0 = mean(season 1), b0 = (mean(season 2) - mean(season 1))/m, s_j = y_j - l0,
+//                  t >= m ; l' = q + alpha ((y - s) - q) ; b += beta ((l'-l) - b) ; s += gamma ((y - l') - s)
+//   SeasonalES     s_j = y_j ; s_j += alpha (y - s_j), t >= m
+// Seasonal rings live in LDS (run-time period).  Same K = 4 candidate sharing as the ETS pass.
+#pragma once
+#include "ets_device.hpp"
+
+namespace anofox {
+
+enum ClassicKind { CK_SES = 0, CK_HOLT = 1, CK_HW = 2, CK_SEASONAL_ES = 3 };
+
+template <int KIND> struct ClassicDim { static constexpr int value = KIND == CK_HOLT ? 2 : (KIND == CK_HW ? 3 : 1); };
+
+struct ClassicFinalOut { double *yhat; int h; bool write; };
+
+template <int KIND, int K, bool FINAL>
+__device__ __forceinline__ void classic_pass(const SeriesView &v, int m,
+                                             const double (&cand)[K][ClassicDim<KIND>::value],
+                                             double (&fout)[K], double *ring, const ClassicFinalOut *fin)
+{
+    const int lane = threadIdx.x;
+    const double *yp = v.y;
+    const size_t ld = v.ld;
+    double sse[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) sse[k] = 0.0;
+
+    if constexpr (KIND == CK_SES) {
+        double l[K];
+        const double y0 = yp[0];
+#pragma unroll
+        for (int k = 0; k < K; k++) l[k] = y0;
+        for (int t = 1; t < v.wave_len; t++) {
+            if (t < v.len) {
+                const double yv = yp[(size_t)t * ld];
+#pragma unroll
+                for (int k = 0; k < K; k++) {
+                    double e = yv - l[k];
+                    sse[k] = fma(e, e, sse[k]);
+                    l[k] = fma(cand[k][0], e, l[k]);
+                }
+            }
+        }
+        if constexpr (FINAL) {
+            if (fin->write) for (int i = 0; i < fin->h; i++) fin->yhat[i] = l[0];
+        }
+    } else if constexpr (KIND == CK_HOLT) {
+        double l[K], b[K];
+        const double y0 = yp[0], y1 = yp[ld];
+#pragma unroll
+        for (int k = 0; k < K; k++) { l[k] = y0; b[k] = y1 - y0; }
+        for (int t = 1; t < v.wave_len; t++) {
+            if (t < v.len) {
+                const double yv = yp[(size_t)t * ld];
+#pragma unroll
+                for (int k = 0; k < K; k++) {
+                    double f = l[k] + b[k];
+                    double e = yv - f;
+                    sse[k] = fma(e, e, sse[k]);
+                    double ln = fma(cand[k][0], e, f);
+                    b[k] = fma(cand[k][1], (ln - l[k]) - b[k], b[k]);
+                    l[k] = ln;
+                }
+            }
+        }
+        if constexpr (FINAL) {
+            if (fin->write) for (int i = 1; i <= fin->h; i++) fin->yhat[i - 1] = l[0] + (double)i * b[0];
+        }
+    } else if constexpr (KIND == CK_HW) {
+        double l[K], b[K];
+        double m1 = 0.0, m2 = 0.0;
+        for (int i = 0; i < m; i++) m1 += yp[(size_t)i * ld];
+        for (int i = m; i < 2 * m; i++) m2 += yp[(size_t)i * ld];
+        m1 /= (double)m;
+        m2 /= (double)m;
+#pragma unroll
+        for (int k = 0; k < K; k++) { l[k] = m1; b[k] = (m2 - m1) / (double)m; }
+        for (int i = 0; i < m; i++) {
+            double s0 = yp[(size_t)i * ld] - m1;
+#pragma unroll
+            for (int k = 0; k < K; k++) ring[(k * m + i) * NM_BLOCK + lane] = s0;
+        }
+        int j = 0;
+        for (int t = m; t < v.wave_len; t++) {
+            if (t < v.len) {
+                const double yv = yp[(size_t)t * ld];
+#pragma unroll
+                for (int k = 0; k < K; k++) {
+                    double s = ring[(k * m + j) * NM_BLOCK + lane];
+                    double q = l[k] + b[k];
+                    double e = yv - (q + s);
+                    sse[k] = fma(e, e, sse[k]);
+                    double ln = fma(cand[k][0], (yv - s) - q, q);
+                    b[k] = fma(cand[k][1], (ln - l[k]) - b[k], b[k]);
+                    ring[(k * m + j) * NM_BLOCK + lane] = fma(cand[k][2], (yv - ln) - s, s);
+                    l[k] = ln;
+                }
+            }
+            j = (j + 1 == m) ? 0 : j + 1;
+        }
+        if constexpr (FINAL) {
+            if (fin->write)
+                for (int i = 1; i <= fin->h; i++) {
+                    int jj = (v.len + i - 1) % m;
+                    fin->yhat[i - 1] = (l[0] + (double)i * b[0]) + ring[(0 * m + jj) * NM_BLOCK + lane];
+                }
+        }
+    } else { // CK_SEASONAL_ES
+        for (int i = 0; i < m; i++) {
+            double s0 = yp[(size_t)i * ld];
+#pragma unroll
+            for (int k = 0; k < K; k++) ring[(k * m + i) * NM_BLOCK + lane] = s0;
+        }
+        int j = 0;
+        for (int t = m; t < v.wave_len; t++) {
+            if (t < v.len) {
+                const double yv = yp[(size_t)t * ld];
+#pragma unroll
+                for (int k = 0; k < K; k++) {
+                    double s = ring[(k * m + j) * NM_BLOCK + lane];
+                    double e = yv - s;
+                    sse[k] = fma(e, e, sse[k]);
+                    ring[(k * m + j) * NM_BLOCK + lane] = fma(cand[k][0], e, s);
+                }
+            }
+            j = (j + 1 == m) ? 0 : j + 1;
+        }
+        if constexpr (FINAL) {
+            if (fin->write)
+                for (int i = 0; i < fin->h; i++) fin->yhat[i] = ring[(0 * m + (v.len + i) % m) * NM_BLOCK + lane];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) fout[k] = sse[k];
+}
+
+template <int KIND>
+struct ClassicModel {
+    static constexpr int DIM = ClassicDim<KIND>::value;
+    SeriesView v;
+    int m;
+    double *ring;
+    __device__ void bounds(double (&lo)[DIM], double (&hi)[DIM], double (&x0)[DIM]) const
+    {
+#pragma unroll
+        for (int i = 0; i < DIM; i++) { lo[i] = PAR_LO; hi[i] = PAR_HI; }
+        if constexpr (KIND == CK_SES || KIND == CK_SEASONAL_ES) x0[0] = 0.5;
+        else if constexpr (KIND == CK_HOLT) { x0[0] = 0.3; x0[1] = 0.1; }
+        else { x0[0] = 0.3; x0[1] = 0.1; x0[2] = 0.1; }
+    }
+    __device__ void eval(const double (&cand)[NM_K][DIM], double (&f)[NM_K]) const
+    {
+        classic_pass<KIND, NM_K, false>(v, m, cand, f, ring, nullptr);
+    }
+};
+
+} // namespace anofox

@@ -1,0 +1,114 @@
+// det_math.hpp -- deterministic fp64 log / exp / pow for the gfx950 kernels.
+//
+// The ETS likelihood needs log(SSE), log|f| and b^phi.  ocml's log/exp and glibc's
+// differ in the last ulp, which is enough to flip a Nelder-Mead comparison and send
+// the GPU and a CPU checker down different optimiser paths.  These versions use only
+// +,-,*,/ (each one IEEE-754 binary64 operation; the build uses -ffp-contract=off),
+// so any IEEE machine reproduces them bit for bit.  Reductions are the classic
+// fdlibm ones: log via x = 2^k(1+f), s = f/(2+f); exp via x = k ln2 + r.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace anofox {
+
+__device__ __forceinline__ double dm_from_bits(uint64_t u) { return __longlong_as_double((long long)u); }
+__device__ __forceinline__ uint64_t dm_bits(double x) { return (uint64_t)__double_as_longlong(x); }
+
+__device__ __forceinline__ double dm_log(double x)
+{
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
+                 Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
+                 Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    uint64_t u = dm_bits(x);
+    uint32_t hx = (uint32_t)(u >> 32);
+    int k = 0;
+    if (x != x) return x;
+    if (hx < 0x00100000u || (hx >> 31)) {
+        if ((u << 1) == 0) return -__builtin_huge_val();
+        if (hx >> 31) return __builtin_nan("");
+        k -= 54;
+        x *= 18014398509481984.0;
+        u = dm_bits(x);
+        hx = (uint32_t)(u >> 32);
+    } else if (hx >= 0x7ff00000u) {
+        return x;
+    } else if (hx == 0x3ff00000u && (u << 32) == 0) {
+        return 0.0;
+    }
+    hx += 0x3ff00000u - 0x3fe6a09eu;
+    k += (int)(hx >> 20) - 0x3ff;
+    hx = (hx & 0x000fffffu) + 0x3fe6a09eu;
+    u = ((uint64_t)hx << 32) | (u & 0xffffffffull);
+    x = dm_from_bits(u);
+
+    double f = x - 1.0;
+    double hfsq = 0.5 * f * f;
+    double s = f / (2.0 + f);
+    double z = s * s;
+    double w = z * z;
+    double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+    double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    double R = t2 + t1;
+    double dk = (double)k;
+    return s * (hfsq + R) + dk * ln2_lo - hfsq + f + dk * ln2_hi;
+}
+
+__device__ __forceinline__ double dm_scalbn(double x, int n)
+{
+    if (n > 1023) {
+        x *= 8.98846567431157953865e307;
+        n -= 1023;
+        if (n > 1023) {
+            x *= 8.98846567431157953865e307;
+            n -= 1023;
+            if (n > 1023) n = 1023;
+        }
+    } else if (n < -1022) {
+        x *= 2.004168360008972778e-292;
+        n += 1022 - 53;
+        if (n < -1022) {
+            x *= 2.004168360008972778e-292;
+            n += 1022 - 53;
+            if (n < -1022) n = -1022;
+        }
+    }
+    return x * dm_from_bits((uint64_t)(0x3ff + n) << 52);
+}
+
+__device__ __forceinline__ double dm_exp(double x)
+{
+    const double ln2hi = 6.93147180369123816490e-01, ln2lo = 1.90821492927058770002e-10,
+                 invln2 = 1.44269504088896338700e+00,
+                 P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03,
+                 P3 = 6.61375632143793436117e-05, P4 = -1.65339022054652515390e-06,
+                 P5 = 4.13813679705723846039e-08;
+    if (x != x) return x;
+    if (x > 709.782712893383973096) return __builtin_huge_val();
+    if (x < -745.13321910194110842) return 0.0;
+    double ax = x < 0 ? -x : x;
+    int k = 0;
+    double hi, lo;
+    if (ax > 0.34657359027997264) {
+        k = (int)(invln2 * x + (x < 0 ? -0.5 : 0.5));
+        hi = x - (double)k * ln2hi;
+        lo = (double)k * ln2lo;
+        x = hi - lo;
+    } else if (ax > 3.725290298461914e-09) {
+        hi = x;
+        lo = 0.0;
+    } else {
+        return 1.0 + x;
+    }
+    double xx = x * x;
+    double c = x - xx * (P1 + xx * (P2 + xx * (P3 + xx * (P4 + xx * P5))));
+    double y = 1.0 + (x * c / (2.0 - c) - lo + hi);
+    if (k == 0) return y;
+    return dm_scalbn(y, k);
+}
+
+__device__ __forceinline__ double dm_pow_pos(double x, double y) { return dm_exp(y * dm_log(x)); }
+
+} // namespace anofox

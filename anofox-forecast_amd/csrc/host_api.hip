@@ -1,0 +1,933 @@
+// host_api.hip -- the C-ABI host layer of the MI355X backend (include/anofox_fcst_hip.h).
+//
+// Replaces crates/anofox-fcst-ffi (lib.rs:3344-3550 anofox_ts_forecast, :5900-5930 free) and the
+// wrapper decisions of crates/anofox-fcst-core/src/forecast.rs:512-733.  One batch = one
+// time-major fp64 block in HBM; the per-series fit/forecast arithmetic runs ONLY on the GPU
+// (kernels.hip, fit_*.hip).  There is no CPU fallback: without a HIP device every entry point
+// fails with INTERNAL_ERROR.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "classic_device.hpp"
+#include "host_semantics.hpp"
+#include "kernels.hpp"
+
+using namespace anofox;
+
+namespace {
+
+constexpr int N_AUX_STREAMS = 8;
+
+struct HipFail { std::string msg; };
+#define HIPCHECK(expr)                                                                             \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) throw HipFail{std::string(#expr) + ": " + hipGetErrorString(_e)};    \
+    } while (0)
+
+template <class T> T *dalloc(size_t n)
+{
+    void *p = nullptr;
+    HIPCHECK(hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)));
+    return (T *)p;
+}
+
+struct Plan {
+    ModelType model;
+    std::string ets_notation;   // explicit ETS spec ("" = none)
+    int ets_spec_id = -1;
+    int pool = 0;
+    std::string static_name;    // model_name when model_code == 0
+    double z = 1.645;
+};
+
+} // namespace
+
+struct AnofoxHipBatch {
+    size_t n = 0, t_max = 0, ld = 0;
+    int h = 0;
+    ForecastOptions opt;
+    Plan plan;
+    bool has_block = false, owns_y = false;
+    double *d_y = nullptr;
+    int32_t *d_len = nullptr;          // lengths with unusable series zeroed
+    bool owns_len = false;
+    std::vector<int32_t> h_len;        // true lengths
+    std::vector<int32_t> h_period;     // per-series period
+    std::vector<int32_t> h_base_status;
+    std::vector<int32_t> h_slot_spec;
+    std::vector<double> h_clean;       // interpolated host copy (only when fitted values requested)
+    std::vector<size_t> h_clean_off;
+    // prep outputs
+    double *d_mean = nullptr, *d_sd = nullptr, *d_fig_add = nullptr, *d_fig_mul = nullptr, *d_l0 = nullptr, *d_b0 = nullptr;
+    uint32_t *d_flags = nullptr;
+    int fig_m = 0;
+    // spec slots
+    int n_slots_cap = 0;
+    double *d_aicc = nullptr, *d_yhat_slots = nullptr;
+    int32_t *d_status_slots = nullptr, *d_evals_slots = nullptr, *d_iters_slots = nullptr, *d_passes_slots = nullptr, *d_slot_spec = nullptr;
+    // outputs
+    double *d_yhat = nullptr, *d_lo = nullptr, *d_hi = nullptr;
+    int32_t *d_model_code = nullptr, *d_status = nullptr, *d_detail = nullptr, *d_passes_total = nullptr, *d_evals_total = nullptr;
+    uint32_t *d_mask = nullptr;
+    int32_t *d_len_group = nullptr;
+    // streams / events
+    hipStream_t own_stream = nullptr;
+    hipStream_t aux[N_AUX_STREAMS] = {};
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_fit0 = nullptr, ev_fit1 = nullptr, ev_fork = nullptr;
+    hipEvent_t ev_join[N_AUX_STREAMS] = {};
+    hipStream_t last_stream = nullptr;
+    bool ran = false, timed_fit = false;
+    uint32_t fit_launches = 0;
+    uint64_t n_problems = 0;
+};
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// option validation shared by every entry point (forecast.rs:512-565, 1278-1314, 1524-1556)
+// ---------------------------------------------------------------------------------------------
+bool make_plan(const ForecastOptions *o, Plan &p, AnofoxError *err)
+{
+    std::string mname = cstr_field(o->model, sizeof o->model);
+    if (!parse_model(mname, p.model)) {
+        set_error(err, INVALID_MODEL, "Invalid model: Unknown model: '" + mname + "'");
+        return false;
+    }
+    if (o->horizon < 0) { set_error(err, PANIC_CAUGHT, "Panic in Rust code"); return false; }
+    if (!o->auto_detect_seasonality && o->seasonal_period > 1 && is_non_seasonal_model(p.model)) {
+        char buf[512];
+        std::snprintf(buf, sizeof buf,
+                      "Invalid input: Model '%s' does not use seasonal_period (got %d). For seasonal forecasting, use: "
+                      "SeasonalNaive, HoltWinters, SeasonalES, AutoETS, AutoMFLES, AutoMSTL, or AutoTBATS.",
+                      model_name(p.model), o->seasonal_period);
+        set_error(err, INVALID_INPUT, buf);
+        return false;
+    }
+    p.static_name = model_name(p.model);
+    p.z = z_for_confidence(o->confidence_level);
+    switch (p.model) {
+    case M_Naive: case M_SeasonalNaive: case M_SMA: case M_RandomWalkDrift: case M_ARIMA:
+    case M_SES: case M_SESOptimized: case M_Holt: case M_HoltWinters: case M_SeasonalES: case M_SeasonalESOptimized:
+        break;
+    case M_ETS: {
+        p.ets_notation = cstr_field(o->ets_model, sizeof o->ets_model);
+        if (!p.ets_notation.empty()) {
+            const std::string &nt = p.ets_notation;
+            if (!valid_ets_notation(nt)) {
+                set_error(err, INVALID_INPUT,
+                          "Invalid input: Invalid ETS model specification '" + nt +
+                              "'. Expected 3 or 4 character notation: Error(A/M) + Trend(A/M/N) + Seasonal(A/M/N), with optional 'd' "
+                              "for damped trend. Examples: 'AAA' (additive), 'MNM' (multiplicative error, no trend), 'AAdA' (additive "
+                              "damped trend). Valid characters: A=Additive, M=Multiplicative, N=None, d=Damped.");
+                return false;
+            }
+            p.ets_spec_id = spec_id_from_notation(nt);
+            if (!spec_is_valid(p.ets_spec_id)) {
+                set_error(err, INVALID_INPUT,
+                          "Invalid input: ETS model '" + nt +
+                              "' is an unstable combination (multiplicative error with additive components). Try one of: 'AAA', 'ANA', "
+                              "'AAdA', 'MNM', 'MAM', 'MAdM', 'MMM', 'MMdM', or use 'AutoETS' for automatic selection.");
+                return false;
+            }
+            p.static_name = "ETS(" + nt + ")";
+        }
+        break;
+    }
+    case M_AutoETS: {
+        std::string pool = cstr_field(o->model_pool, sizeof o->model_pool);
+        p.pool = 0;
+        if (!pool.empty()) {
+            p.pool = parse_model_pool(pool);
+            if (p.pool < 0) {
+                set_error(err, INVALID_INPUT,
+                          "Invalid input: Unknown model_pool '" + pool +
+                              "'. Valid options: complete, no_multiplicative_trend, damped_trend_only, match_error_seasonal, reduced");
+                return false;
+            }
+        }
+        break;
+    }
+    default:
+        set_error(err, INTERNAL_ERROR,
+                  std::string("Internal error: model '") + model_name(p.model) + "' is not implemented by the HIP backend");
+        return false;
+    }
+    return true;
+}
+
+// imputation.rs:61-114
+void fill_nulls_interpolate(const double *values, const uint64_t *validity, size_t n, double *out)
+{
+    auto valid = [&](size_t i) { return validity == nullptr || ((validity[i / 64] >> (i % 64)) & 1ull); };
+    long first = -1, last = -1;
+    for (size_t i = 0; i < n; i++)
+        if (valid(i)) { if (first < 0) first = (long)i; last = (long)i; }
+    for (size_t i = 0; i < n; i++) out[i] = std::nan("");
+    if (first < 0) return;
+    for (long i = 0; i < first; i++) out[i] = values[first];
+    for (size_t i = (size_t)last + 1; i < n; i++) out[i] = values[last];
+    long prev = first;
+    double pv = values[first];
+    out[first] = pv;
+    for (long i = first + 1; i <= last; i++) {
+        if (valid((size_t)i)) {
+            double v = values[i];
+            long gap = i - prev;
+            if (gap > 1) {
+                double slope = (v - pv) / (double)gap;
+                for (long j = 1; j < gap; j++) out[prev + j] = pv + slope * (double)j;
+            }
+            out[i] = v;
+            prev = i;
+            pv = v;
+        }
+    }
+}
+
+// seasonality.rs:323-377: first (strongest) ACF peak or 0
+int detect_seasonality_first(const double *v, size_t n)
+{
+    if (n < 4) return 0;
+    size_t max_lag = n / 2;
+    if (max_lag < 2) return 0;
+    double mean = 0.0;
+    for (size_t i = 0; i < n; i++) mean += v[i];
+    mean /= (double)n;
+    double var = 0.0;
+    for (size_t i = 0; i < n; i++) { double d = v[i] - mean; var += d * d; }
+    if (std::fabs(var) < 2.220446049250313e-16) return 0;
+    std::vector<double> acf(max_lag);
+    for (size_t lag = 1; lag <= max_lag; lag++) {
+        double s = 0.0;
+        for (size_t i = 0; i < n - lag; i++) s += (v[i] - mean) * (v[i + lag] - mean);
+        acf[lag - 1] = s / var;
+    }
+    int best = 0;
+    double best_acf = 0.0;
+    for (size_t i = 1; i + 1 < max_lag; i++)
+        if (acf[i] > acf[i - 1] && acf[i] > acf[i + 1] && acf[i] > 0.1)
+            if (best == 0 || acf[i] > best_acf) { best = (int)(i + 1); best_acf = acf[i]; }
+    return best;
+}
+
+void free_batch_buffers(AnofoxHipBatch *b)
+{
+    auto F = [](void *p) { if (p) (void)hipFree(p); };
+    if (b->owns_y) F(b->d_y);
+    if (b->owns_len) F(b->d_len);
+    F(b->d_mean); F(b->d_sd); F(b->d_fig_add); F(b->d_fig_mul); F(b->d_l0); F(b->d_b0); F(b->d_flags);
+    F(b->d_aicc); F(b->d_yhat_slots); F(b->d_status_slots); F(b->d_evals_slots); F(b->d_iters_slots);
+    F(b->d_passes_slots); F(b->d_slot_spec);
+    F(b->d_yhat); F(b->d_lo); F(b->d_hi); F(b->d_model_code); F(b->d_status); F(b->d_detail);
+    F(b->d_passes_total); F(b->d_evals_total); F(b->d_mask); F(b->d_len_group);
+    if (b->own_stream) (void)hipStreamDestroy(b->own_stream);
+    for (auto &s : b->aux) if (s) (void)hipStreamDestroy(s);
+    for (hipEvent_t e : {b->ev_start, b->ev_stop, b->ev_fit0, b->ev_fit1, b->ev_fork}) if (e) (void)hipEventDestroy(e);
+    for (auto &e : b->ev_join) if (e) (void)hipEventDestroy(e);
+}
+
+int max_slots_for(const Plan &p)
+{
+    if (p.model == M_AutoETS) return 30;
+    if (p.model == M_ETS && p.ets_spec_id >= 0) return 1;
+    return 0;
+}
+
+void alloc_common(AnofoxHipBatch *b)
+{
+    const size_t n = b->n, ld = b->ld, h = (size_t)std::max(b->h, 0);
+    b->d_mean = dalloc<double>(ld);
+    b->d_sd = dalloc<double>(ld);
+    b->d_flags = dalloc<uint32_t>(ld);
+    b->d_yhat = dalloc<double>(n * h);
+    b->d_lo = dalloc<double>(n * h);
+    b->d_hi = dalloc<double>(n * h);
+    b->d_model_code = dalloc<int32_t>(ld);
+    b->d_status = dalloc<int32_t>(ld);
+    b->d_detail = dalloc<int32_t>(ld);
+    b->d_passes_total = dalloc<int32_t>(ld);
+    b->d_evals_total = dalloc<int32_t>(ld);
+    b->d_mask = dalloc<uint32_t>(ld);
+    b->d_len_group = dalloc<int32_t>(ld);
+    HIPCHECK(hipMemset(b->d_model_code, 0, ld * sizeof(int32_t)));
+    HIPCHECK(hipMemset(b->d_detail, 0, ld * sizeof(int32_t)));
+    HIPCHECK(hipMemset(b->d_passes_total, 0, ld * sizeof(int32_t)));
+    HIPCHECK(hipMemset(b->d_evals_total, 0, ld * sizeof(int32_t)));
+    HIPCHECK(hipMemset(b->d_mask, 0, ld * sizeof(uint32_t)));
+    b->n_slots_cap = max_slots_for(b->plan);
+    if (b->n_slots_cap > 0) {
+        const size_t S = (size_t)b->n_slots_cap;
+        b->d_l0 = dalloc<double>(9 * ld);
+        b->d_b0 = dalloc<double>(9 * ld);
+        b->d_aicc = dalloc<double>(S * ld);
+        b->d_yhat_slots = dalloc<double>(S * n * h);
+        b->d_status_slots = dalloc<int32_t>(S * ld);
+        b->d_evals_slots = dalloc<int32_t>(S * ld);
+        b->d_iters_slots = dalloc<int32_t>(S * ld);
+        b->d_passes_slots = dalloc<int32_t>(S * ld);
+        b->d_slot_spec = dalloc<int32_t>(S);
+    }
+    HIPCHECK(hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking));
+    for (auto &s : b->aux) HIPCHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    for (hipEvent_t *e : {&b->ev_start, &b->ev_stop, &b->ev_fit0, &b->ev_fit1}) HIPCHECK(hipEventCreate(e));
+    HIPCHECK(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
+    for (auto &e : b->ev_join) HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+}
+
+void ensure_fig(AnofoxHipBatch *b, int m)
+{
+    if (m <= b->fig_m) return;
+    if (b->d_fig_add) (void)hipFree(b->d_fig_add);
+    if (b->d_fig_mul) (void)hipFree(b->d_fig_mul);
+    b->d_fig_add = dalloc<double>((size_t)m * b->ld);
+    b->d_fig_mul = dalloc<double>((size_t)m * b->ld);
+    b->fig_m = m;
+}
+
+// Series that cannot be forecast at all (forecast.rs:516-525) and per-series periods.
+void finalize_lengths(AnofoxHipBatch *b)
+{
+    const size_t n = b->n;
+    b->h_base_status.assign(n, 0);
+    std::vector<int32_t> eff(b->ld, 0);
+    for (size_t s = 0; s < n; s++) {
+        if (b->h_len[s] < 3) b->h_base_status[s] = INSUFFICIENT_DATA;
+        else eff[s] = b->h_len[s];
+    }
+    if (!b->d_len) { b->d_len = dalloc<int32_t>(b->ld); b->owns_len = true; }
+    HIPCHECK(hipMemcpy(b->d_len, eff.data(), b->ld * sizeof(int32_t), hipMemcpyHostToDevice));
+}
+
+// ---------------------------------------------------------------------------------------------
+// the pipeline for one group of series sharing a seasonal period
+// ---------------------------------------------------------------------------------------------
+void run_classic(AnofoxHipBatch *b, int kind, const int32_t *d_len, int m, int optimized, double alpha, int min_len,
+                 const uint32_t *mask, uint32_t want, int32_t code, bool write_code, hipStream_t st)
+{
+    ClassicArgs a{};
+    a.y = b->d_y; a.ld = b->ld; a.len = d_len; a.n_series = (int)b->n;
+    a.m = m; a.h = b->h; a.optimized = optimized; a.fixed_alpha = alpha;
+    a.mask = mask; a.want = want; a.min_len = min_len;
+    a.yhat = b->d_yhat; a.status = b->d_detail; a.passes = b->d_passes_total;
+    a.model_code = code; a.model_code_out = write_code ? b->d_model_code : nullptr;
+    launch_classic(kind, a, st);
+}
+
+// d_detail holds the per-series fit status of the last model stage; map it into ErrorCodes.
+__global__ void finish_status_kernel(int n, const int32_t *len, const int32_t *detail, int32_t *status)
+{
+    int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= n) return;
+    if (len[s] <= 0) return;                 // not in this group / unusable: keep base status
+    status[s] = detail[s] == FIT_OK ? 0 : COMPUTATION_ERROR;
+}
+
+__global__ void explicit_select_kernel(int n, int h, const int32_t *len, const int32_t *fit_status, const double *yhat_slot,
+                                       const int32_t *passes, const int32_t *evals, double *yhat, int32_t *detail,
+                                       int32_t *passes_total, int32_t *evals_total)
+{
+    int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= n || len[s] <= 0) return;
+    detail[s] = fit_status[s];
+    passes_total[s] = passes[s];
+    evals_total[s] = evals[s];
+    if (fit_status[s] == FIT_OK)
+        for (int i = 0; i < h; i++) yhat[(size_t)s * h + i] = yhat_slot[(size_t)s * h + i];
+}
+
+// AutoETS fallback plan (forecast.rs:1327-1336): 1 Holt-Winters, 2 Holt, 3 SES(0.3)
+__global__ void fallback_plan_kernel(int n, const int32_t *len, int period, uint32_t *mask, int32_t *detail)
+{
+    int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= n) return;
+    const int L = len[s];
+    if (L <= 0) { mask[s] = 0; return; }
+    if (mask[s] == 0) { detail[s] = FIT_OK; return; }
+    mask[s] = (period > 1 && L >= 2 * period) ? 1u : (L >= 10 ? 2u : 3u);
+}
+
+void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const int32_t *d_len, int m, bool skip_constant,
+                      hipStream_t st)
+{
+    const size_t n = b->n, ld = b->ld;
+    // fork: aux streams wait for everything queued on `st` so far
+    HIPCHECK(hipEventRecord(b->ev_fit0, st));
+    for (int i = 0; i < N_AUX_STREAMS; i++) HIPCHECK(hipStreamWaitEvent(b->aux[i], b->ev_fit0, 0));
+    for (size_t k = 0; k < specs.size(); k++) {
+        const int id = specs[k];
+        const int se = spec_season(id), ti = spec_trend_idx(id);
+        const int tt = ti == 0 ? 0 : (ti <= 2 ? 1 : 2);
+        FitArgs a{};
+        a.y = b->d_y; a.ld = ld; a.len = d_len; a.n_series = (int)n;
+        a.m = se != 0 ? m : 1; a.h = b->h;
+        a.l0 = b->d_l0 + (size_t)(se * 3 + tt) * ld;
+        a.b0 = b->d_b0 + (size_t)(se * 3 + tt) * ld;
+        a.fig = se == 1 ? b->d_fig_add : (se == 2 ? b->d_fig_mul : nullptr);
+        a.fig_ld = ld;
+        a.flags = b->d_flags;
+        a.need_positive = spec_has_mult(id) ? 1 : 0;
+        a.skip_constant = skip_constant ? 1 : 0;
+        a.n_param = spec_n_param(id, a.m);
+        a.aicc = b->d_aicc + k * ld;
+        a.yhat = b->d_yhat_slots + k * n * (size_t)b->h;
+        a.status = b->d_status_slots + k * ld;
+        a.evals = b->d_evals_slots + k * ld;
+        a.iters = b->d_iters_slots + k * ld;
+        a.passes = b->d_passes_slots + k * ld;
+        FitLaunchFn fn = ets_fit_launcher(id, a.m);
+        if (!fn) throw HipFail{"no kernel for ETS spec id " + std::to_string(id)};
+        fn(a, b->aux[k % N_AUX_STREAMS]);
+        b->fit_launches++;
+    }
+    for (int i = 0; i < N_AUX_STREAMS; i++) {
+        HIPCHECK(hipEventRecord(b->ev_join[i], b->aux[i]));
+        HIPCHECK(hipStreamWaitEvent(st, b->ev_join[i], 0));
+    }
+    HIPCHECK(hipEventRecord(b->ev_fit1, st));
+    b->timed_fit = true;
+    b->n_problems += (uint64_t)specs.size() * n;
+}
+
+void run_group(AnofoxHipBatch *b, int period, const int32_t *d_len, hipStream_t st)
+{
+    const Plan &p = b->plan;
+    const size_t n = b->n, ld = b->ld;
+    const int blocks256 = (int)((n + 255) / 256);
+    auto prep = [&](int m, bool states) {
+        PrepArgs a{};
+        a.y = b->d_y; a.ld = ld; a.len = d_len; a.n_series = (int)n; a.m = m;
+        a.mean = b->d_mean; a.sd = b->d_sd; a.flags = b->d_flags;
+        if (states) {
+            if (m >= 2) ensure_fig(b, m);
+            a.fig_add = b->d_fig_add; a.fig_mul = b->d_fig_mul; a.l0 = b->d_l0; a.b0 = b->d_b0;
+        }
+        launch_prep(a, st);
+    };
+    auto simple = [&](int kind, int per, int window) {
+        SimpleArgs a{};
+        a.y = b->d_y; a.ld = ld; a.len = d_len; a.n_series = (int)n;
+        a.kind = kind; a.h = b->h; a.period = per; a.window = window;
+        a.yhat = b->d_yhat; a.status = b->d_status;
+        launch_simple(a, st);
+    };
+    auto finish = [&]() { hipLaunchKernelGGL(finish_status_kernel, dim3(blocks256), dim3(256), 0, st, (int)n, d_len, b->d_detail, b->d_status); };
+
+    switch (p.model) {
+    case M_Naive: prep(1, false); simple(SK_NAIVE, 1, 0); break;
+    case M_SeasonalNaive: prep(1, false); simple(SK_SEASONAL_NAIVE, period, 0); break;
+    case M_SMA: prep(1, false); simple(SK_SMA, 1, b->opt.window > 0 ? b->opt.window : std::max(period, 3)); break;
+    case M_RandomWalkDrift: prep(1, false); simple(SK_DRIFT, 1, 0); break;
+    case M_ARIMA: prep(1, false); simple(SK_TOY_ARIMA, 1, 0); break;
+    case M_SES: prep(1, false); run_classic(b, CK_SES, d_len, 1, 0, 0.3, 0, nullptr, 0, 0, false, st); finish(); break;
+    case M_SESOptimized: prep(1, false); run_classic(b, CK_SES, d_len, 1, 1, 0.0, 0, nullptr, 0, 0, false, st); finish(); break;
+    case M_Holt: prep(1, false); run_classic(b, CK_HOLT, d_len, 1, 1, 0.0, 0, nullptr, 0, 0, false, st); finish(); break;
+    case M_HoltWinters: {
+        int m = std::max(period, 2);
+        prep(1, false);
+        if (m > ETS_MAX_PERIOD) { // every series fails like a too-short one
+            HIPCHECK(hipMemsetAsync(b->d_detail, 0xff, ld * sizeof(int32_t), st));
+        } else run_classic(b, CK_HW, d_len, m, 1, 0.0, 2 * m, nullptr, 0, 0, false, st);
+        finish();
+        break;
+    }
+    case M_SeasonalES: case M_SeasonalESOptimized: {
+        int m = std::max(period, 2);
+        prep(1, false);
+        if (m > ETS_MAX_PERIOD) HIPCHECK(hipMemsetAsync(b->d_detail, 0xff, ld * sizeof(int32_t), st));
+        else run_classic(b, CK_SEASONAL_ES, d_len, m, p.model == M_SeasonalESOptimized ? 1 : 0, 0.1, m, nullptr, 0, 0, false, st);
+        finish();
+        break;
+    }
+    case M_ETS:
+        if (p.ets_spec_id >= 0) {
+            int id = p.ets_spec_id;
+            int m = 1;
+            if (spec_season(id) != 0 && period > 1) m = period;
+            else id = id - spec_season(id);             // forecast.rs:1347-1351: no usable period -> non-seasonal
+            prep(m, true);
+            if (spec_season(id) != 0 && m > ETS_MAX_PERIOD) {
+                HIPCHECK(hipMemsetAsync(b->d_detail, 0x04, ld * sizeof(int32_t), st));   // != FIT_OK: unsupported period
+                finish();
+                break;
+            }
+            std::vector<int> specs{id};
+            launch_fit_slots(b, specs, d_len, m, false, st);
+            hipLaunchKernelGGL(explicit_select_kernel, dim3(blocks256), dim3(256), 0, st, (int)n, b->h, d_len, b->d_status_slots,
+                               b->d_yhat_slots, b->d_passes_slots, b->d_evals_slots, b->d_yhat, b->d_detail, b->d_passes_total,
+                               b->d_evals_total);
+            finish();
+        } else {
+            prep(1, false);
+            // default chain decided by length only: mark every usable series for fallback
+            HIPCHECK(hipMemsetAsync(b->d_mask, 0x01, ld * sizeof(uint32_t), st));
+            hipLaunchKernelGGL(fallback_plan_kernel, dim3(blocks256), dim3(256), 0, st, (int)n, d_len, period, b->d_mask, b->d_detail);
+            if (period > 1 && period <= ETS_MAX_PERIOD)
+                run_classic(b, CK_HW, d_len, period, 1, 0.0, 2 * period, b->d_mask, 1u, 0, false, st);
+            run_classic(b, CK_HOLT, d_len, 1, 1, 0.0, 0, b->d_mask, 2u, 0, false, st);
+            run_classic(b, CK_SES, d_len, 1, 0, 0.3, 0, b->d_mask, 3u, 0, false, st);
+            finish();
+        }
+        break;
+    case M_AutoETS: {
+        int m = (period > 1 && period <= ETS_MAX_PERIOD) ? period : 1;
+        prep(m, true);
+        std::vector<int> specs;
+        for (int id = 0; id < 30; id++) {
+            if (spec_season(id) != 0 && m <= 1) continue;
+            if (!spec_is_valid(id) || !pool_allows(p.pool, id)) continue;
+            specs.push_back(id);
+        }
+        // longest kernels first (seasonal, damped, multiplicative) so the tail packs better
+        std::vector<int> order(specs);
+        std::stable_sort(order.begin(), order.end(), [](int a, int c) {
+            auto cost = [](int id) { return spec_dim(id) * 4 + (spec_has_mult(id) ? 8 : 0) + (spec_season(id) ? 6 : 0); };
+            return cost(a) > cost(c);
+        });
+        // slot order must stay the spec-id order for first-minimum tie breaking: map slots by id order
+        b->h_slot_spec.assign(specs.begin(), specs.end());
+        HIPCHECK(hipMemcpyAsync(b->d_slot_spec, b->h_slot_spec.data(), b->h_slot_spec.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        launch_fit_slots(b, specs, d_len, m, true, st);
+        (void)order;
+        SelectArgs sa{};
+        sa.n_series = (int)n; sa.h = b->h; sa.n_slots = (int)specs.size(); sa.ld = ld; sa.len = d_len;
+        sa.aicc = b->d_aicc; sa.yhat_slots = b->d_yhat_slots; sa.slot_spec = b->d_slot_spec;
+        sa.status_slots = b->d_status_slots; sa.passes_slots = b->d_passes_slots; sa.evals_slots = b->d_evals_slots;
+        sa.yhat = b->d_yhat; sa.model_code = b->d_model_code; sa.status = b->d_detail; sa.fallback_mask = b->d_mask;
+        sa.passes_total = b->d_passes_total; sa.evals_total = b->d_evals_total;
+        launch_select(sa, st);
+        hipLaunchKernelGGL(fallback_plan_kernel, dim3(blocks256), dim3(256), 0, st, (int)n, d_len, period, b->d_mask, b->d_detail);
+        if (period > 1 && period <= ETS_MAX_PERIOD)
+            run_classic(b, CK_HW, d_len, period, 1, 0.0, 2 * period, b->d_mask, 1u, 0, true, st);
+        run_classic(b, CK_HOLT, d_len, 1, 1, 0.0, 0, b->d_mask, 2u, 0, true, st);
+        run_classic(b, CK_SES, d_len, 1, 0, 0.3, 0, b->d_mask, 3u, 0, true, st);
+        finish();
+        break;
+    }
+    default: throw HipFail{"model not implemented"};
+    }
+}
+
+void run_batch(AnofoxHipBatch *b, hipStream_t st)
+{
+    const size_t n = b->n, ld = b->ld;
+    b->fit_launches = 0;
+    b->n_problems = 0;
+    b->timed_fit = false;
+    HIPCHECK(hipEventRecord(b->ev_start, st));
+    HIPCHECK(hipMemcpyAsync(b->d_status, b->h_base_status.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemsetAsync(b->d_passes_total, 0, ld * sizeof(int32_t), st));
+    HIPCHECK(hipMemsetAsync(b->d_evals_total, 0, ld * sizeof(int32_t), st));
+    HIPCHECK(hipMemsetAsync(b->d_model_code, 0, ld * sizeof(int32_t), st));
+    // group series by seasonal period (all equal unless auto-detection ran)
+    std::map<int, std::vector<size_t>> groups;
+    bool uniform = true;
+    for (size_t s = 1; s < n; s++) if (b->h_period[s] != b->h_period[0]) { uniform = false; break; }
+    if (uniform) run_group(b, n ? b->h_period[0] : 1, b->d_len, st);
+    else {
+        for (size_t s = 0; s < n; s++) groups[b->h_period[s]].push_back(s);
+        std::vector<int32_t> eff(ld);
+        for (auto &g : groups) {
+            std::fill(eff.begin(), eff.end(), 0);
+            for (size_t s : g.second) if (b->h_base_status[s] == 0) eff[s] = b->h_len[s];
+            HIPCHECK(hipStreamSynchronize(st));   // d_len_group is reused between groups
+            HIPCHECK(hipMemcpy(b->d_len_group, eff.data(), ld * sizeof(int32_t), hipMemcpyHostToDevice));
+            run_group(b, g.first, b->d_len_group, st);
+        }
+    }
+    IntervalArgs ia{};
+    ia.n_series = (int)n; ia.h = b->h; ia.yhat = b->d_yhat; ia.sd = b->d_sd; ia.status = b->d_status; ia.z = b->plan.z;
+    ia.lower = b->d_lo; ia.upper = b->d_hi;
+    launch_intervals(ia, st);
+    HIPCHECK(hipEventRecord(b->ev_stop, st));
+    b->last_stream = st;
+    b->ran = true;
+}
+
+std::string series_error_message(const AnofoxHipBatch *b, size_t s, int code, int detail)
+{
+    char buf[512];
+    if (code == INSUFFICIENT_DATA) {
+        int got = b->h_len[s];
+        std::snprintf(buf, sizeof buf, "Insufficient data: need at least %d observations, got %d", got == 0 ? 1 : 3, got);
+        return buf;
+    }
+    const char *why = detail == FIT_SHORT ? "not enough observations for this model"
+                      : detail == FIT_NONPOSITIVE ? "multiplicative components require strictly positive data"
+                      : detail == FIT_NONFINITE ? "likelihood is not finite" : "unsupported seasonal period";
+    switch (b->plan.model) {
+    case M_ETS:
+        if (b->plan.ets_spec_id >= 0) {
+            std::snprintf(buf, sizeof buf, "Computation error: ETS model '%s' failed to fit: Computation error: Failed to fit ETS model: %s",
+                          b->plan.ets_notation.c_str(), why);
+            return buf;
+        }
+        // fallthrough
+    default:
+        std::snprintf(buf, sizeof buf, "Computation error: %s fit failed: %s", model_name(b->plan.model), why);
+        return buf;
+    }
+}
+
+void fitted_values_host(const double *y, size_t n, ModelType model, size_t period, double *f)
+{
+    // forecast.rs:2593-2643
+    if (model == M_Naive) {
+        f[0] = y[0];
+        for (size_t i = 1; i < n; i++) f[i] = y[i - 1];
+    } else if (model == M_SeasonalNaive) {
+        size_t p = std::min(std::max<size_t>(period, 1), n);
+        for (size_t i = 0; i < p; i++) f[i] = y[0];
+        for (size_t i = p; i < n; i++) f[i] = y[i - p];
+    } else {
+        double level = y[0];
+        f[0] = level;
+        for (size_t i = 1; i < n; i++) { f[i] = level; level = 0.3 * y[i] + (1.0 - 0.3) * level; }
+    }
+}
+
+bool device_ready(AnofoxError *err)
+{
+    int cnt = 0;
+    hipError_t e = hipGetDeviceCount(&cnt);
+    if (e != hipSuccess || cnt <= 0) {
+        set_error(err, INTERNAL_ERROR, "Internal error: no HIP device available (the MI355X backend has no CPU fallback)");
+        return false;
+    }
+    return true;
+}
+
+} // namespace
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+const char *anofox_fcst_version(void) { return "0.1.0-hip-gfx950"; }
+
+int anofox_hip_device_count(void)
+{
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess) return -1;
+    return cnt;
+}
+
+int anofox_hip_set_device(int device) { return hipSetDevice(device) == hipSuccess ? 0 : -1; }
+
+bool anofox_hip_batch_create(size_t n_series, size_t t_max, const ForecastOptions *options, AnofoxHipBatch **out_batch,
+                             AnofoxError *out_error)
+{
+    if (out_error) { out_error->code = SUCCESS; std::memset(out_error->message, 0, sizeof out_error->message); }
+    if (!options || !out_batch) { set_error(out_error, NULL_POINTER, "Null pointer argument"); return false; }
+    Plan plan;
+    if (!make_plan(options, plan, out_error)) return false;
+    if (!device_ready(out_error)) return false;
+    AnofoxHipBatch *b = new AnofoxHipBatch();
+    try {
+        b->n = n_series;
+        b->t_max = t_max;
+        b->ld = (n_series + 63) / 64 * 64;
+        if (b->ld == 0) b->ld = 64;
+        b->h = options->horizon;
+        b->opt = *options;
+        b->plan = plan;
+        alloc_common(b);
+    } catch (const HipFail &f) {
+        set_error(out_error, INTERNAL_ERROR, "Internal error: " + f.msg);
+        free_batch_buffers(b);
+        delete b;
+        return false;
+    }
+    *out_batch = b;
+    return true;
+}
+
+void anofox_hip_batch_destroy(AnofoxHipBatch *b)
+{
+    if (!b) return;
+    if (b->last_stream || b->own_stream) (void)hipDeviceSynchronize();
+    free_batch_buffers(b);
+    delete b;
+}
+
+size_t anofox_hip_batch_ld(const AnofoxHipBatch *b) { return b ? b->ld : 0; }
+
+bool anofox_hip_batch_pack_host(AnofoxHipBatch *b, const double *const *values, const uint64_t *const *validity,
+                                const size_t *lengths, AnofoxError *out_error)
+{
+    if (!b || !values || !lengths) { set_error(out_error, NULL_POINTER, "Null pointer argument"); return false; }
+    try {
+        const size_t n = b->n, ld = b->ld, T = std::max<size_t>(b->t_max, 1);
+        std::vector<double> block(T * ld, 0.0);
+        std::vector<double> clean;
+        b->h_len.assign(n, 0);
+        b->h_period.assign(n, 1);
+        const bool keep = b->opt.include_fitted || b->opt.include_residuals;
+        if (keep) { b->h_clean.clear(); b->h_clean_off.assign(n + 1, 0); }
+        const bool detect = b->opt.auto_detect_seasonality && b->opt.seasonal_period == 0;
+        for (size_t s = 0; s < n; s++) {
+            const size_t len = lengths[s];
+            if (len > b->t_max) throw HipFail{"series longer than the plan's t_max"};
+            b->h_len[s] = (int32_t)len;
+            clean.resize(len);
+            if (len) fill_nulls_interpolate(values[s], validity ? validity[s] : nullptr, len, clean.data());
+            for (size_t t = 0; t < len; t++) block[t * ld + s] = clean[t];
+            int period = 1;
+            if (detect) { int p = len >= 3 ? detect_seasonality_first(clean.data(), len) : 0; period = p > 0 ? p : 1; }
+            else if (b->opt.seasonal_period > 0) period = b->opt.seasonal_period;
+            b->h_period[s] = period;
+            if (keep) { b->h_clean.insert(b->h_clean.end(), clean.begin(), clean.end()); b->h_clean_off[s + 1] = b->h_clean.size(); }
+        }
+        if (!b->d_y || !b->owns_y) { b->d_y = dalloc<double>(T * ld); b->owns_y = true; }
+        HIPCHECK(hipMemcpy(b->d_y, block.data(), T * ld * sizeof(double), hipMemcpyHostToDevice));
+        finalize_lengths(b);
+        b->has_block = true;
+    } catch (const HipFail &f) {
+        set_error(out_error, INTERNAL_ERROR, "Internal error: " + f.msg);
+        return false;
+    }
+    return true;
+}
+
+bool anofox_hip_batch_set_device_block(AnofoxHipBatch *b, const void *d_y, size_t ld, const void *d_len, AnofoxError *out_error)
+{
+    if (!b || !d_y || !d_len) { set_error(out_error, NULL_POINTER, "Null pointer argument"); return false; }
+    if (ld != b->ld) { set_error(out_error, INVALID_INPUT, "Invalid input: leading dimension must equal anofox_hip_batch_ld()"); return false; }
+    if (b->opt.auto_detect_seasonality && b->opt.seasonal_period == 0 && b->plan.model != M_Naive) {
+        // period detection runs in the host packer; a resident block must name its period
+        set_error(out_error, INVALID_INPUT, "Invalid input: a device-resident block requires an explicit seasonal_period");
+        return false;
+    }
+    try {
+        if (b->owns_y && b->d_y) { (void)hipFree(b->d_y); }
+        b->d_y = (double *)d_y;
+        b->owns_y = false;
+        b->h_len.assign(b->n, 0);
+        HIPCHECK(hipMemcpy(b->h_len.data(), d_len, b->n * sizeof(int32_t), hipMemcpyDeviceToHost));
+        b->h_period.assign(b->n, b->opt.seasonal_period > 0 ? b->opt.seasonal_period : 1);
+        finalize_lengths(b);
+        b->has_block = true;
+    } catch (const HipFail &f) {
+        set_error(out_error, INTERNAL_ERROR, "Internal error: " + f.msg);
+        return false;
+    }
+    return true;
+}
+
+bool anofox_hip_batch_run(AnofoxHipBatch *b, void *stream, AnofoxError *out_error)
+{
+    if (!b) { set_error(out_error, NULL_POINTER, "Null pointer argument"); return false; }
+    if (!b->has_block) { set_error(out_error, INVALID_INPUT, "Invalid input: batch has no series block"); return false; }
+    try {
+        run_batch(b, stream ? (hipStream_t)stream : b->own_stream);
+    } catch (const HipFail &f) {
+        set_error(out_error, INTERNAL_ERROR, "Internal error: " + f.msg);
+        return false;
+    }
+    return true;
+}
+
+bool anofox_hip_batch_stats(AnofoxHipBatch *b, AnofoxHipStats *out)
+{
+    if (!b || !out || !b->ran) return false;
+    std::memset(out, 0, sizeof *out);
+    if (hipEventSynchronize(b->ev_stop) != hipSuccess) return false;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, b->ev_start, b->ev_stop) == hipSuccess) out->total_device_ms = ms;
+    if (b->timed_fit && hipEventElapsedTime(&ms, b->ev_fit0, b->ev_fit1) == hipSuccess) out->fit_kernel_ms = ms;
+    std::vector<int32_t> passes(b->n), evals(b->n);
+    if (hipMemcpy(passes.data(), b->d_passes_total, b->n * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) return false;
+    if (hipMemcpy(evals.data(), b->d_evals_total, b->n * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) return false;
+    out->n_series = b->n;
+    out->t_max = b->t_max;
+    out->n_problems = b->n_problems;
+    out->fit_kernel_launches = b->fit_launches;
+    for (size_t s = 0; s < b->n; s++) {
+        uint64_t p = (uint64_t)std::max(passes[s], 0);
+        out->total_passes += p;
+        out->max_passes = std::max<uint64_t>(out->max_passes, p);
+        out->total_evals += (uint64_t)std::max(evals[s], 0);
+        out->algorithmic_bytes += 8ull * (uint64_t)b->h_len[s] * p + 24ull * (uint64_t)std::max(b->h, 0);
+    }
+    return true;
+}
+
+bool anofox_hip_batch_device_results(AnofoxHipBatch *b, void **d_yhat, void **d_lower, void **d_upper, void **d_model_code,
+                                     void **d_status)
+{
+    if (!b) return false;
+    if (d_yhat) *d_yhat = b->d_yhat;
+    if (d_lower) *d_lower = b->d_lo;
+    if (d_upper) *d_upper = b->d_hi;
+    if (d_model_code) *d_model_code = b->d_model_code;
+    if (d_status) *d_status = b->d_status;
+    return true;
+}
+
+void anofox_hip_model_name(const ForecastOptions *options, int32_t model_code, char out_name[64])
+{
+    out_name[0] = 0;
+    if (model_code >= 100 && model_code < 130) { auto_ets_name(model_code - 100, out_name); return; }
+    Plan p;
+    AnofoxError e;
+    if (options && make_plan(options, p, &e)) {
+        std::snprintf(out_name, 64, "%s", p.static_name.c_str());
+    }
+}
+
+bool anofox_hip_batch_fetch(AnofoxHipBatch *b, ForecastResult *out_results, AnofoxError *out_errors)
+{
+    if (!b || !out_results || !b->ran) return false;
+    const size_t n = b->n, h = (size_t)std::max(b->h, 0);
+    if (hipStreamSynchronize(b->last_stream) != hipSuccess) return false;
+    std::vector<double> yhat(n * h), lo(n * h), hi(n * h);
+    std::vector<int32_t> status(n), code(n), detail(n);
+    bool ok = true;
+    if (h) {
+        ok &= hipMemcpy(yhat.data(), b->d_yhat, n * h * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess;
+        ok &= hipMemcpy(lo.data(), b->d_lo, n * h * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess;
+        ok &= hipMemcpy(hi.data(), b->d_hi, n * h * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    ok &= hipMemcpy(status.data(), b->d_status, n * sizeof(int32_t), hipMemcpyDeviceToHost) == hipSuccess;
+    ok &= hipMemcpy(code.data(), b->d_model_code, n * sizeof(int32_t), hipMemcpyDeviceToHost) == hipSuccess;
+    ok &= hipMemcpy(detail.data(), b->d_detail, n * sizeof(int32_t), hipMemcpyDeviceToHost) == hipSuccess;
+    if (!ok) return false;
+    for (size_t s = 0; s < n; s++) {
+        ForecastResult &r = out_results[s];
+        std::memset(&r, 0, sizeof r);
+        if (out_errors) { out_errors[s].code = SUCCESS; std::memset(out_errors[s].message, 0, sizeof out_errors[s].message); }
+        if (status[s] != 0) {
+            if (out_errors) set_error(&out_errors[s], status[s], series_error_message(b, s, status[s], detail[s]));
+            continue;
+        }
+        r.n_forecasts = h;
+        if (h) {
+            r.point_forecasts = (double *)std::malloc(h * sizeof(double));
+            r.lower_bounds = (double *)std::malloc(h * sizeof(double));
+            r.upper_bounds = (double *)std::malloc(h * sizeof(double));
+            if (!r.point_forecasts || !r.lower_bounds || !r.upper_bounds) {
+                std::free(r.point_forecasts); std::free(r.lower_bounds); std::free(r.upper_bounds);
+                std::memset(&r, 0, sizeof r);
+                if (out_errors) set_error(&out_errors[s], ALLOCATION_ERROR, "Failed to allocate point forecasts");
+                continue;
+            }
+            std::memcpy(r.point_forecasts, &yhat[s * h], h * sizeof(double));
+            std::memcpy(r.lower_bounds, &lo[s * h], h * sizeof(double));
+            std::memcpy(r.upper_bounds, &hi[s * h], h * sizeof(double));
+        }
+        if (code[s] >= 100) auto_ets_name(code[s] - 100, r.model_name);
+        else std::snprintf(r.model_name, 64, "%s", b->plan.static_name.c_str());
+        r.aic = std::nan(""); r.bic = std::nan(""); r.mse = std::nan("");
+        if ((b->opt.include_fitted || b->opt.include_residuals) && !b->h_clean_off.empty()) {
+            const size_t len = (size_t)b->h_len[s];
+            const double *y = b->h_clean.data() + b->h_clean_off[s];
+            double *f = (double *)std::malloc(len * sizeof(double));
+            fitted_values_host(y, len, b->plan.model, (size_t)b->h_period[s], f);
+            double sse = 0.0;
+            for (size_t i = 0; i < len; i++) { double d = y[i] - f[i]; sse += d * d; }
+            r.mse = sse / (double)len;
+            if (b->opt.include_residuals) {
+                r.residuals = (double *)std::malloc(len * sizeof(double));
+                for (size_t i = 0; i < len; i++) r.residuals[i] = y[i] - f[i];
+            }
+            if (b->opt.include_fitted) { r.fitted_values = f; r.n_fitted = len; }
+            else std::free(f);
+        }
+    }
+    return true;
+}
+
+void anofox_free_forecast_result(ForecastResult *r)
+{
+    if (!r) return;
+    std::free(r->point_forecasts); r->point_forecasts = nullptr;
+    std::free(r->lower_bounds); r->lower_bounds = nullptr;
+    std::free(r->upper_bounds); r->upper_bounds = nullptr;
+    std::free(r->fitted_values); r->fitted_values = nullptr;
+    std::free(r->residuals); r->residuals = nullptr;
+}
+
+bool anofox_ts_forecast_batch(const double *const *values, const uint64_t *const *validity, const size_t *lengths, size_t n_series,
+                              const ForecastOptions *options, const int *horizons, ForecastResult *out_results,
+                              AnofoxError *out_errors, AnofoxError *out_batch_error)
+{
+    if (out_batch_error) { out_batch_error->code = SUCCESS; std::memset(out_batch_error->message, 0, sizeof out_batch_error->message); }
+    if (!values || !lengths || !options || !out_results) { set_error(out_batch_error, NULL_POINTER, "Null pointer argument"); return false; }
+    for (size_t s = 0; s < n_series; s++) {
+        std::memset(&out_results[s], 0, sizeof(ForecastResult));
+        if (!values[s]) { set_error(out_batch_error, NULL_POINTER, "Null pointer argument"); return false; }
+    }
+    ForecastOptions opt = *options;
+    int hmax = options->horizon;
+    if (horizons) for (size_t s = 0; s < n_series; s++) hmax = std::max(hmax, horizons[s]);
+    opt.horizon = hmax;
+    size_t t_max = 0;
+    for (size_t s = 0; s < n_series; s++) t_max = std::max(t_max, lengths[s]);
+    AnofoxHipBatch *b = nullptr;
+    AnofoxError e;
+    if (!anofox_hip_batch_create(n_series, t_max, &opt, &b, &e)) {
+        if (out_batch_error) *out_batch_error = e;
+        if (out_errors) for (size_t s = 0; s < n_series; s++) out_errors[s] = e;
+        return false;
+    }
+    bool ok = anofox_hip_batch_pack_host(b, values, validity, lengths, &e) && anofox_hip_batch_run(b, nullptr, &e) &&
+              anofox_hip_batch_fetch(b, out_results, out_errors);
+    if (!ok) {
+        if (e.code == SUCCESS) set_error(&e, INTERNAL_ERROR, "Internal error: device batch failed");
+        if (out_batch_error) *out_batch_error = e;
+    } else if (horizons) {
+        // per-series horizon: forecasts are prefix-consistent, so truncate (ts_cv_forecast_native.cpp:676-677)
+        for (size_t s = 0; s < n_series; s++)
+            if (out_results[s].point_forecasts && horizons[s] >= 0 && (size_t)horizons[s] < out_results[s].n_forecasts) {
+                out_results[s].n_forecasts = (size_t)horizons[s];
+                if (horizons[s] == 0) {
+                    std::free(out_results[s].point_forecasts); std::free(out_results[s].lower_bounds); std::free(out_results[s].upper_bounds);
+                    out_results[s].point_forecasts = out_results[s].lower_bounds = out_results[s].upper_bounds = nullptr;
+                }
+            }
+    }
+    anofox_hip_batch_destroy(b);
+    return ok;
+}
+
+bool anofox_ts_forecast(const double *values, const uint64_t *validity, size_t length, const ForecastOptions *options,
+                        ForecastResult *out_result, AnofoxError *out_error)
+{
+    if (out_error) { out_error->code = SUCCESS; std::memset(out_error->message, 0, sizeof out_error->message); }
+    if (!values || !options || !out_result) { set_error(out_error, NULL_POINTER, "Null pointer argument"); return false; }
+    // argument errors come first, exactly like the reference (lib.rs:3368-3380, forecast.rs:514-565)
+    Plan plan;
+    AnofoxError e;
+    e.code = SUCCESS;
+    std::memset(e.message, 0, sizeof e.message);
+    {
+        std::string mname = cstr_field(options->model, sizeof options->model);
+        ModelType mt;
+        if (!parse_model(mname, mt)) { set_error(out_error, INVALID_MODEL, "Invalid model: Unknown model: '" + mname + "'"); return false; }
+        if (options->horizon < 0) { set_error(out_error, PANIC_CAUGHT, "Panic in Rust code"); return false; }
+        if (length == 0) { set_error(out_error, INSUFFICIENT_DATA, "Insufficient data: need at least 1 observations, got 0"); return false; }
+        if (length < 3) {
+            set_error(out_error, INSUFFICIENT_DATA, "Insufficient data: need at least 3 observations, got " + std::to_string(length));
+            return false;
+        }
+    }
+    AnofoxError se;
+    const double *vals[1] = {values};
+    const uint64_t *valid[1] = {validity};
+    size_t lens[1] = {length};
+    ForecastResult r;
+    bool ok = anofox_ts_forecast_batch(vals, validity ? valid : nullptr, lens, 1, options, nullptr, &r, &se, &e);
+    if (!ok) { if (out_error) *out_error = e; return false; }
+    if (se.code != SUCCESS) { if (out_error) *out_error = se; return false; }
+    *out_result = r;
+    return true;
+}
+
+} // extern "C"

@@ -1,0 +1,361 @@
+// kernels.hip -- the non-templated kernels of the batch path: series statistics + ETS initial
+// states (prep), AICc selection, the classic SES/Holt/Holt-Winters/SeasonalES fits, the closed-form
+// baselines and the prediction intervals.  All one-wave workgroups, lane <-> series, coalesced
+// 512-byte rows of the time-major block per time step.
+#include "classic_device.hpp"
+#include "fit_units.hpp"
+#include "kernels.hpp"
+
+namespace anofox {
+
+// ------------------------------------------------------------------------------------------
+// prep: per series mean / sd (forecast.rs:2558-2591), positivity / constancy flags, and the
+// ETS initial states (classical-decomposition seasonal figure; full-sample least-squares level
+// and growth of the seasonally adjusted series; see oracle/ets.c ets_init_states).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NM_BLOCK) void prep_kernel(const PrepArgs a)
+{
+    const int s = blockIdx.x * NM_BLOCK + threadIdx.x;
+    if (s >= a.n_series) return;
+    const int n = a.len[s];
+    const double *y = a.y + s;
+    const size_t ld = a.ld;
+    if (n <= 0) return;   // not in this group: leave whatever another group wrote
+
+    double sum = 0.0;
+    bool positive = true, constant = true, has_nan = false;
+    const double y0 = y[0];
+    for (int t = 0; t < n; t++) {
+        double v = y[(size_t)t * ld];
+        sum += v;
+        if (!(v > 0.0)) positive = false;
+        if (v != y0) constant = false;
+        if (v != v) has_nan = true;
+    }
+    const double mean = sum / (double)n;
+    double var = 0.0;
+    for (int t = 0; t < n; t++) { double d = y[(size_t)t * ld] - mean; var += d * d; }
+    a.mean[s] = mean;
+    a.sd[s] = sqrt(var / (double)n);
+    a.flags[s] = (positive ? SF_POSITIVE : 0u) | (constant ? SF_CONSTANT : 0u) | (has_nan ? SF_HAS_NAN : 0u);
+    if (a.l0 == nullptr) return;
+
+    const int m = a.m;
+    const bool seasonal = (m >= 2 && m <= ETS_MAX_PERIOD && n >= 2 * m);
+    if (seasonal) {
+        const int half = m / 2;
+        const int L = (m % 2 == 0) ? m + 1 : m;
+        const double w = 1.0 / (double)m;
+        const double wend = (m % 2 == 0) ? 0.5 / (double)m : w;
+        for (int type = 1; type <= 2; type++) {
+            if (type == 2 && !positive) break;
+            double *fig = (type == 1 ? a.fig_add : a.fig_mul) + s;
+            double tot = 0.0;
+            for (int j = 0; j < m; j++) {
+                double sj = 0.0;
+                int cnt = 0;
+                for (int i = (j >= half ? j : j + m); i < n - half; i += m) {
+                    double acc = 0.0;
+                    for (int k = 0; k < L; k++) {
+                        double wk = (k == 0 || k == L - 1) ? wend : w;
+                        acc = acc + wk * y[(size_t)(i - half + k) * ld];
+                    }
+                    double d = (type == 1) ? (y[(size_t)i * ld] - acc) : (y[(size_t)i * ld] / acc);
+                    sj = sj + d;
+                    cnt++;
+                }
+                double fj = sj / (double)cnt;
+                fig[(size_t)j * ld] = fj;
+                tot = tot + fj;
+            }
+            const double fmean = tot / (double)m;
+            for (int j = 0; j < m; j++) {
+                double fj = fig[(size_t)j * ld];
+                if (type == 1) fj = fj - fmean;
+                else {
+                    fj = fj / fmean;
+                    if (!(fj >= 1.0e-2)) fj = 1.0e-2;
+                }
+                fig[(size_t)j * ld] = fj;
+            }
+        }
+    }
+
+    // level / growth for season type st = 0 (none), 1 (additive), 2 (multiplicative)
+    for (int st = 0; st <= 2; st++) {
+        if (st > 0 && !seasonal) break;
+        if (st == 2 && !positive) break;
+        const double *fig = (st == 1 ? a.fig_add : a.fig_mul) + s;
+        const int mm = (st == 0) ? 1 : m;
+        int K = 2 * mm > 10 ? 2 * mm : 10;
+        if (K > n) K = n;
+        double sy = 0.0, sxy = 0.0, sk = 0.0, ysa0 = 0.0, ysa1 = 0.0;
+        int j = 0;
+        for (int i = 0; i < n; i++) {
+            double v = y[(size_t)i * ld];
+            if (st == 1) v = v - fig[(size_t)j * ld];
+            else if (st == 2) v = v / fig[(size_t)j * ld];
+            sy = sy + v;
+            sxy = sxy + (double)(i + 1) * v;
+            if (i < K) sk = sk + v;
+            if (i == 0) ysa0 = v;
+            if (i == 1) ysa1 = v;
+            j = (j + 1 == mm) ? 0 : j + 1;
+        }
+        const double dn = (double)n;
+        const double sx = dn * (dn + 1.0) / 2.0;
+        const double sxx = dn * (dn + 1.0) * (2.0 * dn + 1.0) / 6.0;
+        const double slope = (dn * sxy - sx * sy) / (dn * sxx - sx * sx);
+        const double icpt = (sy - slope * sx) / dn;
+        // trend none
+        a.l0[(size_t)(st * 3 + 0) * ld + s] = sk / (double)K;
+        a.b0[(size_t)(st * 3 + 0) * ld + s] = 0.0;
+        // trend additive
+        {
+            double l0 = icpt, b0 = slope;
+            if (fabs(l0 + b0) < 1.0e-8) { l0 = l0 * (1.0 + 1.0e-3); b0 = b0 * (1.0 - 1.0e-3); }
+            a.l0[(size_t)(st * 3 + 1) * ld + s] = l0;
+            a.b0[(size_t)(st * 3 + 1) * ld + s] = b0;
+        }
+        // trend multiplicative
+        {
+            double l0 = icpt + slope;
+            if (fabs(l0) < 1.0e-8) l0 = 1.0e-7;
+            double b0 = (icpt + 2.0 * slope) / l0;
+            l0 = l0 / b0;
+            if (fabs(b0) > 1.0e10) b0 = (b0 < 0.0 ? -1.0e10 : 1.0e10);
+            if (l0 < 1.0e-8 || b0 < 1.0e-8) {
+                l0 = ysa0 > 1.0e-3 ? ysa0 : 1.0e-3;
+                double r = ysa1 / ysa0;
+                b0 = r > 1.0e-3 ? r : 1.0e-3;
+            }
+            a.l0[(size_t)(st * 3 + 2) * ld + s] = l0;
+            a.b0[(size_t)(st * 3 + 2) * ld + s] = b0;
+        }
+    }
+}
+
+void launch_prep(const PrepArgs &a, hipStream_t stream)
+{
+    const int grid = (a.n_series + NM_BLOCK - 1) / NM_BLOCK;
+    hipLaunchKernelGGL(prep_kernel, dim3(grid), dim3(NM_BLOCK), 0, stream, a);
+}
+
+// ------------------------------------------------------------------------------------------
+// AICc selection over the fitted spec slots (first minimum wins, oracle_auto_ets_search).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NM_BLOCK) void select_kernel(const SelectArgs a)
+{
+    const int s = blockIdx.x * NM_BLOCK + threadIdx.x;
+    if (s >= a.n_series) return;
+    if (a.len[s] <= 0) { a.fallback_mask[s] = 0u; return; }
+    int best = -1;
+    double best_aicc = __builtin_huge_val();
+    int passes = 0, evals = 0;
+    for (int k = 0; k < a.n_slots; k++) {
+        passes += a.passes_slots[(size_t)k * a.ld + s];
+        evals += a.evals_slots[(size_t)k * a.ld + s];
+        if (a.status_slots[(size_t)k * a.ld + s] != FIT_OK) continue;
+        double v = a.aicc[(size_t)k * a.ld + s];
+        if (v < best_aicc) { best_aicc = v; best = k; }
+    }
+    a.passes_total[s] = passes;
+    a.evals_total[s] = evals;
+    if (best < 0) {
+        a.status[s] = -1;
+        a.model_code[s] = 0;
+        a.fallback_mask[s] = 1u;
+        return;
+    }
+    a.fallback_mask[s] = 0u;
+    a.status[s] = 0;
+    a.model_code[s] = 100 + a.slot_spec[best];
+    const double *src = a.yhat_slots + ((size_t)best * a.n_series + s) * a.h;
+    double *dst = a.yhat + (size_t)s * a.h;
+    for (int i = 0; i < a.h; i++) dst[i] = src[i];
+}
+
+void launch_select(const SelectArgs &a, hipStream_t stream)
+{
+    const int grid = (a.n_series + NM_BLOCK - 1) / NM_BLOCK;
+    hipLaunchKernelGGL(select_kernel, dim3(grid), dim3(NM_BLOCK), 0, stream, a);
+}
+
+// ------------------------------------------------------------------------------------------
+// classic fits
+// ------------------------------------------------------------------------------------------
+template <int KIND>
+__global__ __launch_bounds__(NM_BLOCK) void classic_kernel(const ClassicArgs a)
+{
+    extern __shared__ double lds[];
+    constexpr int DIM = ClassicDim<KIND>::value;
+    const int s = blockIdx.x * NM_BLOCK + threadIdx.x;
+    const int len = (s < a.n_series) ? a.len[s] : 0;
+    bool selected = (s < a.n_series) && len > 0 && (a.mask == nullptr || a.mask[s] == a.want);
+    int st = FIT_OK;
+    if (selected && len < a.min_len) st = FIT_SHORT;
+    const bool active = selected && st == FIT_OK;
+
+    SeriesView v;
+    v.y = a.y + (s < a.n_series ? s : 0);
+    v.ld = a.ld;
+    v.len = active ? len : 0;
+    v.wave_len = wave_max_i32(v.len);
+    v.wave_min_len = 0;
+    if (v.wave_len == 0) {
+        if (selected) a.status[s] = st;
+        return;
+    }
+    ClassicModel<KIND> mdl;
+    mdl.v = v;
+    mdl.m = a.m;
+    mdl.ring = lds + nm_lds_doubles<DIM>();
+
+    double xbest[DIM], fbest;
+    NmStats ns = {0, 0, 0};
+    const bool optimise = (KIND == CK_HOLT || KIND == CK_HW) ? true : (a.optimized != 0);
+    if (optimise) nm_minimize(mdl, active, lds, xbest, fbest, ns);
+    else xbest[0] = a.fixed_alpha;
+
+    double cand[NM_K][DIM], f[NM_K];
+#pragma unroll
+    for (int k = 0; k < NM_K; k++)
+#pragma unroll
+        for (int i = 0; i < DIM; i++) cand[k][i] = xbest[i];
+    ClassicFinalOut fin;
+    fin.h = a.h;
+    fin.write = active;
+    fin.yhat = a.yhat + (size_t)(s < a.n_series ? s : 0) * a.h;
+    classic_pass<KIND, NM_K, true>(v, a.m, cand, f, mdl.ring, &fin);
+    if (selected) {
+        a.status[s] = st;
+        if (active) {
+            a.passes[s] += ns.passes + 1;
+            if (a.model_code_out) a.model_code_out[s] = a.model_code;
+        }
+    }
+}
+
+void launch_classic(int kind, const ClassicArgs &a, hipStream_t stream)
+{
+    const int grid = (a.n_series + NM_BLOCK - 1) / NM_BLOCK;
+    const int mm = a.m > 0 ? a.m : 1;
+    size_t ring = sizeof(double) * (size_t)NM_K * mm * NM_BLOCK;
+    switch (kind) {
+    case CK_SES:
+        hipLaunchKernelGGL(classic_kernel<CK_SES>, dim3(grid), dim3(NM_BLOCK), sizeof(double) * nm_lds_doubles<1>(), stream, a);
+        break;
+    case CK_HOLT:
+        hipLaunchKernelGGL(classic_kernel<CK_HOLT>, dim3(grid), dim3(NM_BLOCK), sizeof(double) * nm_lds_doubles<2>(), stream, a);
+        break;
+    case CK_HW: {
+        size_t bytes = sizeof(double) * nm_lds_doubles<3>() + ring;
+        if (bytes > 48 * 1024)
+            (void)hipFuncSetAttribute((const void *)classic_kernel<CK_HW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        hipLaunchKernelGGL(classic_kernel<CK_HW>, dim3(grid), dim3(NM_BLOCK), bytes, stream, a);
+        break;
+    }
+    default: {
+        size_t bytes = sizeof(double) * nm_lds_doubles<1>() + ring;
+        if (bytes > 48 * 1024)
+            (void)hipFuncSetAttribute((const void *)classic_kernel<CK_SEASONAL_ES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        hipLaunchKernelGGL(classic_kernel<CK_SEASONAL_ES>, dim3(grid), dim3(NM_BLOCK), bytes, stream, a);
+        break;
+    }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// closed-form baselines (forecast.rs:1026-1100, toy ARIMA :1391-1431)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NM_BLOCK) void simple_kernel(const SimpleArgs a)
+{
+    const int s = blockIdx.x * NM_BLOCK + threadIdx.x;
+    if (s >= a.n_series) return;
+    const int n = a.len[s];
+    if (n <= 0) return;
+    const double *y = a.y + s;
+    const size_t ld = a.ld;
+    double *out = a.yhat + (size_t)s * a.h;
+    const double last = y[(size_t)(n - 1) * ld];
+    switch (a.kind) {
+    case SK_NAIVE:
+        for (int i = 0; i < a.h; i++) out[i] = last;
+        break;
+    case SK_SEASONAL_NAIVE: {
+        int p = a.period < 1 ? 1 : a.period;
+        if (p > n) p = n;
+        for (int i = 0; i < a.h; i++) out[i] = y[(size_t)(n - p + (i % p)) * ld];
+        break;
+    }
+    case SK_SMA: {
+        int w = a.window < n ? a.window : n;
+        double sum = 0.0;
+        for (int k = 0; k < w; k++) sum += y[(size_t)(n - 1 - k) * ld];
+        double v = sum / (double)w;
+        for (int i = 0; i < a.h; i++) out[i] = v;
+        break;
+    }
+    case SK_DRIFT: {
+        double drift = (last - y[0]) / (double)(n - 1);
+        for (int i = 1; i <= a.h; i++) out[i - 1] = last + drift * (double)i;
+        break;
+    }
+    default: { // SK_TOY_ARIMA
+        if (n < 5) { for (int i = 0; i < a.h; i++) out[i] = last; break; }
+        double sd = 0.0;
+        for (int i = 1; i < n; i++) sd += y[(size_t)i * ld] - y[(size_t)(i - 1) * ld];
+        double mean_diff = sd / (double)(n - 1);
+        double prev = last - y[(size_t)(n - 2) * ld], cum = last;
+        for (int i = 0; i < a.h; i++) {
+            double nd = mean_diff + 0.5 * (prev - mean_diff);
+            cum += nd;
+            out[i] = cum;
+            prev = nd;
+        }
+        break;
+    }
+    }
+    a.status[s] = 0;
+}
+
+void launch_simple(const SimpleArgs &a, hipStream_t stream)
+{
+    const int grid = (a.n_series + NM_BLOCK - 1) / NM_BLOCK;
+    hipLaunchKernelGGL(simple_kernel, dim3(grid), dim3(NM_BLOCK), 0, stream, a);
+}
+
+// ------------------------------------------------------------------------------------------
+// intervals: yhat -/+ z sd sqrt(step)   (forecast.rs:2558-2591)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void interval_kernel(const IntervalArgs a)
+{
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t total = (size_t)a.n_series * a.h;
+    if (idx >= total) return;
+    const int s = (int)(idx / a.h), i = (int)(idx % a.h);
+    if (a.status[s] != 0) { a.lower[idx] = __builtin_nan(""); a.upper[idx] = __builtin_nan(""); return; }
+    const double wd = a.z * a.sd[s] * sqrt((double)(i + 1));
+    const double f = a.yhat[idx];
+    a.lower[idx] = f - wd;
+    a.upper[idx] = f + wd;
+}
+
+void launch_intervals(const IntervalArgs &a, hipStream_t stream)
+{
+    const size_t total = (size_t)a.n_series * a.h;
+    if (total == 0) return;
+    hipLaunchKernelGGL(interval_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
+}
+
+// ------------------------------------------------------------------------------------------
+FitLaunchFn ets_fit_launcher(int spec_id, int m)
+{
+    FitLaunchFn f = fit_unit_nonseasonal(spec_id, m);
+    if (!f) f = fit_unit_seasonal_add(spec_id, m);
+    if (!f) f = fit_unit_seasonal_gen_a(spec_id, m);
+    if (!f) f = fit_unit_seasonal_gen_m(spec_id, m);
+    return f;
+}
+
+} // namespace anofox

@@ -1,0 +1,100 @@
+// kernels.hpp -- kernel argument blocks and launch entry points shared by the .hip units
+// and the host layer.  Everything device-side is one-wave (64-thread) workgroups: lane <->
+// series, so a workgroup covers 64 consecutive columns of the time-major block.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace anofox {
+
+// per-series flag bits produced by the prep kernel
+enum : uint32_t { SF_POSITIVE = 1u, SF_CONSTANT = 2u, SF_HAS_NAN = 4u };
+
+// per-(series, spec) fit status
+enum : int32_t { FIT_OK = 0, FIT_SHORT = 1, FIT_NONPOSITIVE = 2, FIT_NONFINITE = 3, FIT_PERIOD = 4, FIT_SKIPPED = 5 };
+
+struct PrepArgs {
+    const double *y; size_t ld; const int32_t *len; int n_series;
+    int m;                 // seasonal period to prepare figures for (<= 1: none)
+    double *mean, *sd;     // population mean / sd of the series (forecast.rs:2558-2591)
+    uint32_t *flags;
+    double *fig_add, *fig_mul;   // [m x ld] seasonal figures (additive / multiplicative)
+    double *l0, *b0;       // [9 x ld]: index (season_type * 3 + trend_type)
+};
+
+struct FitArgs {
+    const double *y; size_t ld; const int32_t *len; int n_series;
+    int m, h;
+    const double *l0, *b0;       // [ld] for this spec's (season, trend) class
+    const double *fig; size_t fig_ld;
+    const uint32_t *flags;
+    int need_positive;           // spec has a multiplicative component
+    int skip_constant;           // AutoETS: constant series go to the fallback chain
+    int n_param;                 // k of the information criteria
+    double *aicc;                // [ld]
+    double *yhat;                // [n_series x h] for this spec
+    int32_t *status;             // [ld]
+    int32_t *evals, *iters, *passes; // [ld]
+};
+
+struct SelectArgs {
+    int n_series, h, n_slots;
+    size_t ld;
+    const int32_t *len;          // series with len <= 0 are not part of this group
+    const double *aicc;          // [n_slots x ld]
+    const double *yhat_slots;    // [n_slots x n_series x h]
+    const int32_t *slot_spec;    // [n_slots] spec id
+    const int32_t *status_slots; // [n_slots x ld]
+    const int32_t *passes_slots; // [n_slots x ld]
+    const int32_t *evals_slots;
+    double *yhat;                // [n_series x h]
+    int32_t *model_code;         // [n_series]
+    int32_t *status;             // [n_series]  0 ok, -1 needs fallback
+    uint32_t *fallback_mask;     // [n_series] 1 where the fallback chain must run
+    int32_t *passes_total;       // [n_series] streamed passes summed over specs (+1 final each)
+    int32_t *evals_total;
+};
+
+struct ClassicArgs {
+    const double *y; size_t ld; const int32_t *len; int n_series;
+    int m, h;
+    int optimized;               // SES / SeasonalES: optimise alpha (else fixed_alpha)
+    double fixed_alpha;
+    const uint32_t *mask;        // NULL = all series; else run only where mask[s] == want
+    uint32_t want;
+    int min_len;                 // series shorter than this fail (status = FIT_SHORT)
+    double *yhat;                // [n_series x h]
+    int32_t *status;             // [n_series]
+    int32_t *passes;             // [n_series] (accumulated)
+    int32_t model_code;          // written to model_code[s] when not NULL
+    int32_t *model_code_out;
+};
+
+enum SimpleKind { SK_NAIVE = 0, SK_SEASONAL_NAIVE = 1, SK_SMA = 2, SK_DRIFT = 3, SK_TOY_ARIMA = 4 };
+struct SimpleArgs {
+    const double *y; size_t ld; const int32_t *len; int n_series;
+    int kind, h, period, window;
+    double *yhat; int32_t *status;
+};
+
+struct IntervalArgs {
+    int n_series, h;
+    const double *yhat, *sd;
+    const int32_t *status;
+    double z;
+    double *lower, *upper;
+};
+
+// ETS fit kernels, one per (spec id, ring variant).  ring: 0 = none / VGPR ring for the
+// compile-time period given, -1 = LDS ring.  Returns NULL when not instantiated.
+typedef void (*FitLaunchFn)(const FitArgs &, hipStream_t);
+FitLaunchFn ets_fit_launcher(int spec_id, int m);
+
+void launch_prep(const PrepArgs &, hipStream_t);
+void launch_select(const SelectArgs &, hipStream_t);
+void launch_classic(int kind, const ClassicArgs &, hipStream_t);
+void launch_simple(const SimpleArgs &, hipStream_t);
+void launch_intervals(const IntervalArgs &, hipStream_t);
+
+} // namespace anofox

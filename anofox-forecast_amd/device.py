@@ -1,0 +1,104 @@
+"""Device-resident batches: the series block lives in HBM as a torch tensor (plumbing only:
+allocation, streams, torch.distributed); all arithmetic is in libanofox_fcst_hip.so.
+
+Layout: time-major fp64 block Y[t, s] of shape [t_max, ld], ld = n_series rounded up to 64, so
+the 64 lanes of a wave read one 512-byte row segment per time step.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import lib as _lib
+
+
+def pack_time_major(series_major: np.ndarray, ld: int | None = None) -> np.ndarray:
+    """[n, T] series-major host array -> [T, ld] time-major (zero padded)."""
+    n, T = series_major.shape
+    ld = ld or (n + 63) // 64 * 64
+    out = np.zeros((T, ld), dtype=np.float64)
+    out[:, :n] = series_major.T
+    return out
+
+
+class DeviceBatch:
+    """anofox_hip_batch_* over torch-owned HBM."""
+
+    def __init__(self, n_series: int, t_max: int, opts: _lib.ForecastOptions, device: torch.device | str = "cuda:0"):
+        self.L = _lib.load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("DeviceBatch needs a HIP device (no CPU fallback)")
+        idx = self.device.index or 0
+        if self.L.anofox_hip_set_device(idx) != 0:
+            raise RuntimeError(f"hipSetDevice({idx}) failed")
+        torch.cuda.set_device(idx)
+        self.n, self.t_max, self.opts = int(n_series), int(t_max), opts
+        self.h = int(opts.horizon)
+        handle = C.c_void_p()
+        err = _lib.AnofoxError()
+        if not self.L.anofox_hip_batch_create(self.n, self.t_max, C.byref(opts), C.byref(handle), C.byref(err)):
+            raise RuntimeError(f"anofox_hip_batch_create failed: [{err.code}] {err.message.decode()}")
+        self.handle = handle
+        self.ld = int(self.L.anofox_hip_batch_ld(handle))
+        self._y = self._len = None
+
+    def set_block(self, y_time_major: torch.Tensor, lengths: torch.Tensor):
+        assert y_time_major.dtype == torch.float64 and y_time_major.is_cuda and y_time_major.is_contiguous()
+        assert tuple(y_time_major.shape) == (self.t_max, self.ld), (tuple(y_time_major.shape), (self.t_max, self.ld))
+        assert lengths.dtype == torch.int32 and lengths.is_cuda and lengths.numel() >= self.n
+        self._y, self._len = y_time_major, lengths
+        err = _lib.AnofoxError()
+        if not self.L.anofox_hip_batch_set_device_block(self.handle, y_time_major.data_ptr(), self.ld, lengths.data_ptr(), C.byref(err)):
+            raise RuntimeError(f"set_device_block failed: [{err.code}] {err.message.decode()}")
+
+    def run(self, stream: torch.cuda.Stream | None = None):
+        st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        err = _lib.AnofoxError()
+        if not self.L.anofox_hip_batch_run(self.handle, C.c_void_p(st.cuda_stream), C.byref(err)):
+            raise RuntimeError(f"anofox_hip_batch_run failed: [{err.code}] {err.message.decode()}")
+
+    def stats(self) -> dict:
+        s = _lib.AnofoxHipStats()
+        if not self.L.anofox_hip_batch_stats(self.handle, C.byref(s)):
+            raise RuntimeError("anofox_hip_batch_stats failed")
+        return {f: getattr(s, f) for f, _ in s._fields_}
+
+    def results(self) -> dict:
+        """Zero-copy torch views of the device result arrays."""
+        ptrs = [C.c_void_p() for _ in range(5)]
+        self.L.anofox_hip_batch_device_results(self.handle, *[C.byref(p) for p in ptrs])
+
+        def view(ptr, shape, dtype, itemsize):
+            n = int(np.prod(shape))
+            if n == 0:
+                return torch.empty(shape, dtype=dtype, device=self.device)
+            iface = {"shape": tuple(shape), "typestr": {8: "<f8", 4: "<i4"}[itemsize], "data": (ptr.value, False), "version": 2}
+            holder = type("H", (), {"__cuda_array_interface__": iface})()
+            return torch.as_tensor(holder, device=self.device)
+
+        return {
+            "yhat": view(ptrs[0], (self.n, self.h), torch.float64, 8),
+            "lower": view(ptrs[1], (self.n, self.h), torch.float64, 8),
+            "upper": view(ptrs[2], (self.n, self.h), torch.float64, 8),
+            "model_code": view(ptrs[3], (self.n,), torch.int32, 4),
+            "status": view(ptrs[4], (self.n,), torch.int32, 4),
+        }
+
+    def model_name(self, code: int) -> str:
+        buf = (C.c_char * 64)()
+        self.L.anofox_hip_model_name(C.byref(self.opts), int(code), buf)
+        return buf.value.decode()
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.L.anofox_hip_batch_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,163 @@
+"""GPU parity: the HIP path (through the C-ABI) against the CPU oracle on identical inputs.
+
+Tolerance: the north star allows 1e-5 relative (fp64); oracle and kernels are written as the same
+sequence of IEEE operations (fma only where stated, -ffp-contract=off), so we assert 1e-12 relative
+and report the worst case.  Model names, error codes and selected specs must match exactly.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-12
+
+
+def _rel(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    if a.shape != b.shape:
+        return np.inf
+    both_nan = np.isnan(a) & np.isnan(b)
+    d = np.abs(a - b) / np.maximum(1.0, np.abs(b))
+    d[both_nan] = 0.0
+    return float(np.max(d)) if d.size else 0.0
+
+
+def _compare(api, O, lib, series, model, h, valids=None, **kw):
+    opts = lib.make_options(model, h, **kw)
+    oo = O.make_options(model, h, **kw)
+    got, berr = api.forecast_batch(series, opts, valids)
+    worst = 0.0
+    for s, y in enumerate(series):
+        ref = O.forecast(y, oo, None if valids is None else valids[s])
+        if not ref["ok"] and ref["code"] in (2, 5):       # statement-level errors abort the batch
+            assert not berr["ok"] and berr["code"] == ref["code"], (model, berr, ref)
+            assert berr["message"] == ref["message"]
+            return 0.0
+        assert berr["ok"], (model, berr)
+        assert got[s]["ok"] == ref["ok"], (model, s, got[s], ref)
+        if not ref["ok"]:
+            assert got[s]["code"] == ref["code"], (model, s, got[s], ref)
+            continue
+        assert got[s]["model_name"] == ref["model_name"], (model, s, got[s]["model_name"], ref["model_name"])
+        for k in ("point", "lower", "upper"):
+            worst = max(worst, _rel(got[s][k], ref[k]))
+    assert worst <= REL_TOL, (model, kw, worst)
+    return worst
+
+
+@pytest.fixture(scope="module")
+def env(hiplib, oracle):
+    import torch
+    assert torch.cuda.is_available()
+    from anofox_forecast_amd import api, synth
+    return api, oracle, hiplib, synth
+
+
+KAT_SERIES = [10, 12, 14, 11, 13, 15, 12, 14, 16, 13, 15, 17, 14, 16, 18, 15, 17, 19, 16, 18, 20, 17, 19, 21]
+KATS = {"SES": 18.943503, "SESOptimized": 19.537535, "SeasonalES": 14.451866, "Holt": 20.330877,
+        "HoltWinters": 19.953912, "Naive": 21.0, "SMA": 19.0, "RandomWalkDrift": 21.478261}
+
+
+def test_reference_kats_through_c_abi(env):
+    """test/sql/ts_model_distinctness.test:116,141,180 via anofox_ts_forecast on the GPU."""
+    api, O, lib, _ = env
+    for model, kat in KATS.items():
+        o = lib.make_options(model, 3, confidence_level=0.95, auto_detect=False, include_fitted=True, include_residuals=True)
+        r = api.forecast_series(KAT_SERIES, o)
+        assert r["ok"], (model, r)
+        assert round(float(r["point"][0]), 6) == kat, (model, r["point"][0], kat)
+    o = lib.make_options("AutoETS", 3, confidence_level=0.95, auto_detect=False)
+    r = api.forecast_series(KAT_SERIES, o)
+    assert r["ok"] and abs(r["point"][0] - 19.956521) / 19.956521 < 1e-5      # :164, north-star tolerance
+    assert r["model_name"].startswith("AutoETS")
+
+
+@pytest.mark.parametrize("model", ["Naive", "SeasonalNaive", "SMA", "RandomWalkDrift", "ARIMA", "SES", "SESOptimized", "Holt",
+                                   "HoltWinters", "SeasonalES", "SeasonalESOptimized", "ETS", "AutoETS"])
+def test_models_match_oracle(env, model):
+    api, O, lib, synth = env
+    Y = synth.gen_series(synth.SEED_M5, 0, 70, 120, 7)
+    kw = {} if model in ("Naive", "SES", "SESOptimized", "Holt", "RandomWalkDrift", "ARIMA") else {"seasonal_period": 7}
+    _compare(api, O, lib, list(Y), model, 14, **kw)
+
+
+@pytest.mark.parametrize("spec", ["ANN", "AAN", "AAdN", "ANA", "AAA", "AAdA", "MNN", "MAN", "MAdN", "MMN", "MMdN", "AMN", "AMdN",
+                                  "ANM", "AAM", "AAdM", "AMA", "AMdA", "AMM", "AMdM", "MNM", "MAM", "MAdM", "MMM", "MMdM"])
+@pytest.mark.parametrize("period", [7, 5])
+def test_ets_specs_match_oracle(env, spec, period):
+    """Every valid spec, VGPR-ring period (7) and LDS-ring period (5), on strictly positive data."""
+    api, O, lib, synth = env
+    Y = synth.gen_series(synth.SEED_M5, 1000, 66, 90, period, positive=True)
+    _compare(api, O, lib, list(Y), "ETS", 10, ets_model=spec, seasonal_period=period)
+
+
+def test_autoets_full_grid_positive(env):
+    api, O, lib, synth = env
+    Y = synth.gen_series(synth.SEED_M5, 2000, 64, 100, 7, positive=True)
+    _compare(api, O, lib, list(Y), "AutoETS", 28, seasonal_period=7)
+
+
+def test_autoets_ragged_nulls_short_constant(env):
+    """Ragged lengths, NULL runs (interpolated), too-short series, constant series (fallback chain)."""
+    api, O, lib, synth = env
+    rng = np.random.default_rng(7)
+    Y = synth.gen_series(synth.SEED_M5, 3000, 40, 150, 7)
+    series, valids = [], []
+    for s in range(40):
+        n = int(rng.integers(3, 150))
+        y = Y[s, :n].copy()
+        v = np.ones(n, bool)
+        if s % 3 == 0:
+            v[rng.integers(0, n, size=max(1, n // 10))] = False
+        series.append(y)
+        valids.append(v)
+    series += [np.full(30, 42.0), np.array([1.0, 2.0]), np.array([]), np.full(8, 3.0), np.arange(9, dtype=float)]
+    valids += [np.ones(len(x), bool) for x in series[40:]]
+    _compare(api, O, lib, series, "AutoETS", 7, valids, seasonal_period=7)
+    _compare(api, O, lib, series, "AutoETS", 7, valids)                       # auto-detected periods
+    _compare(api, O, lib, series, "ETS", 7, valids, seasonal_period=7)        # default chain
+
+
+def test_statement_level_errors(env):
+    api, O, lib, _ = env
+    y = [list(np.arange(20.0) + 1)]
+    _compare(api, O, lib, y, "ETS", 3, ets_model="MAA", seasonal_period=7)
+    _compare(api, O, lib, y, "ETS", 3, ets_model="XYZ")
+    _compare(api, O, lib, y, "Naive", 3, seasonal_period=7)
+    _compare(api, O, lib, y, "AutoETS", 3, model_pool="bogus")
+    _compare(api, O, lib, y, "NoSuchModel", 3)
+
+
+def test_error_isolation(env):
+    """A bad series yields an error, neighbours still forecast (ts_forecast_error_isolation.test:14-60)."""
+    api, O, lib, _ = env
+    series = [np.arange(30.0), np.array([1.0, 2.0]), np.arange(40.0) * 2]
+    got, berr = api.forecast_batch(series, lib.make_options("Holt", 5))
+    assert berr["ok"] and got[0]["ok"] and got[2]["ok"] and not got[1]["ok"] and got[1]["code"] == 6
+
+
+def test_ts_forecast_by_operator(env):
+    api, O, lib, synth = env
+    Y = synth.gen_series(synth.SEED_M5, 0, 5, 60, 7)
+    grp = np.repeat(np.array(["a", "b", "c", "d", "e"], dtype=object), 60)
+    ds = np.tile(np.arange("2024-01-01", "2024-03-01", dtype="datetime64[D]"), 5)
+    perm = np.random.default_rng(1).permutation(len(grp))       # the operator sorts by date itself
+    out = api.ts_forecast_by(grp[perm], ds[perm], Y.reshape(-1)[perm], "AutoETS", 14, "1d", {"seasonal_period": "7"})
+    assert len(out["yhat"]) == 5 * 14
+    assert list(out["forecast_step"][:14]) == list(range(1, 15))
+    assert out["ds"][0] == np.datetime64("2024-03-01") and out["ds"][13] == np.datetime64("2024-03-14")
+    assert np.all(out["yhat_lower"] <= out["yhat"]) and np.all(out["yhat"] <= out["yhat_upper"])
+    oo = O.make_options("AutoETS", 14, seasonal_period=7)
+    first = {}
+    for g in grp[perm]:
+        first.setdefault(g, len(first))
+    for g, k in first.items():
+        ref = O.forecast(Y["abcde".index(g)], oo)
+        np.testing.assert_allclose(out["yhat"][k * 14:(k + 1) * 14], ref["point"], rtol=REL_TOL)
+        assert out["model_name"][k * 14] == ref["model_name"]
+    with pytest.raises(api.InvalidInputException, match="only valid when method='ETS'"):
+        api.ts_forecast_by(grp, ds, Y.reshape(-1), "Naive", 3, "1d", {"model": "AAA"})
+    with pytest.raises(api.InvalidInputException, match="Unknown parameter"):
+        api.ts_forecast_by(grp, ds, Y.reshape(-1), "ETS", 3, "1d", {"methd": "AAA"})
+    with pytest.raises(api.InvalidInputException, match="does not use seasonal_period"):
+        api.ts_forecast_by(grp, ds, Y.reshape(-1), "Naive", 3, "1d", {"seasonal_period": "7"})
