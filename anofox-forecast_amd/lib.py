@@ -91,6 +91,12 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing: build it with `make -C anofox-forecast_amd/csrc` "
                            "(or __graft_entry__.build()); the backend has no CPU fallback")
+    try:
+        # PyTorch-ROCm bundles its own HIP runtime; load it first so that this library binds to the
+        # same one (two HIP runtimes in one process do not share devices, streams or allocations).
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     P = C.POINTER
     L.anofox_ts_forecast.restype = C.c_bool

@@ -768,6 +768,20 @@ void oracle_free_forecast_result(ForecastResult *r)
     free(r->residuals); r->residuals = NULL;
 }
 
+/* test hook: fit one spec id, report optimiser effort and criteria */
+int oracle_ets_fit_spec(const double *y, int n, int spec_id, int m, int *iters, int *evals, double *aicc, double *par)
+{
+    EtsSpec sp = spec_from_id(spec_id, m);
+    EtsFit fit;
+    double sfin[ETS_MAX_PERIOD];
+    int st = ets_fit(&sp, y, n, &fit, sfin);
+    if (iters) *iters = fit.iters;
+    if (evals) *evals = fit.evals;
+    if (aicc) *aicc = fit.aicc;
+    if (par) for (int i = 0; i < ETS_MAX_DIM; i++) par[i] = fit.par[i];
+    return st;
+}
+
 /* test hooks */
 double oracle_det_log(double x) { return det_log(x); }
 double oracle_det_exp(double x) { return det_exp(x); }

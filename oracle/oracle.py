@@ -130,7 +130,8 @@ def forecast(values, opts, valid=None):
     C.memset(C.byref(res), 0, C.sizeof(res))
     err = AnofoxError()
     mask = validity_mask(valid) if valid is not None else None
-    ok = lib().oracle_ts_forecast(y.ctypes.data if len(y) else None, mask.ctypes.data if mask is not None else None,
+    dummy = np.zeros(1)
+    ok = lib().oracle_ts_forecast(y.ctypes.data if len(y) else dummy.ctypes.data, mask.ctypes.data if mask is not None else None,
                                   len(y), C.byref(opts), C.byref(res), C.byref(err))
     out = {"ok": bool(ok), "code": int(err.code), "message": err.message.decode(errors="replace")}
     if ok:

@@ -1,0 +1,93 @@
+"""Writes tests/golden/reference_kats.json: the known-answer vectors that the reference's OWN tests
+hold for the forecast path, transcribed as data (inputs + expected outputs, each with its source
+file:line).  Nothing here is computed: the reference cannot be built or imported in this image
+(no cargo/rustc, no DuckDB), so these literals are the only pins that exist.
+Run:  python tests/golden/make_golden.py
+"""
+import json
+import math
+import os
+
+DISTINCT = [10, 12, 14, 11, 13, 15, 12, 14, 16, 13, 15, 17, 14, 16, 18, 15, 17, 19, 16, 18, 20, 17, 19, 21]
+ONE_TO_TEN = [float(i) for i in range(1, 11)]
+
+
+def seasonal_data():
+    # crates/anofox-fcst-ffi/tests/core_ffi_parity.rs:55-65
+    out = []
+    for i in range(60):
+        trend = 10.0 + 0.15 * i
+        season = 5.0 * math.sin(2.0 * math.pi * i / 12.0)
+        noise = ((i * 7 + 3) % 11) * 0.1 - 0.5
+        out.append(trend + season + noise)
+    return out
+
+
+def toy_arima_expected(data, h):
+    # the closed form the reference test itself evaluates: core_ffi_parity.rs:680-704
+    diff = [b - a for a, b in zip(data[:-1], data[1:])]
+    mean_diff = sum(diff) / len(diff)
+    prev, cum, out = diff[-1], data[-1], []
+    for _ in range(h):
+        nd = mean_diff + 0.5 * (prev - mean_diff)
+        cum += nd
+        out.append(cum)
+        prev = nd
+    return out
+
+
+# options of _ts_forecast(values, horizon, model): src/table_functions/ts_forecast.cpp:406-411
+SCALAR_OPTS = {"confidence_level": 0.95, "seasonal_period": 0, "auto_detect": False, "include_fitted": True, "include_residuals": True}
+
+cases = []
+for model, kat, line in [("SES", 18.943503, 116), ("SESOptimized", 19.537535, 116), ("SeasonalES", 14.451866, 116),
+                         ("SeasonalESOptimized", 18.803254, 116), ("Holt", 20.330877, 141), ("HoltWinters", 19.953912, 141),
+                         ("AutoETS", 19.956521, 164), ("AutoARIMA", 18.014537, 164), ("Naive", 21.0, 180), ("SMA", 19.0, 180),
+                         ("RandomWalkDrift", 21.478261, 180)]:
+    cases.append({"source": f"test/sql/ts_model_distinctness.test:{line}", "model": model, "values": DISTINCT, "horizon": 3,
+                  "options": SCALAR_OPTS, "check": "round6_first", "expected": kat})
+cases += [
+    {"source": "test/sql/ts_forecast_basic_models.test:128-156", "model": "SeasonalNaive", "values": [1, 2, 3, 4] * 3, "horizon": 4,
+     "options": SCALAR_OPTS, "check": "abs_all", "tol": 0.01, "expected": [4.0, 4.0, 4.0, 4.0]},
+    {"source": "test/sql/ts_forecast_basic_models.test:317-346", "model": "RandomWalkDrift", "values": ONE_TO_TEN, "horizon": 3,
+     "options": SCALAR_OPTS, "check": "abs_all", "tol": 0.1, "expected": [11.0, 12.0, 13.0]},
+    {"source": "test/sql/ts_forecast_basic_models.test:84", "model": "SMA", "values": ONE_TO_TEN, "horizon": 3,
+     "options": SCALAR_OPTS, "check": "abs_all", "tol": 0.1, "expected": [9.0, 9.0, 9.0]},
+    {"source": "test/sql/ts_forecast.test:76-86", "model": "NAIVE", "values": [1, 2, 3, 4, 5], "horizon": 3,
+     "options": SCALAR_OPTS, "check": "abs_all", "tol": 0.01, "expected": [5.0, 5.0, 5.0]},
+    {"source": "test/sql/ts_forecast_auto.test:98", "model": "AutoETS", "values": [42.0] * 30, "horizon": 5,
+     "options": SCALAR_OPTS, "check": "abs_all", "tol": 1.0, "expected": [42.0] * 5},
+    {"source": "crates/anofox-fcst-ffi/tests/core_ffi_parity.rs:680-704", "model": "ARIMA", "values": seasonal_data(), "horizon": 5,
+     "options": {"confidence_level": 0.95, "seasonal_period": 0, "auto_detect": False}, "check": "bits_all",
+     "expected": toy_arima_expected(seasonal_data(), 5)},
+]
+
+errors = [
+    # (source, model, options, expected code, message substring) -- test/sql/ts_native_param_validation.test:126-198
+    {"source": "ts_native_param_validation.test:126-139", "model": "ETS", "options": {"ets_model": "XYZ"}, "code": 2, "substr": "Invalid ETS model specification"},
+    {"source": "ts_native_param_validation.test:133-139", "model": "ETS", "options": {"ets_model": "AAAAA"}, "code": 2, "substr": "Invalid ETS model specification"},
+    {"source": "ts_native_param_validation.test:142-149", "model": "ETS", "options": {"ets_model": "MAA"}, "code": 2, "substr": "unstable"},
+    {"source": "ts_native_param_validation.test:150-155", "model": "ETS", "options": {"ets_model": "MAdA"}, "code": 2, "substr": "unstable"},
+    {"source": "ts_native_param_validation.test:176-184", "model": "Naive", "options": {"seasonal_period": 7, "auto_detect": False}, "code": 2, "substr": "does not use seasonal_period"},
+    {"source": "ts_native_param_validation.test:185-191", "model": "SES", "options": {"seasonal_period": 7, "auto_detect": False}, "code": 2, "substr": "does not use seasonal_period"},
+    {"source": "crates/anofox-fcst-core/src/forecast.rs:253-255", "model": "NoSuchModel", "options": {}, "code": 5, "substr": "Unknown model"},
+    {"source": "crates/anofox-fcst-core/src/forecast.rs:3313-3342", "model": "ETS", "options": {"ets_model": "AAA", "seasonal_period": 12, "auto_detect": False},
+     "values": [100.0, 101.0, 102.0, 103.0, 104.0], "code": 3, "substr": "failed to fit"},
+    {"source": "crates/anofox-fcst-core/src/forecast.rs:516-525", "model": "Naive", "options": {}, "values": [1.0, 2.0], "code": 6, "substr": "Insufficient data"},
+]
+
+interp = [
+    {"source": "crates/anofox-fcst-core/src/imputation.rs:157-166", "values": [1.0, 0.0, 0.0, 4.0], "valid": [1, 0, 0, 1], "expected": [1.0, 2.0, 3.0, 4.0]},
+]
+
+names = {
+    # forecast.rs:2855-2961: every non-auto model returns exactly its enum name; auto models a prefix
+    "exact": ["Naive", "SMA", "SeasonalNaive", "SES", "SESOptimized", "RandomWalkDrift", "Holt", "HoltWinters", "SeasonalES",
+              "SeasonalESOptimized", "ETS", "ARIMA"],
+    "prefix": ["AutoETS"],
+}
+
+here = os.path.dirname(os.path.abspath(__file__))
+with open(os.path.join(here, "reference_kats.json"), "w") as f:
+    json.dump({"cases": cases, "errors": errors, "interpolation": interp, "names": names}, f, indent=1)
+print("wrote", len(cases), "cases,", len(errors), "error cases")

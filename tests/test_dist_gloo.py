@@ -1,0 +1,46 @@
+"""CPU: the multi-GPU path (series-range sharding + the gather of forecast chunks) with world_size 2
+over gloo -- the same code bench.py runs over RCCL."""
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _worker(rank, world, port, n_total, h, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from anofox_forecast_amd.dist import gather_forecasts, shard_range
+    lo, hi = shard_range(n_total, rank, world)
+    ids = torch.arange(lo, hi, dtype=torch.float64)
+    local = {"yhat": ids[:, None] * 10 + torch.arange(h, dtype=torch.float64)[None, :],
+             "lower": ids[:, None] - 1 + torch.zeros(h, dtype=torch.float64)[None, :],
+             "upper": ids[:, None] + 1 + torch.zeros(h, dtype=torch.float64)[None, :],
+             "model_code": (100 + ids % 30).to(torch.int32), "status": torch.zeros(hi - lo, dtype=torch.int32)}
+    out = gather_forecasts(local, n_total, rank, world)
+    if rank == 0:
+        ret["yhat"] = out["yhat"].numpy()
+        ret["code"] = out["model_code"].numpy()
+    else:
+        assert out is None
+    dist.destroy_process_group()
+
+
+def test_shard_ranges_cover_everything():
+    from anofox_forecast_amd.dist import shard_range
+    for n, g in [(30490, 8), (30490, 1), (7, 4), (1000000, 8), (3, 8)]:
+        r = [shard_range(n, k, g) for k in range(g)]
+        assert r[0][0] == 0 and r[-1][1] == n and all(a[1] == b[0] for a, b in zip(r, r[1:]))
+        assert max(hi - lo for lo, hi in r) == -(-n // g)
+
+
+def test_gather_world2_gloo():
+    n_total, h, world = 37, 5, 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, 29517 + os.getpid() % 500, n_total, h, ret), nprocs=world, join=True)
+    ids = np.arange(n_total, dtype=np.float64)
+    np.testing.assert_array_equal(ret["yhat"], ids[:, None] * 10 + np.arange(h)[None, :])
+    np.testing.assert_array_equal(ret["code"], (100 + ids % 30).astype(np.int32))

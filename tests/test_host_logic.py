@@ -1,0 +1,76 @@
+"""CPU: host logic of the operator mirror (frequency strings, forecast timestamps, bind validation,
+validity masks) against the reference's binding behaviour."""
+import numpy as np
+import pytest
+
+from anofox_forecast_amd import api
+
+
+def test_parse_frequency():
+    # src/table_functions/ts_fill_gaps_native.cpp:21-90
+    P = api.parse_frequency
+    assert (P("1d").seconds, P("1d").type) == (86400, "FIXED")
+    assert P("2h").seconds == 7200 and P("30m").seconds == 1800 and P("15min").seconds == 900 and P("1w").seconds == 604800
+    assert (P("1mo").seconds, P("1mo").type) == (1, "MONTHLY") and P("2q").type == "QUARTERLY" and P("1y").type == "YEARLY"
+    assert P("1 day").seconds == 86400 and P("3 hours").seconds == 10800 and P("1 month").type == "MONTHLY"
+    assert P("1 QUARTER").type == "QUARTERLY" and P("2 years").seconds == 2
+    r = P(1)                       # integer literal (ts_integer_frequency.test:137)
+    assert r.seconds == 1 and r.is_raw
+    with pytest.raises(api.InvalidInputException, match="Invalid frequency"):
+        P("fortnightly")
+
+
+def test_forecast_dates():
+    us = api._US_PER_DAY
+    d = lambda s: int(np.datetime64(s, "D").astype(np.int64)) * us
+    f = api.parse_frequency
+    assert api.compute_forecast_date(d("2024-01-31"), 1, f("1mo"), "DATE") == d("2024-02-29")      # day clamp, leap year
+    assert api.compute_forecast_date(d("2023-01-31"), 1, f("1mo"), "DATE") == d("2023-02-28")
+    assert api.compute_forecast_date(d("2024-11-15"), 3, f("1mo"), "DATE") == d("2025-02-15")      # year rollover
+    assert api.compute_forecast_date(d("2024-01-31"), 1, f("1q"), "DATE") == d("2024-04-30")
+    assert api.compute_forecast_date(d("2024-02-29"), 1, f("1y"), "DATE") == d("2025-02-28")
+    assert api.compute_forecast_date(d("2024-01-01"), 2, f("1d"), "TIMESTAMP") == d("2024-01-03")
+    assert api.compute_forecast_date(d("2024-01-01"), 1, f("1"), "DATE") == d("2024-01-02")         # raw integer on a date column = days
+    assert api.compute_forecast_date(100, 3, f("5"), "BIGINT") == 115                                # integer columns: raw units
+    assert api.compute_forecast_date(100, 2, f("1d"), "INTEGER") == 100 + 2 * 86400
+
+
+def test_bind_validation_messages():
+    # src/table_functions/ts_forecast_native.cpp:357-399 and test/sql/ts_native_param_validation.test
+    B = api.bind
+    with pytest.raises(api.InvalidInputException, match="Unknown parameter"):
+        B("ETS", 3, "1d", {"methd": "AAA"})
+    for bad in ("1.5", "0", "-0.1", "1.0"):
+        with pytest.raises(api.InvalidInputException, match="Invalid confidence_level"):
+            B("AutoETS", 3, "1d", {"confidence_level": bad})
+    with pytest.raises(api.InvalidInputException, match="only valid when method='ETS'"):
+        B("Naive", 3, "1d", {"model": "AAA"})
+    with pytest.raises(api.InvalidInputException, match="only valid when method='SMA'"):
+        B("Naive", 3, "1d", {"window": "5"})
+    with pytest.raises(api.InvalidInputException, match="positive integer"):
+        B("SMA", 3, "1d", {"window": "-2"})
+    with pytest.raises(api.InvalidInputException, match="only valid for multi-seasonal"):
+        B("AutoETS", 3, "1d", {"seasonal_periods": "[7, 365]"})
+    b = B("AutoETS", 28, "1d", {"seasonal_period": "7"})
+    assert b.seasonal_period == 7 and b.confidence_level == 0.90 and b.horizon == 28
+    o = api.options_from_bind(b)
+    assert o.model == b"AutoETS" and o.seasonal_period == 7 and not o.auto_detect_seasonality and o.confidence_level == 0.90
+    o = api.options_from_bind(B("AutoETS", 3, "1d", None))
+    assert o.auto_detect_seasonality and o.seasonal_period == 0           # ts_forecast_scalar.cpp:450
+    b = B("ETS", 3, "1d", {"model": "AAdA", "seasonal_period": 12, "confidence_level": 0.95})   # typed STRUCT values
+    assert b.model_spec == "AAdA" and b.seasonal_period == 12 and b.confidence_level == 0.95
+
+
+def test_validity_mask_bits():
+    v = np.zeros(130, bool)
+    v[[0, 63, 64, 129]] = True
+    w = api.validity_mask(v)
+    assert len(w) == 3 and int(w[0]) == (1 | (1 << 63)) and int(w[1]) == 1 and int(w[2]) == 2
+
+
+def test_synthetic_generator_is_shard_consistent():
+    from anofox_forecast_amd import synth
+    a = synth.gen_series(synth.SEED_M5, 0, 2100, 64)
+    b = synth.gen_series(synth.SEED_M5, 1000, 1100, 64)
+    assert np.array_equal(a[1000:], b) and 0.3 < (a == 0).mean() < 0.8
+    assert synth.gen_series(synth.SEED_M5, 5, 3, 64, positive=True).min() >= 1.0

@@ -1,0 +1,120 @@
+"""CPU: the oracle (oracle/*.c) against every known-answer vector the reference's own tests hold for
+the forecast path (tests/golden/reference_kats.json, transcribed by tests/golden/make_golden.py).
+
+Status of the pin (stated in DESIGN.md section 3 as well):
+  * exact to the 6 decimals the reference prints: SES, SESOptimized, SeasonalES, Holt, HoltWinters,
+    Naive, SMA, RandomWalkDrift, SeasonalNaive, toy ARIMA (bit-exact closed form);
+  * within the north star's 1e-5 relative tolerance: AutoETS (3.7e-8), SeasonalESOptimized (7.9e-6);
+  * AutoARIMA: not yet restated (marked xfail).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = json.load(open(os.path.join(HERE, "golden", "reference_kats.json")))
+
+REL_ONLY = {"AutoETS", "SeasonalESOptimized"}      # reproduced within 1e-5 relative, not to 6 decimals
+NOT_RESTATED = {"AutoARIMA"}
+
+
+def _opts(O, model, horizon, o):
+    return O.make_options(model, horizon, ets_model=o.get("ets_model", ""), seasonal_period=o.get("seasonal_period", 0),
+                          confidence_level=o.get("confidence_level", 0.90), auto_detect=o.get("auto_detect"),
+                          include_fitted=o.get("include_fitted", False), include_residuals=o.get("include_residuals", False))
+
+
+@pytest.mark.parametrize("case", GOLD["cases"], ids=[f'{c["model"]}@{c["source"].split("/")[-1]}' for c in GOLD["cases"]])
+def test_known_answers(oracle, case):
+    if case["model"] in NOT_RESTATED:
+        pytest.xfail("AutoARIMA arithmetic is not restated yet")
+    r = oracle.forecast(case["values"], _opts(oracle, case["model"], case["horizon"], case["options"]))
+    assert r["ok"], r
+    if case["check"] == "round6_first":
+        got, exp = float(r["point"][0]), case["expected"]
+        if case["model"] in REL_ONLY:
+            assert abs(got - exp) / abs(exp) < 1e-5, (got, exp)
+        else:
+            assert round(got, 6) == exp, (got, exp)
+    elif case["check"] == "abs_all":
+        assert np.all(np.abs(r["point"] - np.array(case["expected"])) < case["tol"])
+    elif case["check"] == "bits_all":
+        assert list(r["point"]) == case["expected"]
+
+
+@pytest.mark.parametrize("case", GOLD["errors"], ids=[f'{c["model"]}-{c["substr"][:12]}' for c in GOLD["errors"]])
+def test_error_table(oracle, case):
+    values = case.get("values", list(np.arange(1.0, 31.0)))
+    r = oracle.forecast(values, _opts(oracle, case["model"], 3, case["options"]))
+    assert not r["ok"] and r["code"] == case["code"], r
+    assert case["substr"] in r["message"], r
+
+
+def test_interpolation(oracle):
+    for c in GOLD["interpolation"]:
+        v = np.array(c["values"], dtype=np.float64)
+        out = np.empty_like(v)
+        oracle.lib().oracle_fill_nulls_interpolate(v.ctypes.data, oracle.validity_mask(c["valid"]).ctypes.data, len(v), out.ctypes.data)
+        np.testing.assert_allclose(out, c["expected"], atol=1e-3)
+    # edge extension + interior runs (imputation.rs:72-111)
+    v = np.array([0, 0, 2.0, 0, 0, 8.0, 0], dtype=np.float64)
+    out = np.empty_like(v)
+    oracle.lib().oracle_fill_nulls_interpolate(v.ctypes.data, oracle.validity_mask([0, 0, 1, 0, 0, 1, 0]).ctypes.data, 7, out.ctypes.data)
+    assert list(out) == [2.0, 2.0, 2.0, 4.0, 6.0, 8.0, 8.0]
+    # all NULL -> NaN vector -> flows on
+    oracle.lib().oracle_fill_nulls_interpolate(v.ctypes.data, oracle.validity_mask([0] * 7).ctypes.data, 7, out.ctypes.data)
+    assert np.all(np.isnan(out))
+
+
+def test_model_names(oracle):
+    rng = np.random.default_rng(0)
+    y = 50 + np.arange(48) * 0.5 + 10 * np.sin(2 * np.pi * np.arange(48) / 12) + rng.normal(0, 0.5, 48)
+    for m in GOLD["names"]["exact"]:
+        kw = {} if m in ("Naive", "SES", "SESOptimized", "Holt", "RandomWalkDrift", "ARIMA") else {"seasonal_period": 12}
+        r = oracle.forecast(y, oracle.make_options(m, 3, **kw))
+        assert r["ok"] and r["model_name"] == m, (m, r)
+    for m in GOLD["names"]["prefix"]:
+        r = oracle.forecast(y, oracle.make_options(m, 3, seasonal_period=12))
+        assert r["ok"] and r["model_name"].startswith(m) and "(" in r["model_name"], r
+    r = oracle.forecast(y, oracle.make_options("ETS", 3, ets_model="AAdA", seasonal_period=12))
+    assert r["model_name"] == "ETS(AAdA)"
+    r = oracle.forecast(np.full(30, 42.0), oracle.make_options("AutoETS", 5))
+    assert r["model_name"] == "AutoETS"                  # fallback chain keeps the bare name (forecast.rs:1636-1638)
+
+
+def test_aliases_and_intervals(oracle):
+    y = list(np.arange(1.0, 21.0))
+    for alias, name in [("naive", "Naive"), ("snaive", "SeasonalNaive"), ("hw", "HoltWinters"), ("auto", "AutoETS"), ("drift", "RandomWalkDrift"),
+                        ("RandomWalkWithDrift", "RandomWalkDrift")]:
+        r = oracle.forecast(y, oracle.make_options(alias, 2, seasonal_period=4 if alias in ("snaive", "hw") else 0))
+        assert r["ok"] and r["model_name"].startswith(name), (alias, r)
+    sd = np.std(y)
+    for conf, z in [(0.99, 2.576), (0.95, 1.96), (0.90, 1.645), (0.85, 1.28), (0.5, 1.0)]:
+        r = oracle.forecast(y, oracle.make_options("Naive", 3, confidence_level=conf))
+        np.testing.assert_allclose(r["upper"] - r["point"], z * sd * np.sqrt([1, 2, 3]), rtol=1e-13)
+        np.testing.assert_allclose(r["point"] - r["lower"], z * sd * np.sqrt([1, 2, 3]), rtol=1e-13)
+        assert np.isnan(r["aic"]) and np.isnan(r["bic"]) and np.isnan(r["mse"])
+    r = oracle.forecast(y, oracle.make_options("Naive", 3, include_fitted=True, include_residuals=True))
+    assert list(r["fitted"]) == [1.0] + y[:-1] and r["n_fitted"] == 20 and abs(r["mse"] - 19 / 20) < 1e-12
+
+
+def test_det_math_accuracy(oracle):
+    L = oracle.lib()
+    xs = np.concatenate([np.logspace(-300, 300, 2001), np.linspace(0.5, 2.0, 1001), [1.0, 5e-324, 1e-310]])
+    for x in xs:
+        a, b = L.oracle_det_log(float(x)), np.log(x)
+        assert abs(a - b) <= 2 * np.spacing(abs(b)) + 1e-300, (x, a, b)
+    for x in np.linspace(-700, 700, 4001):
+        a, b = L.oracle_det_exp(float(x)), np.exp(x)
+        assert abs(a - b) <= 2 * np.spacing(b), (x, a, b)
+    assert L.oracle_det_log(0.0) == -np.inf and np.isnan(L.oracle_det_log(-1.0)) and L.oracle_det_exp(-1000.0) == 0.0
+
+
+def test_detect_seasonality(oracle):
+    t = np.arange(120)
+    y = np.sin(2 * np.pi * t / 12) + 0.01 * np.cos(t)
+    assert oracle.lib().oracle_detect_seasonality_first(np.ascontiguousarray(y).ctypes.data, len(y)) == 12
+    assert oracle.lib().oracle_detect_seasonality_first(np.ones(50).ctypes.data, 50) == 0
+    assert oracle.lib().oracle_detect_seasonality_first(np.ones(3).ctypes.data, 3) == 0
