@@ -323,8 +323,11 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
     if constexpr (FINAL) { if (fin->sse_out && v.len > 0) *fin->sse_out = st[0].sse; }
 }
 
-// Nelder-Mead model adaptor
-template <class Cfg, int MS>
+// Nelder-Mead model adaptor.  CPL = candidates per lane: 4 -> one lane evaluates all four trial points
+// of its problem (throughput form, one y load feeds four recursions); 1 -> the four trial points of a
+// problem sit in four adjacent lanes (latency form: a quarter of the per-pass latency and VGPRs, four
+// times the waves), results exchanged with wave shuffles.  Both give bit-identical objective values.
+template <class Cfg, int MS, int CPL>
 struct EtsModel {
     static constexpr int DIM = Cfg::DIM;
     SeriesView v;
@@ -340,7 +343,19 @@ struct EtsModel {
     }
     __device__ void eval(const double (&cand)[NM_K][DIM], double (&f)[NM_K]) const
     {
-        ets_pass<Cfg, MS, NM_K, false>(v, in, cand, f, ring, nullptr);
+        if constexpr (CPL == NM_K) {
+            ets_pass<Cfg, MS, NM_K, false>(v, in, cand, f, ring, nullptr);
+        } else {
+            const int sub = threadIdx.x & 3;
+            double mine[1][DIM], f1[1];
+#pragma unroll
+            for (int i = 0; i < DIM; i++)
+                mine[0][i] = sub == 0 ? cand[0][i] : (sub == 1 ? cand[1][i] : (sub == 2 ? cand[2][i] : cand[3][i]));
+            ets_pass<Cfg, MS, 1, false>(v, in, mine, f1, ring, nullptr);
+            const int base = threadIdx.x & ~3;
+#pragma unroll
+            for (int k = 0; k < NM_K; k++) f[k] = __shfl(f1[0], base + k);
+        }
     }
 };
 

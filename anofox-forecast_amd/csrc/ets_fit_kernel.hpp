@@ -1,106 +1,178 @@
-// ets_fit_kernel.hpp -- fit one ETS spec for every series of the batch.
+// ets_fit_kernel.hpp -- fit one ETS spec for every series of the batch, in resumable rounds.
 //
-// grid = ceil(n_series / 64) one-wave workgroups; lane <-> series.  Each lane runs its own
-// Nelder-Mead (nm.hpp) over the smoothing parameters; every objective evaluation is a
-// streamed pass over the lane's column of the time-major block (ets_device.hpp).  After
-// convergence one more pass with the optimum produces the final states, the h forecasts and
-// the information criteria.  Dominant cost: passes x 8 T bytes per series -> HBM/L2 stream +
-// fp64 VALU recursion; no MFMA (scan, not a contraction).
+// round kernel : grid = ceil(n_active / 64) one-wave workgroups; lane <-> one still-running
+//                (series, spec) problem.  Each lane advances its own Nelder-Mead (nm.hpp) by at most
+//                `budget` streamed passes over its column of the time-major block (ets_device.hpp),
+//                then parks the simplex in HBM.  Between rounds the host enqueues a stable compaction
+//                of the unfinished problems and a column gather (kernels.hip), so every wave of the next
+//                round is full again and still reads 512 contiguous bytes per time step.
+// final kernel : one K = 1 pass per series with the optimum -> final states, h forecasts, AICc.
+//
+// Dominant cost: passes x 8 T bytes per problem -> HBM/L2 stream + fp64 VALU recursion; no MFMA
+// (a scan, not a contraction).
 #pragma once
 #include "ets_device.hpp"
 #include "kernels.hpp"
 
 namespace anofox {
 
-template <class Cfg, int MS>
-__global__ __launch_bounds__(NM_BLOCK) void ets_fit_kernel(const FitArgs a)
+template <class Cfg, int MS, int CPL>
+__global__ __launch_bounds__(NM_BLOCK) void ets_round_kernel(const FitArgs a)
 {
     extern __shared__ double lds[];
+    constexpr int D = Cfg::DIM;
+    constexpr int LPP = NM_K / CPL;              // lanes per problem (1 or 4)
+    constexpr int PPB = NM_BLOCK / LPP;          // problems per workgroup
     const int lane = threadIdx.x;
-    const int s = blockIdx.x * NM_BLOCK + lane;
-    const int len = (s < a.n_series) ? a.len[s] : 0;
+    const int n_act = a.n_active ? *a.n_active : a.n_series;
+    if ((int)blockIdx.x * PPB >= n_act) return;
+    const int p = blockIdx.x * PPB + lane / LPP;
+    const bool valid = p < n_act;
+    const int s = valid ? (a.series_of ? a.series_of[p] : p) : 0;
+    const int len = valid ? a.len[s] : 0;
 
-    // admissibility of this (series, spec) -- mirrors oracle ets_fit preconditions
-    int st = FIT_OK;
-    const uint32_t fl = (s < a.n_series) ? a.flags[s] : 0u;
-    if (len <= 0) st = FIT_SKIPPED;
-    else if (Cfg::S != C_NONE && len < 2 * a.m) st = FIT_SHORT;
-    else if (len < a.n_param + 2) st = FIT_SHORT;
-    else if (a.need_positive && !(fl & SF_POSITIVE)) st = FIT_NONPOSITIVE;
-    else if (a.skip_constant && (fl & SF_CONSTANT)) st = FIT_SKIPPED;
-    const bool active = (st == FIT_OK);
+    bool active = valid;
+    if (a.first_round) {
+        // admissibility of this (series, spec) -- mirrors the preconditions of oracle ets_fit
+        int st = FIT_OK;
+        const uint32_t fl = valid ? a.flags[s] : 0u;
+        if (len <= 0) st = FIT_SKIPPED;
+        else if (Cfg::S != C_NONE && len < 2 * a.m) st = FIT_SHORT;
+        else if (len < a.n_param + 2) st = FIT_SHORT;
+        else if (a.need_positive && !(fl & SF_POSITIVE)) st = FIT_NONPOSITIVE;
+        else if (a.skip_constant && (fl & SF_CONSTANT)) st = FIT_SKIPPED;
+        active = valid && st == FIT_OK;
+        if (valid) {
+            a.status[s] = st;
+            if (!active) { a.st.done[s] = 1; a.st.passes[s] = 0; a.st.evals[s] = 0; a.st.iters[s] = 0; }
+        }
+    }
 
     SeriesView v;
-    v.y = a.y + (s < a.n_series ? s : 0);
+    v.y = a.y_round + (valid ? p : 0);
+    v.ld = a.ld_round;
+    v.len = active ? len : 0;
+    v.wave_len = wave_max_i32(v.len);
+    v.wave_min_len = wave_min_i32(active ? len : 0x7fffffff);
+    if (v.wave_len == 0) return;
+
+    EtsModel<Cfg, MS, CPL> mdl;
+    mdl.v = v;
+    mdl.in.l0 = active ? a.l0[s] : 0.0;
+    mdl.in.b0 = (active && Cfg::T != C_NONE) ? a.b0[s] : 0.0;
+    mdl.in.fig = a.fig ? a.fig + s : nullptr;
+    mdl.in.fig_ld = a.fig_ld;
+    mdl.in.m = a.m;
+    mdl.ring = lds + nm_lds_doubles<D>();
+
+    NmRun r;
+    if (a.first_round) nm_init_simplex(mdl, lds, r, active);
+    else {
+        // resume: simplex and counters were parked in HBM, indexed by series
+#pragma unroll
+        for (int k = 0; k <= D; k++) {
+#pragma unroll
+            for (int i = 0; i < D; i++) ANOFOX_SIM(k, i) = active ? a.st.sim[(size_t)(k * D + i) * a.ld + s] : 0.0;
+            ANOFOX_FS(k) = active ? a.st.fs[(size_t)k * a.ld + s] : 0.0;
+        }
+        r.phase = active ? a.st.phase[s] : NM_ITER;
+        r.evals = active ? a.st.evals[s] : 0;
+        r.iters = active ? a.st.iters[s] : 0;
+        r.passes = active ? a.st.passes[s] : 0;
+        r.done = !active;
+    }
+
+    nm_advance(mdl, lds, r, a.budget);
+
+    if (active && (lane % LPP) == 0) {
+#pragma unroll
+        for (int k = 0; k <= D; k++) {
+#pragma unroll
+            for (int i = 0; i < D; i++) a.st.sim[(size_t)(k * D + i) * a.ld + s] = ANOFOX_SIM(k, i);
+            a.st.fs[(size_t)k * a.ld + s] = ANOFOX_FS(k);
+        }
+        a.st.phase[s] = r.phase;
+        a.st.evals[s] = r.evals;
+        a.st.iters[s] = r.iters;
+        a.st.passes[s] = r.passes;
+        a.st.done[s] = r.done ? 1 : 0;
+    }
+}
+
+template <class Cfg, int MS>
+__global__ __launch_bounds__(NM_BLOCK) void ets_final_kernel(const FitArgs a)
+{
+    extern __shared__ double lds[];
+    constexpr int D = Cfg::DIM;
+    const int lane = threadIdx.x;
+    const int s = blockIdx.x * NM_BLOCK + lane;
+    const bool valid = s < a.n_series;
+    const int len = valid ? a.len[s] : 0;
+    int st = valid ? a.status[s] : FIT_SKIPPED;
+    const bool active = valid && len > 0 && st == FIT_OK;
+
+    SeriesView v;
+    v.y = a.y + (valid ? s : 0);
     v.ld = a.ld;
     v.len = active ? len : 0;
     v.wave_len = wave_max_i32(v.len);
     v.wave_min_len = wave_min_i32(active ? len : 0x7fffffff);
-    if (v.wave_len == 0) {                  // nothing to do in this wave
-        if (s < a.n_series) {
-            a.status[s] = st; a.aicc[s] = __builtin_huge_val();
-            a.evals[s] = 0; a.iters[s] = 0; a.passes[s] = 0;
-        }
+    if (v.wave_len == 0) {
+        if (valid && len > 0) { a.aicc[s] = __builtin_huge_val(); a.evals[s] = 0; a.iters[s] = 0; a.passes[s] = 0; }
         return;
     }
-    if (v.wave_min_len == 0x7fffffff) v.wave_min_len = 0;
+    EtsInit in;
+    in.l0 = active ? a.l0[s] : 0.0;
+    in.b0 = (active && Cfg::T != C_NONE) ? a.b0[s] : 0.0;
+    in.fig = a.fig ? a.fig + (valid ? s : 0) : nullptr;
+    in.fig_ld = a.fig_ld;
+    in.m = a.m;
 
-    EtsModel<Cfg, MS> mdl;
-    mdl.v = v;
-    mdl.in.l0 = active ? a.l0[s] : 0.0;
-    mdl.in.b0 = (active && Cfg::T != C_NONE) ? a.b0[s] : 0.0;
-    mdl.in.fig = a.fig ? a.fig + (s < a.n_series ? s : 0) : nullptr;
-    mdl.in.fig_ld = a.fig_ld;
-    mdl.in.m = a.m;
-    double *simplex = lds;
-    mdl.ring = lds + nm_lds_doubles<Cfg::DIM>();
-
-    double xbest[Cfg::DIM], fbest;
-    NmStats ns;
-    nm_minimize(mdl, active, simplex, xbest, fbest, ns);
-
-    // final pass: candidate 0 = optimum; forecasts written straight from the live states
-    double cand[NM_K][Cfg::DIM], f[NM_K];
+    double cand[1][D], f[1];
 #pragma unroll
-    for (int k = 0; k < NM_K; k++)
-#pragma unroll
-        for (int i = 0; i < Cfg::DIM; i++) cand[k][i] = xbest[i];
+    for (int i = 0; i < D; i++) cand[0][i] = active ? a.st.sim[(size_t)i * a.ld + s] : 0.5;
     EtsFinalOut fin;
     fin.h = a.h;
-    fin.yhat = a.yhat + (size_t)(s < a.n_series ? s : 0) * a.h;
+    fin.yhat = a.yhat + (size_t)(valid ? s : 0) * a.h;
     fin.sse_out = nullptr;
-    SeriesView vf = v;                     // inactive lanes must not write
-    ets_pass<Cfg, MS, NM_K, true>(vf, mdl.in, cand, f, mdl.ring, &fin);
+    ets_pass<Cfg, MS, 1, true>(v, in, cand, f, lds, &fin);
 
-    if (s < a.n_series) {
+    if (valid && len > 0) {
         double aicc = __builtin_huge_val();
         if (active) {
             const double lik = f[0];
-            if (!(fabs(lik) <= 1.7976931348623157e308)) st = FIT_NONFINITE;
+            if (!(fabs(lik) <= 1.7976931348623157e308)) { st = FIT_NONFINITE; a.status[s] = st; }
             else {
                 const double dk = (double)a.n_param, dn = (double)len;
                 const double aic = lik + 2.0 * dk;
                 aicc = aic + 2.0 * dk * (dk + 1.0) / (dn - dk - 1.0);
             }
         }
-        a.status[s] = st;
         a.aicc[s] = aicc;
-        a.evals[s] = active ? ns.evals : 0;
-        a.iters[s] = active ? ns.iters : 0;
-        a.passes[s] = active ? ns.passes + 1 : 0;
+        a.evals[s] = active ? a.st.evals[s] : 0;
+        a.iters[s] = active ? a.st.iters[s] : 0;
+        a.passes[s] = active ? a.st.passes[s] + 1 : 0;
     }
 }
 
+template <class Cfg, int MS, int CPL>
+void ets_round_launch(const FitArgs &a, hipStream_t stream)
+{
+    constexpr int PPB = NM_BLOCK / (NM_K / CPL);
+    const int grid = (a.n_series + PPB - 1) / PPB;
+    size_t lds_bytes = sizeof(double) * (size_t)nm_lds_doubles<Cfg::DIM>();
+    if (MS == -1) lds_bytes += sizeof(double) * (size_t)CPL * (size_t)a.m * NM_BLOCK;
+    if (lds_bytes > 48 * 1024)
+        (void)hipFuncSetAttribute((const void *)ets_round_kernel<Cfg, MS, CPL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipLaunchKernelGGL((ets_round_kernel<Cfg, MS, CPL>), dim3(grid), dim3(NM_BLOCK), lds_bytes, stream, a);
+}
+
 template <class Cfg, int MS>
-void ets_fit_launch(const FitArgs &a, hipStream_t stream)
+void ets_final_launch(const FitArgs &a, hipStream_t stream)
 {
     const int grid = (a.n_series + NM_BLOCK - 1) / NM_BLOCK;
-    size_t lds_bytes = sizeof(double) * (size_t)nm_lds_doubles<Cfg::DIM>();
-    if (MS == -1) lds_bytes += sizeof(double) * (size_t)NM_K * (size_t)a.m * NM_BLOCK;
-    if (lds_bytes > 48 * 1024)
-        (void)hipFuncSetAttribute((const void *)ets_fit_kernel<Cfg, MS>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds_bytes);
-    hipLaunchKernelGGL((ets_fit_kernel<Cfg, MS>), dim3(grid), dim3(NM_BLOCK), lds_bytes, stream, a);
+    size_t lds_bytes = (MS == -1) ? sizeof(double) * (size_t)a.m * NM_BLOCK : 0;
+    hipLaunchKernelGGL((ets_final_kernel<Cfg, MS>), dim3(grid), dim3(NM_BLOCK), lds_bytes, stream, a);
 }
 
 } // namespace anofox

@@ -1,7 +1,7 @@
 // ETS fit kernels without a seasonal component (10 specs).
 #include "fit_units.hpp"
 namespace anofox {
-FitLaunchFn fit_unit_nonseasonal(int spec_id, int m)
+FitLaunchers fit_unit_nonseasonal(int spec_id, int m)
 {
     (void)m;
     switch (spec_id) {
@@ -9,7 +9,7 @@ FitLaunchFn fit_unit_nonseasonal(int spec_id, int m)
         ANOFOX_NONSEASONAL_CASE(9) ANOFOX_NONSEASONAL_CASE(12) ANOFOX_NONSEASONAL_CASE(15)
         ANOFOX_NONSEASONAL_CASE(18) ANOFOX_NONSEASONAL_CASE(21) ANOFOX_NONSEASONAL_CASE(24)
         ANOFOX_NONSEASONAL_CASE(27)
-    default: return nullptr;
+    default: return FitLaunchers{nullptr, nullptr, nullptr};
     }
 }
 } // namespace anofox

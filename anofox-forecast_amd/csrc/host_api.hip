@@ -82,10 +82,18 @@ struct AnofoxHipBatch {
     hipStream_t aux[N_AUX_STREAMS] = {};
     hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_fit0 = nullptr, ev_fit1 = nullptr, ev_fork = nullptr;
     hipEvent_t ev_join[N_AUX_STREAMS] = {};
+    // per aux stream: gathered block of the running problems, ping-pong column maps + counts, parked NM state
+    struct Lane {
+        double *ybuf = nullptr;
+        int32_t *map[2] = {nullptr, nullptr};
+        int32_t *cnt = nullptr;          // [2]
+        anofox::NmStateBuf st{};
+    } lanes[N_AUX_STREAMS];
     hipStream_t last_stream = nullptr;
     bool ran = false, timed_fit = false;
     uint32_t fit_launches = 0;
     uint64_t n_problems = 0;
+    int cpl = 1;   // candidates per lane of the round kernels (env ANOFOX_HIP_CPL = 1 | 4)
 };
 
 namespace {
@@ -231,6 +239,10 @@ void free_batch_buffers(AnofoxHipBatch *b)
     for (auto &s : b->aux) if (s) (void)hipStreamDestroy(s);
     for (hipEvent_t e : {b->ev_start, b->ev_stop, b->ev_fit0, b->ev_fit1, b->ev_fork}) if (e) (void)hipEventDestroy(e);
     for (auto &e : b->ev_join) if (e) (void)hipEventDestroy(e);
+    for (auto &l : b->lanes) {
+        F(l.ybuf); F(l.map[0]); F(l.map[1]); F(l.cnt);
+        F(l.st.sim); F(l.st.fs); F(l.st.phase); F(l.st.evals); F(l.st.iters); F(l.st.passes); F(l.st.done);
+    }
 }
 
 int max_slots_for(const Plan &p)
@@ -273,6 +285,22 @@ void alloc_common(AnofoxHipBatch *b)
         b->d_iters_slots = dalloc<int32_t>(S * ld);
         b->d_passes_slots = dalloc<int32_t>(S * ld);
         b->d_slot_spec = dalloc<int32_t>(S);
+        const int n_lanes = std::min<int>(N_AUX_STREAMS, b->n_slots_cap);
+        const size_t T = std::max<size_t>(b->t_max, 1);
+        for (int q = 0; q < n_lanes; q++) {
+            auto &l = b->lanes[q];
+            l.ybuf = dalloc<double>(T * ld);
+            l.map[0] = dalloc<int32_t>(ld);
+            l.map[1] = dalloc<int32_t>(ld);
+            l.cnt = dalloc<int32_t>(2);
+            l.st.sim = dalloc<double>(20 * ld);
+            l.st.fs = dalloc<double>(5 * ld);
+            l.st.phase = dalloc<int32_t>(ld);
+            l.st.evals = dalloc<int32_t>(ld);
+            l.st.iters = dalloc<int32_t>(ld);
+            l.st.passes = dalloc<int32_t>(ld);
+            l.st.done = dalloc<int32_t>(ld);
+        }
     }
     HIPCHECK(hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking));
     for (auto &s : b->aux) HIPCHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
@@ -357,11 +385,34 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
                       hipStream_t st)
 {
     const size_t n = b->n, ld = b->ld;
+    // Round budgets (streamed passes per launch).  Geometric, so every round retires roughly half of the
+    // still-running problems and the compaction + gather in between stays a few percent of the passes.
+    static const int BUDGET[] = {32, 32, 64, 128, 256, 1024};
+    const int n_rounds = (int)(sizeof BUDGET / sizeof BUDGET[0]);
+    const int n_lanes = std::min<int>(N_AUX_STREAMS, b->n_slots_cap);
     // fork: aux streams wait for everything queued on `st` so far
     HIPCHECK(hipEventRecord(b->ev_fit0, st));
-    for (int i = 0; i < N_AUX_STREAMS; i++) HIPCHECK(hipStreamWaitEvent(b->aux[i], b->ev_fit0, 0));
-    for (size_t k = 0; k < specs.size(); k++) {
+    for (int i = 0; i < n_lanes; i++) HIPCHECK(hipStreamWaitEvent(b->aux[i], b->ev_fit0, 0));
+    // enqueue order: most expensive specs first, dealt round-robin over the streams, so the long
+    // multiplicative / damped / seasonal fits start together instead of queueing behind each other
+    std::vector<size_t> order(specs.size());
+    for (size_t i = 0; i < order.size(); i++) order[i] = i;
+    auto cost = [&](int id) {
+        int c = spec_dim(id) * 2 + (spec_season(id) ? 2 : 0);
+        const int ti = spec_trend_idx(id);
+        if (spec_error(id) == 1) c += 4;
+        if (spec_season(id) == 2) c += 6;
+        if (ti >= 3) c += 6;
+        if (ti == 4) c += 20;       // b^phi every step
+        return c;
+    };
+    std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return cost(specs[x]) > cost(specs[y]); });
+    for (size_t oi = 0; oi < order.size(); oi++) {
+        const size_t k = order[oi];
         const int id = specs[k];
+        const int q = (int)(oi % (size_t)n_lanes);
+        auto &lane = b->lanes[q];
+        hipStream_t sq = b->aux[q];
         const int se = spec_season(id), ti = spec_trend_idx(id);
         const int tt = ti == 0 ? 0 : (ti <= 2 ? 1 : 2);
         FitArgs a{};
@@ -381,12 +432,27 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
         a.evals = b->d_evals_slots + k * ld;
         a.iters = b->d_iters_slots + k * ld;
         a.passes = b->d_passes_slots + k * ld;
-        FitLaunchFn fn = ets_fit_launcher(id, a.m);
-        if (!fn) throw HipFail{"no kernel for ETS spec id " + std::to_string(id)};
-        fn(a, b->aux[k % N_AUX_STREAMS]);
-        b->fit_launches++;
+        a.st = lane.st;
+        FitLaunchers fn = ets_fit_launcher(id, a.m);
+        if (!fn.round || !fn.final) throw HipFail{"no kernel for ETS spec id " + std::to_string(id)};
+        for (int r = 0; r < n_rounds; r++) {
+            a.budget = BUDGET[r];
+            a.first_round = (r == 0);
+            if (r == 0) {
+                a.y_round = b->d_y; a.ld_round = ld; a.series_of = nullptr; a.n_active = nullptr;
+            } else {
+                const int32_t *prev_map = (r == 1) ? nullptr : lane.map[(r - 1) & 1];
+                const int32_t *prev_cnt = (r == 1) ? nullptr : lane.cnt + ((r - 1) & 1);
+                launch_compact(prev_map, prev_cnt, (int)n, lane.st.done, lane.map[r & 1], lane.cnt + (r & 1), sq);
+                launch_gather_columns(b->d_y, ld, lane.map[r & 1], lane.cnt + (r & 1), (int)n, (int)b->t_max, lane.ybuf, ld, sq);
+                a.y_round = lane.ybuf; a.ld_round = ld; a.series_of = lane.map[r & 1]; a.n_active = lane.cnt + (r & 1);
+            }
+            (b->cpl == 1 ? fn.round_lpc : fn.round)(a, sq);
+            b->fit_launches++;
+        }
+        fn.final(a, sq);
     }
-    for (int i = 0; i < N_AUX_STREAMS; i++) {
+    for (int i = 0; i < n_lanes; i++) {
         HIPCHECK(hipEventRecord(b->ev_join[i], b->aux[i]));
         HIPCHECK(hipStreamWaitEvent(st, b->ev_join[i], 0));
     }
@@ -638,6 +704,7 @@ bool anofox_hip_batch_create(size_t n_series, size_t t_max, const ForecastOption
         b->h = options->horizon;
         b->opt = *options;
         b->plan = plan;
+        if (const char *e = std::getenv("ANOFOX_HIP_CPL")) b->cpl = (std::atoi(e) == 4) ? 4 : 1;
         alloc_common(b);
     } catch (const HipFail &f) {
         set_error(out_error, INTERNAL_ERROR, "Internal error: " + f.msg);

@@ -349,13 +349,81 @@ void launch_intervals(const IntervalArgs &a, hipStream_t stream)
 }
 
 // ------------------------------------------------------------------------------------------
-FitLaunchFn ets_fit_launcher(int spec_id, int m)
+FitLaunchers ets_fit_launcher(int spec_id, int m)
 {
-    FitLaunchFn f = fit_unit_nonseasonal(spec_id, m);
-    if (!f) f = fit_unit_seasonal_add(spec_id, m);
-    if (!f) f = fit_unit_seasonal_gen_a(spec_id, m);
-    if (!f) f = fit_unit_seasonal_gen_m(spec_id, m);
+    FitLaunchers f = fit_unit_nonseasonal(spec_id, m);
+    if (!f.round) f = fit_unit_seasonal_add(spec_id, m);
+    if (!f.round) f = fit_unit_seasonal_gen_a(spec_id, m);
+    if (!f.round) f = fit_unit_seasonal_gen_m(spec_id, m);
     return f;
+}
+
+// ------------------------------------------------------------------------------------------
+// stable compaction of the running problems (one 1024-thread workgroup, chunked ballot scan)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void compact_kernel(const int32_t *series_prev, const int32_t *n_prev_ptr, int n_series,
+                                                       const int32_t *done, int32_t *series_next, int32_t *n_next_ptr)
+{
+    __shared__ int wave_count[16];
+    __shared__ int base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_prev = n_prev_ptr ? *n_prev_ptr : n_series;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (int start = 0; start < n_prev; start += 1024) {
+        const int idx = start + tid;
+        int s = 0;
+        bool keep = false;
+        if (idx < n_prev) {
+            s = series_prev ? series_prev[idx] : idx;
+            keep = done[s] == 0;
+        }
+        const unsigned long long bal = __ballot(keep);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_count[wave] = __popcll(bal);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; w++) off += wave_count[w];
+        if (keep) series_next[off + before] = s;
+        __syncthreads();
+        if (tid == 0) {
+            int tot = 0;
+            for (int w = 0; w < 16; w++) tot += wave_count[w];
+            base += tot;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) *n_next_ptr = base;
+}
+
+void launch_compact(const int32_t *series_prev, const int32_t *n_prev, int n_series, const int32_t *done,
+                    int32_t *series_next, int32_t *n_next, hipStream_t stream)
+{
+    hipLaunchKernelGGL(compact_kernel, dim3(1), dim3(1024), 0, stream, series_prev, n_prev, n_series, done, series_next, n_next);
+}
+
+// ------------------------------------------------------------------------------------------
+// column gather: rebuild a dense time-major block of the running problems so that the next round
+// still reads 512 contiguous bytes per wave and time step (reads here are the only uncoalesced ones)
+// ------------------------------------------------------------------------------------------
+constexpr int GATHER_TB = 32;
+__global__ __launch_bounds__(NM_BLOCK) void gather_columns_kernel(const double *y, size_t ld, const int32_t *series_of,
+                                                                  const int32_t *n_active, int t_max, double *out, size_t ld_out)
+{
+    const int n_act = *n_active;
+    if ((int)blockIdx.x * NM_BLOCK >= n_act) return;
+    const int p = blockIdx.x * NM_BLOCK + threadIdx.x;
+    const int s = series_of[p < n_act ? p : n_act - 1];
+    const int t0 = blockIdx.y * GATHER_TB;
+    const int t1 = t0 + GATHER_TB < t_max ? t0 + GATHER_TB : t_max;
+    for (int t = t0; t < t1; t++) out[(size_t)t * ld_out + p] = y[(size_t)t * ld + s];
+}
+
+void launch_gather_columns(const double *y, size_t ld, const int32_t *series_of, const int32_t *n_active, int n_series,
+                           int t_max, double *out, size_t ld_out, hipStream_t stream)
+{
+    dim3 grid((n_series + NM_BLOCK - 1) / NM_BLOCK, (t_max + GATHER_TB - 1) / GATHER_TB);
+    hipLaunchKernelGGL(gather_columns_kernel, grid, dim3(NM_BLOCK), 0, stream, y, ld, series_of, n_active, t_max, out, ld_out);
 }
 
 } // namespace anofox

@@ -23,8 +23,22 @@ struct PrepArgs {
     double *l0, *b0;       // [9 x ld]: index (season_type * 3 + trend_type)
 };
 
+// Nelder-Mead state parked in HBM between rounds, indexed by series (stride ld)
+struct NmStateBuf {
+    double *sim;                 // [(D+1)*D x ld], vertex k coordinate i at row k*D+i
+    double *fs;                  // [(D+1) x ld]
+    int32_t *phase, *evals, *iters, *passes, *done;   // [ld]
+};
+
 struct FitArgs {
     const double *y; size_t ld; const int32_t *len; int n_series;
+    // round-specific view: the block this round streams (original or gathered columns), the column ->
+    // series map (NULL = identity) and the device-side count of running problems (NULL = n_series)
+    const double *y_round; size_t ld_round;
+    const int32_t *series_of;
+    const int32_t *n_active;
+    int budget, first_round;
+    NmStateBuf st;
     int m, h;
     const double *l0, *b0;       // [ld] for this spec's (season, trend) class
     const double *fig; size_t fig_ld;
@@ -89,7 +103,16 @@ struct IntervalArgs {
 // ETS fit kernels, one per (spec id, ring variant).  ring: 0 = none / VGPR ring for the
 // compile-time period given, -1 = LDS ring.  Returns NULL when not instantiated.
 typedef void (*FitLaunchFn)(const FitArgs &, hipStream_t);
-FitLaunchFn ets_fit_launcher(int spec_id, int m);
+struct FitLaunchers { FitLaunchFn round, round_lpc, final; };   // round: 4 candidates per lane; round_lpc: 1
+FitLaunchers ets_fit_launcher(int spec_id, int m);
+
+// stable compaction of the unfinished problems: series_next[0..n_next) = the series of the previous
+// map whose done flag is 0, in order (single workgroup; deterministic)
+void launch_compact(const int32_t *series_prev, const int32_t *n_prev, int n_series, const int32_t *done,
+                    int32_t *series_next, int32_t *n_next, hipStream_t);
+// out[t * ld_out + p] = y[t * ld + series_of[p]] for p < *n_active, t < t_max
+void launch_gather_columns(const double *y, size_t ld, const int32_t *series_of, const int32_t *n_active, int n_series,
+                           int t_max, double *out, size_t ld_out, hipStream_t);
 
 void launch_prep(const PrepArgs &, hipStream_t);
 void launch_select(const SelectArgs &, hipStream_t);

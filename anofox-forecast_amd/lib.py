@@ -9,6 +9,10 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# The batch path runs the candidate ETS specs on concurrent HIP streams; ROCm maps streams onto 4
+# hardware queues by default, which serialises them.  Must be set before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libanofox_fcst_hip.so")
 
