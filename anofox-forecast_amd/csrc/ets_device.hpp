@@ -185,29 +185,35 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
 #pragma unroll
             for (int k = 0; k < K; k++) s[k][j] = f0;
         }
-        int t0 = 0;
-        // full blocks where every active lane of the wave is in range: no per-step predicate
-        double yc[MS];
-        if (v.wave_min_len >= MS) {
+        // Full blocks (every active lane of the wave in range): no per-step predicate.  NB register
+        // buffers of one period each keep NB-1 blocks of y loads in flight ahead of the recursion, so a
+        // wave that is alone on its SIMD (late rounds) still covers the HBM miss latency.
+        constexpr int NB = (K == 1 && Cfg::ADDITIVE) ? 4 : 2;   // division-heavy steps are long enough with one block ahead
+        const int nfull = v.wave_min_len / MS;
+        double yb[NB][MS];
 #pragma unroll
-            for (int j = 0; j < MS; j++) yc[j] = yp[(size_t)j * ld];
-        }
-        for (; t0 + MS <= v.wave_min_len; t0 += MS) {
-            double yn[MS];
-            const bool more = (t0 + 2 * MS <= v.wave_min_len);
-            if (more) {
+        for (int i = 0; i < NB; i++)
+            if (i < nfull) {
 #pragma unroll
-                for (int j = 0; j < MS; j++) yn[j] = yp[(size_t)(t0 + MS + j) * ld];
+                for (int j = 0; j < MS; j++) yb[i][j] = yp[(size_t)(i * MS + j) * ld];
             }
+        for (int blk = 0; blk < nfull; blk += NB) {
 #pragma unroll
-            for (int j = 0; j < MS; j++)
+            for (int i = 0; i < NB; i++) {
+                if (blk + i < nfull) {
 #pragma unroll
-                for (int k = 0; k < K; k++) ets_step<Cfg>(par[k], st[k], yc[j], s[k][j]);
-            if (more) {
+                    for (int j = 0; j < MS; j++)
 #pragma unroll
-                for (int j = 0; j < MS; j++) yc[j] = yn[j];
+                        for (int k = 0; k < K; k++) ets_step<Cfg>(par[k], st[k], yb[i][j], s[k][j]);
+                    const int nxt = blk + i + NB;
+                    if (nxt < nfull) {
+#pragma unroll
+                        for (int j = 0; j < MS; j++) yb[i][j] = yp[(size_t)(nxt * MS + j) * ld];
+                    }
+                }
             }
         }
+        int t0 = nfull * MS;
         // ragged tail: per-lane predicate
         for (; t0 < v.wave_len; t0 += MS) {
 #pragma unroll
@@ -240,28 +246,32 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
     } else if constexpr (MS == 0) {
         double dummy = 0.0;
         constexpr int U = 8;
-        int t0 = 0;
-        double yc[U];
-        if (v.wave_min_len >= U) {
+        constexpr int NB = (K == 1 && Cfg::ADDITIVE) ? 4 : 2;   // division-heavy steps are long enough with one block ahead
+        const int nfull = v.wave_min_len / U;
+        double yb[NB][U];
 #pragma unroll
-            for (int j = 0; j < U; j++) yc[j] = yp[(size_t)j * ld];
-        }
-        for (; t0 + U <= v.wave_min_len; t0 += U) {
-            double yn[U];
-            const bool more = (t0 + 2 * U <= v.wave_min_len);
-            if (more) {
+        for (int i = 0; i < NB; i++)
+            if (i < nfull) {
 #pragma unroll
-                for (int j = 0; j < U; j++) yn[j] = yp[(size_t)(t0 + U + j) * ld];
+                for (int j = 0; j < U; j++) yb[i][j] = yp[(size_t)(i * U + j) * ld];
             }
+        for (int blk = 0; blk < nfull; blk += NB) {
 #pragma unroll
-            for (int j = 0; j < U; j++)
+            for (int i = 0; i < NB; i++) {
+                if (blk + i < nfull) {
 #pragma unroll
-                for (int k = 0; k < K; k++) ets_step<Cfg>(par[k], st[k], yc[j], dummy);
-            if (more) {
+                    for (int j = 0; j < U; j++)
 #pragma unroll
-                for (int j = 0; j < U; j++) yc[j] = yn[j];
+                        for (int k = 0; k < K; k++) ets_step<Cfg>(par[k], st[k], yb[i][j], dummy);
+                    const int nxt = blk + i + NB;
+                    if (nxt < nfull) {
+#pragma unroll
+                        for (int j = 0; j < U; j++) yb[i][j] = yp[(size_t)(nxt * U + j) * ld];
+                    }
+                }
             }
         }
+        int t0 = nfull * U;
         for (; t0 < v.wave_len; t0++) {
             if (t0 < v.len) {
                 const double yv = yp[(size_t)t0 * ld];

@@ -14,10 +14,13 @@
 #include "ets_device.hpp"
 #include "kernels.hpp"
 
+#ifndef ANOFOX_ROUND_WAVES
+#define ANOFOX_ROUND_WAVES 2   // min waves per SIMD of the round kernels (caps VGPRs at 256); measured best of 1/2/4
+#endif
 namespace anofox {
 
 template <class Cfg, int MS, int CPL>
-__global__ __launch_bounds__(NM_BLOCK) void ets_round_kernel(const FitArgs a)
+__global__ __launch_bounds__(NM_BLOCK, ANOFOX_ROUND_WAVES) void ets_round_kernel(const FitArgs a)
 {
     extern __shared__ double lds[];
     constexpr int D = Cfg::DIM;
