@@ -102,9 +102,23 @@ __device__ __forceinline__ double dm_exp(double x)
     } else {
         return 1.0 + x;
     }
-    double xx = x * x;
-    double c = x - xx * (P1 + xx * (P2 + xx * (P3 + xx * (P4 + xx * P5))));
-    double y = 1.0 + (x * c / (2.0 - c) - lo + hi);
+    // division-free: Taylor polynomial of e^r, degree 13, Horner with fused multiply-adds
+    // (|r| <= 0.35: remainder < 5e-18).  Same coefficients and order as the CPU checker.
+    (void)P1; (void)P2; (void)P3; (void)P4; (void)P5; (void)hi; (void)lo;
+    double p = 1.0 / 6227020800.0;
+    p = fma(p, x, 1.0 / 479001600.0);
+    p = fma(p, x, 1.0 / 39916800.0);
+    p = fma(p, x, 1.0 / 3628800.0);
+    p = fma(p, x, 1.0 / 362880.0);
+    p = fma(p, x, 1.0 / 40320.0);
+    p = fma(p, x, 1.0 / 5040.0);
+    p = fma(p, x, 1.0 / 720.0);
+    p = fma(p, x, 1.0 / 120.0);
+    p = fma(p, x, 1.0 / 24.0);
+    p = fma(p, x, 1.0 / 6.0);
+    p = fma(p, x, 0.5);
+    p = fma(p, x, 1.0);
+    double y = fma(p, x, 1.0);
     if (k == 0) return y;
     return dm_scalbn(y, k);
 }

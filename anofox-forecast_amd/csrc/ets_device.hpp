@@ -106,9 +106,17 @@ __device__ __forceinline__ void ets_step(const EtsPar &p, EtsState &st, double y
         double f = q;
         if constexpr (Cfg::S == C_ADD) f = q + s;
         else if constexpr (Cfg::S == C_MUL) f = q * s;
+        // ONE reciprocal per step serves every quotient: 1/f (relative error; 1/s = q/f and 1/q = s/f
+        // for a multiplicative season) and 1/l (multiplicative growth) come from 1/(f l), 1/f or 1/l.
+        // An fp64 division is ~20 VALU instructions here, so this halves the general recursion.
+        constexpr bool need_f = (Cfg::E == C_MUL) || (Cfg::S == C_MUL);
+        double rf = 0.0, rl = 0.0;
+        if constexpr (need_f && Cfg::T == C_MUL) { double R = 1.0 / (f * st.l); rf = R * st.l; rl = R * f; }
+        else if constexpr (need_f) rf = 1.0 / f;
+        else if constexpr (Cfg::T == C_MUL) rl = 1.0 / st.l;
         double e = y - f;
         if constexpr (Cfg::E == C_MUL) {
-            e = e / f;
+            e = e * rf;
             int ex;
             st.mant = frexp(st.mant * fabs(f), &ex);
             st.eacc += ex;
@@ -116,20 +124,20 @@ __device__ __forceinline__ void ets_step(const EtsPar &p, EtsState &st, double y
         st.sse = fma(e, e, st.sse);
         double pp = y;
         if constexpr (Cfg::S == C_ADD) pp = y - s;
-        else if constexpr (Cfg::S == C_MUL) pp = (fabs(s) < ETS_TOL) ? ETS_HUGEN : y / s;
+        else if constexpr (Cfg::S == C_MUL) pp = y * (rf * q);
         double lnew = fma(p.alpha, pp - q, q);
         if constexpr (Cfg::T == C_ADD) {
             double r = lnew - st.l;
             st.b = fma(p.bstar, r - phib, phib);
         } else if constexpr (Cfg::T == C_MUL) {
-            double r = (fabs(st.l) < ETS_TOL) ? ETS_HUGEN : lnew / st.l;
+            double r = lnew * rl;
             st.b = fma(p.bstar, r - phib, phib);
         }
         if constexpr (Cfg::S == C_ADD) {
             double tt = y - q;
             s = fma(p.gamma, tt - s, s);
         } else if constexpr (Cfg::S == C_MUL) {
-            double tt = (fabs(q) < ETS_TOL) ? ETS_HUGEN : y / q;
+            double tt = y * (rf * s);
             s = fma(p.gamma, tt - s, s);
         }
         st.l = lnew;
@@ -350,6 +358,14 @@ struct EtsModel {
         if constexpr (Cfg::T != C_NONE) { lo[k] = PAR_LO; hi[k] = PAR_HI; x0[k] = 0.1; k++; }
         if constexpr (Cfg::S != C_NONE) { lo[k] = PAR_LO; hi[k] = PAR_HI; x0[k] = 0.1; k++; }
         if constexpr (Cfg::D) { lo[k] = PHI_LO; hi[k] = PHI_HI; x0[k] = 0.9; k++; }
+    }
+    __device__ double eval1(const double (&x)[DIM]) const
+    {
+        double c1[1][DIM], f1[1];
+#pragma unroll
+        for (int i = 0; i < DIM; i++) c1[0][i] = x[i];
+        ets_pass<Cfg, MS, 1, false>(v, in, c1, f1, ring, nullptr);
+        return f1[0];
     }
     __device__ void eval(const double (&cand)[NM_K][DIM], double (&f)[NM_K]) const
     {

@@ -19,12 +19,14 @@
 #endif
 namespace anofox {
 
-template <class Cfg, int MS, int CPL>
+// SPEC = false: sequential Nelder-Mead, one lane per problem (64 problems per wave)
+// SPEC = true : speculative, the four trial points of a problem in four adjacent lanes (16 problems per wave)
+template <class Cfg, int MS, bool SPEC>
 __global__ __launch_bounds__(NM_BLOCK, ANOFOX_ROUND_WAVES) void ets_round_kernel(const FitArgs a)
 {
     extern __shared__ double lds[];
     constexpr int D = Cfg::DIM;
-    constexpr int LPP = NM_K / CPL;              // lanes per problem (1 or 4)
+    constexpr int LPP = SPEC ? NM_K : 1;         // lanes per problem
     constexpr int PPB = NM_BLOCK / LPP;          // problems per workgroup
     const int lane = threadIdx.x;
     const int n_act = a.n_active ? *a.n_active : a.n_series;
@@ -52,14 +54,14 @@ __global__ __launch_bounds__(NM_BLOCK, ANOFOX_ROUND_WAVES) void ets_round_kernel
     }
 
     SeriesView v;
-    v.y = a.y_round + (valid ? p : 0);
+    v.y = a.y_round + (valid ? (a.gathered ? p : s) : 0);
     v.ld = a.ld_round;
     v.len = active ? len : 0;
     v.wave_len = wave_max_i32(v.len);
     v.wave_min_len = wave_min_i32(active ? len : 0x7fffffff);
     if (v.wave_len == 0) return;
 
-    EtsModel<Cfg, MS, CPL> mdl;
+    EtsModel<Cfg, MS, 1> mdl;
     mdl.v = v;
     mdl.in.l0 = active ? a.l0[s] : 0.0;
     mdl.in.b0 = (active && Cfg::T != C_NONE) ? a.b0[s] : 0.0;
@@ -85,7 +87,8 @@ __global__ __launch_bounds__(NM_BLOCK, ANOFOX_ROUND_WAVES) void ets_round_kernel
         r.done = !active;
     }
 
-    nm_advance(mdl, lds, r, a.budget);
+    if constexpr (SPEC) nm_advance_spec(mdl, lds, r, a.budget);
+    else nm_advance_seq(mdl, lds, r, a.budget);
 
     if (active && (lane % LPP) == 0) {
 #pragma unroll
@@ -158,16 +161,16 @@ __global__ __launch_bounds__(NM_BLOCK) void ets_final_kernel(const FitArgs a)
     }
 }
 
-template <class Cfg, int MS, int CPL>
+template <class Cfg, int MS, bool SPEC>
 void ets_round_launch(const FitArgs &a, hipStream_t stream)
 {
-    constexpr int PPB = NM_BLOCK / (NM_K / CPL);
+    constexpr int PPB = NM_BLOCK / (SPEC ? NM_K : 1);
     const int grid = (a.n_series + PPB - 1) / PPB;
     size_t lds_bytes = sizeof(double) * (size_t)nm_lds_doubles<Cfg::DIM>();
-    if (MS == -1) lds_bytes += sizeof(double) * (size_t)CPL * (size_t)a.m * NM_BLOCK;
+    if (MS == -1) lds_bytes += sizeof(double) * (size_t)a.m * NM_BLOCK;
     if (lds_bytes > 48 * 1024)
-        (void)hipFuncSetAttribute((const void *)ets_round_kernel<Cfg, MS, CPL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    hipLaunchKernelGGL((ets_round_kernel<Cfg, MS, CPL>), dim3(grid), dim3(NM_BLOCK), lds_bytes, stream, a);
+        (void)hipFuncSetAttribute((const void *)ets_round_kernel<Cfg, MS, SPEC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipLaunchKernelGGL((ets_round_kernel<Cfg, MS, SPEC>), dim3(grid), dim3(NM_BLOCK), lds_bytes, stream, a);
 }
 
 template <class Cfg, int MS>

@@ -14,7 +14,7 @@ template <int ID> struct SpecOf {
 };
 template <int ID, int MS> FitLaunchers launchers_of()
 {
-    return FitLaunchers{&ets_round_launch<typename SpecOf<ID>::Cfg, MS, 1>, &ets_round_launch<typename SpecOf<ID>::Cfg, MS, 1>,
+    return FitLaunchers{&ets_round_launch<typename SpecOf<ID>::Cfg, MS, false>, &ets_round_launch<typename SpecOf<ID>::Cfg, MS, true>,
                         &ets_final_launch<typename SpecOf<ID>::Cfg, MS>};
 }
 // seasonal spec: VGPR ring for the listed compile-time periods, LDS ring otherwise

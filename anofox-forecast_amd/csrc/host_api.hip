@@ -22,7 +22,7 @@ using namespace anofox;
 
 namespace {
 
-constexpr int N_AUX_STREAMS = 8;
+constexpr int N_AUX_STREAMS = 32;   // one stream per candidate ETS spec (the hardware multiplexes them onto GPU_MAX_HW_QUEUES queues)
 
 struct HipFail { std::string msg; };
 #define HIPCHECK(expr)                                                                             \
@@ -77,6 +77,7 @@ struct AnofoxHipBatch {
     int32_t *d_model_code = nullptr, *d_status = nullptr, *d_detail = nullptr, *d_passes_total = nullptr, *d_evals_total = nullptr;
     uint32_t *d_mask = nullptr;
     int32_t *d_len_group = nullptr;
+    int32_t *d_count = nullptr;
     // streams / events
     hipStream_t own_stream = nullptr;
     hipStream_t aux[N_AUX_STREAMS] = {};
@@ -93,7 +94,9 @@ struct AnofoxHipBatch {
     bool ran = false, timed_fit = false;
     uint32_t fit_launches = 0;
     uint64_t n_problems = 0;
-    int cpl = 1;   // candidates per lane of the round kernels (env ANOFOX_HIP_CPL = 1 | 4)
+    int seq_rounds = 3;      // rounds run by the sequential Nelder-Mead driver before switching to the speculative one
+    int seq_rounds_env = -1; // ANOFOX_HIP_SEQ_ROUNDS override (-1 = decide from the number of live problems)
+    bool use_gather = false; // rebuild a dense block of the running problems between rounds (else index y by series)
 };
 
 namespace {
@@ -234,7 +237,7 @@ void free_batch_buffers(AnofoxHipBatch *b)
     F(b->d_aicc); F(b->d_yhat_slots); F(b->d_status_slots); F(b->d_evals_slots); F(b->d_iters_slots);
     F(b->d_passes_slots); F(b->d_slot_spec);
     F(b->d_yhat); F(b->d_lo); F(b->d_hi); F(b->d_model_code); F(b->d_status); F(b->d_detail);
-    F(b->d_passes_total); F(b->d_evals_total); F(b->d_mask); F(b->d_len_group);
+    F(b->d_passes_total); F(b->d_evals_total); F(b->d_mask); F(b->d_len_group); F(b->d_count);
     if (b->own_stream) (void)hipStreamDestroy(b->own_stream);
     for (auto &s : b->aux) if (s) (void)hipStreamDestroy(s);
     for (hipEvent_t e : {b->ev_start, b->ev_stop, b->ev_fit0, b->ev_fit1, b->ev_fork}) if (e) (void)hipEventDestroy(e);
@@ -268,6 +271,7 @@ void alloc_common(AnofoxHipBatch *b)
     b->d_evals_total = dalloc<int32_t>(ld);
     b->d_mask = dalloc<uint32_t>(ld);
     b->d_len_group = dalloc<int32_t>(ld);
+    b->d_count = dalloc<int32_t>(2);
     HIPCHECK(hipMemset(b->d_model_code, 0, ld * sizeof(int32_t)));
     HIPCHECK(hipMemset(b->d_detail, 0, ld * sizeof(int32_t)));
     HIPCHECK(hipMemset(b->d_passes_total, 0, ld * sizeof(int32_t)));
@@ -289,7 +293,7 @@ void alloc_common(AnofoxHipBatch *b)
         const size_t T = std::max<size_t>(b->t_max, 1);
         for (int q = 0; q < n_lanes; q++) {
             auto &l = b->lanes[q];
-            l.ybuf = dalloc<double>(T * ld);
+            if (b->use_gather) l.ybuf = dalloc<double>(T * ld);
             l.map[0] = dalloc<int32_t>(ld);
             l.map[1] = dalloc<int32_t>(ld);
             l.cnt = dalloc<int32_t>(2);
@@ -370,6 +374,22 @@ __global__ void explicit_select_kernel(int n, int h, const int32_t *len, const i
         for (int i = 0; i < h; i++) yhat[(size_t)s * h + i] = yhat_slot[(size_t)s * h + i];
 }
 
+// count[0] = usable strictly positive series, count[1] = usable series (one workgroup)
+__global__ void count_positive_kernel(int n, const int32_t *len, const uint32_t *flags, int32_t *count)
+{
+    __shared__ int sp[1024], su[1024];
+    int p = 0, u = 0;
+    for (int s = threadIdx.x; s < n; s += 1024)
+        if (len[s] > 0) { u++; if (flags[s] & SF_POSITIVE) p++; }
+    sp[threadIdx.x] = p; su[threadIdx.x] = u;
+    __syncthreads();
+    for (int o = 512; o >= 1; o >>= 1) {
+        if ((int)threadIdx.x < o) { sp[threadIdx.x] += sp[threadIdx.x + o]; su[threadIdx.x] += su[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { count[0] = sp[0]; count[1] = su[0]; }
+}
+
 // AutoETS fallback plan (forecast.rs:1327-1336): 1 Holt-Winters, 2 Holt, 3 SES(0.3)
 __global__ void fallback_plan_kernel(int n, const int32_t *len, int period, uint32_t *mask, int32_t *detail)
 {
@@ -407,15 +427,17 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
         return c;
     };
     std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return cost(specs[x]) > cost(specs[y]); });
+    std::vector<FitArgs> args(order.size());
+    std::vector<FitLaunchers> fns(order.size());
     for (size_t oi = 0; oi < order.size(); oi++) {
         const size_t k = order[oi];
         const int id = specs[k];
         const int q = (int)(oi % (size_t)n_lanes);
         auto &lane = b->lanes[q];
-        hipStream_t sq = b->aux[q];
         const int se = spec_season(id), ti = spec_trend_idx(id);
         const int tt = ti == 0 ? 0 : (ti <= 2 ? 1 : 2);
-        FitArgs a{};
+        FitArgs &a = args[oi];
+        a = FitArgs{};
         a.y = b->d_y; a.ld = ld; a.len = d_len; a.n_series = (int)n;
         a.m = se != 0 ? m : 1; a.h = b->h;
         a.l0 = b->d_l0 + (size_t)(se * 3 + tt) * ld;
@@ -433,25 +455,42 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
         a.iters = b->d_iters_slots + k * ld;
         a.passes = b->d_passes_slots + k * ld;
         a.st = lane.st;
-        FitLaunchers fn = ets_fit_launcher(id, a.m);
-        if (!fn.round || !fn.final) throw HipFail{"no kernel for ETS spec id " + std::to_string(id)};
-        for (int r = 0; r < n_rounds; r++) {
-            a.budget = BUDGET[r];
+        fns[oi] = ets_fit_launcher(id, a.m);
+        if (!fns[oi].round_seq || !fns[oi].round_spec || !fns[oi].final) throw HipFail{"no kernel for ETS spec id " + std::to_string(id)};
+    }
+    // Round-major submission: round r of every spec is enqueued before round r+1 of any, each spec on its
+    // own stream, so that all specs advance together and the hardware queues never hold a long spec behind
+    // another one.  Early rounds run the sequential driver (least arithmetic while problems outnumber
+    // lanes), late rounds the speculative one (shortest critical path for the stragglers).
+    for (int r = 0; r < n_rounds; r++) {
+        for (size_t oi = 0; oi < order.size(); oi++) {
+            const int q = (int)(oi % (size_t)n_lanes);
+            auto &lane = b->lanes[q];
+            hipStream_t sq = b->aux[q];
+            FitArgs &a = args[oi];
+            const bool spec_mode = r >= b->seq_rounds;
+            a.budget = spec_mode ? BUDGET[r] : (BUDGET[r] * 7) / 4;     // ~1.7 passes per iteration when sequential
             a.first_round = (r == 0);
+            a.gathered = 0;
             if (r == 0) {
                 a.y_round = b->d_y; a.ld_round = ld; a.series_of = nullptr; a.n_active = nullptr;
             } else {
                 const int32_t *prev_map = (r == 1) ? nullptr : lane.map[(r - 1) & 1];
                 const int32_t *prev_cnt = (r == 1) ? nullptr : lane.cnt + ((r - 1) & 1);
                 launch_compact(prev_map, prev_cnt, (int)n, lane.st.done, lane.map[r & 1], lane.cnt + (r & 1), sq);
-                launch_gather_columns(b->d_y, ld, lane.map[r & 1], lane.cnt + (r & 1), (int)n, (int)b->t_max, lane.ybuf, ld, sq);
-                a.y_round = lane.ybuf; a.ld_round = ld; a.series_of = lane.map[r & 1]; a.n_active = lane.cnt + (r & 1);
+                a.series_of = lane.map[r & 1]; a.n_active = lane.cnt + (r & 1);
+                if (b->use_gather && lane.ybuf) {
+                    launch_gather_columns(b->d_y, ld, lane.map[r & 1], lane.cnt + (r & 1), (int)n, (int)b->t_max, lane.ybuf, ld, sq);
+                    a.y_round = lane.ybuf; a.ld_round = ld; a.gathered = 1;
+                } else {
+                    a.y_round = b->d_y; a.ld_round = ld;
+                }
             }
-            (b->cpl == 1 ? fn.round_lpc : fn.round)(a, sq);
+            (spec_mode ? fns[oi].round_spec : fns[oi].round_seq)(a, sq);
             b->fit_launches++;
         }
-        fn.final(a, sq);
     }
+    for (size_t oi = 0; oi < order.size(); oi++) fns[oi].final(args[oi], b->aux[oi % (size_t)n_lanes]);
     for (int i = 0; i < n_lanes; i++) {
         HIPCHECK(hipEventRecord(b->ev_join[i], b->aux[i]));
         HIPCHECK(hipStreamWaitEvent(st, b->ev_join[i], 0));
@@ -550,17 +589,22 @@ void run_group(AnofoxHipBatch *b, int period, const int32_t *d_len, hipStream_t 
             if (!spec_is_valid(id) || !pool_allows(p.pool, id)) continue;
             specs.push_back(id);
         }
-        // longest kernels first (seasonal, damped, multiplicative) so the tail packs better
-        std::vector<int> order(specs);
-        std::stable_sort(order.begin(), order.end(), [](int a, int c) {
-            auto cost = [](int id) { return spec_dim(id) * 4 + (spec_has_mult(id) ? 8 : 0) + (spec_season(id) ? 6 : 0); };
-            return cost(a) > cost(c);
-        });
-        // slot order must stay the spec-id order for first-minimum tie breaking: map slots by id order
+        // slot order = spec-id order (first minimum wins ties in the selection)
         b->h_slot_spec.assign(specs.begin(), specs.end());
         HIPCHECK(hipMemcpyAsync(b->d_slot_spec, b->h_slot_spec.data(), b->h_slot_spec.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        if (b->seq_rounds_env < 0) {
+            // Choose the Nelder-Mead driver of the early rounds from the number of LIVE problems: strictly
+            // positive series run every spec, the others only the additive ones.  One 4-byte read-back.
+            hipLaunchKernelGGL(count_positive_kernel, dim3(1), dim3(1024), 0, st, (int)n, d_len, b->d_flags, b->d_count);
+            int32_t cnt[2] = {0, 0};
+            HIPCHECK(hipMemcpyAsync(cnt, b->d_count, sizeof cnt, hipMemcpyDeviceToHost, st));
+            HIPCHECK(hipStreamSynchronize(st));
+            size_t n_add = 0;
+            for (int id : specs) if (!spec_has_mult(id)) n_add++;
+            const double live = (double)cnt[0] * (double)specs.size() + (double)(cnt[1] - cnt[0]) * (double)n_add;
+            b->seq_rounds = live >= 8.0 * 65536.0 ? 3 : 0;    // >= 8 problems per SIMD lane-slot: VALU-bound, go sequential
+        }
         launch_fit_slots(b, specs, d_len, m, true, st);
-        (void)order;
         SelectArgs sa{};
         sa.n_series = (int)n; sa.h = b->h; sa.n_slots = (int)specs.size(); sa.ld = ld; sa.len = d_len;
         sa.aicc = b->d_aicc; sa.yhat_slots = b->d_yhat_slots; sa.slot_spec = b->d_slot_spec;
@@ -704,7 +748,8 @@ bool anofox_hip_batch_create(size_t n_series, size_t t_max, const ForecastOption
         b->h = options->horizon;
         b->opt = *options;
         b->plan = plan;
-        if (const char *e = std::getenv("ANOFOX_HIP_CPL")) b->cpl = (std::atoi(e) == 4) ? 4 : 1;
+        if (const char *e = std::getenv("ANOFOX_HIP_SEQ_ROUNDS")) { b->seq_rounds_env = std::atoi(e); b->seq_rounds = b->seq_rounds_env; }
+        if (const char *e = std::getenv("ANOFOX_HIP_GATHER")) b->use_gather = std::atoi(e) != 0;
         alloc_common(b);
     } catch (const HipFail &f) {
         set_error(out_error, INTERNAL_ERROR, "Internal error: " + f.msg);

@@ -352,9 +352,9 @@ void launch_intervals(const IntervalArgs &a, hipStream_t stream)
 FitLaunchers ets_fit_launcher(int spec_id, int m)
 {
     FitLaunchers f = fit_unit_nonseasonal(spec_id, m);
-    if (!f.round) f = fit_unit_seasonal_add(spec_id, m);
-    if (!f.round) f = fit_unit_seasonal_gen_a(spec_id, m);
-    if (!f.round) f = fit_unit_seasonal_gen_m(spec_id, m);
+    if (!f.final) f = fit_unit_seasonal_add(spec_id, m);
+    if (!f.final) f = fit_unit_seasonal_gen_a(spec_id, m);
+    if (!f.final) f = fit_unit_seasonal_gen_m(spec_id, m);
     return f;
 }
 

@@ -38,6 +38,7 @@ struct FitArgs {
     const int32_t *series_of;
     const int32_t *n_active;
     int budget, first_round;
+    int gathered;                // y_round holds the running problems' columns densely (column p), else index by series
     NmStateBuf st;
     int m, h;
     const double *l0, *b0;       // [ld] for this spec's (season, trend) class
@@ -103,7 +104,7 @@ struct IntervalArgs {
 // ETS fit kernels, one per (spec id, ring variant).  ring: 0 = none / VGPR ring for the
 // compile-time period given, -1 = LDS ring.  Returns NULL when not instantiated.
 typedef void (*FitLaunchFn)(const FitArgs &, hipStream_t);
-struct FitLaunchers { FitLaunchFn round, round_lpc, final; };   // round: 4 candidates per lane; round_lpc: 1
+struct FitLaunchers { FitLaunchFn round_seq, round_spec, final; };   // sequential / speculative Nelder-Mead rounds
 FitLaunchers ets_fit_launcher(int spec_id, int m);
 
 // stable compaction of the unfinished problems: series_next[0..n_next) = the series of the previous

@@ -1,4 +1,4 @@
-// nm.hpp -- per-lane bounded Nelder-Mead for gfx950, one optimisation problem per lane.
+// nm.hpp -- per-problem bounded Nelder-Mead for gfx950.
 //
 // Semantics: scipy-style Nelder-Mead (rho 1, chi 2, psi 0.5, sigma 0.5; initial simplex
 // x0 and x0 with one coordinate scaled by 1.05; bounds by clipping; stop when the simplex
@@ -6,25 +6,30 @@
 // evaluations).  These constants are what the reference's known-answer vectors pin for the
 // SES / Holt / HoltWinters optimisers.
 //
-// MI355X mapping: an objective evaluation is one streamed pass over the lane's series, so
-// the four trial points of an iteration (reflection, expansion, outside and inside
-// contraction) -- all functions of the centroid and the worst vertex only -- are evaluated
-// SPECULATIVELY in the same pass (K = 4 candidates per lane share every y load).  The
-// accept/shrink decision then uses exactly the values a sequential Nelder-Mead would have
-// computed, so the trajectory is identical to the sequential algorithm; `evals` counts the
-// sequential evaluations, `passes` the streamed passes.  The simplex lives in LDS between
-// passes so that the pass itself owns the VGPR budget.
+// MI355X mapping: an objective evaluation is one streamed pass over the problem's series.  Two
+// interchangeable drivers walk the SAME trajectory (they only differ in which trial points get
+// evaluated when, never in the values used):
+//   * nm_advance_seq  -- one lane per problem, one trial point per pass, exactly the sequential
+//                        algorithm (~1.7 passes per iteration).  Least arithmetic: used while the
+//                        batch still offers more problems than the chip has lanes (VALU-bound).
+//   * nm_advance_spec -- the four trial points of an iteration (reflection, expansion, outside and
+//                        inside contraction -- all functions of the centroid and the worst vertex only)
+//                        are evaluated SPECULATIVELY in one pass, by four adjacent lanes (or by one lane
+//                        holding four recursions).  One pass per iteration: used when problems are few and
+//                        the critical path (passes of the slowest problem) is what is left.
+// `evals` counts the evaluations of the sequential algorithm in both drivers; `passes` the streamed
+// passes.  The simplex lives in LDS between passes so that the pass owns the VGPR budget.
 //
-// The optimiser is RESUMABLE: nm_advance() runs at most `budget` passes and leaves a state
-// (simplex in LDS + NmRun) that a later launch continues bit-for-bit.  The ETS fit uses this to
-// run in rounds with compaction of the unfinished problems in between (iteration counts differ
-// by 5-10x between series, so a run-to-completion wave idles most of its lanes).
+// Both drivers are RESUMABLE at iteration boundaries: they run about `budget` passes and leave a state
+// (simplex + NmRun) that a later launch continues bit-for-bit.  The ETS fit runs in rounds with a
+// compaction of the unfinished problems in between (iteration counts differ by 5-10x between series,
+// so a run-to-completion wave would idle most of its lanes).
 #pragma once
 #include <hip/hip_runtime.h>
 
 namespace anofox {
 
-constexpr int NM_K = 4;          // candidates evaluated per streamed pass
+constexpr int NM_K = 4;          // trial points of one iteration
 constexpr int NM_BLOCK = 64;     // one wave per workgroup: all wave-uniform loops need no barrier
 
 __device__ __forceinline__ double nm_clip(double v, double lo, double hi)
@@ -34,7 +39,8 @@ __device__ __forceinline__ double nm_clip(double v, double lo, double hi)
     return v;
 }
 
-enum { NM_INIT0 = 0, NM_INIT1 = 1, NM_ITER = 2, NM_SHRINK = 3 };
+// phases; only NM_INIT0 (nothing evaluated yet) and NM_ITER (sorted simplex) exist at round boundaries
+enum { NM_INIT0 = 0, NM_INIT1 = 1, NM_ITER = 2, NM_SHRINK = 3, NM_SEQ_INIT = 4, NM_SEQ_E = 5, NM_SEQ_OC = 6, NM_SEQ_IC = 7, NM_SEQ_SHRINK = 8 };
 
 struct NmRun { int phase; int evals; int iters; int passes; bool done; };
 struct NmStats { int iters; int evals; int passes; };
@@ -45,10 +51,85 @@ template <int D> constexpr int nm_lds_doubles() { return ((D + 1) * D + (D + 1))
 #define ANOFOX_SIM(k, i) lds[((k) * D + (i)) * NM_BLOCK + lane]
 #define ANOFOX_FS(k) lds[((D + 1) * D + (k)) * NM_BLOCK + lane]
 
+template <int D> __device__ __forceinline__ bool nm_converged(const double *lds, int lane)
+{
+    bool small = true;
+#pragma unroll
+    for (int k = 1; k <= D; k++) {
+#pragma unroll
+        for (int i = 0; i < D; i++)
+            if (!(fabs(ANOFOX_SIM(k, i) - ANOFOX_SIM(0, i)) <= 1.0e-4)) small = false;
+        if (!(fabs(ANOFOX_FS(0) - ANOFOX_FS(k)) <= 1.0e-8)) small = false;
+    }
+    return small;
+}
+
+// trial point `which` (0 reflection, 1 expansion, 2 outside, 3 inside contraction), coordinate i
+template <int D> __device__ __forceinline__ double nm_trial(const double *lds, int lane, int which, int i, double lo, double hi)
+{
+    double s = ANOFOX_SIM(0, i);
+#pragma unroll
+    for (int k = 1; k < D; k++) s = s + ANOFOX_SIM(k, i);
+    const double xb = s / (double)D;
+    const double xw = ANOFOX_SIM(D, i);
+    const double a = which == 0 ? 2.0 : (which == 1 ? 3.0 : (which == 2 ? 1.5 : 0.5));
+    const double b = which == 0 ? 1.0 : (which == 1 ? 2.0 : 0.5);
+    const double v = which == 3 ? a * xb + b * xw : a * xb - b * xw;
+    return nm_clip(v, lo, hi);
+}
+
+// replace the worst vertex by trial point `which` with value fnew, stable re-insertion
+template <int D> __device__ __forceinline__ void nm_accept(double *lds, int lane, int which, double fnew, const double (&lo)[D], const double (&hi)[D])
+{
+    double xn[D];
+#pragma unroll
+    for (int i = 0; i < D; i++) xn[i] = nm_trial<D>(lds, lane, which, i, lo[i], hi[i]);
+#pragma unroll
+    for (int i = 0; i < D; i++) ANOFOX_SIM(D, i) = xn[i];
+    ANOFOX_FS(D) = fnew;
+#pragma unroll
+    for (int k = D; k >= 1; k--) {
+        if (ANOFOX_FS(k) < ANOFOX_FS(k - 1)) {
+            double t = ANOFOX_FS(k); ANOFOX_FS(k) = ANOFOX_FS(k - 1); ANOFOX_FS(k - 1) = t;
+#pragma unroll
+            for (int i = 0; i < D; i++) {
+                double u = ANOFOX_SIM(k, i); ANOFOX_SIM(k, i) = ANOFOX_SIM(k - 1, i); ANOFOX_SIM(k - 1, i) = u;
+            }
+        }
+    }
+}
+
+template <int D> __device__ __forceinline__ void nm_shrink_vertices(double *lds, int lane, const double (&lo)[D], const double (&hi)[D])
+{
+#pragma unroll
+    for (int k = 1; k <= D; k++)
+#pragma unroll
+        for (int i = 0; i < D; i++)
+            ANOFOX_SIM(k, i) = nm_clip(ANOFOX_SIM(0, i) + 0.5 * (ANOFOX_SIM(k, i) - ANOFOX_SIM(0, i)), lo[i], hi[i]);
+}
+
+template <int D> __device__ __forceinline__ void nm_sort_all(double *lds, int lane)
+{
+#pragma unroll
+    for (int k = 1; k <= D; k++) {
+#pragma unroll
+        for (int j = k; j >= 1; j--) {
+            if (ANOFOX_FS(j) < ANOFOX_FS(j - 1)) {
+                double t = ANOFOX_FS(j); ANOFOX_FS(j) = ANOFOX_FS(j - 1); ANOFOX_FS(j - 1) = t;
+#pragma unroll
+                for (int i = 0; i < D; i++) {
+                    double u = ANOFOX_SIM(j, i); ANOFOX_SIM(j, i) = ANOFOX_SIM(j - 1, i); ANOFOX_SIM(j - 1, i) = u;
+                }
+            }
+        }
+    }
+}
+
 // Model concept:
 //   static constexpr int DIM;
 //   __device__ void bounds(double (&lo)[DIM], double (&hi)[DIM], double (&x0)[DIM]);
-//   __device__ void eval(const double (&cand)[NM_K][DIM], double (&f)[NM_K]);   // one streamed pass
+//   __device__ void eval(const double (&cand)[NM_K][DIM], double (&f)[NM_K]);   // one pass, four trial points
+//   __device__ double eval1(const double (&x)[DIM]);                             // one pass, one point
 template <class Model>
 __device__ void nm_init_simplex(Model &mdl, double *lds, NmRun &r, bool active)
 {
@@ -75,8 +156,9 @@ __device__ void nm_init_simplex(Model &mdl, double *lds, NmRun &r, bool active)
     r.done = !active;
 }
 
+// ---- speculative driver: one pass per iteration --------------------------------------------------
 template <class Model>
-__device__ void nm_advance(Model &mdl, double *lds, NmRun &r, int budget)
+__device__ void nm_advance_spec(Model &mdl, double *lds, NmRun &r, int budget)
 {
     constexpr int D = Model::DIM;
     const int lane = threadIdx.x;
@@ -84,11 +166,11 @@ __device__ void nm_advance(Model &mdl, double *lds, NmRun &r, int budget)
     mdl.bounds(lo, hi, x0);
     const int maxiter = 200 * D, maxfun = 200 * D;
     int phase = r.phase, evals = r.evals, iters = r.iters, passes = r.passes;
-    bool done = r.done;
+    bool done = r.done, parked = false;
     double cand[NM_K][D], fc[NM_K];
 
     for (int pass = 0;; pass++) {
-        if (!done) {
+        if (!done && !parked) {
             if (phase == NM_INIT0) {
 #pragma unroll
                 for (int k = 0; k < NM_K; k++)
@@ -99,30 +181,12 @@ __device__ void nm_advance(Model &mdl, double *lds, NmRun &r, int budget)
                 for (int i = 0; i < D; i++) cand[0][i] = ANOFOX_SIM(D, i);
             } else if (phase == NM_ITER) {
                 if (!(evals < maxfun && iters < maxiter)) done = true;
-                else {
-                    bool small = true;
-#pragma unroll
-                    for (int k = 1; k <= D; k++) {
-#pragma unroll
-                        for (int i = 0; i < D; i++)
-                            if (!(fabs(ANOFOX_SIM(k, i) - ANOFOX_SIM(0, i)) <= 1.0e-4)) small = false;
-                        if (!(fabs(ANOFOX_FS(0) - ANOFOX_FS(k)) <= 1.0e-8)) small = false;
-                    }
-                    if (small) done = true;
-                }
+                else if (nm_converged<D>(lds, lane)) done = true;
                 if (!done) {
 #pragma unroll
-                    for (int i = 0; i < D; i++) {
-                        double s = ANOFOX_SIM(0, i);
+                    for (int k = 0; k < NM_K; k++)
 #pragma unroll
-                        for (int k = 1; k < D; k++) s = s + ANOFOX_SIM(k, i);
-                        double xb = s / (double)D;
-                        double xw = ANOFOX_SIM(D, i);
-                        cand[0][i] = nm_clip(2.0 * xb - xw, lo[i], hi[i]);        // reflection
-                        cand[1][i] = nm_clip(3.0 * xb - 2.0 * xw, lo[i], hi[i]);  // expansion
-                        cand[2][i] = nm_clip(1.5 * xb - 0.5 * xw, lo[i], hi[i]);  // outside contraction
-                        cand[3][i] = nm_clip(0.5 * xb + 0.5 * xw, lo[i], hi[i]);  // inside contraction
-                    }
+                        for (int i = 0; i < D; i++) cand[k][i] = nm_trial<D>(lds, lane, k, i, lo[i], hi[i]);
                 }
             } else { // NM_SHRINK: vertices 1..D already contracted towards the best
 #pragma unroll
@@ -131,30 +195,32 @@ __device__ void nm_advance(Model &mdl, double *lds, NmRun &r, int budget)
                     for (int i = 0; i < D; i++) cand[k][i] = ANOFOX_SIM(k + 1 <= D ? k + 1 : D, i);
             }
         }
-        if (__all(done) || pass >= budget) break;
+        // once the budget is used a lane parks at its next iteration boundary (INIT1 / SHRINK first finish
+        // their iteration); the wave leaves when every lane is done or parked
+        if (!done && pass >= budget && (phase == NM_ITER || phase == NM_INIT0)) parked = true;
+        if (__all(done || parked)) break;
 
         mdl.eval(cand, fc);
-        passes += done ? 0 : 1;
+        passes += (done || parked) ? 0 : 1;
 
-        if (!done) {
-            bool need_sort = false;
+        if (!done && !parked) {
             if (phase == NM_INIT0) {
 #pragma unroll
                 for (int k = 0; k < NM_K; k++)
                     if (k <= D) ANOFOX_FS(k) = fc[k];
                 evals += (D + 1 < NM_K ? D + 1 : NM_K);
                 phase = (D + 1 > NM_K) ? NM_INIT1 : NM_ITER;
-                need_sort = (phase == NM_ITER);
+                if (phase == NM_ITER) nm_sort_all<D>(lds, lane);
             } else if (phase == NM_INIT1) {
                 ANOFOX_FS(D) = fc[0];
                 evals += 1;
                 phase = NM_ITER;
-                need_sort = true;
+                nm_sort_all<D>(lds, lane);
             } else if (phase == NM_ITER) {
                 const double fxr = fc[0];
                 evals += 1;
-                bool shrink = false, take = true;
-                int which = 0; // 0 reflection, 1 expansion, 2 outside, 3 inside contraction
+                bool shrink = false;
+                int which = 0;
                 double fnew = fxr;
                 if (fxr < ANOFOX_FS(0)) {
                     evals += 1;
@@ -163,46 +229,16 @@ __device__ void nm_advance(Model &mdl, double *lds, NmRun &r, int budget)
                     which = 0;
                 } else if (fxr < ANOFOX_FS(D)) {
                     evals += 1;
-                    if (fc[2] <= fxr) { which = 2; fnew = fc[2]; } else { shrink = true; take = false; }
+                    if (fc[2] <= fxr) { which = 2; fnew = fc[2]; } else shrink = true;
                 } else {
                     evals += 1;
-                    if (fc[3] < ANOFOX_FS(D)) { which = 3; fnew = fc[3]; } else { shrink = true; take = false; }
+                    if (fc[3] < ANOFOX_FS(D)) { which = 3; fnew = fc[3]; } else shrink = true;
                 }
-                if (take) {
-                    // the trial point is recomputed (same operations, same bits) rather than kept live
-                    // across the streamed pass: 32 fewer VGPRs inside the hot loop
-#pragma unroll
-                    for (int i = 0; i < D; i++) {
-                        double s = ANOFOX_SIM(0, i);
-#pragma unroll
-                        for (int k = 1; k < D; k++) s = s + ANOFOX_SIM(k, i);
-                        double xb = s / (double)D;
-                        double xw = ANOFOX_SIM(D, i);
-                        double a = which == 0 ? 2.0 : (which == 1 ? 3.0 : (which == 2 ? 1.5 : 0.5));
-                        double b = which == 0 ? 1.0 : (which == 1 ? 2.0 : 0.5);
-                        double v = which == 3 ? a * xb + b * xw : a * xb - b * xw;
-                        ANOFOX_SIM(D, i) = nm_clip(v, lo[i], hi[i]);
-                    }
-                    ANOFOX_FS(D) = fnew;
-                    // stable re-insertion of the last vertex
-#pragma unroll
-                    for (int k = D; k >= 1; k--) {
-                        if (ANOFOX_FS(k) < ANOFOX_FS(k - 1)) {
-                            double t = ANOFOX_FS(k); ANOFOX_FS(k) = ANOFOX_FS(k - 1); ANOFOX_FS(k - 1) = t;
-#pragma unroll
-                            for (int i = 0; i < D; i++) {
-                                double u = ANOFOX_SIM(k, i); ANOFOX_SIM(k, i) = ANOFOX_SIM(k - 1, i); ANOFOX_SIM(k - 1, i) = u;
-                            }
-                        }
-                    }
+                if (!shrink) {
+                    nm_accept<D>(lds, lane, which, fnew, lo, hi);
                     iters += 1;
-                }
-                if (shrink) {
-#pragma unroll
-                    for (int k = 1; k <= D; k++)
-#pragma unroll
-                        for (int i = 0; i < D; i++)
-                            ANOFOX_SIM(k, i) = nm_clip(ANOFOX_SIM(0, i) + 0.5 * (ANOFOX_SIM(k, i) - ANOFOX_SIM(0, i)), lo[i], hi[i]);
+                } else {
+                    nm_shrink_vertices<D>(lds, lane, lo, hi);
                     phase = NM_SHRINK;
                 }
             } else { // NM_SHRINK results
@@ -212,30 +248,99 @@ __device__ void nm_advance(Model &mdl, double *lds, NmRun &r, int budget)
                 evals += D;
                 iters += 1;
                 phase = NM_ITER;
-                need_sort = true;
-            }
-            if (need_sort) {
-                // stable insertion sort of all vertices by value
-#pragma unroll
-                for (int k = 1; k <= D; k++) {
-#pragma unroll
-                    for (int j = k; j >= 1; j--) {
-                        if (ANOFOX_FS(j) < ANOFOX_FS(j - 1)) {
-                            double t = ANOFOX_FS(j); ANOFOX_FS(j) = ANOFOX_FS(j - 1); ANOFOX_FS(j - 1) = t;
-#pragma unroll
-                            for (int i = 0; i < D; i++) {
-                                double u = ANOFOX_SIM(j, i); ANOFOX_SIM(j, i) = ANOFOX_SIM(j - 1, i); ANOFOX_SIM(j - 1, i) = u;
-                            }
-                        }
-                    }
-                }
+                nm_sort_all<D>(lds, lane);
             }
         }
     }
     r.phase = phase; r.evals = evals; r.iters = iters; r.passes = passes; r.done = done;
 }
 
-// one-shot convenience (classic models): run to completion
+// ---- sequential driver: one trial point per pass ---------------------------------------------------
+template <class Model>
+__device__ void nm_advance_seq(Model &mdl, double *lds, NmRun &r, int budget)
+{
+    constexpr int D = Model::DIM;
+    const int lane = threadIdx.x;
+    double lo[D], hi[D], x0[D];
+    mdl.bounds(lo, hi, x0);
+    const int maxiter = 200 * D, maxfun = 200 * D;
+    int phase = r.phase, evals = r.evals, iters = r.iters, passes = r.passes;
+    bool done = r.done, parked = false;
+    int vi = 0;            // vertex cursor of the INIT / SHRINK sweeps
+    double fxr = 0.0;      // reflection value of the running iteration
+    double x[D];
+
+    for (int pass = 0;; pass++) {
+        if (!done && !parked) {
+            if (phase == NM_INIT0) { phase = NM_SEQ_INIT; vi = 0; }
+            if (phase == NM_SEQ_INIT) {
+#pragma unroll
+                for (int i = 0; i < D; i++) x[i] = ANOFOX_SIM(vi, i);
+            } else if (phase == NM_ITER) {
+                if (!(evals < maxfun && iters < maxiter)) done = true;
+                else if (nm_converged<D>(lds, lane)) done = true;
+                if (!done) {
+#pragma unroll
+                    for (int i = 0; i < D; i++) x[i] = nm_trial<D>(lds, lane, 0, i, lo[i], hi[i]);
+                }
+            } else if (phase == NM_SEQ_E || phase == NM_SEQ_OC || phase == NM_SEQ_IC) {
+                const int which = phase == NM_SEQ_E ? 1 : (phase == NM_SEQ_OC ? 2 : 3);
+#pragma unroll
+                for (int i = 0; i < D; i++) x[i] = nm_trial<D>(lds, lane, which, i, lo[i], hi[i]);
+            } else { // NM_SEQ_SHRINK
+#pragma unroll
+                for (int i = 0; i < D; i++) x[i] = ANOFOX_SIM(1 + vi, i);
+            }
+        }
+        if (!done && pass >= budget && (phase == NM_ITER || phase == NM_INIT0)) parked = true;
+        if (__all(done || parked)) break;
+
+        const double f = mdl.eval1(x);
+        passes += (done || parked) ? 0 : 1;
+
+        if (!done && !parked) {
+            if (phase == NM_SEQ_INIT) {
+                ANOFOX_FS(vi) = f;
+                vi += 1;
+                evals += 1;
+                if (vi == D + 1) { nm_sort_all<D>(lds, lane); phase = NM_ITER; }
+            } else if (phase == NM_ITER) {
+                fxr = f;
+                evals += 1;
+                if (fxr < ANOFOX_FS(0)) phase = NM_SEQ_E;
+                else if (fxr < ANOFOX_FS(D - 1)) { nm_accept<D>(lds, lane, 0, fxr, lo, hi); iters += 1; }
+                else if (fxr < ANOFOX_FS(D)) phase = NM_SEQ_OC;
+                else phase = NM_SEQ_IC;
+            } else if (phase == NM_SEQ_E) {
+                evals += 1;
+                if (f < fxr) nm_accept<D>(lds, lane, 1, f, lo, hi);
+                else nm_accept<D>(lds, lane, 0, fxr, lo, hi);
+                iters += 1;
+                phase = NM_ITER;
+            } else if (phase == NM_SEQ_OC || phase == NM_SEQ_IC) {
+                evals += 1;
+                const bool ok = (phase == NM_SEQ_OC) ? (f <= fxr) : (f < ANOFOX_FS(D));
+                if (ok) {
+                    nm_accept<D>(lds, lane, phase == NM_SEQ_OC ? 2 : 3, f, lo, hi);
+                    iters += 1;
+                    phase = NM_ITER;
+                } else {
+                    nm_shrink_vertices<D>(lds, lane, lo, hi);
+                    vi = 0;
+                    phase = NM_SEQ_SHRINK;
+                }
+            } else { // NM_SEQ_SHRINK
+                ANOFOX_FS(1 + vi) = f;
+                vi += 1;
+                evals += 1;
+                if (vi == D) { iters += 1; nm_sort_all<D>(lds, lane); phase = NM_ITER; }
+            }
+        }
+    }
+    r.phase = phase; r.evals = evals; r.iters = iters; r.passes = passes; r.done = done;
+}
+
+// one-shot convenience (classic models): speculative driver run to completion
 template <class Model>
 __device__ void nm_minimize(Model &mdl, bool active, double *lds, double (&xbest)[Model::DIM], double &fbest, NmStats &stats)
 {
@@ -243,7 +348,7 @@ __device__ void nm_minimize(Model &mdl, bool active, double *lds, double (&xbest
     const int lane = threadIdx.x;
     NmRun r;
     nm_init_simplex(mdl, lds, r, active);
-    nm_advance(mdl, lds, r, 0x7fffffff);
+    nm_advance_spec(mdl, lds, r, 0x7fffffff);
 #pragma unroll
     for (int i = 0; i < D; i++) xbest[i] = ANOFOX_SIM(0, i);
     fbest = ANOFOX_FS(0);
