@@ -361,45 +361,38 @@ FitLaunchers ets_fit_launcher(int spec_id, int m)
 // ------------------------------------------------------------------------------------------
 // stable compaction of the running problems (one 1024-thread workgroup, chunked ballot scan)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void compact_kernel(const int32_t *series_prev, const int32_t *n_prev_ptr, int n_series,
-                                                       const int32_t *done, int32_t *series_next, int32_t *n_next_ptr)
+// One wave per 64 candidates: ballot, one atomic per wave to reserve a slot range, ordered within the
+// wave.  The order of the waves' ranges is not deterministic -- it only decides which column a problem
+// occupies in the next round, never a result (every problem is independent of its position).
+__global__ __launch_bounds__(NM_BLOCK) void compact_kernel(const int32_t *series_prev, const int32_t *n_prev_ptr, int n_series,
+                                                           const int32_t *done, int32_t *series_next, int32_t *n_next_ptr)
 {
-    __shared__ int wave_count[16];
-    __shared__ int base;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_prev = n_prev_ptr ? *n_prev_ptr : n_series;
-    if (tid == 0) base = 0;
-    __syncthreads();
-    for (int start = 0; start < n_prev; start += 1024) {
-        const int idx = start + tid;
-        int s = 0;
-        bool keep = false;
-        if (idx < n_prev) {
-            s = series_prev ? series_prev[idx] : idx;
-            keep = done[s] == 0;
-        }
-        const unsigned long long bal = __ballot(keep);
-        const int before = __popcll(bal & ((1ull << lane) - 1ull));
-        if (lane == 0) wave_count[wave] = __popcll(bal);
-        __syncthreads();
-        int off = base;
-        for (int w = 0; w < wave; w++) off += wave_count[w];
-        if (keep) series_next[off + before] = s;
-        __syncthreads();
-        if (tid == 0) {
-            int tot = 0;
-            for (int w = 0; w < 16; w++) tot += wave_count[w];
-            base += tot;
-        }
-        __syncthreads();
+    if ((int)blockIdx.x * NM_BLOCK >= n_prev) return;
+    const int lane = threadIdx.x;
+    const int idx = blockIdx.x * NM_BLOCK + lane;
+    int s = 0;
+    bool keep = false;
+    if (idx < n_prev) {
+        s = series_prev ? series_prev[idx] : idx;
+        keep = done[s] == 0;
     }
-    if (tid == 0) *n_next_ptr = base;
+    const unsigned long long bal = __ballot(keep);
+    const int cnt = __popcll(bal);
+    if (cnt == 0) return;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(n_next_ptr, cnt);
+    base = __shfl(base, 0);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (keep) series_next[base + before] = s;
 }
 
 void launch_compact(const int32_t *series_prev, const int32_t *n_prev, int n_series, const int32_t *done,
                     int32_t *series_next, int32_t *n_next, hipStream_t stream)
 {
-    hipLaunchKernelGGL(compact_kernel, dim3(1), dim3(1024), 0, stream, series_prev, n_prev, n_series, done, series_next, n_next);
+    (void)hipMemsetAsync(n_next, 0, sizeof(int32_t), stream);
+    const int grid = (n_series + NM_BLOCK - 1) / NM_BLOCK;
+    hipLaunchKernelGGL(compact_kernel, dim3(grid), dim3(NM_BLOCK), 0, stream, series_prev, n_prev, n_series, done, series_next, n_next);
 }
 
 // ------------------------------------------------------------------------------------------
