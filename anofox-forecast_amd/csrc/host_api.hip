@@ -602,7 +602,7 @@ void run_group(AnofoxHipBatch *b, int period, const int32_t *d_len, hipStream_t 
             size_t n_add = 0;
             for (int id : specs) if (!spec_has_mult(id)) n_add++;
             const double live = (double)cnt[0] * (double)specs.size() + (double)(cnt[1] - cnt[0]) * (double)n_add;
-            b->seq_rounds = live >= 8.0 * 65536.0 ? 3 : 0;    // >= 8 problems per SIMD lane-slot: VALU-bound, go sequential
+            b->seq_rounds = live >= 8.0 * 65536.0 ? 4 : 0;    // >= 8 problems per SIMD lane-slot: VALU-bound, go sequential
         }
         launch_fit_slots(b, specs, d_len, m, true, st);
         SelectArgs sa{};

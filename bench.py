@@ -30,7 +30,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before HIP initialises: one hardware queue per spec stream
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # before HIP initialises: the spec streams need hardware queues
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
@@ -151,6 +151,16 @@ def main():
                          "kernel": "ets_fit_kernel<spec,period> (all spec launches of one step, concurrent streams)",
                          "kernel_ms": round(fit_ms_avg, 3), "algorithmic_bytes": int(np.mean(alg_bytes))},
         }
+        # HBM traffic of the fit kernels comes from separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE,
+        # corrected as MI355X_MICROARCH.md prescribes); the committed summary is quoted when it was taken on
+        # this workload and shape, else the field stays null.
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            if tr.get("workload") == args.workload and n == n_def and T == T_def:
+                out["roofline"]["traffic"] = int(tr["ets_round_kernel_traffic_bytes_per_step"])
+                out["roofline"]["traffic_source"] = "profiles/r01_pmc_traffic.json (PMC passes, per step)"
+        except (OSError, ValueError, KeyError):
+            pass
         # ---- CPU baseline: the oracle ("port") on a bounded sample of the same workload -------------
         sample = cpu_def if args.cpu_sample < 0 else args.cpu_sample
         if sample > 0:
