@@ -161,3 +161,46 @@ def test_ts_forecast_by_operator(env):
         api.ts_forecast_by(grp, ds, Y.reshape(-1), "ETS", 3, "1d", {"methd": "AAA"})
     with pytest.raises(api.InvalidInputException, match="does not use seasonal_period"):
         api.ts_forecast_by(grp, ds, Y.reshape(-1), "Naive", 3, "1d", {"seasonal_period": "7"})
+
+
+@pytest.mark.parametrize("seq_rounds", ["0", "2", "6"])
+@pytest.mark.parametrize("gather", ["0", "1"])
+def test_schedule_variants_are_bit_identical(env, monkeypatch, seq_rounds, gather):
+    """The sequential and the speculative Nelder-Mead drivers, with or without the column gather between
+    rounds, must walk the same trajectory: every schedule reproduces the oracle bit for bit."""
+    api, O, lib, synth = env
+    monkeypatch.setenv("ANOFOX_HIP_SEQ_ROUNDS", seq_rounds)
+    monkeypatch.setenv("ANOFOX_HIP_GATHER", gather)
+    Y = synth.gen_series(synth.SEED_M5, 5000, 130, 160, 7, positive=True)
+    series = [Y[s, : 160 - (s % 5) * 9] for s in range(130)]          # ragged lengths
+    _compare(api, O, lib, series, "AutoETS", 12, seasonal_period=7)
+    _compare(api, O, lib, series, "ETS", 12, ets_model="MAdM", seasonal_period=7)
+
+
+def test_device_resident_batch_and_stats(env):
+    """Block already in HBM (torch tensor) -> anofox_hip_batch_* -> device results; counters are consistent."""
+    import torch
+    api, O, lib, synth = env
+    from anofox_forecast_amd.device import DeviceBatch, pack_time_major
+    n, T, h = 200, 96, 8
+    Y = synth.gen_series(synth.SEED_M5, 7000, n, T, 7)
+    opts = lib.make_options("AutoETS", h, seasonal_period=7)
+    b = DeviceBatch(n, T, opts, "cuda:0")
+    y = torch.from_numpy(pack_time_major(Y, b.ld)).cuda()
+    ln = torch.full((b.ld,), T, dtype=torch.int32, device="cuda")
+    ln[n:] = 0
+    b.set_block(y, ln)
+    b.run()
+    torch.cuda.synchronize()
+    out = b.results()
+    st = b.stats()
+    oo = O.make_options("AutoETS", h, seasonal_period=7)
+    yhat = out["yhat"].cpu().numpy()
+    codes = out["model_code"].cpu().numpy()
+    for s in range(0, n, 17):
+        ref = O.forecast(Y[s], oo)
+        assert _rel(yhat[s], ref["point"]) <= REL_TOL
+        assert b.model_name(int(codes[s])) == ref["model_name"]
+    assert st["n_series"] == n and st["total_passes"] >= st["total_evals"] / 4 and st["fit_kernel_ms"] > 0
+    assert st["algorithmic_bytes"] == 8 * T * st["total_passes"] + 24 * h * n
+    b.close()
