@@ -78,6 +78,9 @@ struct AnofoxHipBatch {
     uint32_t *d_mask = nullptr;
     int32_t *d_len_group = nullptr;
     int32_t *d_count = nullptr;
+    // AutoARIMA workspace
+    double *ar_w = nullptr, *ar_wmean = nullptr, *ar_wsd = nullptr, *ar_l0 = nullptr, *ar_l1 = nullptr, *ar_x = nullptr, *ar_aicc = nullptr;
+    int32_t *ar_wlen = nullptr, *ar_d = nullptr, *ar_D = nullptr, *ar_order = nullptr, *ar_status = nullptr, *ar_evals = nullptr, *ar_passes = nullptr, *ar_models = nullptr;
     // streams / events
     hipStream_t own_stream = nullptr;
     hipStream_t aux[N_AUX_STREAMS] = {};
@@ -151,6 +154,8 @@ bool make_plan(const ForecastOptions *o, Plan &p, AnofoxError *err)
         }
         break;
     }
+    case M_AutoARIMA:
+        break;
     case M_AutoETS: {
         std::string pool = cstr_field(o->model_pool, sizeof o->model_pool);
         p.pool = 0;
@@ -238,6 +243,8 @@ void free_batch_buffers(AnofoxHipBatch *b)
     F(b->d_passes_slots); F(b->d_slot_spec);
     F(b->d_yhat); F(b->d_lo); F(b->d_hi); F(b->d_model_code); F(b->d_status); F(b->d_detail);
     F(b->d_passes_total); F(b->d_evals_total); F(b->d_mask); F(b->d_len_group); F(b->d_count);
+    F(b->ar_w); F(b->ar_wmean); F(b->ar_wsd); F(b->ar_l0); F(b->ar_l1); F(b->ar_x); F(b->ar_aicc); F(b->ar_wlen); F(b->ar_d); F(b->ar_D);
+    F(b->ar_order); F(b->ar_status); F(b->ar_evals); F(b->ar_passes); F(b->ar_models);
     if (b->own_stream) (void)hipStreamDestroy(b->own_stream);
     for (auto &s : b->aux) if (s) (void)hipStreamDestroy(s);
     for (hipEvent_t e : {b->ev_start, b->ev_stop, b->ev_fit0, b->ev_fit1, b->ev_fork}) if (e) (void)hipEventDestroy(e);
@@ -272,6 +279,16 @@ void alloc_common(AnofoxHipBatch *b)
     b->d_mask = dalloc<uint32_t>(ld);
     b->d_len_group = dalloc<int32_t>(ld);
     b->d_count = dalloc<int32_t>(2);
+    if (b->plan.model == M_AutoARIMA) {
+        const size_t T = std::max<size_t>(b->t_max, 1);
+        b->ar_w = dalloc<double>(T * ld);
+        HIPCHECK(hipMemset(b->ar_w, 0, T * ld * sizeof(double)));
+        b->ar_wmean = dalloc<double>(ld); b->ar_wsd = dalloc<double>(ld); b->ar_l0 = dalloc<double>(ld); b->ar_l1 = dalloc<double>(ld);
+        b->ar_x = dalloc<double>(6 * ld); b->ar_aicc = dalloc<double>(ld);
+        b->ar_wlen = dalloc<int32_t>(ld); b->ar_d = dalloc<int32_t>(ld); b->ar_D = dalloc<int32_t>(ld); b->ar_order = dalloc<int32_t>(5 * ld);
+        b->ar_status = dalloc<int32_t>(ld); b->ar_evals = dalloc<int32_t>(ld); b->ar_passes = dalloc<int32_t>(ld); b->ar_models = dalloc<int32_t>(ld);
+        HIPCHECK(hipMemset(b->ar_wlen, 0, ld * sizeof(int32_t)));
+    }
     HIPCHECK(hipMemset(b->d_model_code, 0, ld * sizeof(int32_t)));
     HIPCHECK(hipMemset(b->d_detail, 0, ld * sizeof(int32_t)));
     HIPCHECK(hipMemset(b->d_passes_total, 0, ld * sizeof(int32_t)));
@@ -620,6 +637,25 @@ void run_group(AnofoxHipBatch *b, int period, const int32_t *d_len, hipStream_t 
         finish();
         break;
     }
+    case M_AutoARIMA: {
+        prep(1, false);
+        ArimaArgs aa{};
+        aa.y = b->d_y; aa.ld = ld; aa.len = d_len; aa.n_series = (int)n;
+        aa.m = (period > 1 && period <= 24) ? period : 1;     // seasonal terms for m <= 24 (oracle ARIMA_MAX_PERIOD)
+        aa.h = b->h;
+        aa.w = b->ar_w; aa.wlen = b->ar_wlen; aa.d = b->ar_d; aa.D = b->ar_D; aa.wmean = b->ar_wmean; aa.wsd = b->ar_wsd;
+        aa.last_d0 = b->ar_l0; aa.last_d1 = b->ar_l1; aa.order = b->ar_order; aa.xbest = b->ar_x; aa.aicc = b->ar_aicc;
+        aa.status = b->d_detail; aa.evals = b->d_evals_total; aa.passes = b->d_passes_total; aa.models = b->ar_models;
+        aa.yhat = b->d_yhat; aa.model_code = b->d_model_code;
+        HIPCHECK(hipEventRecord(b->ev_fit0, st));
+        launch_arima(aa, st);
+        HIPCHECK(hipEventRecord(b->ev_fit1, st));
+        b->timed_fit = true;
+        b->fit_launches += 3;
+        b->n_problems += n;
+        finish();
+        break;
+    }
     default: throw HipFail{"model not implemented"};
     }
 }
@@ -889,6 +925,7 @@ bool anofox_hip_batch_device_results(AnofoxHipBatch *b, void **d_yhat, void **d_
 void anofox_hip_model_name(const ForecastOptions *options, int32_t model_code, char out_name[64])
 {
     out_name[0] = 0;
+    if (model_code >= 1000000) { auto_arima_name(model_code, options ? options->seasonal_period : 1, out_name); return; }
     if (model_code >= 100 && model_code < 130) { auto_ets_name(model_code - 100, out_name); return; }
     Plan p;
     AnofoxError e;
@@ -937,7 +974,8 @@ bool anofox_hip_batch_fetch(AnofoxHipBatch *b, ForecastResult *out_results, Anof
             std::memcpy(r.lower_bounds, &lo[s * h], h * sizeof(double));
             std::memcpy(r.upper_bounds, &hi[s * h], h * sizeof(double));
         }
-        if (code[s] >= 100) auto_ets_name(code[s] - 100, r.model_name);
+        if (code[s] >= 1000000) auto_arima_name(code[s], b->h_period[s], r.model_name);
+        else if (code[s] >= 100) auto_ets_name(code[s] - 100, r.model_name);
         else std::snprintf(r.model_name, 64, "%s", b->plan.static_name.c_str());
         r.aic = std::nan(""); r.bic = std::nan(""); r.mse = std::nan("");
         if ((b->opt.include_fitted || b->opt.include_residuals) && !b->h_clean_off.empty()) {

@@ -148,6 +148,16 @@ inline void auto_ets_name(int spec_id, char out[64])
     std::snprintf(out, 64, "AutoETS(%s,%s,%s)", E[spec_error(spec_id)], T[spec_trend_idx(spec_id)], S[spec_season(spec_id)]);
 }
 
+// model_code of the AutoARIMA kernels: 1000000 + p*1e5 + d*1e4 + q*1e3 + P*100 + D*10 + Q  (forecast.rs:1469-1493)
+inline void auto_arima_name(int code, int period, char out[64])
+{
+    int v = code - 1000000;
+    int p = v / 100000, d = (v / 10000) % 10, q = (v / 1000) % 10, P = (v / 100) % 10, D = (v / 10) % 10, Q = v % 10;
+    int s = (period > 1 && period <= 24) ? period : 1;
+    if (s > 1 && (P || D || Q)) std::snprintf(out, 64, "AutoARIMA(%d,%d,%d)(%d,%d,%d)[%d]", p, d, q, P, D, Q, s);
+    else std::snprintf(out, 64, "AutoARIMA(%d,%d,%d)", p, d, q);
+}
+
 inline double z_for_confidence(double c)
 {
     return c >= 0.99 ? 2.576 : c >= 0.95 ? 1.96 : c >= 0.90 ? 1.645 : c >= 0.80 ? 1.28 : 1.0;

@@ -17,6 +17,7 @@ Workloads (--workload):
     autoets_m5            same shape, raw intermittent counts (zeros -> only the 6 additive specs admissible)
     ets_aaa_m5            ETS(A,A,A) single spec on the same batch
     autoets_stress        n x 1,024 AutoETS (use --n-series; the 1M config shards over 8 GPUs)
+    autoarima_m5          AutoARIMA stepwise search, m = 7, on the M5-shape batch (BASELINE config 4)
 """
 from __future__ import annotations
 
@@ -54,6 +55,7 @@ WORKLOADS = {
     "autoets_m5": ("AutoETS", "", 30490, 1913, 7, False, 20260101, 8192),
     "ets_aaa_m5": ("ETS", "AAA", 30490, 1913, 7, False, 20260101, 8192),
     "autoets_stress": ("AutoETS", "", 125000, 1024, 7, False, 20260102, 8192),
+    "autoarima_m5": ("AutoARIMA", "", 30490, 1913, 7, False, 20260101, 512),
 }
 
 

@@ -1,11 +1,445 @@
-/* arima.c -- TEST INFRASTRUCTURE (oracle). AutoARIMA restatement: see arima.h. */
+/*
+ * arima.c -- TEST INFRASTRUCTURE (oracle).  Not part of the product.
+ * AutoARIMA restatement (see arima.h for provenance and for what is and is not pinned).
+ * Same rules as ets.c: -ffp-contract=off, fma() only where written, det_log/det_exp instead of libm, so the
+ * HIP kernels can reproduce every value bit for bit.
+ */
 #include "arima.h"
+#include "det_math.h"
+
+#include <float.h>
+#include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---------------------------------------------------------------------------------------------- */
+/* differencing decisions                                                                          */
+/* ---------------------------------------------------------------------------------------------- */
+
+/* KPSS level-stationarity test (Kwiatkowski et al. 1992), Bartlett window with lag trunc(3 sqrt(n)/13)
+ * (forecast::ndiffs), 5 % critical value 0.463.  Returns 1 when stationarity is rejected. */
+int oracle_arima_kpss_reject(const double *x, int n)
+{
+    if (n < 4) return 0;
+    double s = 0.0;
+    for (int i = 0; i < n; i++) s = s + x[i];
+    const double mean = s / (double)n;
+    double cum = 0.0, eta = 0.0, s2 = 0.0;
+    for (int i = 0; i < n; i++) {
+        double e = x[i] - mean;
+        cum = cum + e;
+        eta = fma(cum, cum, eta);
+        s2 = fma(e, e, s2);
+    }
+    const double dn = (double)n;
+    eta = eta / (dn * dn);
+    s2 = s2 / dn;
+    const int lag = (int)(3.0 * sqrt(dn) / 13.0);
+    for (int k = 1; k <= lag; k++) {
+        double acc = 0.0;
+        for (int t = k; t < n; t++) acc = fma(x[t] - mean, x[t - k] - mean, acc);
+        double wgt = 1.0 - (double)k / ((double)lag + 1.0);
+        s2 = s2 + 2.0 * wgt * (acc / dn);
+    }
+    if (!(s2 > 0.0)) return 0;          /* constant series: stationary */
+    return (eta / s2) > 0.463;
+}
+
+/* Strength of seasonality 1 - Var(remainder)/Var(detrended) of the classical additive decomposition
+ * (centred moving average trend, per-phase means), in [0, 1]; 0 when the series is too short. */
+double oracle_arima_seasonal_strength(const double *y, int n, int m)
+{
+    if (m < 2 || n < 3 * m) return 0.0;
+    const int half = m / 2;
+    const int L = (m % 2 == 0) ? m + 1 : m;
+    const double w = 1.0 / (double)m;
+    const double wend = (m % 2 == 0) ? 0.5 / (double)m : w;
+    double fig[ARIMA_MAX_PERIOD];
+    double tot = 0.0;
+    for (int j = 0; j < m; j++) {
+        double sj = 0.0;
+        int cnt = 0;
+        for (int i = (j >= half ? j : j + m); i < n - half; i += m) {
+            double acc = 0.0;
+            for (int k = 0; k < L; k++) acc = acc + ((k == 0 || k == L - 1) ? wend : w) * y[i - half + k];
+            sj = sj + (y[i] - acc);
+            cnt++;
+        }
+        fig[j] = sj / (double)cnt;
+        tot = tot + fig[j];
+    }
+    const double fmean = tot / (double)m;
+    for (int j = 0; j < m; j++) fig[j] = fig[j] - fmean;
+    /* variances of detrended and remainder over the valid range (two passes each) */
+    const int nv = n - 2 * half;
+    double sd = 0.0, sr = 0.0;
+    for (int i = half; i < n - half; i++) {
+        double acc = 0.0;
+        for (int k = 0; k < L; k++) acc = acc + ((k == 0 || k == L - 1) ? wend : w) * y[i - half + k];
+        double d = y[i] - acc;
+        sd = sd + d;
+        sr = sr + (d - fig[i % m]);
+    }
+    const double md = sd / (double)nv, mr = sr / (double)nv;
+    double vd = 0.0, vr = 0.0;
+    for (int i = half; i < n - half; i++) {
+        double acc = 0.0;
+        for (int k = 0; k < L; k++) acc = acc + ((k == 0 || k == L - 1) ? wend : w) * y[i - half + k];
+        double d = y[i] - acc;
+        double r = d - fig[i % m];
+        vd = fma(d - md, d - md, vd);
+        vr = fma(r - mr, r - mr, vr);
+    }
+    if (!(vd > 0.0)) return 0.0;
+    double f = 1.0 - vr / vd;
+    if (f < 0.0) f = 0.0;
+    if (f > 1.0) f = 1.0;
+    return f;
+}
+
+/* ---------------------------------------------------------------------------------------------- */
+/* conditional sum of squares                                                                      */
+/* ---------------------------------------------------------------------------------------------- */
+
+static double det_tanh(double u)
+{
+    /* (e^{2u} - 1)/(e^{2u} + 1), odd, saturating */
+    if (u > 20.0) return 1.0;
+    if (u < -20.0) return -1.0;
+    double e2 = det_exp(2.0 * u);
+    return (e2 - 1.0) / (e2 + 1.0);
+}
+
+/* partial autocorrelations -> coefficients of a stationary AR polynomial (Durbin-Levinson / Jones 1980) */
+static void pacf_to_ar(const double *u, int k, double *phi)
+{
+    double work[ARIMA_MAX_P];
+    for (int j = 0; j < k; j++) {
+        double a = det_tanh(u[j]);
+        for (int i = 0; i < j; i++) work[i] = phi[i] - a * phi[j - 1 - i];
+        for (int i = 0; i < j; i++) phi[i] = work[i];
+        phi[j] = a;
+    }
+}
+
+/* expand (1 - sum phi_i B^i)(1 - sum Phi_I B^{mI}) = 1 - sum a_k B^k ; returns the order */
+static int expand_poly(const double *ns, int p, const double *se, int P, int m, double *a)
+{
+    const int L = p + m * P;
+    for (int k = 0; k <= L; k++) a[k] = 0.0;
+    for (int i = 1; i <= p; i++) a[i] = ns[i - 1];
+    for (int I = 1; I <= P; I++) {
+        a[m * I] = a[m * I] + se[I - 1];
+        for (int i = 1; i <= p; i++) a[m * I + i] = a[m * I + i] - ns[i - 1] * se[I - 1];
+    }
+    return L;
+}
+
+typedef struct { double a[ARIMA_MAX_LAG + 1], b[ARIMA_MAX_LAG + 1]; int La, Lb; double mu; } ArimaPoly;
+
+static void build_poly(const ArimaOrder *o, const double *x, ArimaPoly *pl)
+{
+    double phi[ARIMA_MAX_P], th[ARIMA_MAX_P], Phi[ARIMA_MAX_SP], Th[ARIMA_MAX_SP];
+    int k = 0;
+    pacf_to_ar(x + k, o->p, phi); k += o->p;
+    pacf_to_ar(x + k, o->q, th); k += o->q;
+    pacf_to_ar(x + k, o->P, Phi); k += o->P;
+    pacf_to_ar(x + k, o->Q, Th); k += o->Q;
+    pl->mu = o->with_constant ? x[k] : 0.0;
+    const int m = o->s > 1 ? o->s : 1;
+    pl->La = expand_poly(phi, o->p, Phi, o->P, m, pl->a);
+    /* MA: 1 + theta(B) with theta = -psi keeps 1 - psi(B) invertible */
+    double b[ARIMA_MAX_LAG + 1];
+    pl->Lb = expand_poly(th, o->q, Th, o->Q, m, b);
+    for (int i = 0; i <= pl->Lb; i++) pl->b[i] = -b[i];
+}
+
+/* objective 0.5 log(CSS / nu); e_t = (w_t - mu) - sum a_k (w_{t-k} - mu) - sum b_k e_{t-k}, t >= La */
+static double css_eval(const ArimaPoly *pl, const double *w, int n, double *e, double *css_out, int *nu_out)
+{
+    const int nc = pl->La;
+    const int nu = n - nc;
+    if (nu <= 0) { if (css_out) *css_out = INFINITY; if (nu_out) *nu_out = 0; return INFINITY; }
+    double css = 0.0;
+    for (int t = 0; t < nc; t++) e[t] = 0.0;
+    for (int t = nc; t < n; t++) {
+        double acc = w[t] - pl->mu;
+        for (int k = 1; k <= pl->La; k++) acc = fma(-pl->a[k], w[t - k] - pl->mu, acc);
+        const int kb = (t - nc) < pl->Lb ? (t - nc) : pl->Lb;
+        for (int k = 1; k <= kb; k++) acc = fma(-pl->b[k], e[t - k], acc);
+        e[t] = acc;
+        css = fma(acc, acc, css);
+    }
+    if (css_out) *css_out = css;
+    if (nu_out) *nu_out = nu;
+    if (!(fabs(css) <= DBL_MAX)) return INFINITY;
+    double v = css / (double)nu;
+    if (v < 1.0e-300) v = 1.0e-300;
+    return 0.5 * det_log(v);
+}
+
+double oracle_arima_css(const ArimaOrder *ord, const double *x, const double *w, int n, double *css_out, int *nu_out)
+{
+    ArimaPoly pl;
+    build_poly(ord, x, &pl);
+    double *e = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    double f = css_eval(&pl, w, n, e, css_out, nu_out);
+    free(e);
+    return f;
+}
+
+/* ---------------------------------------------------------------------------------------------- */
+/* Nelder-Mead with absolute initial steps, run-time dimension (same accept / shrink rules as ets.c) */
+/* ---------------------------------------------------------------------------------------------- */
+
+typedef struct { const ArimaOrder *ord; const double *w; int n; double *e; } CssCtx;
+
+static double css_obj(const double *x, CssCtx *c)
+{
+    ArimaPoly pl;
+    build_poly(c->ord, x, &pl);
+    return css_eval(&pl, c->w, c->n, c->e, NULL, NULL);
+}
+
+static void nm_steps(CssCtx *ctx, int n, const double *x0, const double *step, double *xbest, double *fbest, int *iters_out, int *evals_out)
+{
+    double sim[ARIMA_MAX_DIM + 1][ARIMA_MAX_DIM], fs[ARIMA_MAX_DIM + 1], xb[ARIMA_MAX_DIM], xr[ARIMA_MAX_DIM], xt[ARIMA_MAX_DIM];
+    const int maxiter = 200 * n, maxfun = 200 * n;
+    int evals = 0, iters = 1;
+    if (n == 0) { *fbest = css_obj(x0, ctx); *iters_out = 0; *evals_out = 1; return; }
+    for (int i = 0; i < n; i++) sim[0][i] = x0[i];
+    for (int k = 0; k < n; k++) {
+        for (int i = 0; i < n; i++) sim[k + 1][i] = x0[i];
+        sim[k + 1][k] = x0[k] + step[k];
+    }
+    for (int k = 0; k <= n; k++) { fs[k] = css_obj(sim[k], ctx); evals++; }
+#define SORT_FROM(k0)                                                                                  \
+    for (int k = (k0); k <= n; k++) {                                                                  \
+        double fk = fs[k], tmp[ARIMA_MAX_DIM];                                                         \
+        memcpy(tmp, sim[k], sizeof tmp);                                                               \
+        int j = k;                                                                                     \
+        while (j > 0 && fk < fs[j - 1]) { fs[j] = fs[j - 1]; memcpy(sim[j], sim[j - 1], sizeof tmp); j--; } \
+        fs[j] = fk; memcpy(sim[j], tmp, sizeof tmp);                                                   \
+    }
+    SORT_FROM(1)
+    while (evals < maxfun && iters < maxiter) {
+        int small = 1;
+        for (int k = 1; k <= n && small; k++) {
+            for (int i = 0; i < n; i++) if (!(fabs(sim[k][i] - sim[0][i]) <= 1.0e-4)) small = 0;
+            if (!(fabs(fs[0] - fs[k]) <= 1.0e-8)) small = 0;
+        }
+        if (small) break;
+        for (int i = 0; i < n; i++) {
+            double s = sim[0][i];
+            for (int k = 1; k < n; k++) s = s + sim[k][i];
+            xb[i] = s / (double)n;
+        }
+        const double *xw = sim[n];
+        for (int i = 0; i < n; i++) xr[i] = 2.0 * xb[i] - xw[i];
+        double fxr = css_obj(xr, ctx); evals++;
+        int doshrink = 0;
+        double fnew = 0.0; const double *xnew = NULL;
+        if (fxr < fs[0]) {
+            for (int i = 0; i < n; i++) xt[i] = 3.0 * xb[i] - 2.0 * xw[i];
+            double fxe = css_obj(xt, ctx); evals++;
+            if (fxe < fxr) { xnew = xt; fnew = fxe; } else { xnew = xr; fnew = fxr; }
+        } else if (fxr < fs[n - 1]) { xnew = xr; fnew = fxr; }
+        else if (fxr < fs[n]) {
+            for (int i = 0; i < n; i++) xt[i] = 1.5 * xb[i] - 0.5 * xw[i];
+            double fxc = css_obj(xt, ctx); evals++;
+            if (fxc <= fxr) { xnew = xt; fnew = fxc; } else doshrink = 1;
+        } else {
+            for (int i = 0; i < n; i++) xt[i] = 0.5 * xb[i] + 0.5 * xw[i];
+            double fxcc = css_obj(xt, ctx); evals++;
+            if (fxcc < fs[n]) { xnew = xt; fnew = fxcc; } else doshrink = 1;
+        }
+        if (!doshrink) {
+            double tmp[ARIMA_MAX_DIM];
+            for (int i = 0; i < n; i++) tmp[i] = xnew[i];
+            int j = n;
+            while (j > 0 && fnew < fs[j - 1]) { fs[j] = fs[j - 1]; memcpy(sim[j], sim[j - 1], sizeof tmp); j--; }
+            fs[j] = fnew;
+            for (int i = 0; i < n; i++) sim[j][i] = tmp[i];
+        } else {
+            for (int k = 1; k <= n; k++) {
+                for (int i = 0; i < n; i++) sim[k][i] = sim[0][i] + 0.5 * (sim[k][i] - sim[0][i]);
+                fs[k] = css_obj(sim[k], ctx); evals++;
+            }
+            SORT_FROM(1)
+        }
+        iters++;
+    }
+#undef SORT_FROM
+    for (int i = 0; i < n; i++) xbest[i] = sim[0][i];
+    *fbest = fs[0];
+    *iters_out = iters;
+    *evals_out = evals;
+}
+
+/* ---------------------------------------------------------------------------------------------- */
+/* model fit, stepwise search, forecast                                                            */
+/* ---------------------------------------------------------------------------------------------- */
+
+static int model_dim(const ArimaOrder *o) { return o->p + o->q + o->P + o->Q + (o->with_constant ? 1 : 0); }
+
+static int fit_model(const ArimaOrder *o, const double *w, int n, double wmean, double wsd, double *e, ArimaFit *fit)
+{
+    const int dim = model_dim(o);
+    const int k = dim + 1;                              /* + innovation variance */
+    fit->ord = *o;
+    fit->aicc = INFINITY;
+    fit->evals = fit->iters = 0;
+    const int La = o->p + (o->s > 1 ? o->s : 1) * o->P;
+    if (n - La <= 0 || n - k - 1 <= 0) return 0;
+    double x0[ARIMA_MAX_DIM], step[ARIMA_MAX_DIM];
+    for (int i = 0; i < dim; i++) { x0[i] = 0.0; step[i] = 0.25; }
+    if (o->with_constant) { x0[dim - 1] = wmean; step[dim - 1] = wsd > 0.0 ? 0.1 * wsd : 1.0e-4; }
+    CssCtx ctx = { o, w, n, e };
+    double f;
+    nm_steps(&ctx, dim, x0, step, fit->x, &f, &fit->iters, &fit->evals);
+    ArimaPoly pl;
+    build_poly(o, fit->x, &pl);
+    int nu;
+    css_eval(&pl, w, n, e, &fit->css, &nu);
+    if (!(fabs(fit->css) <= DBL_MAX)) return 0;
+    double v = fit->css / (double)nu;
+    if (v < 1.0e-300) v = 1.0e-300;
+    fit->sigma2 = v;
+    fit->n_used = n;
+    const double dn = (double)n, dk = (double)k;
+    fit->aicc = dn * det_log(v) + 2.0 * dk + 2.0 * dk * (dk + 1.0) / (dn - dk - 1.0);
+    return fabs(fit->aicc) <= DBL_MAX;
+}
+
+static int order_key(const ArimaOrder *o) { return (((o->p * 6 + o->q) * 3 + o->P) * 3 + o->Q) * 2 + (o->with_constant ? 1 : 0); }
+
+int oracle_auto_arima_detail(const double *y, int n, int period, int h, double *out, ArimaFit *best_out, int *models_tried, int *total_evals)
+{
+    if (models_tried) *models_tried = 0;
+    if (total_evals) *total_evals = 0;
+    if (n < 3) return 0;
+    const int m = (period > 1 && period <= ARIMA_MAX_PERIOD) ? period : 1;
+    double *buf = (double *)malloc(sizeof(double) * (size_t)n * 3);
+    double *x = buf, *e = buf + n, *tmp = buf + 2 * n;
+    memcpy(x, y, sizeof(double) * (size_t)n);
+    int len = n, D = 0, d = 0;
+    if (m > 1 && oracle_arima_seasonal_strength(y, n, m) > 0.64 && n > m + 2) {
+        D = 1;
+        for (int t = m; t < len; t++) tmp[t - m] = x[t] - x[t - m];
+        len -= m;
+        memcpy(x, tmp, sizeof(double) * (size_t)len);
+    }
+    while (d < 2 && len > 3 && oracle_arima_kpss_reject(x, len)) {
+        for (int t = 1; t < len; t++) tmp[t - 1] = x[t] - x[t - 1];
+        len -= 1;
+        memcpy(x, tmp, sizeof(double) * (size_t)len);
+        d++;
+    }
+    const double *w = x;
+    double s = 0.0;
+    for (int i = 0; i < len; i++) s = s + w[i];
+    const double wmean = s / (double)len;
+    double v = 0.0;
+    for (int i = 0; i < len; i++) v = fma(w[i] - wmean, w[i] - wmean, v);
+    const double wsd = sqrt(v / (double)len);
+    const int allow_c = (d + D <= 1);
+    const int maxP = (m > 1) ? ARIMA_MAX_SP : 0;
+
+    unsigned char tried[6 * 6 * 3 * 3 * 2];
+    memset(tried, 0, sizeof tried);
+    ArimaFit best, cur;
+    best.aicc = INFINITY;
+    int have = 0, n_models = 0, evals = 0;
+
+#define TRY(pp, qq, PP, QQ, cc)                                                                          \
+    do {                                                                                                 \
+        ArimaOrder o_ = { (pp), d, (qq), (PP), D, (QQ), m, (cc) };                                       \
+        if (o_.p >= 0 && o_.q >= 0 && o_.P >= 0 && o_.Q >= 0 && o_.p <= ARIMA_MAX_P && o_.q <= ARIMA_MAX_P && \
+            o_.P <= maxP && o_.Q <= maxP && o_.p + o_.q + o_.P + o_.Q <= ARIMA_MAX_ORDER && (!o_.with_constant || allow_c) && \
+            n_models < ARIMA_MAX_MODELS && !tried[order_key(&o_)]) {                                     \
+            tried[order_key(&o_)] = 1;                                                                   \
+            n_models++;                                                                                  \
+            int ok_ = fit_model(&o_, w, len, wmean, wsd, e, &cur);                                       \
+            evals += cur.evals;                                                                          \
+            if (ok_ && cur.aicc < best.aicc) { best = cur; have = 1; improved = 1; }                     \
+        }                                                                                                \
+    } while (0)
+
+    int improved = 0;
+    const int c0 = allow_c ? 1 : 0;
+    TRY(2, 2, maxP ? 1 : 0, maxP ? 1 : 0, c0);
+    TRY(0, 0, 0, 0, c0);
+    TRY(1, 0, maxP ? 1 : 0, 0, c0);
+    TRY(0, 1, 0, maxP ? 1 : 0, c0);
+    if (allow_c) TRY(0, 0, 0, 0, 0);
+    while (have) {
+        improved = 0;
+        const ArimaOrder b = best.ord;
+        static const int dP[8] = { -1, 0, 1, 0, -1, -1, 1, 1 }, dQ[8] = { 0, -1, 0, 1, -1, 1, -1, 1 };
+        for (int k = 0; k < 8 && !improved; k++) TRY(b.p, b.q, b.P + dP[k], b.Q + dQ[k], b.with_constant);
+        for (int k = 0; k < 8 && !improved; k++) TRY(b.p + dP[k], b.q + dQ[k], b.P, b.Q, b.with_constant);
+        if (!improved) TRY(b.p, b.q, b.P, b.Q, !b.with_constant);
+        if (!improved) break;
+    }
+#undef TRY
+    if (models_tried) *models_tried = n_models;
+    if (total_evals) *total_evals = evals;
+    if (!have) { free(buf); return 0; }
+
+    /* forecast the differenced series, then integrate */
+    ArimaPoly pl;
+    build_poly(&best.ord, best.x, &pl);
+    int nu;
+    css_eval(&pl, w, len, e, NULL, &nu);
+    double *wf = (double *)malloc(sizeof(double) * (size_t)(len + h) * 2);
+    double *ef = wf + (len + h);
+    memcpy(wf, w, sizeof(double) * (size_t)len);
+    memcpy(ef, e, sizeof(double) * (size_t)len);
+    for (int j = 0; j < h; j++) {
+        const int t = len + j;
+        double acc = pl.mu;
+        for (int k = 1; k <= pl.La; k++) if (t - k >= 0) acc = fma(pl.a[k], wf[t - k] - pl.mu, acc);
+        for (int k = 1; k <= pl.Lb; k++) if (t - k >= 0 && t - k < len) acc = fma(pl.b[k], ef[t - k], acc);
+        wf[t] = acc;
+        ef[t] = 0.0;
+    }
+    /* undo the d ordinary differences (innermost first), then the seasonal one */
+    double *lev = (double *)malloc(sizeof(double) * (size_t)(n + h) * 3);
+    /* rebuild the chain of partially differenced series to get their last values */
+    double *z0 = lev, *z1 = lev + (n + h), *z2 = lev + 2 * (n + h);
+    int l0 = n;
+    memcpy(z0, y, sizeof(double) * (size_t)n);
+    if (D) { for (int t = m; t < l0; t++) z1[t - m] = z0[t] - z0[t - m]; } else memcpy(z1, z0, sizeof(double) * (size_t)l0);
+    int l1 = l0 - D * m;                                 /* z1: after seasonal differencing */
+    double last_d0 = z1[l1 - 1];                          /* last value at difference level 0 (of z1) */
+    double last_d1 = (d >= 1 && l1 >= 2) ? z1[l1 - 1] - z1[l1 - 2] : 0.0;   /* last first difference */
+    (void)z2;
+    for (int j = 0; j < h; j++) {
+        double val = wf[len + j];
+        if (d == 2) { last_d1 = last_d1 + val; val = last_d1; }
+        if (d >= 1) { last_d0 = last_d0 + val; val = last_d0; }
+        z1[l1 + j] = val;                                 /* forecast of the seasonally differenced series */
+    }
+    for (int j = 0; j < h; j++) {
+        double val = z1[l1 + j];
+        if (D) { val = val + z0[l0 + j - m]; }
+        z0[l0 + j] = val;
+        out[j] = val;
+    }
+    if (best_out) *best_out = best;
+    free(lev);
+    free(wf);
+    free(buf);
+    return 1;
+}
 
 int oracle_auto_arima(const double *y, int n, int period, int h, double *out, ArimaOrder *ord)
 {
-    (void)y; (void)n; (void)period; (void)h; (void)out; (void)ord;
-    return 0; /* not yet restated */
+    ArimaFit fit;
+    if (!oracle_auto_arima_detail(y, n, period, h, out, &fit, NULL, NULL)) return 0;
+    *ord = fit.ord;
+    return 1;
 }
 
 void oracle_arima_name(const ArimaOrder *o, char out[64])

@@ -1,17 +1,50 @@
 /*
  * arima.h -- TEST INFRASTRUCTURE (oracle).  Not part of the product.
- * AutoARIMA restatement (reference call site crates/anofox-fcst-core/src/forecast.rs:1435-1521;
- * arithmetic in the un-vendored anofox-forecast 0.15.3 crate).
+ *
+ * AutoARIMA restatement.  Reference call site: crates/anofox-fcst-core/src/forecast.rs:1435-1521
+ * (AutoARIMAConfig::default()[.with_seasonal_period(m)], model.fit, model.predict, name from
+ * selected_full_order()).  The arithmetic lives in the un-vendored crate anofox-forecast 0.15.3, so this is
+ * the published Hyndman-Khandakar procedure (forecast::auto.arima / StatsForecast lineage):
+ *   D  : seasonal strength of the classical decomposition > 0.64            (max D = 1)
+ *   d  : KPSS level test, lag trunc(3 sqrt(n)/13), 5% critical value 0.463  (max d = 2)
+ *   fit: conditional sum of squares over tanh-PACF transformed coefficients, Nelder-Mead
+ *   search: stepwise over (p,q,P,Q,constant), p,q <= 5, P,Q <= 2, p+q+P+Q <= 5, AICc
+ * The only numeric pin in the reference tree is the 6-decimal KAT 18.014537 of
+ * test/sql/ts_model_distinctness.test:164; it is NOT reproduced to that precision (parity unpinned).
  */
 #ifndef ORACLE_ARIMA_H
 #define ORACLE_ARIMA_H
 #ifdef __cplusplus
 extern "C" {
 #endif
+
+#define ARIMA_MAX_P 5
+#define ARIMA_MAX_SP 2
+#define ARIMA_MAX_ORDER 5
+#define ARIMA_MAX_PERIOD 24        /* seasonal ARIMA terms only for m <= 24 (else non-seasonal search) */
+#define ARIMA_MAX_DIM 6            /* p+q+P+Q <= 5, plus the constant */
+#define ARIMA_MAX_LAG (ARIMA_MAX_P + ARIMA_MAX_SP * ARIMA_MAX_PERIOD)
+#define ARIMA_MAX_MODELS 94
+
 typedef struct ArimaOrder { int p, d, q, P, D, Q, s; int with_constant; } ArimaOrder;
+
+typedef struct ArimaFit {
+    ArimaOrder ord;
+    double x[ARIMA_MAX_DIM];   /* optimiser coordinates: u (tanh-PACF) for phi, theta, Phi, Theta, then mu */
+    double css, sigma2, aicc;
+    int n_used, evals, iters;
+} ArimaFit;
+
 /* returns 1 on success (h forecasts in out, selected order in ord), 0 on failure */
 int oracle_auto_arima(const double *y, int n, int period, int h, double *out, ArimaOrder *ord);
 void oracle_arima_name(const ArimaOrder *ord, char out[64]);
+
+/* pieces, exported for tests */
+int oracle_arima_kpss_reject(const double *x, int n);
+double oracle_arima_seasonal_strength(const double *y, int n, int m);
+double oracle_arima_css(const ArimaOrder *ord, const double *x, const double *w, int n, double *css_out, int *nu_out);
+int oracle_auto_arima_detail(const double *y, int n, int period, int h, double *out, ArimaFit *fit, int *models_tried, int *total_evals);
+
 #ifdef __cplusplus
 }
 #endif

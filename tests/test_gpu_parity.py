@@ -204,3 +204,18 @@ def test_device_resident_batch_and_stats(env):
     assert st["n_series"] == n and st["total_passes"] >= st["total_evals"] / 4 and st["fit_kernel_ms"] > 0
     assert st["algorithmic_bytes"] == 8 * T * st["total_passes"] + 24 * h * n
     b.close()
+
+
+def test_auto_arima_matches_oracle(env):
+    """AutoARIMA (stepwise CSS search) on the GPU walks the oracle's search bit for bit: same selected order,
+    same forecasts -- seasonal (m = 7: VGPR-free generic lag polynomials), non-seasonal, ragged, short."""
+    api, O, lib, synth = env
+    Y = synth.gen_series(synth.SEED_M5, 9000, 70, 150, 7)
+    rng = np.random.default_rng(11)
+    series = [Y[s, : 150 - (s % 7) * 11] for s in range(64)]
+    series += [np.cumsum(rng.normal(0.1, 1.0, 120)), 20 + 5 * np.sin(2 * np.pi * np.arange(140) / 7) + rng.normal(0, 0.3, 140),
+               np.array(KAT_SERIES, dtype=float), np.arange(8.0), np.array([1.0, 2.0, 3.0]), np.full(40, 7.0)]
+    _compare(api, O, lib, series, "AutoARIMA", 10, seasonal_period=7)
+    _compare(api, O, lib, series, "AutoARIMA", 10)                        # auto-detected periods (host packer)
+    r = api.forecast_series(KAT_SERIES, lib.make_options("AutoARIMA", 3, auto_detect=False))
+    assert r["ok"] and r["model_name"].startswith("AutoARIMA(") and abs(r["point"][0] - 18.014537) / 18.014537 < 2e-3
