@@ -52,7 +52,7 @@ __device__ __forceinline__ void ar_pacf(const double *u, int k, double *phi)
     }
 }
 
-// LDS layout per wave (doubles, lane-minor): [simplex 42 + values 7][acoef L1][bcoef L1][ering L1][tried 11]
+// LDS layout per wave (doubles, lane-minor): [simplex 42 + values 7][acoef L1][bcoef L1][e ring L1][v ring L1][tried 11]
 struct ArLds {
     double *base; int L1;
     __device__ double &sim(int k, int i) const { return base[(k * AR_MAXDIM + i) * NM_BLOCK + threadIdx.x]; }
@@ -60,9 +60,27 @@ struct ArLds {
     __device__ double &a(int k) const { return base[(49 + k) * NM_BLOCK + threadIdx.x]; }
     __device__ double &b(int k) const { return base[(49 + L1 + k) * NM_BLOCK + threadIdx.x]; }
     __device__ double &e(int k) const { return base[(49 + 2 * L1 + k) * NM_BLOCK + threadIdx.x]; }
-    __device__ uint32_t &tried(int wd) const { return ((uint32_t *)(base + (size_t)(49 + 3 * L1) * NM_BLOCK))[wd * NM_BLOCK + threadIdx.x]; }
+    __device__ double &v(int k) const { return base[(49 + 3 * L1 + k) * NM_BLOCK + threadIdx.x]; }
+    __device__ uint32_t &tried(int wd) const { return ((uint32_t *)(base + (size_t)(49 + 4 * L1) * NM_BLOCK))[wd * NM_BLOCK + threadIdx.x]; }
 };
-static size_t ar_lds_bytes(int m) { int L1 = AR_MAXP + AR_MAXSP * m + 1; return sizeof(double) * (size_t)(49 + 3 * L1 + 11) * NM_BLOCK; }
+static size_t ar_lds_bytes(int m) { int L1 = AR_MAXP + AR_MAXSP * m + 1; return sizeof(double) * (size_t)(49 + 4 * L1 + 11) * NM_BLOCK; }
+
+// the four factor polynomials of a trial point, zero padded (registers)
+struct ArFac { double phi[AR_MAXP], th[AR_MAXP], Phi[AR_MAXSP], Th[AR_MAXSP]; double mu; int nc; };
+__device__ __forceinline__ void ar_factors(const ArOrd &o, int m, const double *x, ArFac &f)
+{
+#pragma unroll
+    for (int i = 0; i < AR_MAXP; i++) { f.phi[i] = 0.0; f.th[i] = 0.0; }
+#pragma unroll
+    for (int i = 0; i < AR_MAXSP; i++) { f.Phi[i] = 0.0; f.Th[i] = 0.0; }
+    int k = 0;
+    ar_pacf(x + k, o.p, f.phi); k += o.p;
+    ar_pacf(x + k, o.q, f.th); k += o.q;
+    ar_pacf(x + k, o.P, f.Phi); k += o.P;
+    ar_pacf(x + k, o.Q, f.Th); k += o.Q;
+    f.mu = o.c ? x[k] : 0.0;
+    f.nc = o.p + m * o.P;
+}
 
 // expanded lag polynomials of the trial point x into LDS
 __device__ __forceinline__ void ar_build_poly(const ArOrd &o, int m, const double *x, const ArLds &L, int &La, int &Lb, double &mu)
@@ -91,24 +109,47 @@ __device__ __forceinline__ void ar_build_poly(const ArOrd &o, int m, const doubl
     for (int i = 0; i <= Lb; i++) L.b(i) = -L.b(i);
 }
 
-// One CSS pass for the whole wave: e_t = (w_t - mu) - sum a_k (w_{t-k} - mu) - sum b_k e_{t-k}, t >= La.
-// Lane-private coefficients and the e ring (slot t % ring) live in LDS, w streams from HBM/L2.
-__device__ __forceinline__ double ar_css_pass(const double *w, size_t ld, int len, int wave_len, bool live, int La, int Lb, double mu,
+// One CSS pass for the whole wave, CASCADED form (oracle/arima.c css_eval): fixed 5 + 2 + 5 + 2 fused
+// multiply-adds per step whatever the lane's orders (absent coefficients are exact zeros), the short lags in
+// VGPR shift registers, the seasonal lags in LDS rings (slot t % ring, read before write), w streamed from HBM.
+//     v_t = w'_t - sum phi_i w'_{t-i} ; z_t = v_t - sum Phi_I v_{t-mI} ; u_t = z_t + sum theta_j u_{t-j} ;
+//     e_t = u_t + sum Theta_J e_{t-mJ}   (z, u, e from t >= nc = p + m P on)
+__device__ __forceinline__ double ar_css_pass(const double *w, size_t ld, int len, int wave_len, bool live, const ArFac &f, int m,
                                               const ArLds &L, int ring)
 {
     double css = 0.0;
-    const int waveLa = ar_wave_max(live ? La : 0), waveLb = ar_wave_max(live ? Lb : 0);
-    for (int k = 0; k < ring; k++) L.e(k) = 0.0;
+    double wl[AR_MAXP] = {0, 0, 0, 0, 0}, ul[AR_MAXP] = {0, 0, 0, 0, 0};
+    for (int k = 0; k < ring; k++) { L.e(k) = 0.0; L.v(k) = 0.0; }
+    int i0 = 0, i1 = (ring - m % ring) % ring, i2 = (ring - (2 * m) % ring) % ring;     // slots of t, t - m, t - 2m
     for (int t = 0; t < wave_len; t++) {
-        const bool on = live && t >= La && t < len;
-        double acc = 0.0;
-        if (on) acc = w[(size_t)t * ld] - mu;
-        for (int k = 1; k <= waveLa; k++)
-            if (on && k <= La) acc = fma(-L.a(k), w[(size_t)(t - k) * ld] - mu, acc);
-        const int kb = (t - La) < Lb ? (t - La) : Lb;
-        for (int k = 1; k <= waveLb; k++)
-            if (on && k <= kb) acc = fma(-L.b(k), L.e((t - k) % ring), acc);
-        if (on) { L.e(t % ring) = acc; css = fma(acc, acc, css); }
+        if (live && t < len) {
+            const double wp = w[(size_t)t * ld] - f.mu;
+            double vt = wp;
+#pragma unroll
+            for (int i = 0; i < AR_MAXP; i++) vt = fma(-f.phi[i], wl[i], vt);
+            const double vm1 = L.v(i1), vm2 = L.v(i2);
+            L.v(i0) = vt;
+            if (t >= f.nc) {
+                double z = fma(-f.Phi[0], vm1, vt);
+                z = fma(-f.Phi[1], vm2, z);
+                double u = z;
+#pragma unroll
+                for (int j = 0; j < AR_MAXP; j++) u = fma(f.th[j], ul[j], u);
+                double et = fma(f.Th[0], L.e(i1), u);
+                et = fma(f.Th[1], L.e(i2), et);
+                L.e(i0) = et;
+                css = fma(et, et, css);
+#pragma unroll
+                for (int j = AR_MAXP - 1; j > 0; j--) ul[j] = ul[j - 1];
+                ul[0] = u;
+            }
+#pragma unroll
+            for (int i = AR_MAXP - 1; i > 0; i--) wl[i] = wl[i - 1];
+            wl[0] = wp;
+        }
+        i0 = (i0 + 1 == ring) ? 0 : i0 + 1;
+        i1 = (i1 + 1 == ring) ? 0 : i1 + 1;
+        i2 = (i2 + 1 == ring) ? 0 : i2 + 1;
     }
     return css;
 }
@@ -390,16 +431,15 @@ __global__ __launch_bounds__(NM_BLOCK) void arima_search_kernel(const ArimaArgs 
             } else if (ph == PH_SHRINK) { for (int i = 0; i < D; i++) x[i] = L.sim(1 + vi, i); }
             else { for (int i = 0; i < D; i++) x[i] = L.sim(0, i); }      // PH_FINAL
         }
-        int La = 0, Lb = 0;
-        double mu = 0.0;
-        if (!fin) ar_build_poly(cur, m, x, L, La, Lb, mu);
+        ArFac fac;
+        ar_factors(cur, m, x, fac);
         if (__all(fin)) break;
 
         // ---- 3. one streamed pass -------------------------------------------------------------------
-        const double css = ar_css_pass(w, ld, len, wave_len, !fin, La, Lb, mu, L, ring);
+        const double css = ar_css_pass(w, ld, len, wave_len, !fin, fac, m, L, ring);
         if (fin) continue;
         passes++;
-        const int nu = len - La;
+        const int nu = len - fac.nc;
         double v = css / (double)nu;
         double f = __builtin_huge_val();
         if (fabs(css) <= 1.7976931348623157e308) {
@@ -483,8 +523,10 @@ __global__ __launch_bounds__(NM_BLOCK) void arima_forecast_kernel(const ArimaArg
     }
     int La = 0, Lb = 0;
     double mu = 0.0;
+    ArFac fac;
+    ar_factors(o, m, x, fac);
     if (live) ar_build_poly(o, m, x, L, La, Lb, mu);
-    (void)ar_css_pass(w, ld, len, wave_len, live, La, Lb, mu, L, ring);
+    (void)ar_css_pass(w, ld, len, wave_len, live, fac, m, L, ring);
     if (!live) return;
     const int n = a.len[s], h = a.h;
     const int d = a.d[s], Dd = a.D[s];

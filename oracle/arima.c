@@ -136,47 +136,80 @@ static int expand_poly(const double *ns, int p, const double *se, int P, int m, 
     return L;
 }
 
-typedef struct { double a[ARIMA_MAX_LAG + 1], b[ARIMA_MAX_LAG + 1]; int La, Lb; double mu; } ArimaPoly;
+typedef struct {
+    double a[ARIMA_MAX_LAG + 1], b[ARIMA_MAX_LAG + 1];    /* expanded polynomials (forecast stage) */
+    double phi[ARIMA_MAX_P], th[ARIMA_MAX_P], Phi[ARIMA_MAX_SP], Th[ARIMA_MAX_SP];   /* zero padded factors */
+    int La, Lb, m;
+    double mu;
+} ArimaPoly;
 
 static void build_poly(const ArimaOrder *o, const double *x, ArimaPoly *pl)
 {
-    double phi[ARIMA_MAX_P], th[ARIMA_MAX_P], Phi[ARIMA_MAX_SP], Th[ARIMA_MAX_SP];
+    for (int i = 0; i < ARIMA_MAX_P; i++) pl->phi[i] = pl->th[i] = 0.0;
+    for (int i = 0; i < ARIMA_MAX_SP; i++) pl->Phi[i] = pl->Th[i] = 0.0;
     int k = 0;
-    pacf_to_ar(x + k, o->p, phi); k += o->p;
-    pacf_to_ar(x + k, o->q, th); k += o->q;
-    pacf_to_ar(x + k, o->P, Phi); k += o->P;
-    pacf_to_ar(x + k, o->Q, Th); k += o->Q;
+    pacf_to_ar(x + k, o->p, pl->phi); k += o->p;
+    pacf_to_ar(x + k, o->q, pl->th); k += o->q;
+    pacf_to_ar(x + k, o->P, pl->Phi); k += o->P;
+    pacf_to_ar(x + k, o->Q, pl->Th); k += o->Q;
     pl->mu = o->with_constant ? x[k] : 0.0;
     const int m = o->s > 1 ? o->s : 1;
-    pl->La = expand_poly(phi, o->p, Phi, o->P, m, pl->a);
-    /* MA: 1 + theta(B) with theta = -psi keeps 1 - psi(B) invertible */
+    pl->m = m;
+    pl->La = expand_poly(pl->phi, o->p, pl->Phi, o->P, m, pl->a);
+    /* MA polynomial (1 - theta(B))(1 - Theta(B^m)) with the same stationary-region transform: invertible */
     double b[ARIMA_MAX_LAG + 1];
-    pl->Lb = expand_poly(th, o->q, Th, o->Q, m, b);
+    pl->Lb = expand_poly(pl->th, o->q, pl->Th, o->Q, m, b);
     for (int i = 0; i <= pl->Lb; i++) pl->b[i] = -b[i];
 }
 
-/* objective 0.5 log(CSS / nu); e_t = (w_t - mu) - sum a_k (w_{t-k} - mu) - sum b_k e_{t-k}, t >= La */
+/*
+ * Conditional sum of squares, objective 0.5 log(CSS / nu), in CASCADED form (four short filters instead of
+ * the two expanded lag polynomials; algebraically identical, fixed 5 + 2 + 5 + 2 terms per step whatever
+ * the orders, which is what lets a GPU wave run lanes with different orders through one code path):
+ *     w'_t = w_t - mu
+ *     v_t  = w'_t - sum_{i<=5} phi_i w'_{t-i}                      (t >= 0, missing history = 0)
+ *     z_t  = v_t  - sum_{I<=2} Phi_I v_{t-mI}                      (t >= nc = p + m P)
+ *     u_t  = z_t  + sum_{j<=5} theta_j u_{t-j}                     (u = 0 before nc)
+ *     e_t  = u_t  + sum_{J<=2} Theta_J e_{t-mJ}                    (e = 0 before nc)
+ * Coefficients beyond the model's orders are exact zeros.
+ */
 static double css_eval(const ArimaPoly *pl, const double *w, int n, double *e, double *css_out, int *nu_out)
 {
-    const int nc = pl->La;
+    const int nc = pl->La, m = pl->m;
     const int nu = n - nc;
     if (nu <= 0) { if (css_out) *css_out = INFINITY; if (nu_out) *nu_out = 0; return INFINITY; }
     double css = 0.0;
-    for (int t = 0; t < nc; t++) e[t] = 0.0;
-    for (int t = nc; t < n; t++) {
-        double acc = w[t] - pl->mu;
-        for (int k = 1; k <= pl->La; k++) acc = fma(-pl->a[k], w[t - k] - pl->mu, acc);
-        const int kb = (t - nc) < pl->Lb ? (t - nc) : pl->Lb;
-        for (int k = 1; k <= kb; k++) acc = fma(-pl->b[k], e[t - k], acc);
-        e[t] = acc;
-        css = fma(acc, acc, css);
+    double *v = (double *)malloc(sizeof(double) * (size_t)n);
+    double wl[ARIMA_MAX_P] = {0, 0, 0, 0, 0}, ul[ARIMA_MAX_P] = {0, 0, 0, 0, 0};
+    for (int t = 0; t < n; t++) {
+        const double wp = w[t] - pl->mu;
+        double vt = wp;
+        for (int i = 0; i < ARIMA_MAX_P; i++) vt = fma(-pl->phi[i], wl[i], vt);
+        v[t] = vt;
+        if (t >= nc) {
+            double z = vt;
+            for (int I = 1; I <= ARIMA_MAX_SP; I++) z = fma(-pl->Phi[I - 1], (t - m * I >= 0) ? v[t - m * I] : 0.0, z);
+            double u = z;
+            for (int j = 0; j < ARIMA_MAX_P; j++) u = fma(pl->th[j], ul[j], u);
+            double et = u;
+            for (int J = 1; J <= ARIMA_MAX_SP; J++) et = fma(pl->Th[J - 1], (t - m * J >= 0) ? e[t - m * J] : 0.0, et);
+            e[t] = et;
+            css = fma(et, et, css);
+            for (int j = ARIMA_MAX_P - 1; j > 0; j--) ul[j] = ul[j - 1];
+            ul[0] = u;
+        } else {
+            e[t] = 0.0;
+        }
+        for (int i = ARIMA_MAX_P - 1; i > 0; i--) wl[i] = wl[i - 1];
+        wl[0] = wp;
     }
+    free(v);
     if (css_out) *css_out = css;
     if (nu_out) *nu_out = nu;
     if (!(fabs(css) <= DBL_MAX)) return INFINITY;
-    double v = css / (double)nu;
-    if (v < 1.0e-300) v = 1.0e-300;
-    return 0.5 * det_log(v);
+    double vv = css / (double)nu;
+    if (vv < 1.0e-300) vv = 1.0e-300;
+    return 0.5 * det_log(vv);
 }
 
 double oracle_arima_css(const ArimaOrder *ord, const double *x, const double *w, int n, double *css_out, int *nu_out)
