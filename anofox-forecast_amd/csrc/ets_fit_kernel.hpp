@@ -31,6 +31,7 @@ __global__ __launch_bounds__(NM_BLOCK, ANOFOX_ROUND_WAVES) void ets_round_kernel
     const int lane = threadIdx.x;
     const int n_act = a.n_active ? *a.n_active : a.n_series;
     if ((int)blockIdx.x * PPB >= n_act) return;
+    if (a.spec_below >= 0 && SPEC != (n_act <= a.spec_below)) return;   // the other driver owns this round
     const int p = blockIdx.x * PPB + lane / LPP;
     const bool valid = p < n_act;
     const int s = valid ? (a.series_of ? a.series_of[p] : p) : 0;

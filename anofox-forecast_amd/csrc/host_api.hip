@@ -99,6 +99,7 @@ struct AnofoxHipBatch {
     uint64_t n_problems = 0;
     int seq_rounds = 3;      // rounds run by the sequential Nelder-Mead driver before switching to the speculative one
     int seq_rounds_env = -1; // ANOFOX_HIP_SEQ_ROUNDS override (-1 = decide from the number of live problems)
+    int spec_below = 8192;   // per spec: switch to the speculative driver once this few problems are still running
     bool use_gather = false; // rebuild a dense block of the running problems between rounds (else index y by series)
 };
 
@@ -486,8 +487,8 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
             hipStream_t sq = b->aux[q];
             FitArgs &a = args[oi];
             const bool spec_mode = r >= b->seq_rounds;
-            a.budget = spec_mode ? BUDGET[r] : (BUDGET[r] * 7) / 4;     // ~1.7 passes per iteration when sequential
             a.first_round = (r == 0);
+            a.spec_below = -1;
             a.gathered = 0;
             if (r == 0) {
                 a.y_round = b->d_y; a.ld_round = ld; a.series_of = nullptr; a.n_active = nullptr;
@@ -503,7 +504,19 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
                     a.y_round = b->d_y; a.ld_round = ld;
                 }
             }
-            (spec_mode ? fns[oi].round_spec : fns[oi].round_seq)(a, sq);
+            if (r == 0 || b->seq_rounds_env >= 0 || b->seq_rounds == 0) {
+                // first round (no device count yet) or a forced schedule: the host picks the driver
+                a.budget = spec_mode ? BUDGET[r] : (BUDGET[r] * 7) / 4;     // ~1.7 passes per iteration when sequential
+                (spec_mode ? fns[oi].round_spec : fns[oi].round_seq)(a, sq);
+            } else {
+                // later rounds: enqueue both drivers, the device-side count of running problems picks one --
+                // sequential (least arithmetic) while this spec still fills >= 1/8 of the chip, else speculative
+                a.spec_below = b->spec_below;
+                a.budget = (BUDGET[r] * 7) / 4;
+                fns[oi].round_seq(a, sq);
+                a.budget = BUDGET[r];
+                fns[oi].round_spec(a, sq);
+            }
             b->fit_launches++;
         }
     }
@@ -789,6 +802,7 @@ bool anofox_hip_batch_create(size_t n_series, size_t t_max, const ForecastOption
         // candidate spec: on by default while that stays under 24 GiB of the 288 GB HBM
         b->use_gather = (double)max_slots_for(plan) * (double)std::max<size_t>(t_max, 1) * (double)b->ld * 8.0 <= 24.0 * 1073741824.0;
         if (const char *e = std::getenv("ANOFOX_HIP_GATHER")) b->use_gather = std::atoi(e) != 0;
+        if (const char *e = std::getenv("ANOFOX_HIP_SPEC_BELOW")) b->spec_below = std::atoi(e);
         alloc_common(b);
     } catch (const HipFail &f) {
         set_error(out_error, INTERNAL_ERROR, "Internal error: " + f.msg);

@@ -38,6 +38,8 @@ struct FitArgs {
     const int32_t *series_of;
     const int32_t *n_active;
     int budget, first_round;
+    int spec_below;              // device-side driver choice: the speculative kernel runs iff n_active <= spec_below,
+                                 // the sequential one iff n_active > spec_below (both are enqueued; -1 = unconditional)
     int gathered;                // y_round holds the running problems' columns densely (column p), else index by series
     NmStateBuf st;
     int m, h;
