@@ -9,139 +9,6 @@
 namespace anofox {
 
 // ------------------------------------------------------------------------------------------
-// prep: per series mean / sd (forecast.rs:2558-2591), positivity / constancy flags, and the
-// ETS initial states (classical-decomposition seasonal figure; full-sample least-squares level
-// and growth of the seasonally adjusted series; see oracle/ets.c ets_init_states).
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NM_BLOCK) void prep_kernel(const PrepArgs a)
-{
-    const int s = blockIdx.x * NM_BLOCK + threadIdx.x;
-    if (s >= a.n_series) return;
-    const int n = a.len[s];
-    const double *y = a.y + s;
-    const size_t ld = a.ld;
-    if (n <= 0) return;   // not in this group: leave whatever another group wrote
-
-    double sum = 0.0;
-    bool positive = true, constant = true, has_nan = false;
-    const double y0 = y[0];
-    for (int t = 0; t < n; t++) {
-        double v = y[(size_t)t * ld];
-        sum += v;
-        if (!(v > 0.0)) positive = false;
-        if (v != y0) constant = false;
-        if (v != v) has_nan = true;
-    }
-    const double mean = sum / (double)n;
-    double var = 0.0;
-    for (int t = 0; t < n; t++) { double d = y[(size_t)t * ld] - mean; var += d * d; }
-    a.mean[s] = mean;
-    a.sd[s] = sqrt(var / (double)n);
-    a.flags[s] = (positive ? SF_POSITIVE : 0u) | (constant ? SF_CONSTANT : 0u) | (has_nan ? SF_HAS_NAN : 0u);
-    if (a.l0 == nullptr) return;
-
-    const int m = a.m;
-    const bool seasonal = (m >= 2 && m <= ETS_MAX_PERIOD && n >= 2 * m);
-    if (seasonal) {
-        const int half = m / 2;
-        const int L = (m % 2 == 0) ? m + 1 : m;
-        const double w = 1.0 / (double)m;
-        const double wend = (m % 2 == 0) ? 0.5 / (double)m : w;
-        for (int type = 1; type <= 2; type++) {
-            if (type == 2 && !positive) break;
-            double *fig = (type == 1 ? a.fig_add : a.fig_mul) + s;
-            double tot = 0.0;
-            for (int j = 0; j < m; j++) {
-                double sj = 0.0;
-                int cnt = 0;
-                for (int i = (j >= half ? j : j + m); i < n - half; i += m) {
-                    double acc = 0.0;
-                    for (int k = 0; k < L; k++) {
-                        double wk = (k == 0 || k == L - 1) ? wend : w;
-                        acc = acc + wk * y[(size_t)(i - half + k) * ld];
-                    }
-                    double d = (type == 1) ? (y[(size_t)i * ld] - acc) : (y[(size_t)i * ld] / acc);
-                    sj = sj + d;
-                    cnt++;
-                }
-                double fj = sj / (double)cnt;
-                fig[(size_t)j * ld] = fj;
-                tot = tot + fj;
-            }
-            const double fmean = tot / (double)m;
-            for (int j = 0; j < m; j++) {
-                double fj = fig[(size_t)j * ld];
-                if (type == 1) fj = fj - fmean;
-                else {
-                    fj = fj / fmean;
-                    if (!(fj >= 1.0e-2)) fj = 1.0e-2;
-                }
-                fig[(size_t)j * ld] = fj;
-            }
-        }
-    }
-
-    // level / growth for season type st = 0 (none), 1 (additive), 2 (multiplicative)
-    for (int st = 0; st <= 2; st++) {
-        if (st > 0 && !seasonal) break;
-        if (st == 2 && !positive) break;
-        const double *fig = (st == 1 ? a.fig_add : a.fig_mul) + s;
-        const int mm = (st == 0) ? 1 : m;
-        int K = 2 * mm > 10 ? 2 * mm : 10;
-        if (K > n) K = n;
-        double sy = 0.0, sxy = 0.0, sk = 0.0, ysa0 = 0.0, ysa1 = 0.0;
-        int j = 0;
-        for (int i = 0; i < n; i++) {
-            double v = y[(size_t)i * ld];
-            if (st == 1) v = v - fig[(size_t)j * ld];
-            else if (st == 2) v = v / fig[(size_t)j * ld];
-            sy = sy + v;
-            sxy = sxy + (double)(i + 1) * v;
-            if (i < K) sk = sk + v;
-            if (i == 0) ysa0 = v;
-            if (i == 1) ysa1 = v;
-            j = (j + 1 == mm) ? 0 : j + 1;
-        }
-        const double dn = (double)n;
-        const double sx = dn * (dn + 1.0) / 2.0;
-        const double sxx = dn * (dn + 1.0) * (2.0 * dn + 1.0) / 6.0;
-        const double slope = (dn * sxy - sx * sy) / (dn * sxx - sx * sx);
-        const double icpt = (sy - slope * sx) / dn;
-        // trend none
-        a.l0[(size_t)(st * 3 + 0) * ld + s] = sk / (double)K;
-        a.b0[(size_t)(st * 3 + 0) * ld + s] = 0.0;
-        // trend additive
-        {
-            double l0 = icpt, b0 = slope;
-            if (fabs(l0 + b0) < 1.0e-8) { l0 = l0 * (1.0 + 1.0e-3); b0 = b0 * (1.0 - 1.0e-3); }
-            a.l0[(size_t)(st * 3 + 1) * ld + s] = l0;
-            a.b0[(size_t)(st * 3 + 1) * ld + s] = b0;
-        }
-        // trend multiplicative
-        {
-            double l0 = icpt + slope;
-            if (fabs(l0) < 1.0e-8) l0 = 1.0e-7;
-            double b0 = (icpt + 2.0 * slope) / l0;
-            l0 = l0 / b0;
-            if (fabs(b0) > 1.0e10) b0 = (b0 < 0.0 ? -1.0e10 : 1.0e10);
-            if (l0 < 1.0e-8 || b0 < 1.0e-8) {
-                l0 = ysa0 > 1.0e-3 ? ysa0 : 1.0e-3;
-                double r = ysa1 / ysa0;
-                b0 = r > 1.0e-3 ? r : 1.0e-3;
-            }
-            a.l0[(size_t)(st * 3 + 2) * ld + s] = l0;
-            a.b0[(size_t)(st * 3 + 2) * ld + s] = b0;
-        }
-    }
-}
-
-void launch_prep(const PrepArgs &a, hipStream_t stream)
-{
-    const int grid = (a.n_series + NM_BLOCK - 1) / NM_BLOCK;
-    hipLaunchKernelGGL(prep_kernel, dim3(grid), dim3(NM_BLOCK), 0, stream, a);
-}
-
-// ------------------------------------------------------------------------------------------
 // AICc selection over the fitted spec slots (first minimum wins, oracle_auto_ets_search).
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NM_BLOCK) void select_kernel(const SelectArgs a)

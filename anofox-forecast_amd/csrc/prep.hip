@@ -1,0 +1,184 @@
+// prep.hip -- per-series statistics and ETS initial states in TWO streamed passes over the time-major block.
+//
+//   pass A: sum (-> mean), positivity / constancy flags, and the classical decomposition: a sliding window of
+//           the last L = 2*(m/2)+1 observations (LDS ring) gives the centred moving average of every interior
+//           point; the detrended value (y - trend, y / trend) is added to its phase's accumulator (LDS).
+//   pass B: sum of squared deviations (-> sd, forecast.rs:2558-2591) and, for the three season types at once,
+//           the sums of the full-sample least-squares line of the seasonally adjusted series and of its first
+//           K values (level-only start).
+// Same operations in the same order as oracle/ets.c (ets_init_states) and oracle/forecast.c (intervals), so the
+// results are bit-identical; only the number of times y is streamed changed (2 instead of ~22).
+#include "ets_device.hpp"
+#include "kernels.hpp"
+
+namespace anofox {
+
+__global__ __launch_bounds__(NM_BLOCK) void prep_kernel(const PrepArgs a)
+{
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const int s = blockIdx.x * NM_BLOCK + lane;
+    const bool valid = s < a.n_series;
+    const int n = valid ? a.len[s] : 0;
+    const int wave_n = wave_max_i32(n);
+    if (wave_n == 0) return;
+    const double *y = a.y + (valid ? s : 0);
+    const size_t ld = a.ld;
+    const bool states = a.l0 != nullptr;
+    const int m = a.m;
+    const bool want_season = states && m >= 2 && m <= ETS_MAX_PERIOD;
+    const int half = m / 2, L = 2 * half + 1;
+    // LDS (lane-minor): window ring [L], sumA [m], sumM [m], cnt [m]
+    double *ring = lds;
+    double *sumA = lds + (size_t)(want_season ? L : 0) * NM_BLOCK;
+    double *sumM = sumA + (size_t)(want_season ? m : 0) * NM_BLOCK;
+    double *cnt = sumM + (size_t)(want_season ? m : 0) * NM_BLOCK;
+    if (want_season)
+        for (int j = 0; j < m; j++) { sumA[j * NM_BLOCK + lane] = 0.0; sumM[j * NM_BLOCK + lane] = 0.0; cnt[j * NM_BLOCK + lane] = 0.0; }
+    const double w = want_season ? 1.0 / (double)m : 0.0;
+    const double wend = (want_season && m % 2 == 0) ? 0.5 / (double)m : w;
+    const bool seasonal = want_season && n >= 2 * m;
+
+    // ---- pass A ----------------------------------------------------------------------------------------
+    double sum = 0.0;
+    bool positive = true, constant = true, has_nan = false;
+    const double y0 = n > 0 ? y[0] : 0.0;
+    int slot = 0;                       // t % L
+    int ph = 0;                         // (t - half) % m, phase of the window centre
+    if (want_season) ph = ((-half) % m + m) % m;
+    for (int t = 0; t < wave_n; t++) {
+        if (t < n) {
+            const double v = y[(size_t)t * ld];
+            sum += v;
+            if (!(v > 0.0)) positive = false;
+            if (v != y0) constant = false;
+            if (v != v) has_nan = true;
+            if (seasonal) {
+                ring[slot * NM_BLOCK + lane] = v;
+                if (t >= L - 1) {
+                    double acc = 0.0;
+                    int k0 = slot + 1 == L ? 0 : slot + 1;           // slot of t - L + 1
+                    int kc = 0;
+                    double yc = 0.0;
+                    for (int k = 0; k < L; k++) {
+                        const double wk = (k == 0 || k == L - 1) ? wend : w;
+                        const double yv = ring[k0 * NM_BLOCK + lane];
+                        acc = acc + wk * yv;
+                        if (kc == half) yc = yv;
+                        kc++;
+                        k0 = k0 + 1 == L ? 0 : k0 + 1;
+                    }
+                    sumA[ph * NM_BLOCK + lane] = sumA[ph * NM_BLOCK + lane] + (yc - acc);
+                    sumM[ph * NM_BLOCK + lane] = sumM[ph * NM_BLOCK + lane] + (yc / acc);
+                    cnt[ph * NM_BLOCK + lane] += 1.0;
+                }
+            }
+        }
+        slot = slot + 1 == L ? 0 : slot + 1;
+        if (want_season) ph = ph + 1 == m ? 0 : ph + 1;
+    }
+    if (n <= 0) return;
+    const double mean = sum / (double)n;
+    a.mean[s] = mean;
+    a.flags[s] = (positive ? SF_POSITIVE : 0u) | (constant ? SF_CONSTANT : 0u) | (has_nan ? SF_HAS_NAN : 0u);
+
+    // seasonal figures (normalised), kept in LDS for pass B and written to HBM for the fit kernels
+    if (seasonal) {
+        for (int type = 1; type <= 2; type++) {
+            if (type == 2 && !positive) break;
+            double *acc = type == 1 ? sumA : sumM;
+            double tot = 0.0;
+            for (int j = 0; j < m; j++) {
+                const double fj = acc[j * NM_BLOCK + lane] / cnt[j * NM_BLOCK + lane];
+                acc[j * NM_BLOCK + lane] = fj;
+                tot = tot + fj;
+            }
+            const double fmean = tot / (double)m;
+            double *fig = (type == 1 ? a.fig_add : a.fig_mul) + s;
+            for (int j = 0; j < m; j++) {
+                double fj = acc[j * NM_BLOCK + lane];
+                if (type == 1) fj = fj - fmean;
+                else {
+                    fj = fj / fmean;
+                    if (!(fj >= 1.0e-2)) fj = 1.0e-2;
+                }
+                acc[j * NM_BLOCK + lane] = fj;
+                fig[(size_t)j * ld] = fj;
+            }
+        }
+    }
+
+    // ---- pass B ----------------------------------------------------------------------------------------
+    double var = 0.0;
+    double sy[3] = {0, 0, 0}, sxy[3] = {0, 0, 0}, sk[3] = {0, 0, 0}, ysa0[3] = {0, 0, 0}, ysa1[3] = {0, 0, 0};
+    const bool useA = seasonal, useM = seasonal && positive;
+    int K0 = 10 > n ? n : 10;
+    int Km = 2 * m > 10 ? 2 * m : 10;
+    if (Km > n) Km = n;
+    int j = 0;
+    for (int t = 0; t < n; t++) {
+        const double v = y[(size_t)t * ld];
+        const double dv = v - mean;
+        var += dv * dv;
+        if (states) {
+            double vs[3];
+            vs[0] = v;
+            vs[1] = useA ? v - sumA[j * NM_BLOCK + lane] : 0.0;
+            vs[2] = useM ? v / sumM[j * NM_BLOCK + lane] : 0.0;
+#pragma unroll
+            for (int st = 0; st < 3; st++) {
+                sy[st] = sy[st] + vs[st];
+                sxy[st] = sxy[st] + (double)(t + 1) * vs[st];
+                if (t < (st == 0 ? K0 : Km)) sk[st] = sk[st] + vs[st];
+                if (t == 0) ysa0[st] = vs[st];
+                if (t == 1) ysa1[st] = vs[st];
+            }
+            if (want_season) j = j + 1 == m ? 0 : j + 1;
+        }
+    }
+    a.sd[s] = sqrt(var / (double)n);
+    if (!states) return;
+    const double dn = (double)n;
+    const double sx = dn * (dn + 1.0) / 2.0;
+    const double sxx = dn * (dn + 1.0) * (2.0 * dn + 1.0) / 6.0;
+    for (int st = 0; st <= 2; st++) {
+        if (st == 1 && !useA) break;
+        if (st == 2 && !useM) break;
+        const double slope = (dn * sxy[st] - sx * sy[st]) / (dn * sxx - sx * sx);
+        const double icpt = (sy[st] - slope * sx) / dn;
+        const int K = st == 0 ? K0 : Km;
+        a.l0[(size_t)(st * 3 + 0) * ld + s] = sk[st] / (double)K;
+        a.b0[(size_t)(st * 3 + 0) * ld + s] = 0.0;
+        {
+            double l0 = icpt, b0 = slope;
+            if (fabs(l0 + b0) < 1.0e-8) { l0 = l0 * (1.0 + 1.0e-3); b0 = b0 * (1.0 - 1.0e-3); }
+            a.l0[(size_t)(st * 3 + 1) * ld + s] = l0;
+            a.b0[(size_t)(st * 3 + 1) * ld + s] = b0;
+        }
+        {
+            double l0 = icpt + slope;
+            if (fabs(l0) < 1.0e-8) l0 = 1.0e-7;
+            double b0 = (icpt + 2.0 * slope) / l0;
+            l0 = l0 / b0;
+            if (fabs(b0) > 1.0e10) b0 = (b0 < 0.0 ? -1.0e10 : 1.0e10);
+            if (l0 < 1.0e-8 || b0 < 1.0e-8) {
+                l0 = ysa0[st] > 1.0e-3 ? ysa0[st] : 1.0e-3;
+                double r = ysa1[st] / ysa0[st];
+                b0 = r > 1.0e-3 ? r : 1.0e-3;
+            }
+            a.l0[(size_t)(st * 3 + 2) * ld + s] = l0;
+            a.b0[(size_t)(st * 3 + 2) * ld + s] = b0;
+        }
+    }
+}
+
+void launch_prep(const PrepArgs &a, hipStream_t stream)
+{
+    const int grid = (a.n_series + NM_BLOCK - 1) / NM_BLOCK;
+    size_t lds_bytes = 0;
+    if (a.l0 != nullptr && a.m >= 2 && a.m <= ETS_MAX_PERIOD) lds_bytes = sizeof(double) * (size_t)((2 * (a.m / 2) + 1) + 3 * a.m) * NM_BLOCK;
+    if (lds_bytes > 48 * 1024) (void)hipFuncSetAttribute((const void *)prep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipLaunchKernelGGL(prep_kernel, dim3(grid), dim3(NM_BLOCK), lds_bytes, stream, a);
+}
+
+} // namespace anofox
