@@ -114,44 +114,125 @@ __device__ __forceinline__ void ar_build_poly(const ArOrd &o, int m, const doubl
 // VGPR shift registers, the seasonal lags in LDS rings (slot t % ring, read before write), w streamed from HBM.
 //     v_t = w'_t - sum phi_i w'_{t-i} ; z_t = v_t - sum Phi_I v_{t-mI} ; u_t = z_t + sum theta_j u_{t-j} ;
 //     e_t = u_t + sum Theta_J e_{t-mJ}   (z, u, e from t >= nc = p + m P on)
-__device__ __forceinline__ double ar_css_pass(const double *w, size_t ld, int len, int wave_len, bool live, const ArFac &f, int m,
-                                              const ArLds &L, int ring)
+// MODE 0: seasonal lags read from the LDS rings step by step (m = 2, 3: a lag can fall inside a sub-block);
+// MODE 1: m >= 4, every seasonal lag of a 4-step sub-block was produced before it, so its 16 ring values are fetched up
+//         front (independent LDS reads) and the four steps run in registers; MODE 2: m = 1, no seasonal factors at all.
+// The step is branch-free: every lane computes every step of the wave, the ring stores are predicated on t < len, and
+// the pre-sample / past-the-end steps contribute exact zeros (selects, not arithmetic on possibly non-finite padding).
+template <int MODE>
+__device__ __noinline__ double ar_css_pass_impl(const double *w, size_t ld, int len, int wave_len, bool live, const ArFac &fin, int m,
+                                                const ArLds &L, int ring)
 {
+    // out of line on purpose: the pass gets its own register allocation (the search kernel around it is a large state
+    // machine), and the coefficients are copied out of the caller's (scratch-resident) block once per pass
+    double phi[AR_MAXP], th[AR_MAXP], Phi[AR_MAXSP], Th[AR_MAXSP];
+#pragma unroll
+    for (int q = 0; q < AR_MAXP; q++) { phi[q] = -fin.phi[q]; th[q] = fin.th[q]; }
+#pragma unroll
+    for (int q = 0; q < AR_MAXSP; q++) { Phi[q] = -fin.Phi[q]; Th[q] = fin.Th[q]; }
+    const double mu = fin.mu;
+    const int nc = fin.nc;
+    const int lim = live ? len : 0;
     double css = 0.0;
     double wl[AR_MAXP] = {0, 0, 0, 0, 0}, ul[AR_MAXP] = {0, 0, 0, 0, 0};
     for (int k = 0; k < ring; k++) { L.e(k) = 0.0; L.v(k) = 0.0; }
     int i0 = 0, i1 = (ring - m % ring) % ring, i2 = (ring - (2 * m) % ring) % ring;     // slots of t, t - m, t - 2m
-    for (int t = 0; t < wave_len; t++) {
-        if (live && t < len) {
-            const double wp = w[(size_t)t * ld] - f.mu;
-            double vt = wp;
+    // w is streamed through NB register buffers of U steps each, so NB-1 blocks of loads stay in flight ahead
+    // of the recursion (the block W has U spare rows, reads past a lane's length are harmless)
+    constexpr int U = 8, NB = 4;
+    const int nblk = (wave_len + U - 1) / U;
+    double wb[NB][U];
 #pragma unroll
-            for (int i = 0; i < AR_MAXP; i++) vt = fma(-f.phi[i], wl[i], vt);
-            const double vm1 = L.v(i1), vm2 = L.v(i2);
-            L.v(i0) = vt;
-            if (t >= f.nc) {
-                double z = fma(-f.Phi[0], vm1, vt);
-                z = fma(-f.Phi[1], vm2, z);
-                double u = z;
+    for (int i = 0; i < NB; i++)
+        if (i < nblk) {
 #pragma unroll
-                for (int j = 0; j < AR_MAXP; j++) u = fma(f.th[j], ul[j], u);
-                double et = fma(f.Th[0], L.e(i1), u);
-                et = fma(f.Th[1], L.e(i2), et);
-                L.e(i0) = et;
-                css = fma(et, et, css);
-#pragma unroll
-                for (int j = AR_MAXP - 1; j > 0; j--) ul[j] = ul[j - 1];
-                ul[0] = u;
-            }
-#pragma unroll
-            for (int i = AR_MAXP - 1; i > 0; i--) wl[i] = wl[i - 1];
-            wl[0] = wp;
+            for (int j = 0; j < U; j++) wb[i][j] = w[(size_t)(i * U + j) * ld];
         }
-        i0 = (i0 + 1 == ring) ? 0 : i0 + 1;
-        i1 = (i1 + 1 == ring) ? 0 : i1 + 1;
-        i2 = (i2 + 1 == ring) ? 0 : i2 + 1;
+    for (int blk = 0; blk < nblk; blk += NB) {
+#pragma unroll
+        for (int i = 0; i < NB; i++) {
+            if (blk + i < nblk) {
+#pragma unroll
+                for (int sb = 0; sb < U; sb += 4) {
+                    double vm1[4], vm2[4], em1[4], em2[4], vnew[4], enew[4];
+                    int c0[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        c0[j] = i0 + j; if (c0[j] >= ring) c0[j] -= ring;
+                        if (MODE == 1) {
+                            int a1 = i1 + j; if (a1 >= ring) a1 -= ring;
+                            int a2 = i2 + j; if (a2 >= ring) a2 -= ring;
+                            vm1[j] = L.v(a1); vm2[j] = L.v(a2); em1[j] = L.e(a1); em2[j] = L.e(a2);
+                        }
+                    }
+                    const int t0 = (blk + i) * U + sb;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int t = t0 + j;
+                        const double wp = wb[i][sb + j] - mu;
+                        double vt = wp;
+#pragma unroll
+                        for (int q = 0; q < AR_MAXP; q++) vt = fma(phi[q], wl[q], vt);
+#pragma unroll
+                        for (int q = AR_MAXP - 1; q > 0; q--) wl[q] = wl[q - 1];
+                        wl[0] = wp;
+                        double z = vt;
+                        if (MODE == 0) {
+                            int a1 = i1 + j; if (a1 >= ring) a1 -= ring;
+                            int a2 = i2 + j; if (a2 >= ring) a2 -= ring;
+                            vm1[j] = L.v(a1); vm2[j] = L.v(a2); em1[j] = L.e(a1); em2[j] = L.e(a2);
+                            if (t < lim) L.v(c0[j]) = vt;
+                        }
+                        if (MODE != 2) {
+                            z = fma(Phi[0], vm1[j], z);
+                            z = fma(Phi[1], vm2[j], z);
+                        }
+                        // the newest lag enters last, so consecutive steps are one fused multiply-add apart
+                        double u = z;
+#pragma unroll
+                        for (int q = AR_MAXP - 1; q >= 0; q--) u = fma(th[q], ul[q], u);
+                        const bool on = t >= nc;
+                        u = on ? u : 0.0;
+#pragma unroll
+                        for (int q = AR_MAXP - 1; q > 0; q--) ul[q] = ul[q - 1];
+                        ul[0] = u;
+                        double et = u;
+                        if (MODE != 2) {
+                            et = fma(Th[0], em1[j], et);
+                            et = fma(Th[1], em2[j], et);
+                            et = on ? et : 0.0;
+                        }
+                        if (MODE == 0) { if (t < lim) L.e(c0[j]) = et; }
+                        vnew[j] = vt; enew[j] = et;
+                        const double ec = (t < lim) ? et : 0.0;
+                        css = fma(ec, ec, css);
+                    }
+                    if (MODE != 0) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            if (t0 + j < lim) { L.v(c0[j]) = vnew[j]; L.e(c0[j]) = enew[j]; }
+                    }
+                    i0 += 4; if (i0 >= ring) i0 -= ring;
+                    i1 += 4; if (i1 >= ring) i1 -= ring;
+                    i2 += 4; if (i2 >= ring) i2 -= ring;
+                }
+                const int nxt = blk + i + NB;
+                if (nxt < nblk) {
+#pragma unroll
+                    for (int j = 0; j < U; j++) wb[i][j] = w[(size_t)(nxt * U + j) * ld];
+                }
+            }
+        }
     }
     return css;
+}
+
+__device__ __forceinline__ double ar_css_pass(const double *w, size_t ld, int len, int wave_len, bool live, const ArFac &f, int m,
+                                              const ArLds &L, int ring)
+{
+    if (m >= 4) return ar_css_pass_impl<1>(w, ld, len, wave_len, live, f, m, L, ring);
+    if (m <= 1) return ar_css_pass_impl<2>(w, ld, len, wave_len, live, f, m, L, ring);
+    return ar_css_pass_impl<0>(w, ld, len, wave_len, live, f, m, L, ring);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -282,8 +282,8 @@ void alloc_common(AnofoxHipBatch *b)
     b->d_count = dalloc<int32_t>(2);
     if (b->plan.model == M_AutoARIMA) {
         const size_t T = std::max<size_t>(b->t_max, 1);
-        b->ar_w = dalloc<double>(T * ld);
-        HIPCHECK(hipMemset(b->ar_w, 0, T * ld * sizeof(double)));
+        b->ar_w = dalloc<double>((T + 8) * ld);              // + 8 spare rows: the CSS pass streams whole 8-step blocks
+        HIPCHECK(hipMemset(b->ar_w, 0, (T + 8) * ld * sizeof(double)));
         b->ar_wmean = dalloc<double>(ld); b->ar_wsd = dalloc<double>(ld); b->ar_l0 = dalloc<double>(ld); b->ar_l1 = dalloc<double>(ld);
         b->ar_x = dalloc<double>(6 * ld); b->ar_aicc = dalloc<double>(ld);
         b->ar_wlen = dalloc<int32_t>(ld); b->ar_d = dalloc<int32_t>(ld); b->ar_D = dalloc<int32_t>(ld); b->ar_order = dalloc<int32_t>(5 * ld);

@@ -190,7 +190,7 @@ static double css_eval(const ArimaPoly *pl, const double *w, int n, double *e, d
             double z = vt;
             for (int I = 1; I <= ARIMA_MAX_SP; I++) z = fma(-pl->Phi[I - 1], (t - m * I >= 0) ? v[t - m * I] : 0.0, z);
             double u = z;
-            for (int j = 0; j < ARIMA_MAX_P; j++) u = fma(pl->th[j], ul[j], u);
+            for (int j = ARIMA_MAX_P - 1; j >= 0; j--) u = fma(pl->th[j], ul[j], u);   /* newest lag last: one fma between steps */
             double et = u;
             for (int J = 1; J <= ARIMA_MAX_SP; J++) et = fma(pl->Th[J - 1], (t - m * J >= 0) ? e[t - m * J] : 0.0, et);
             e[t] = et;
