@@ -12,6 +12,7 @@
 // expanded lag polynomials (kept in LDS per lane), so the wave always executes ONE code path: "evaluate the next
 // trial point of whatever model this lane is fitting".  No MFMA (scalar recursions).
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include "det_math.hpp"
 #include "kernels.hpp"
@@ -52,18 +53,26 @@ __device__ __forceinline__ void ar_pacf(const double *u, int k, double *phi)
     }
 }
 
-// LDS layout per wave (doubles, lane-minor): [simplex 42 + values 7][acoef L1][bcoef L1][e ring L1][v ring L1][tried 11]
+// LDS layout per wave (lane-minor): [ring: R slots x 64 lanes x {e, v}][simplex 42 + values 7][acoef L1][bcoef L1][tried 11 words]
+// The ring holds e_t and v_t of step t side by side in slot t & (R - 1), R = the power of two >= 2 m + 6, so that one
+// 128-bit LDS access moves both and the slot index is a wave-uniform mask (no wrap arithmetic per lane).
+typedef double ar_ev_t __attribute__((ext_vector_type(2)));
+__host__ __device__ inline int ar_ring_slots(int m) { int r = 8; while (r < 2 * m + 6) r <<= 1; return r; }
 struct ArLds {
-    double *base; int L1;
-    __device__ double &sim(int k, int i) const { return base[(k * AR_MAXDIM + i) * NM_BLOCK + threadIdx.x]; }
-    __device__ double &fs(int k) const { return base[((AR_MAXDIM + 1) * AR_MAXDIM + k) * NM_BLOCK + threadIdx.x]; }
-    __device__ double &a(int k) const { return base[(49 + k) * NM_BLOCK + threadIdx.x]; }
-    __device__ double &b(int k) const { return base[(49 + L1 + k) * NM_BLOCK + threadIdx.x]; }
-    __device__ double &e(int k) const { return base[(49 + 2 * L1 + k) * NM_BLOCK + threadIdx.x]; }
-    __device__ double &v(int k) const { return base[(49 + 3 * L1 + k) * NM_BLOCK + threadIdx.x]; }
-    __device__ uint32_t &tried(int wd) const { return ((uint32_t *)(base + (size_t)(49 + 4 * L1) * NM_BLOCK))[wd * NM_BLOCK + threadIdx.x]; }
+    double *base; int L1; int R;
+    __device__ double *coef() const { return base + (size_t)2 * R * NM_BLOCK; }
+    __device__ double &sim(int k, int i) const { return coef()[(k * AR_MAXDIM + i) * NM_BLOCK + threadIdx.x]; }
+    __device__ double &fs(int k) const { return coef()[((AR_MAXDIM + 1) * AR_MAXDIM + k) * NM_BLOCK + threadIdx.x]; }
+    __device__ double &a(int k) const { return coef()[(49 + k) * NM_BLOCK + threadIdx.x]; }
+    __device__ double &b(int k) const { return coef()[(49 + L1 + k) * NM_BLOCK + threadIdx.x]; }
+    __device__ double e_at(int t) const { return base[((size_t)(t & (R - 1)) * NM_BLOCK + threadIdx.x) * 2]; }
+    __device__ uint32_t &tried(int wd) const { return ((uint32_t *)(coef() + (size_t)(49 + 2 * L1) * NM_BLOCK))[wd * NM_BLOCK + threadIdx.x]; }
 };
-static size_t ar_lds_bytes(int m) { int L1 = AR_MAXP + AR_MAXSP * m + 1; return sizeof(double) * (size_t)(49 + 4 * L1 + 11) * NM_BLOCK; }
+static size_t ar_lds_bytes(int m)
+{
+    const int L1 = AR_MAXP + AR_MAXSP * m + 1;
+    return sizeof(double) * (size_t)(2 * ar_ring_slots(m) + 49 + 2 * L1 + 11) * NM_BLOCK;
+}
 
 // the four factor polynomials of a trial point, zero padded (registers)
 struct ArFac { double phi[AR_MAXP], th[AR_MAXP], Phi[AR_MAXSP], Th[AR_MAXSP]; double mu; int nc; };
@@ -114,14 +123,16 @@ __device__ __forceinline__ void ar_build_poly(const ArOrd &o, int m, const doubl
 // VGPR shift registers, the seasonal lags in LDS rings (slot t % ring, read before write), w streamed from HBM.
 //     v_t = w'_t - sum phi_i w'_{t-i} ; z_t = v_t - sum Phi_I v_{t-mI} ; u_t = z_t + sum theta_j u_{t-j} ;
 //     e_t = u_t + sum Theta_J e_{t-mJ}   (z, u, e from t >= nc = p + m P on)
-// MODE 0: seasonal lags read from the LDS rings step by step (m = 2, 3: a lag can fall inside a sub-block);
-// MODE 1: m >= 4, every seasonal lag of a 4-step sub-block was produced before it, so its 16 ring values are fetched up
+// MODE 0: seasonal lags read from the LDS ring step by step (m = 2, 3: a lag can fall inside a sub-block);
+// MODE 1: m >= 4, every seasonal lag of a 4-step sub-block was produced before it, so its 8 ring slots are fetched up
 //         front (independent LDS reads) and the four steps run in registers; MODE 2: m = 1, no seasonal factors at all.
-// The step is branch-free: every lane computes every step of the wave, the ring stores are predicated on t < len, and
-// the pre-sample / past-the-end steps contribute exact zeros (selects, not arithmetic on possibly non-finite padding).
+// The step is branch-free.  A block of S steps runs ungated when every live lane is inside its sample for the whole block
+// and past its warm-up (base >= max nc, base + S <= min len over the live lanes; finished lanes compute into their own
+// slots and are ignored); otherwise the gated variant predicates the ring stores on t < len and selects exact zeros for
+// the warm-up and past-the-end steps (selects, not arithmetic on possibly non-finite padding).
 template <int MODE>
-__device__ __noinline__ double ar_css_pass_impl(const double *w, size_t ld, int len, int wave_len, bool live, const ArFac &fin, int m,
-                                                const ArLds &L, int ring)
+__device__ __noinline__ double ar_css_pass_impl(const double *w, size_t ld, int len, int wave_len_v, bool live, const ArFac &fin, int m_v,
+                                                const ArLds &L)
 {
     // out of line on purpose: the pass gets its own register allocation (the search kernel around it is a large state
     // machine), and the coefficients are copied out of the caller's (scratch-resident) block once per pass
@@ -132,107 +143,114 @@ __device__ __noinline__ double ar_css_pass_impl(const double *w, size_t ld, int 
     for (int q = 0; q < AR_MAXSP; q++) { Phi[q] = -fin.Phi[q]; Th[q] = fin.Th[q]; }
     const double mu = fin.mu;
     const int nc = fin.nc;
+    // wave-uniform quantities in scalar registers
+    const int wave_len = __builtin_amdgcn_readfirstlane(wave_len_v);
+    const int m = __builtin_amdgcn_readfirstlane(m_v);
+    const int mask = __builtin_amdgcn_readfirstlane(L.R) - 1;
     const int lim = live ? len : 0;
+    const int nc_max = __builtin_amdgcn_readfirstlane(ar_wave_max(live ? nc : 0));
+    const int len_min = -__builtin_amdgcn_readfirstlane(ar_wave_max(live ? -len : -0x3fffffff));
+    // explicit address spaces: through the call boundary the pointers are generic, and generic (flat) loads would make
+    // every LDS wait also wait for the HBM prefetch in flight
+    typedef const __attribute__((address_space(1))) double *gptr_t;
+    typedef __attribute__((address_space(3))) ar_ev_t *lptr_t;
+    const gptr_t wg = (gptr_t)w;
+    const lptr_t ring = (lptr_t)(L.base) + threadIdx.x;        // slot k of this lane: ring[k * NM_BLOCK]
     double css = 0.0;
     double wl[AR_MAXP] = {0, 0, 0, 0, 0}, ul[AR_MAXP] = {0, 0, 0, 0, 0};
-    for (int k = 0; k < ring; k++) { L.e(k) = 0.0; L.v(k) = 0.0; }
-    int i0 = 0, i1 = (ring - m % ring) % ring, i2 = (ring - (2 * m) % ring) % ring;     // slots of t, t - m, t - 2m
-    // w is streamed through NB register buffers of U steps each, so NB-1 blocks of loads stay in flight ahead
-    // of the recursion (the block W has U spare rows, reads past a lane's length are harmless)
-    constexpr int U = 8, NB = 4;
-    const int nblk = (wave_len + U - 1) / U;
-    double wb[NB][U];
+    for (int k = 0; k <= mask; k++) ring[k * NM_BLOCK] = ar_ev_t{0.0, 0.0};
+    // w is double-buffered in registers: the S rows of the NEXT iteration are requested before the S steps of the current
+    // one run, and are only touched (copied into cur) after them, so the HBM latency sits behind S steps of recursion and
+    // the loop has a single, already satisfied, wait per iteration.  The loads are unconditional: the block W has 2 S
+    // spare rows, and steps past a lane's length contribute nothing.
+    constexpr int S = 32;
+    double cur[S], nxt[S];
+    gptr_t wp_next = wg;
 #pragma unroll
-    for (int i = 0; i < NB; i++)
-        if (i < nblk) {
+    for (int j = 0; j < S; j++) cur[j] = wp_next[(size_t)j * ld];
+    wp_next += (size_t)S * ld;
+
+    auto block = [&](const int base, auto gated_tag) __attribute__((always_inline)) {
+        constexpr bool GATED = decltype(gated_tag)::value;
 #pragma unroll
-            for (int j = 0; j < U; j++) wb[i][j] = w[(size_t)(i * U + j) * ld];
-        }
-    for (int blk = 0; blk < nblk; blk += NB) {
+        for (int sb = 0; sb < S; sb += 4) {
+            const int t0 = base + sb;
+            ar_ev_t s1[4], s2[4];                 // slots t - m and t - 2m: {e, v}
+            double vnew[4], enew[4];
+            if (MODE == 1) {
 #pragma unroll
-        for (int i = 0; i < NB; i++) {
-            if (blk + i < nblk) {
-#pragma unroll
-                for (int sb = 0; sb < U; sb += 4) {
-                    double vm1[4], vm2[4], em1[4], em2[4], vnew[4], enew[4];
-                    int c0[4];
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        c0[j] = i0 + j; if (c0[j] >= ring) c0[j] -= ring;
-                        if (MODE == 1) {
-                            int a1 = i1 + j; if (a1 >= ring) a1 -= ring;
-                            int a2 = i2 + j; if (a2 >= ring) a2 -= ring;
-                            vm1[j] = L.v(a1); vm2[j] = L.v(a2); em1[j] = L.e(a1); em2[j] = L.e(a2);
-                        }
-                    }
-                    const int t0 = (blk + i) * U + sb;
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const int t = t0 + j;
-                        const double wp = wb[i][sb + j] - mu;
-                        double vt = wp;
-#pragma unroll
-                        for (int q = 0; q < AR_MAXP; q++) vt = fma(phi[q], wl[q], vt);
-#pragma unroll
-                        for (int q = AR_MAXP - 1; q > 0; q--) wl[q] = wl[q - 1];
-                        wl[0] = wp;
-                        double z = vt;
-                        if (MODE == 0) {
-                            int a1 = i1 + j; if (a1 >= ring) a1 -= ring;
-                            int a2 = i2 + j; if (a2 >= ring) a2 -= ring;
-                            vm1[j] = L.v(a1); vm2[j] = L.v(a2); em1[j] = L.e(a1); em2[j] = L.e(a2);
-                            if (t < lim) L.v(c0[j]) = vt;
-                        }
-                        if (MODE != 2) {
-                            z = fma(Phi[0], vm1[j], z);
-                            z = fma(Phi[1], vm2[j], z);
-                        }
-                        // the newest lag enters last, so consecutive steps are one fused multiply-add apart
-                        double u = z;
-#pragma unroll
-                        for (int q = AR_MAXP - 1; q >= 0; q--) u = fma(th[q], ul[q], u);
-                        const bool on = t >= nc;
-                        u = on ? u : 0.0;
-#pragma unroll
-                        for (int q = AR_MAXP - 1; q > 0; q--) ul[q] = ul[q - 1];
-                        ul[0] = u;
-                        double et = u;
-                        if (MODE != 2) {
-                            et = fma(Th[0], em1[j], et);
-                            et = fma(Th[1], em2[j], et);
-                            et = on ? et : 0.0;
-                        }
-                        if (MODE == 0) { if (t < lim) L.e(c0[j]) = et; }
-                        vnew[j] = vt; enew[j] = et;
-                        const double ec = (t < lim) ? et : 0.0;
-                        css = fma(ec, ec, css);
-                    }
-                    if (MODE != 0) {
-#pragma unroll
-                        for (int j = 0; j < 4; j++)
-                            if (t0 + j < lim) { L.v(c0[j]) = vnew[j]; L.e(c0[j]) = enew[j]; }
-                    }
-                    i0 += 4; if (i0 >= ring) i0 -= ring;
-                    i1 += 4; if (i1 >= ring) i1 -= ring;
-                    i2 += 4; if (i2 >= ring) i2 -= ring;
-                }
-                const int nxt = blk + i + NB;
-                if (nxt < nblk) {
-#pragma unroll
-                    for (int j = 0; j < U; j++) wb[i][j] = w[(size_t)(nxt * U + j) * ld];
+                for (int j = 0; j < 4; j++) {
+                    s1[j] = ring[((t0 + j - m) & mask) * NM_BLOCK];
+                    s2[j] = ring[((t0 + j - 2 * m) & mask) * NM_BLOCK];
                 }
             }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int t = t0 + j;
+                const double wp = cur[sb + j] - mu;
+                double vt = wp;
+#pragma unroll
+                for (int q = 0; q < AR_MAXP; q++) vt = fma(phi[q], wl[q], vt);
+#pragma unroll
+                for (int q = AR_MAXP - 1; q > 0; q--) wl[q] = wl[q - 1];
+                wl[0] = wp;
+                double z = vt;
+                if (MODE == 0) {
+                    s1[j] = ring[((t - m) & mask) * NM_BLOCK];
+                    s2[j] = ring[((t - 2 * m) & mask) * NM_BLOCK];
+                }
+                if (MODE != 2) {
+                    z = fma(Phi[0], s1[j].y, z);
+                    z = fma(Phi[1], s2[j].y, z);
+                }
+                // the newest lag enters last, so consecutive steps are one fused multiply-add apart
+                double u = z;
+#pragma unroll
+                for (int q = AR_MAXP - 1; q >= 0; q--) u = fma(th[q], ul[q], u);
+                const bool on = t >= nc;
+                if (GATED) u = on ? u : 0.0;
+#pragma unroll
+                for (int q = AR_MAXP - 1; q > 0; q--) ul[q] = ul[q - 1];
+                ul[0] = u;
+                double et = u;
+                if (MODE != 2) {
+                    et = fma(Th[0], s1[j].x, et);
+                    et = fma(Th[1], s2[j].x, et);
+                    if (GATED) et = on ? et : 0.0;
+                }
+                if (MODE == 0) {
+                    if (!GATED || t < lim) ring[(t & mask) * NM_BLOCK] = ar_ev_t{et, vt};
+                }
+                vnew[j] = vt; enew[j] = et;
+                const double ec = (!GATED || t < lim) ? et : 0.0;
+                css = fma(ec, ec, css);
+            }
+            if (MODE != 0) {
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (!GATED || t0 + j < lim) ring[((t0 + j) & mask) * NM_BLOCK] = ar_ev_t{enew[j], vnew[j]};
+            }
         }
+    };
+
+    for (int base = 0; base < wave_len; base += S) {
+#pragma unroll
+        for (int j = 0; j < S; j++) nxt[j] = wp_next[(size_t)j * ld];
+        wp_next += (size_t)S * ld;
+        if (base >= nc_max && base + S <= len_min) block(base, std::false_type{});
+        else block(base, std::true_type{});
+#pragma unroll
+        for (int j = 0; j < S; j++) cur[j] = nxt[j];
     }
     return css;
 }
 
 __device__ __forceinline__ double ar_css_pass(const double *w, size_t ld, int len, int wave_len, bool live, const ArFac &f, int m,
-                                              const ArLds &L, int ring)
+                                              const ArLds &L)
 {
-    if (m >= 4) return ar_css_pass_impl<1>(w, ld, len, wave_len, live, f, m, L, ring);
-    if (m <= 1) return ar_css_pass_impl<2>(w, ld, len, wave_len, live, f, m, L, ring);
-    return ar_css_pass_impl<0>(w, ld, len, wave_len, live, f, m, L, ring);
+    if (m >= 4) return ar_css_pass_impl<1>(w, ld, len, wave_len, live, f, m, L);
+    if (m <= 1) return ar_css_pass_impl<2>(w, ld, len, wave_len, live, f, m, L);
+    return ar_css_pass_impl<0>(w, ld, len, wave_len, live, f, m, L);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -319,7 +337,7 @@ __device__ double ar_seasonal_strength(const double *y, size_t ld, int n, int m,
 
 __global__ __launch_bounds__(NM_BLOCK) void arima_prep_kernel(const ArimaArgs a)
 {
-    extern __shared__ double lds[];
+    extern __shared__ __attribute__((aligned(16))) double lds[];
     const int s = blockIdx.x * NM_BLOCK + threadIdx.x;
     if (s >= a.n_series) return;
     const int n = a.len[s];
@@ -410,15 +428,14 @@ __device__ __forceinline__ void ar_sort(const ArLds &L, int D)
 
 __global__ __launch_bounds__(NM_BLOCK) void arima_search_kernel(const ArimaArgs a)
 {
-    extern __shared__ double lds[];
+    extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x;
     const int s = blockIdx.x * NM_BLOCK + lane;
     const bool valid = s < a.n_series;
     const int len = valid ? a.wlen[s] : 0;
     const bool live = valid && len >= 3;
     const int m = a.m;
-    ArLds L{lds, AR_MAXP + AR_MAXSP * m + 1};
-    const int ring = L.L1;
+    ArLds L{lds, AR_MAXP + AR_MAXSP * m + 1, ar_ring_slots(m)};
     const double *w = a.w + (valid ? s : 0);
     const size_t ld = a.ld;
     const int wave_len = ar_wave_max(live ? len : 0);
@@ -517,7 +534,7 @@ __global__ __launch_bounds__(NM_BLOCK) void arima_search_kernel(const ArimaArgs 
         if (__all(fin)) break;
 
         // ---- 3. one streamed pass -------------------------------------------------------------------
-        const double css = ar_css_pass(w, ld, len, wave_len, !fin, fac, m, L, ring);
+        const double css = ar_css_pass(w, ld, len, wave_len, !fin, fac, m, L);
         if (fin) continue;
         passes++;
         const int nu = len - fac.nc;
@@ -582,15 +599,14 @@ __global__ __launch_bounds__(NM_BLOCK) void arima_search_kernel(const ArimaArgs 
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NM_BLOCK) void arima_forecast_kernel(const ArimaArgs a)
 {
-    extern __shared__ double lds[];
+    extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x;
     const int s = blockIdx.x * NM_BLOCK + lane;
     const bool valid = s < a.n_series;
     const int len = valid ? a.wlen[s] : 0;
     const bool live = valid && len >= 3 && a.status[s] == FIT_OK;
     const int m = a.m;
-    ArLds L{lds, AR_MAXP + AR_MAXSP * m + 1};
-    const int ring = L.L1;
+    ArLds L{lds, AR_MAXP + AR_MAXSP * m + 1, ar_ring_slots(m)};
     const double *w = a.w + (valid ? s : 0);
     const size_t ld = a.ld;
     const int wave_len = ar_wave_max(live ? len : 0);
@@ -607,7 +623,7 @@ __global__ __launch_bounds__(NM_BLOCK) void arima_forecast_kernel(const ArimaArg
     ArFac fac;
     ar_factors(o, m, x, fac);
     if (live) ar_build_poly(o, m, x, L, La, Lb, mu);
-    (void)ar_css_pass(w, ld, len, wave_len, live, fac, m, L, ring);
+    (void)ar_css_pass(w, ld, len, wave_len, live, fac, m, L);
     if (!live) return;
     const int n = a.len[s], h = a.h;
     const int d = a.d[s], Dd = a.D[s];
@@ -621,7 +637,7 @@ __global__ __launch_bounds__(NM_BLOCK) void arima_forecast_kernel(const ArimaArg
                 acc = fma(L.a(k), wv - mu, acc);
             }
         for (int k = 1; k <= Lb; k++)
-            if (t - k >= 0 && t - k < len) acc = fma(L.b(k), L.e((t - k) % ring), acc);
+            if (t - k >= 0 && t - k < len) acc = fma(L.b(k), L.e_at(t - k), acc);
         out[j] = acc;
     }
     double last_d0 = a.last_d0[s], last_d1 = a.last_d1[s];

@@ -35,6 +35,7 @@ struct SeriesView {
     int len;           // this lane's length (0 = no series)
     int wave_len;      // max len over the wave (uniform)
     int wave_min_len;  // min len over the wave's active lanes (uniform)
+    int rows;          // rows the block holds (row indices are clamped to rows - 1 by the streaming loads)
 };
 
 __device__ __forceinline__ int wave_max_i32(int v)
@@ -185,107 +186,61 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
     const double *yp = v.y;
     const size_t ld = v.ld;
 
-    if constexpr (MS > 0) {
-        double s[K][MS];
+    // y is streamed through two register buffers of S steps: the S rows of the NEXT block are requested before the S
+    // steps of the current one run and are only touched (copied into cur) after them, so every wave keeps S loads in
+    // flight behind S steps of recursion and the loop has one, already satisfied, wait per block.  The loads are
+    // unconditional (row index clamped to the block's last row, wave-uniform scalar arithmetic); a block that reaches past
+    // the shortest active series of the wave runs with a per-step predicate.
+    const int wave_len = __builtin_amdgcn_readfirstlane(v.wave_len);
+    const int wave_min_len = __builtin_amdgcn_readfirstlane(v.wave_min_len);
+    const int row_max = __builtin_amdgcn_readfirstlane(v.rows) - 1;
+    // block length by the weight of a step: ~28-32 steps for the additive class (5-10 operations a step), half that when
+    // a step holds a reciprocal, a quarter when it holds a pow (damped multiplicative trend) -- those are long enough to
+    // cover the latency with fewer rows in flight, and their own register needs leave less room for the buffers
+    constexpr int S_TARGET = Cfg::ADDITIVE ? 32 : ((Cfg::T == C_MUL && Cfg::D) ? 8 : 16);
+    constexpr int S = (MS > 0) ? ((S_TARGET / MS > 0 ? S_TARGET / MS : 1) * MS) : S_TARGET;
+    double cur[S], nxt[S];
+    auto load_rows = [&](double (&buf)[S], const int row0) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < MS; j++) {
-            double f0 = in.fig[(size_t)j * in.fig_ld];
-#pragma unroll
-            for (int k = 0; k < K; k++) s[k][j] = f0;
+        for (int j = 0; j < S; j++) {
+            int r = row0 + j;
+            r = r < row_max ? r : row_max;
+            buf[j] = yp[(size_t)r * ld];
         }
-        // Full blocks (every active lane of the wave in range): no per-step predicate.  NB register
-        // buffers of one period each keep NB-1 blocks of y loads in flight ahead of the recursion, so a
-        // wave that is alone on its SIMD (late rounds) still covers the HBM miss latency.
-        constexpr int NB = (K == 1 && Cfg::ADDITIVE) ? 4 : 2;   // division-heavy steps are long enough with one block ahead
-        const int nfull = v.wave_min_len / MS;
-        double yb[NB][MS];
-#pragma unroll
-        for (int i = 0; i < NB; i++)
-            if (i < nfull) {
-#pragma unroll
-                for (int j = 0; j < MS; j++) yb[i][j] = yp[(size_t)(i * MS + j) * ld];
-            }
-        for (int blk = 0; blk < nfull; blk += NB) {
-#pragma unroll
-            for (int i = 0; i < NB; i++) {
-                if (blk + i < nfull) {
-#pragma unroll
-                    for (int j = 0; j < MS; j++)
-#pragma unroll
-                        for (int k = 0; k < K; k++) ets_step<Cfg>(par[k], st[k], yb[i][j], s[k][j]);
-                    const int nxt = blk + i + NB;
-                    if (nxt < nfull) {
-#pragma unroll
-                        for (int j = 0; j < MS; j++) yb[i][j] = yp[(size_t)(nxt * MS + j) * ld];
-                    }
-                }
-            }
-        }
-        int t0 = nfull * MS;
-        // ragged tail: per-lane predicate
-        for (; t0 < v.wave_len; t0 += MS) {
+    };
+    load_rows(cur, 0);
+
+    if constexpr (MS >= 0) {
+        constexpr int MR = MS > 0 ? MS : 1;
+        double s[K][MR];
+        if constexpr (MS > 0) {
 #pragma unroll
             for (int j = 0; j < MS; j++) {
-                const int t = t0 + j;
-                if (t < v.len) {
-                    const double yv = yp[(size_t)t * ld];
+                double f0 = in.fig[(size_t)j * in.fig_ld];
 #pragma unroll
-                    for (int k = 0; k < K; k++) ets_step<Cfg>(par[k], st[k], yv, s[k][j]);
-                }
+                for (int k = 0; k < K; k++) s[k][j] = f0;
             }
+        } else {
+#pragma unroll
+            for (int k = 0; k < K; k++) s[k][0] = 0.0;
         }
-        if constexpr (FINAL) {
-            double pp = par[0].phi, phistar = par[0].phi;
-            for (int i = 0; i < fin->h; i++) {
-                double f;
-                if constexpr (Cfg::T == C_NONE) f = st[0].l;
-                else if constexpr (Cfg::T == C_ADD) f = st[0].l + phistar * st[0].b;
-                else f = (st[0].b > 0.0) ? st[0].l * dm_pow_pos(st[0].b, phistar) : __builtin_nan("");
-                const int j = (v.len + i) % MS;
-                double sv = s[0][0];
+        for (int base = 0; base < wave_len; base += S) {
+            load_rows(nxt, base + S);
+            if (base + S <= wave_min_len) {
 #pragma unroll
-                for (int jj = 1; jj < MS; jj++) sv = (j == jj) ? s[0][jj] : sv;
-                f = (Cfg::S == C_ADD) ? f + sv : f * sv;
-                if (v.len > 0) fin->yhat[i] = f;
-                pp = pp * par[0].phi;
-                phistar = phistar + pp;
-            }
-        }
-    } else if constexpr (MS == 0) {
-        double dummy = 0.0;
-        constexpr int U = 8;
-        constexpr int NB = (K == 1 && Cfg::ADDITIVE) ? 4 : 2;   // division-heavy steps are long enough with one block ahead
-        const int nfull = v.wave_min_len / U;
-        double yb[NB][U];
+                for (int j = 0; j < S; j++)
 #pragma unroll
-        for (int i = 0; i < NB; i++)
-            if (i < nfull) {
+                    for (int k = 0; k < K; k++) ets_step<Cfg>(par[k], st[k], cur[j], s[k][MS > 0 ? j % MR : 0]);
+            } else {
 #pragma unroll
-                for (int j = 0; j < U; j++) yb[i][j] = yp[(size_t)(i * U + j) * ld];
-            }
-        for (int blk = 0; blk < nfull; blk += NB) {
+                for (int j = 0; j < S; j++)
+                    if (base + j < v.len) {
 #pragma unroll
-            for (int i = 0; i < NB; i++) {
-                if (blk + i < nfull) {
-#pragma unroll
-                    for (int j = 0; j < U; j++)
-#pragma unroll
-                        for (int k = 0; k < K; k++) ets_step<Cfg>(par[k], st[k], yb[i][j], dummy);
-                    const int nxt = blk + i + NB;
-                    if (nxt < nfull) {
-#pragma unroll
-                        for (int j = 0; j < U; j++) yb[i][j] = yp[(size_t)(nxt * U + j) * ld];
+                        for (int k = 0; k < K; k++) ets_step<Cfg>(par[k], st[k], cur[j], s[k][MS > 0 ? j % MR : 0]);
                     }
-                }
             }
-        }
-        int t0 = nfull * U;
-        for (; t0 < v.wave_len; t0++) {
-            if (t0 < v.len) {
-                const double yv = yp[(size_t)t0 * ld];
 #pragma unroll
-                for (int k = 0; k < K; k++) ets_step<Cfg>(par[k], st[k], yv, dummy);
-            }
+            for (int j = 0; j < S; j++) cur[j] = nxt[j];
         }
         if constexpr (FINAL) {
             double pp = par[0].phi, phistar = par[0].phi;
@@ -294,31 +249,44 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
                 if constexpr (Cfg::T == C_NONE) f = st[0].l;
                 else if constexpr (Cfg::T == C_ADD) f = st[0].l + phistar * st[0].b;
                 else f = (st[0].b > 0.0) ? st[0].l * dm_pow_pos(st[0].b, phistar) : __builtin_nan("");
+                if constexpr (MS > 0) {
+                    const int j = (v.len + i) % MS;
+                    double sv = s[0][0];
+#pragma unroll
+                    for (int jj = 1; jj < MS; jj++) sv = (j == jj) ? s[0][jj] : sv;
+                    f = (Cfg::S == C_ADD) ? f + sv : f * sv;
+                }
                 if (v.len > 0) fin->yhat[i] = f;
                 pp = pp * par[0].phi;
                 phistar = phistar + pp;
             }
         }
     } else {
-        // run-time period: ring[(k * m + j) * 64 + lane] in LDS
-        const int m = in.m;
+        // run-time period: ring[(k * m + j) * 64 + lane] in LDS, phase j advanced as a wave-uniform counter
+        const int m = __builtin_amdgcn_readfirstlane(in.m);
         for (int j = 0; j < m; j++) {
             double f0 = in.fig[(size_t)j * in.fig_ld];
 #pragma unroll
             for (int k = 0; k < K; k++) ring[(k * m + j) * NM_BLOCK + lane] = f0;
         }
         int j = 0;
-        for (int t = 0; t < v.wave_len; t++) {
-            if (t < v.len) {
-                const double yv = yp[(size_t)t * ld];
+        for (int base = 0; base < wave_len; base += S) {
+            load_rows(nxt, base + S);
+            const bool full = base + S <= wave_min_len;
 #pragma unroll
-                for (int k = 0; k < K; k++) {
-                    double sv = ring[(k * m + j) * NM_BLOCK + lane];
-                    ets_step<Cfg>(par[k], st[k], yv, sv);
-                    ring[(k * m + j) * NM_BLOCK + lane] = sv;
+            for (int i = 0; i < S; i++) {
+                if (full || base + i < v.len) {
+#pragma unroll
+                    for (int k = 0; k < K; k++) {
+                        double sv = ring[(k * m + j) * NM_BLOCK + lane];
+                        ets_step<Cfg>(par[k], st[k], cur[i], sv);
+                        ring[(k * m + j) * NM_BLOCK + lane] = sv;
+                    }
                 }
+                j = (j + 1 == m) ? 0 : j + 1;
             }
-            j = (j + 1 == m) ? 0 : j + 1;
+#pragma unroll
+            for (int i = 0; i < S; i++) cur[i] = nxt[i];
         }
         if constexpr (FINAL) {
             double pp = par[0].phi, phistar = par[0].phi;

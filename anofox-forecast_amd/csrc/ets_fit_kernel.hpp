@@ -3,7 +3,7 @@
 // round kernel : grid = ceil(n_active / 64) one-wave workgroups; lane <-> one still-running
 //                (series, spec) problem.  Each lane advances its own Nelder-Mead (nm.hpp) by at most
 //                `budget` streamed passes over its column of the time-major block (ets_device.hpp),
-//                then parks the simplex in HBM.  Between rounds the host enqueues a stable compaction
+//                then parks the simplex in HBM.  Between rounds the host enqueues a compaction
 //                of the unfinished problems and a column gather (kernels.hip), so every wave of the next
 //                round is full again and still reads 512 contiguous bytes per time step.
 // final kernel : one K = 1 pass per series with the optimum -> final states, h forecasts, AICc.
@@ -60,6 +60,7 @@ __global__ __launch_bounds__(NM_BLOCK, ANOFOX_ROUND_WAVES) void ets_round_kernel
     v.len = active ? len : 0;
     v.wave_len = wave_max_i32(v.len);
     v.wave_min_len = wave_min_i32(active ? len : 0x7fffffff);
+    v.rows = a.t_rows;
     if (v.wave_len == 0) return;
 
     EtsModel<Cfg, MS, 1> mdl;
@@ -124,6 +125,7 @@ __global__ __launch_bounds__(NM_BLOCK) void ets_final_kernel(const FitArgs a)
     v.len = active ? len : 0;
     v.wave_len = wave_max_i32(v.len);
     v.wave_min_len = wave_min_i32(active ? len : 0x7fffffff);
+    v.rows = a.t_rows;
     if (v.wave_len == 0) {
         if (valid && len > 0) { a.aicc[s] = __builtin_huge_val(); a.evals[s] = 0; a.iters[s] = 0; a.passes[s] = 0; }
         return;

@@ -282,8 +282,8 @@ void alloc_common(AnofoxHipBatch *b)
     b->d_count = dalloc<int32_t>(2);
     if (b->plan.model == M_AutoARIMA) {
         const size_t T = std::max<size_t>(b->t_max, 1);
-        b->ar_w = dalloc<double>((T + 8) * ld);              // + 8 spare rows: the CSS pass streams whole 8-step blocks
-        HIPCHECK(hipMemset(b->ar_w, 0, (T + 8) * ld * sizeof(double)));
+        b->ar_w = dalloc<double>((T + 72) * ld);             // spare rows: the CSS pass prefetches whole 32-step blocks ahead
+        HIPCHECK(hipMemset(b->ar_w, 0, (T + 72) * ld * sizeof(double)));
         b->ar_wmean = dalloc<double>(ld); b->ar_wsd = dalloc<double>(ld); b->ar_l0 = dalloc<double>(ld); b->ar_l1 = dalloc<double>(ld);
         b->ar_x = dalloc<double>(6 * ld); b->ar_aicc = dalloc<double>(ld);
         b->ar_wlen = dalloc<int32_t>(ld); b->ar_d = dalloc<int32_t>(ld); b->ar_D = dalloc<int32_t>(ld); b->ar_order = dalloc<int32_t>(5 * ld);
@@ -456,7 +456,7 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
         const int tt = ti == 0 ? 0 : (ti <= 2 ? 1 : 2);
         FitArgs &a = args[oi];
         a = FitArgs{};
-        a.y = b->d_y; a.ld = ld; a.len = d_len; a.n_series = (int)n;
+        a.y = b->d_y; a.ld = ld; a.len = d_len; a.n_series = (int)n; a.t_rows = (int)std::max<size_t>(b->t_max, 1);
         a.m = se != 0 ? m : 1; a.h = b->h;
         a.l0 = b->d_l0 + (size_t)(se * 3 + tt) * ld;
         a.b0 = b->d_b0 + (size_t)(se * 3 + tt) * ld;

@@ -226,7 +226,7 @@ FitLaunchers ets_fit_launcher(int spec_id, int m)
 }
 
 // ------------------------------------------------------------------------------------------
-// stable compaction of the running problems (one 1024-thread workgroup, chunked ballot scan)
+// compaction of the running problems (ballot per wave + one atomic; order of survivors not preserved)
 // ------------------------------------------------------------------------------------------
 // One wave per 64 candidates: ballot, one atomic per wave to reserve a slot range, ordered within the
 // wave.  The order of the waves' ranges is not deterministic -- it only decides which column a problem

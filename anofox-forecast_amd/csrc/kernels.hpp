@@ -32,6 +32,7 @@ struct NmStateBuf {
 
 struct FitArgs {
     const double *y; size_t ld; const int32_t *len; int n_series;
+    int t_rows;                  // rows held by the blocks y and y_round (streaming loads clamp to the last one)
     // round-specific view: the block this round streams (original or gathered columns), the column ->
     // series map (NULL = identity) and the device-side count of running problems (NULL = n_series)
     const double *y_round; size_t ld_round;
@@ -109,8 +110,8 @@ typedef void (*FitLaunchFn)(const FitArgs &, hipStream_t);
 struct FitLaunchers { FitLaunchFn round_seq, round_spec, final; };   // sequential / speculative Nelder-Mead rounds
 FitLaunchers ets_fit_launcher(int spec_id, int m);
 
-// stable compaction of the unfinished problems: series_next[0..n_next) = the series of the previous
-// map whose done flag is 0, in order (single workgroup; deterministic)
+// compaction of the unfinished problems: series_next[0..n_next) = the series of the previous map whose done flag
+// is 0 (one ballot + one atomic per wave; the order of the survivors is not preserved, results do not depend on it)
 void launch_compact(const int32_t *series_prev, const int32_t *n_prev, int n_series, const int32_t *done,
                     int32_t *series_next, int32_t *n_next, hipStream_t);
 // out[t * ld_out + p] = y[t * ld + series_of[p]] for p < *n_active, t < t_max
