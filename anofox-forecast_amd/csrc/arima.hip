@@ -1,6 +1,5 @@
 // arima.hip -- AutoARIMA on gfx950: differencing tests, stepwise (p,q,P,Q,constant) search with a
-// conditional-sum-of-squares fit per candidate, forecast + integration.  Lane <-> series; every objective
-// evaluation is one streamed pass over the lane's column of the differenced time-major block W[t * ld + s].
+// conditional-sum-of-squares fit per candidate, forecast + integration.
 //
 // Reference call site: crates/anofox-fcst-core/src/forecast.rs:1435-1521 (AutoARIMAConfig::default()
 // [.with_seasonal_period(m)]); the arithmetic is in the un-vendored anofox-forecast 0.15.3 crate, so this
@@ -8,11 +7,21 @@
 // D by seasonal strength > 0.64, d by KPSS (lag trunc(3 sqrt(n)/13), 0.463), CSS over tanh-PACF coefficients
 // minimised by Nelder-Mead (absolute initial steps), stepwise neighbourhood search on AICc.
 //
-// Per-lane search state machine: candidate models differ between lanes, but the CSS recursion is generic in the
-// expanded lag polynomials (kept in LDS per lane), so the wave always executes ONE code path: "evaluate the next
-// trial point of whatever model this lane is fitting".  No MFMA (scalar recursions).
+// Organisation (problem-parallel): the fit of one candidate order depends on nothing but the series (fixed start,
+// fixed steps), so the stepwise search is split into
+//   advance  one lane per series: replays the sequential search against a per-series cache of candidate results; when
+//            it meets a candidate that has not been fitted yet it queues that one and every other unfitted candidate
+//            of the same sweep (speculation: the sequential search would stop the sweep at its first improvement);
+//   fit      persistent lanes pull (series, order) problems from the queue, longest dimension first, and run
+//            Nelder-Mead to completion -- every objective evaluation is one streamed pass of the CSS recursion over the
+//            lane's row of the series-major differenced block W[s * tw + t]; results go to the cache;
+// repeated until no series queues anything.  Replay reproduces the sequential search exactly (same candidates tried,
+// same order, same model count), so the selected model and its coefficients are those of the checker.  No MFMA
+// (scalar recursions); the pass is VALU-issue bound.
 #include <hip/hip_runtime.h>
 #include <type_traits>
+#include <stdexcept>
+#include <string>
 
 #include "det_math.hpp"
 #include "kernels.hpp"
@@ -21,6 +30,10 @@
 namespace anofox {
 
 constexpr int AR_MAXP = 5, AR_MAXSP = 2, AR_MAXORDER = 5, AR_MAXDIM = 6, AR_MAXMODELS = 94;
+constexpr int AR_KEYS = 6 * 6 * 3 * 3 * 2;            // order keys (p, q, P, Q, constant)
+constexpr int AR_KEYWORDS = (AR_KEYS + 31) / 32;      // bitmap words
+constexpr int AR_SWEEP = 17;                          // candidates of one sweep (8 seasonal, 8 non-seasonal, constant)
+constexpr int AR_S = 32;                              // steps per streamed block of the CSS pass
 
 __device__ __forceinline__ int ar_wave_max(int v)
 {
@@ -56,23 +69,22 @@ __device__ __forceinline__ void ar_pacf(const double *u, int k, double *phi)
 // LDS layout per wave (lane-minor): [ring: R slots x 64 lanes x {e, v}][simplex 42 + values 7][acoef L1][bcoef L1][tried 11 words]
 // The ring holds e_t and v_t of step t side by side in slot t & (R - 1), R = the power of two >= 2 m + 6, so that one
 // 128-bit LDS access moves both and the slot index is a wave-uniform mask (no wrap arithmetic per lane).
+
+// LDS per wave (lane-minor): [ring: R slots x 64 lanes x {e, v}][simplex 42 + values 7]
+// The ring holds e_t and v_t of step t side by side in slot t mod R, R = 2 m + 6 (the two seasonal lags of a 4-step
+// sub-block plus the q + m Q residuals the forecast needs), so that one 128-bit LDS access moves both; slot indices are
+// wave-uniform and kept in scalar registers.
 typedef double ar_ev_t __attribute__((ext_vector_type(2)));
-__host__ __device__ inline int ar_ring_slots(int m) { int r = 8; while (r < 2 * m + 6) r <<= 1; return r; }
+__host__ __device__ inline int ar_ring_slots(int m) { return 2 * m + 6; }
 struct ArLds {
-    double *base; int L1; int R;
-    __device__ double *coef() const { return base + (size_t)2 * R * NM_BLOCK; }
-    __device__ double &sim(int k, int i) const { return coef()[(k * AR_MAXDIM + i) * NM_BLOCK + threadIdx.x]; }
-    __device__ double &fs(int k) const { return coef()[((AR_MAXDIM + 1) * AR_MAXDIM + k) * NM_BLOCK + threadIdx.x]; }
-    __device__ double &a(int k) const { return coef()[(49 + k) * NM_BLOCK + threadIdx.x]; }
-    __device__ double &b(int k) const { return coef()[(49 + L1 + k) * NM_BLOCK + threadIdx.x]; }
-    __device__ double e_at(int t) const { return base[((size_t)(t & (R - 1)) * NM_BLOCK + threadIdx.x) * 2]; }
-    __device__ uint32_t &tried(int wd) const { return ((uint32_t *)(coef() + (size_t)(49 + 2 * L1) * NM_BLOCK))[wd * NM_BLOCK + threadIdx.x]; }
+    double *base; int R;
+    int col;              // lane column holding this lane's simplex (its own, or its group leader's in the speculative fit)
+    __device__ double *smp() const { return base + (size_t)2 * R * NM_BLOCK; }
+    __device__ double &sim(int k, int i) const { return smp()[(k * AR_MAXDIM + i) * NM_BLOCK + col]; }
+    __device__ double &fs(int k) const { return smp()[((AR_MAXDIM + 1) * AR_MAXDIM + k) * NM_BLOCK + col]; }
+    __device__ double e_at(int t) const { return base[((size_t)(t % R) * NM_BLOCK + threadIdx.x) * 2]; }
 };
-static size_t ar_lds_bytes(int m)
-{
-    const int L1 = AR_MAXP + AR_MAXSP * m + 1;
-    return sizeof(double) * (size_t)(2 * ar_ring_slots(m) + 49 + 2 * L1 + 11) * NM_BLOCK;
-}
+static size_t ar_lds_bytes(int m) { return sizeof(double) * (size_t)(2 * ar_ring_slots(m) + 49) * NM_BLOCK; }
 
 // the four factor polynomials of a trial point, zero padded (registers)
 struct ArFac { double phi[AR_MAXP], th[AR_MAXP], Phi[AR_MAXSP], Th[AR_MAXSP]; double mu; int nc; };
@@ -91,8 +103,13 @@ __device__ __forceinline__ void ar_factors(const ArOrd &o, int m, const double *
     f.nc = o.p + m * o.P;
 }
 
-// expanded lag polynomials of the trial point x into LDS
-__device__ __forceinline__ void ar_build_poly(const ArOrd &o, int m, const double *x, const ArLds &L, int &La, int &Lb, double &mu)
+// expanded lag polynomials of the fitted model (forecast only), in LDS after the ring
+struct ArPolyLds {
+    double *base; int L1;
+    __device__ double &a(int k) const { return base[k * NM_BLOCK + threadIdx.x]; }
+    __device__ double &b(int k) const { return base[(L1 + k) * NM_BLOCK + threadIdx.x]; }
+};
+__device__ __forceinline__ void ar_build_poly(const ArOrd &o, int m, const double *x, const ArPolyLds &L, int &La, int &Lb, double &mu)
 {
     double phi[AR_MAXP], th[AR_MAXP], Phi[AR_MAXSP], Th[AR_MAXSP];
     int k = 0;
@@ -120,21 +137,25 @@ __device__ __forceinline__ void ar_build_poly(const ArOrd &o, int m, const doubl
 
 // One CSS pass for the whole wave, CASCADED form (oracle/arima.c css_eval): fixed 5 + 2 + 5 + 2 fused
 // multiply-adds per step whatever the lane's orders (absent coefficients are exact zeros), the short lags in
-// VGPR shift registers, the seasonal lags in LDS rings (slot t % ring, read before write), w streamed from HBM.
+// VGPR shift registers, the seasonal lags in the LDS ring, w streamed from the lane's own row.
 //     v_t = w'_t - sum phi_i w'_{t-i} ; z_t = v_t - sum Phi_I v_{t-mI} ; u_t = z_t + sum theta_j u_{t-j} ;
 //     e_t = u_t + sum Theta_J e_{t-mJ}   (z, u, e from t >= nc = p + m P on)
-// MODE 0: seasonal lags read from the LDS ring step by step (m = 2, 3: a lag can fall inside a sub-block);
+// MODE 0: seasonal lags read from the ring step by step (m = 2, 3: a lag can fall inside a sub-block);
 // MODE 1: m >= 4, every seasonal lag of a 4-step sub-block was produced before it, so its 8 ring slots are fetched up
 //         front (independent LDS reads) and the four steps run in registers; MODE 2: m = 1, no seasonal factors at all.
 // The step is branch-free.  A block of S steps runs ungated when every live lane is inside its sample for the whole block
-// and past its warm-up (base >= max nc, base + S <= min len over the live lanes; finished lanes compute into their own
+// and past its warm-up (base >= max nc, base + S <= min len over the live lanes; idle lanes compute into their own
 // slots and are ignored); otherwise the gated variant predicates the ring stores on t < len and selects exact zeros for
 // the warm-up and past-the-end steps (selects, not arithmetic on possibly non-finite padding).
+// Lanes of a wave work on different series (and different lengths): each streams its own row.  The row is double-buffered
+// in registers: the S values of the NEXT block are requested (eight 128-bit loads... per lane) before the S steps of the
+// current one run and are only touched afterwards, so the HBM/L2 latency sits behind S steps of recursion.  Rows carry
+// 2 S spare elements, so the loads are unconditional.
 template <int MODE>
-__device__ __noinline__ double ar_css_pass_impl(const double *w, size_t ld, int len, int wave_len_v, bool live, const ArFac &fin, int m_v,
+__device__ __noinline__ double ar_css_pass_impl(const double *wrow, int len, int wave_len_v, bool live, const ArFac &fin, int m_v,
                                                 const ArLds &L)
 {
-    // out of line on purpose: the pass gets its own register allocation (the search kernel around it is a large state
+    // out of line on purpose: the pass gets its own register allocation (the fit kernel around it is a large state
     // machine), and the coefficients are copied out of the caller's (scratch-resident) block once per pass
     double phi[AR_MAXP], th[AR_MAXP], Phi[AR_MAXSP], Th[AR_MAXSP];
 #pragma unroll
@@ -146,48 +167,47 @@ __device__ __noinline__ double ar_css_pass_impl(const double *w, size_t ld, int 
     // wave-uniform quantities in scalar registers
     const int wave_len = __builtin_amdgcn_readfirstlane(wave_len_v);
     const int m = __builtin_amdgcn_readfirstlane(m_v);
-    const int mask = __builtin_amdgcn_readfirstlane(L.R) - 1;
+    const int R = __builtin_amdgcn_readfirstlane(L.R);
     const int lim = live ? len : 0;
     const int nc_max = __builtin_amdgcn_readfirstlane(ar_wave_max(live ? nc : 0));
     const int len_min = -__builtin_amdgcn_readfirstlane(ar_wave_max(live ? -len : -0x3fffffff));
     // explicit address spaces: through the call boundary the pointers are generic, and generic (flat) loads would make
-    // every LDS wait also wait for the HBM prefetch in flight
-    typedef const __attribute__((address_space(1))) double *gptr_t;
+    // every LDS wait also wait for the row prefetch in flight
+    typedef const __attribute__((address_space(1))) ar_ev_t *gptr_t;
     typedef __attribute__((address_space(3))) ar_ev_t *lptr_t;
-    const gptr_t wg = (gptr_t)w;
+    gptr_t wp_next = (gptr_t)wrow;
     const lptr_t ring = (lptr_t)(L.base) + threadIdx.x;        // slot k of this lane: ring[k * NM_BLOCK]
     double css = 0.0;
     double wl[AR_MAXP] = {0, 0, 0, 0, 0}, ul[AR_MAXP] = {0, 0, 0, 0, 0};
-    for (int k = 0; k <= mask; k++) ring[k * NM_BLOCK] = ar_ev_t{0.0, 0.0};
-    // w is double-buffered in registers: the S rows of the NEXT iteration are requested before the S steps of the current
-    // one run, and are only touched (copied into cur) after them, so the HBM latency sits behind S steps of recursion and
-    // the loop has a single, already satisfied, wait per iteration.  The loads are unconditional: the block W has 2 S
-    // spare rows, and steps past a lane's length contribute nothing.
-    constexpr int S = 32;
-    double cur[S], nxt[S];
-    gptr_t wp_next = wg;
+    for (int k = 0; k < R; k++) ring[k * NM_BLOCK] = ar_ev_t{0.0, 0.0};
+    constexpr int S = AR_S;
+    ar_ev_t cur[S / 2], nxt[S / 2];
 #pragma unroll
-    for (int j = 0; j < S; j++) cur[j] = wp_next[(size_t)j * ld];
-    wp_next += (size_t)S * ld;
+    for (int j = 0; j < S / 2; j++) cur[j] = wp_next[j];
+    wp_next += S / 2;
+    // ring slots of t0, t0 - m, t0 - 2m (scalar, advanced by 4 per sub-block)
+    int s0 = 0, s1 = (R - m % R) % R, s2 = (R - (2 * m) % R) % R;
+    auto wrap = [&](int x) __attribute__((always_inline)) { return x >= R ? x - R : x; };
 
     auto block = [&](const int base, auto gated_tag) __attribute__((always_inline)) {
         constexpr bool GATED = decltype(gated_tag)::value;
 #pragma unroll
         for (int sb = 0; sb < S; sb += 4) {
             const int t0 = base + sb;
-            ar_ev_t s1[4], s2[4];                 // slots t - m and t - 2m: {e, v}
+            ar_ev_t l1[4], l2[4];                 // slots t - m and t - 2m: {e, v}
             double vnew[4], enew[4];
             if (MODE == 1) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    s1[j] = ring[((t0 + j - m) & mask) * NM_BLOCK];
-                    s2[j] = ring[((t0 + j - 2 * m) & mask) * NM_BLOCK];
+                    l1[j] = ring[wrap(s1 + j) * NM_BLOCK];
+                    l2[j] = ring[wrap(s2 + j) * NM_BLOCK];
                 }
             }
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int t = t0 + j;
-                const double wp = cur[sb + j] - mu;
+                const double wv = ((sb + j) & 1) ? cur[(sb + j) / 2].y : cur[(sb + j) / 2].x;
+                const double wp = wv - mu;
                 double vt = wp;
 #pragma unroll
                 for (int q = 0; q < AR_MAXP; q++) vt = fma(phi[q], wl[q], vt);
@@ -196,12 +216,12 @@ __device__ __noinline__ double ar_css_pass_impl(const double *w, size_t ld, int 
                 wl[0] = wp;
                 double z = vt;
                 if (MODE == 0) {
-                    s1[j] = ring[((t - m) & mask) * NM_BLOCK];
-                    s2[j] = ring[((t - 2 * m) & mask) * NM_BLOCK];
+                    l1[j] = ring[wrap(s1 + j) * NM_BLOCK];
+                    l2[j] = ring[wrap(s2 + j) * NM_BLOCK];
                 }
                 if (MODE != 2) {
-                    z = fma(Phi[0], s1[j].y, z);
-                    z = fma(Phi[1], s2[j].y, z);
+                    z = fma(Phi[0], l1[j].y, z);
+                    z = fma(Phi[1], l2[j].y, z);
                 }
                 // the newest lag enters last, so consecutive steps are one fused multiply-add apart
                 double u = z;
@@ -214,12 +234,12 @@ __device__ __noinline__ double ar_css_pass_impl(const double *w, size_t ld, int 
                 ul[0] = u;
                 double et = u;
                 if (MODE != 2) {
-                    et = fma(Th[0], s1[j].x, et);
-                    et = fma(Th[1], s2[j].x, et);
+                    et = fma(Th[0], l1[j].x, et);
+                    et = fma(Th[1], l2[j].x, et);
                     if (GATED) et = on ? et : 0.0;
                 }
                 if (MODE == 0) {
-                    if (!GATED || t < lim) ring[(t & mask) * NM_BLOCK] = ar_ev_t{et, vt};
+                    if (!GATED || t < lim) ring[wrap(s0 + j) * NM_BLOCK] = ar_ev_t{et, vt};
                 }
                 vnew[j] = vt; enew[j] = et;
                 const double ec = (!GATED || t < lim) ? et : 0.0;
@@ -228,29 +248,82 @@ __device__ __noinline__ double ar_css_pass_impl(const double *w, size_t ld, int 
             if (MODE != 0) {
 #pragma unroll
                 for (int j = 0; j < 4; j++)
-                    if (!GATED || t0 + j < lim) ring[((t0 + j) & mask) * NM_BLOCK] = ar_ev_t{enew[j], vnew[j]};
+                    if (!GATED || t0 + j < lim) ring[wrap(s0 + j) * NM_BLOCK] = ar_ev_t{enew[j], vnew[j]};
             }
+            s0 = wrap(s0 + 4); s1 = wrap(s1 + 4); s2 = wrap(s2 + 4);
         }
     };
 
     for (int base = 0; base < wave_len; base += S) {
 #pragma unroll
-        for (int j = 0; j < S; j++) nxt[j] = wp_next[(size_t)j * ld];
-        wp_next += (size_t)S * ld;
+        for (int j = 0; j < S / 2; j++) nxt[j] = wp_next[j];
+        wp_next += S / 2;
         if (base >= nc_max && base + S <= len_min) block(base, std::false_type{});
         else block(base, std::true_type{});
 #pragma unroll
-        for (int j = 0; j < S; j++) cur[j] = nxt[j];
+        for (int j = 0; j < S / 2; j++) cur[j] = nxt[j];
     }
     return css;
 }
 
-__device__ __forceinline__ double ar_css_pass(const double *w, size_t ld, int len, int wave_len, bool live, const ArFac &f, int m,
-                                              const ArLds &L)
+__device__ __forceinline__ double ar_css_pass(const double *wrow, int len, int wave_len, bool live, const ArFac &f, int m, const ArLds &L)
 {
-    if (m >= 4) return ar_css_pass_impl<1>(w, ld, len, wave_len, live, f, m, L);
-    if (m <= 1) return ar_css_pass_impl<2>(w, ld, len, wave_len, live, f, m, L);
-    return ar_css_pass_impl<0>(w, ld, len, wave_len, live, f, m, L);
+    if (m >= 4) return ar_css_pass_impl<1>(wrow, len, wave_len, live, f, m, L);
+    if (m <= 1) return ar_css_pass_impl<2>(wrow, len, wave_len, live, f, m, L);
+    return ar_css_pass_impl<0>(wrow, len, wave_len, live, f, m, L);
+}
+
+// ------------------------------------------------------------------------------------------------
+// workspace (one allocation per batch, carved by ArWs::carve; see arima_workspace_bytes)
+// ------------------------------------------------------------------------------------------------
+struct ArWs {
+    double *W;            // [n x tw] differenced series, series-major, 2 S spare elements per row
+    double *cache_aicc;   // [n x AR_KEYS] AICc of every fitted candidate (+inf: fit failed)
+    double *cache_x;      // [n x AR_KEYS x 6] optimiser coordinates of every fitted candidate
+    int32_t *cache_evals; // [n x AR_KEYS]
+    uint32_t *computed;   // [n x AR_KEYWORDS] candidate has been fitted or queued
+    uint32_t *tried;      // [n x AR_KEYWORDS] candidate has been tried by the (replayed) sequential search
+    double *best_aicc;    // [n]
+    int32_t *state;       // [n x 8] stage, idx, base key, best key, have, improved, n_models, fin
+    int32_t *q_series, *q_key;   // [7 x cap] problem queues by dimension
+    int32_t *counts;      // [16] 0..6 queue lengths, 8 fetch cursor
+    double *simplex;      // unused (simplex lives in LDS)
+    size_t tw, cap;
+    static size_t align(size_t x) { return (x + 255) & ~(size_t)255; }
+    size_t carve(char *p, int n, int t_max)
+    {
+        tw = (size_t)((t_max + AR_S - 1) / AR_S) * AR_S + 2 * AR_S;
+        cap = (size_t)n * AR_SWEEP;
+        size_t off = 0;
+        auto take = [&](size_t bytes) { char *r = p ? p + off : nullptr; off += align(bytes); return r; };
+        W = (double *)take(sizeof(double) * (size_t)n * tw);
+        cache_aicc = (double *)take(sizeof(double) * (size_t)n * AR_KEYS);
+        cache_x = (double *)take(sizeof(double) * (size_t)n * AR_KEYS * AR_MAXDIM);
+        cache_evals = (int32_t *)take(sizeof(int32_t) * (size_t)n * AR_KEYS);
+        computed = (uint32_t *)take(sizeof(uint32_t) * (size_t)n * AR_KEYWORDS);
+        tried = (uint32_t *)take(sizeof(uint32_t) * (size_t)n * AR_KEYWORDS);
+        best_aicc = (double *)take(sizeof(double) * (size_t)n);
+        state = (int32_t *)take(sizeof(int32_t) * (size_t)n * 8);
+        q_series = (int32_t *)take(sizeof(int32_t) * 7 * cap);
+        q_key = (int32_t *)take(sizeof(int32_t) * 7 * cap);
+        counts = (int32_t *)take(sizeof(int32_t) * 16);
+        simplex = nullptr;
+        return off;
+    }
+};
+size_t arima_workspace_bytes(int n_series, int t_max) { ArWs w; return w.carve(nullptr, n_series > 0 ? n_series : 1, t_max > 0 ? t_max : 1); }
+
+enum { AS_STAGE = 0, AS_IDX, AS_BASE, AS_BEST, AS_HAVE, AS_IMPROVED, AS_NMODELS, AS_FIN };
+
+__device__ __forceinline__ ArOrd ar_unkey(int key)
+{
+    ArOrd o;
+    o.c = key & 1; key >>= 1;
+    o.Q = key % 3; key /= 3;
+    o.P = key % 3; key /= 3;
+    o.q = key % 6; key /= 6;
+    o.p = key;
+    return o;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -335,52 +408,188 @@ __device__ double ar_seasonal_strength(const double *y, size_t ld, int n, int m,
     return f;
 }
 
-__global__ __launch_bounds__(NM_BLOCK) void arima_prep_kernel(const ArimaArgs a)
+__global__ __launch_bounds__(NM_BLOCK) void arima_prep_kernel(const ArimaArgs a, const ArWs ws)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int s = blockIdx.x * NM_BLOCK + threadIdx.x;
     if (s >= a.n_series) return;
+    // search state of this series (a series outside this period group keeps wlen = 0 and is skipped everywhere)
+    for (int i = 0; i < 8; i++) ws.state[(size_t)s * 8 + i] = 0;
+    for (int i = 0; i < AR_KEYWORDS; i++) { ws.computed[(size_t)s * AR_KEYWORDS + i] = 0u; ws.tried[(size_t)s * AR_KEYWORDS + i] = 0u; }
+    ws.best_aicc[s] = __builtin_huge_val();
     const int n = a.len[s];
-    if (n <= 0) { a.wlen[s] = 0; return; }
+    if (n <= 0) { a.wlen[s] = 0; ws.state[(size_t)s * 8 + AS_FIN] = 1; return; }
     const double *y = a.y + s;
-    double *w = a.w + s;
+    double *w = ws.W + (size_t)s * ws.tw;
     const size_t ld = a.ld;
     const int m = a.m;
     int len = n, D = 0, d = 0;
     if (m > 1 && ar_seasonal_strength(y, ld, n, m, lds + threadIdx.x) > 0.64 && n > m + 2) {
         D = 1;
-        for (int t = m; t < n; t++) w[(size_t)(t - m) * ld] = y[(size_t)t * ld] - y[(size_t)(t - m) * ld];
+        for (int t = m; t < n; t++) w[t - m] = y[(size_t)t * ld] - y[(size_t)(t - m) * ld];
         len = n - m;
     } else {
-        for (int t = 0; t < n; t++) w[(size_t)t * ld] = y[(size_t)t * ld];
+        for (int t = 0; t < n; t++) w[t] = y[(size_t)t * ld];
     }
     // integration constants of the seasonally differenced series (before the ordinary differences)
-    a.last_d0[s] = w[(size_t)(len - 1) * ld];
-    a.last_d1[s] = len >= 2 ? w[(size_t)(len - 1) * ld] - w[(size_t)(len - 2) * ld] : 0.0;
-    while (d < 2 && len > 3 && ar_kpss_reject(w, ld, len)) {
+    a.last_d0[s] = w[len - 1];
+    a.last_d1[s] = len >= 2 ? w[len - 1] - w[len - 2] : 0.0;
+    while (d < 2 && len > 3 && ar_kpss_reject(w, 1, len)) {
         double prev = w[0];
         for (int t = 1; t < len; t++) {
-            double cur = w[(size_t)t * ld];
-            w[(size_t)(t - 1) * ld] = cur - prev;
+            double cur = w[t];
+            w[t - 1] = cur - prev;
             prev = cur;
         }
         len -= 1;
         d++;
     }
+    for (int t = len; t < (int)ws.tw; t++) w[t] = 0.0;       // padding read by the streamed blocks (never used)
     double sum = 0.0;
-    for (int i = 0; i < len; i++) sum = sum + w[(size_t)i * ld];
+    for (int i = 0; i < len; i++) sum = sum + w[i];
     const double wmean = sum / (double)len;
     double v = 0.0;
-    for (int i = 0; i < len; i++) { double dd = w[(size_t)i * ld] - wmean; v = fma(dd, dd, v); }
+    for (int i = 0; i < len; i++) { double dd = w[i] - wmean; v = fma(dd, dd, v); }
     a.wlen[s] = len;
     a.d[s] = d;
     a.D[s] = D;
     a.wmean[s] = wmean;
     a.wsd[s] = sqrt(v / (double)len);
+    if (len < 3) ws.state[(size_t)s * 8 + AS_FIN] = 1;
 }
 
 // ------------------------------------------------------------------------------------------------
-// stepwise search
+// advance: replay of the sequential stepwise search against the cache; queues what is missing
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool ar_candidate(int stage, int idx, const ArOrd &base, int allow_c, int maxP, ArOrd &o)
+{
+    if (stage == 0) {
+        const int sP = maxP ? 1 : 0;
+        if (idx == 0) o = ArOrd{2, 2, sP, sP, allow_c};
+        else if (idx == 1) o = ArOrd{0, 0, 0, 0, allow_c};
+        else if (idx == 2) o = ArOrd{1, 0, sP, 0, allow_c};
+        else if (idx == 3) o = ArOrd{0, 1, 0, sP, allow_c};
+        else o = ArOrd{0, 0, 0, 0, allow_c ? 0 : -1};   // only when a constant is allowed
+    } else {
+        const int dPv[8] = {-1, 0, 1, 0, -1, -1, 1, 1}, dQv[8] = {0, -1, 0, 1, -1, 1, -1, 1};
+        if (idx < 8) o = ArOrd{base.p, base.q, base.P + dPv[idx], base.Q + dQv[idx], base.c};
+        else if (idx < 16) o = ArOrd{base.p + dPv[idx - 8], base.q + dQv[idx - 8], base.P, base.Q, base.c};
+        else o = ArOrd{base.p, base.q, base.P, base.Q, 1 - base.c};
+    }
+    return !(o.c < 0 || o.p < 0 || o.q < 0 || o.P < 0 || o.Q < 0 || o.p > AR_MAXP || o.q > AR_MAXP || o.P > maxP || o.Q > maxP ||
+             o.p + o.q + o.P + o.Q > AR_MAXORDER || (o.c && !allow_c));
+}
+
+__global__ __launch_bounds__(256) void arima_advance_kernel(const ArimaArgs a, const ArWs ws, const int lookahead)
+{
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= a.n_series) return;
+    int32_t *st = ws.state + (size_t)s * 8;
+    if (st[AS_FIN]) return;
+    const int len = a.wlen[s];
+    const int m = a.m;
+    const int allow_c = (a.d[s] + a.D[s] <= 1) ? 1 : 0;
+    const int maxP = m > 1 ? AR_MAXSP : 0;
+    uint32_t *tried = ws.tried + (size_t)s * AR_KEYWORDS;
+    uint32_t *computed = ws.computed + (size_t)s * AR_KEYWORDS;
+    int stage = st[AS_STAGE], idx = st[AS_IDX], n_models = st[AS_NMODELS];
+    bool have = st[AS_HAVE] != 0, improved = st[AS_IMPROVED] != 0, fin = false;
+    int best_key = st[AS_BEST];
+    ArOrd base = ar_unkey(st[AS_BASE]);
+    double best_aicc = ws.best_aicc[s];
+    int evals = a.evals[s];
+    auto impossible = [&](const ArOrd &o) { return len - (o.p + m * o.P) <= 0 || len - (ar_dim(o) + 1) - 1 <= 0; };
+
+    for (;;) {
+        if (stage == 0) {
+            if (idx >= 5) {
+                if (!have) { fin = true; break; }
+                stage = 1; idx = 0; base = ar_unkey(best_key); improved = false;
+                continue;
+            }
+        } else {
+            if (improved) { base = ar_unkey(best_key); idx = 0; improved = false; }
+            if (idx >= AR_SWEEP) { fin = true; break; }
+        }
+        ArOrd o;
+        if (!ar_candidate(stage, idx, base, allow_c, maxP, o) || n_models >= AR_MAXMODELS) { idx++; continue; }
+        const int key = ar_key(o);
+        if (tried[key >> 5] & (1u << (key & 31))) { idx++; continue; }
+        const bool imp = impossible(o);
+        if (!imp && !(computed[key >> 5] & (1u << (key & 31)))) {
+            // not fitted yet: queue it together with every other unfitted candidate of this sweep, then wait for the fit
+            const int last = stage == 0 ? 5 : AR_SWEEP;
+            auto emit = [&](const ArOrd &c) {
+                const int ck = ar_key(c);
+                if ((tried[ck >> 5] | computed[ck >> 5]) & (1u << (ck & 31))) return;
+                if (impossible(c)) return;
+                computed[ck >> 5] |= (1u << (ck & 31));
+                const int dim = ar_dim(c);
+                const int pos = atomicAdd(&ws.counts[dim], 1);
+                if ((size_t)pos >= ws.cap) { atomicSub(&ws.counts[dim], 1); computed[ck >> 5] &= ~(1u << (ck & 31)); return; }
+                ws.q_series[(size_t)dim * ws.cap + pos] = s;
+                ws.q_key[(size_t)dim * ws.cap + pos] = ck;
+            };
+            for (int j = idx; j < last; j++) {
+                ArOrd c;
+                if (ar_candidate(stage, j, base, allow_c, maxP, c)) emit(c);
+            }
+            if (lookahead) {
+                // idle lanes ahead (short queue): also fit the sweep that would follow whichever candidate is accepted,
+                // so that the next replay usually runs two sweeps deep before it has to wait again
+                for (int j = idx - 1; j < last; j++) {
+                    ArOrd nb;
+                    if (j < idx) { if (!(stage == 0 && have)) continue; nb = ar_unkey(best_key); }   // initial stage: the best so far may stay
+                    else {
+                        if (!ar_candidate(stage, j, base, allow_c, maxP, nb)) continue;
+                        const int nk = ar_key(nb);
+                        if (tried[nk >> 5] & (1u << (nk & 31))) continue;
+                    }
+                    for (int jj = 0; jj < AR_SWEEP; jj++) {
+                        ArOrd c;
+                        if (ar_candidate(1, jj, nb, allow_c, maxP, c)) emit(c);
+                    }
+                }
+            }
+            break;
+        }
+        // the sequential search tries this candidate now
+        tried[key >> 5] |= (1u << (key & 31));
+        n_models++;
+        idx++;
+        if (!imp) {
+            evals += ws.cache_evals[(size_t)s * AR_KEYS + key];
+            const double aicc = ws.cache_aicc[(size_t)s * AR_KEYS + key];
+            if (fabs(aicc) <= 1.7976931348623157e308 && aicc < best_aicc) { best_aicc = aicc; best_key = key; have = true; improved = true; }
+        }
+    }
+    st[AS_STAGE] = stage; st[AS_IDX] = idx; st[AS_BASE] = ar_key(base); st[AS_BEST] = best_key;
+    st[AS_HAVE] = have ? 1 : 0; st[AS_IMPROVED] = improved ? 1 : 0; st[AS_NMODELS] = n_models; st[AS_FIN] = fin ? 1 : 0;
+    ws.best_aicc[s] = best_aicc;
+    a.evals[s] = evals;
+    if (fin) {
+        const size_t ld = a.ld;
+        const ArOrd best = ar_unkey(best_key);
+        a.status[s] = have ? FIT_OK : FIT_SHORT;
+        a.aicc[s] = best_aicc;
+        a.order[(size_t)0 * ld + s] = best.p; a.order[(size_t)1 * ld + s] = best.q; a.order[(size_t)2 * ld + s] = best.P;
+        a.order[(size_t)3 * ld + s] = best.Q; a.order[(size_t)4 * ld + s] = best.c;
+        for (int i = 0; i < AR_MAXDIM; i++)
+            a.xbest[(size_t)i * ld + s] = have ? ws.cache_x[((size_t)s * AR_KEYS + best_key) * AR_MAXDIM + i] : 0.0;
+        a.models[s] = n_models;
+    }
+}
+
+// series that never enter the search (too short / not in this group)
+__global__ __launch_bounds__(256) void arima_skip_kernel(const ArimaArgs a)
+{
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= a.n_series || a.len[s] <= 0) return;
+    if (a.wlen[s] < 3) { a.status[s] = FIT_SHORT; a.models[s] = 0; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fit: persistent lanes, one (series, order) problem at a time from the queue
 // ------------------------------------------------------------------------------------------------
 enum { PH_NEXT = 0, PH_INIT, PH_ITER, PH_E, PH_OC, PH_IC, PH_SHRINK, PH_FINAL };
 
@@ -426,84 +635,52 @@ __device__ __forceinline__ void ar_sort(const ArLds &L, int D)
     }
 }
 
-__global__ __launch_bounds__(NM_BLOCK) void arima_search_kernel(const ArimaArgs a)
+__global__ __launch_bounds__(NM_BLOCK) void arima_fit_kernel(const ArimaArgs a, const ArWs ws, const int total)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int lane = threadIdx.x;
-    const int s = blockIdx.x * NM_BLOCK + lane;
-    const bool valid = s < a.n_series;
-    const int len = valid ? a.wlen[s] : 0;
-    const bool live = valid && len >= 3;
     const int m = a.m;
-    ArLds L{lds, AR_MAXP + AR_MAXSP * m + 1, ar_ring_slots(m)};
-    const double *w = a.w + (valid ? s : 0);
-    const size_t ld = a.ld;
-    const int wave_len = ar_wave_max(live ? len : 0);
-    if (wave_len == 0) {
-        if (valid) { a.status[s] = FIT_SHORT; a.evals[s] = 0; a.passes[s] = 0; a.models[s] = 0; }
-        return;
+    ArLds L{lds, ar_ring_slots(m), (int)threadIdx.x};
+    // queue: dimension 6 first (longest fits first, so the tail of the launch is made of short ones)
+    int qoff[8];
+    {
+        int acc = 0;
+        for (int dmn = AR_MAXDIM; dmn >= 0; dmn--) { qoff[dmn] = acc; acc += ws.counts[dmn]; }
     }
-    const int d = live ? a.d[s] : 0, Dd = live ? a.D[s] : 0;
-    const double wmean = live ? a.wmean[s] : 0.0, wsd = live ? a.wsd[s] : 0.0;
-    const int allow_c = (d + Dd <= 1) ? 1 : 0;
-    const int maxP = m > 1 ? AR_MAXSP : 0;
-    for (int wd = 0; wd < 21; wd++) L.tried(wd) = 0u;
 
-    bool fin = !live;
-    ArOrd best{0, 0, 0, 0, 0}, base{0, 0, 0, 0, 0}, cur{0, 0, 0, 0, 0};
-    double best_aicc = __builtin_huge_val(), bestx[AR_MAXDIM] = {0, 0, 0, 0, 0, 0};
-    bool have = false, improved = false;
-    int stage = 0, idx = 0, n_models = 0, evals = 0, passes = 0;
-    int ph = PH_NEXT, D = 0, vi = 0, nm_evals = 0, nm_iters = 1;
+    bool fin = false;
+    int s = 0, key = 0, len = 0, D = 0;
+    ArOrd cur{0, 0, 0, 0, 0};
+    const double *wrow = ws.W;
+    int ph = PH_NEXT, vi = 0, nm_evals = 0, nm_iters = 1, passes = 0;
     double fxr = 0.0;
 
     for (;;) {
-        // ---- 1. next candidate model of this lane (no pass needed) ----------------------------------
-        while (!fin && ph == PH_NEXT) {
-            ArOrd o;
-            if (stage == 0) {
-                if (idx >= 5) {
-                    if (!have) { fin = true; break; }
-                    stage = 1; idx = 0; base = best; improved = false;
-                    continue;
+        // ---- 1. next problem of this lane ------------------------------------------------------------
+        if (!fin && ph == PH_NEXT) {
+            const int item = atomicAdd(&ws.counts[8], 1);
+            if (item >= total) fin = true;
+            else {
+                int dmn = 0;
+                for (int k = AR_MAXDIM; k >= 0; k--)
+                    if (item >= qoff[k] && item < qoff[k] + ws.counts[k]) dmn = k;
+                const size_t qi = (size_t)dmn * ws.cap + (size_t)(item - qoff[dmn]);
+                s = ws.q_series[qi]; key = ws.q_key[qi];
+                cur = ar_unkey(key);
+                D = dmn;
+                len = a.wlen[s];
+                wrow = ws.W + (size_t)s * ws.tw;
+                const double wmean = a.wmean[s], wsd = a.wsd[s];
+                for (int i = 0; i < D; i++) L.sim(0, i) = 0.0;
+                if (cur.c) L.sim(0, D - 1) = wmean;
+                for (int k = 0; k < D; k++) {
+                    for (int i = 0; i < D; i++) L.sim(k + 1, i) = L.sim(0, i);
+                    const double step = (cur.c && k == D - 1) ? (wsd > 0.0 ? 0.1 * wsd : 1.0e-4) : 0.25;
+                    L.sim(k + 1, k) = L.sim(0, k) + step;
                 }
-                const int sP = maxP ? 1 : 0;
-                if (idx == 0) o = ArOrd{2, 2, sP, sP, allow_c};
-                else if (idx == 1) o = ArOrd{0, 0, 0, 0, allow_c};
-                else if (idx == 2) o = ArOrd{1, 0, sP, 0, allow_c};
-                else if (idx == 3) o = ArOrd{0, 1, 0, sP, allow_c};
-                else o = ArOrd{0, 0, 0, 0, allow_c ? 0 : -1};   // only when a constant is allowed
-                idx++;
-            } else {
-                if (improved) { base = best; idx = 0; improved = false; }
-                if (idx >= 17) { fin = true; break; }
-                const int dPv[8] = {-1, 0, 1, 0, -1, -1, 1, 1}, dQv[8] = {0, -1, 0, 1, -1, 1, -1, 1};
-                if (idx < 8) o = ArOrd{base.p, base.q, base.P + dPv[idx], base.Q + dQv[idx], base.c};
-                else if (idx < 16) o = ArOrd{base.p + dPv[idx - 8], base.q + dQv[idx - 8], base.P, base.Q, base.c};
-                else o = ArOrd{base.p, base.q, base.P, base.Q, 1 - base.c};
-                idx++;
+                nm_evals = 0; nm_iters = 1; vi = 0; passes = 0;
+                if (D == 0) { ph = PH_FINAL; nm_evals = 1; }
+                else ph = PH_INIT;
             }
-            if (o.c < 0 || o.p < 0 || o.q < 0 || o.P < 0 || o.Q < 0 || o.p > AR_MAXP || o.q > AR_MAXP || o.P > maxP || o.Q > maxP ||
-                o.p + o.q + o.P + o.Q > AR_MAXORDER || (o.c && !allow_c) || n_models >= AR_MAXMODELS)
-                continue;
-            const int key = ar_key(o);
-            if (L.tried(key >> 5) & (1u << (key & 31))) continue;
-            L.tried(key >> 5) |= (1u << (key & 31));
-            n_models++;
-            D = ar_dim(o);
-            const int La0 = o.p + m * o.P;
-            if (len - La0 <= 0 || len - (D + 1) - 1 <= 0) continue;        // fit impossible: candidate fails
-            cur = o;
-            for (int i = 0; i < D; i++) L.sim(0, i) = 0.0;
-            if (o.c) L.sim(0, D - 1) = wmean;
-            for (int k = 0; k < D; k++) {
-                for (int i = 0; i < D; i++) L.sim(k + 1, i) = L.sim(0, i);
-                const double step = (o.c && k == D - 1) ? (wsd > 0.0 ? 0.1 * wsd : 1.0e-4) : 0.25;
-                L.sim(k + 1, k) = L.sim(0, k) + step;
-            }
-            nm_evals = 0; nm_iters = 1; vi = 0;
-            if (D == 0) { ph = PH_FINAL; nm_evals = 1; }
-            else ph = PH_INIT;
         }
         // ---- 2. trial point of the running fit ------------------------------------------------------
         double x[AR_MAXDIM] = {0, 0, 0, 0, 0, 0};
@@ -534,7 +711,8 @@ __global__ __launch_bounds__(NM_BLOCK) void arima_search_kernel(const ArimaArgs 
         if (__all(fin)) break;
 
         // ---- 3. one streamed pass -------------------------------------------------------------------
-        const double css = ar_css_pass(w, ld, len, wave_len, !fin, fac, m, L);
+        const int wave_len = ar_wave_max(fin ? 0 : len);
+        const double css = ar_css_pass(wrow, len, wave_len, !fin, fac, m, L);
         if (fin) continue;
         passes++;
         const int nu = len - fac.nc;
@@ -571,33 +749,160 @@ __global__ __launch_bounds__(NM_BLOCK) void arima_search_kernel(const ArimaArgs 
         } else if (ph == PH_SHRINK) {
             L.fs(1 + vi) = f; vi++; nm_evals++;
             if (vi == D) { nm_iters++; ar_sort(L, D); ph = PH_ITER; }
-        } else { // PH_FINAL: information criterion of the fitted candidate
-            evals += nm_evals;
+        } else { // PH_FINAL: information criterion of the fitted candidate -> cache
+            double aicc = __builtin_huge_val();
             if (fabs(css) <= 1.7976931348623157e308) {
                 const double dn = (double)len, dk = (double)(D + 1);
-                const double aicc = dn * dm_log(v) + 2.0 * dk + 2.0 * dk * (dk + 1.0) / (dn - dk - 1.0);
-                if (fabs(aicc) <= 1.7976931348623157e308 && aicc < best_aicc) {
-                    best_aicc = aicc; best = cur; have = true; improved = true;
-                    for (int i = 0; i < AR_MAXDIM; i++) bestx[i] = i < D ? L.sim(0, i) : 0.0;
-                }
+                aicc = dn * dm_log(v) + 2.0 * dk + 2.0 * dk * (dk + 1.0) / (dn - dk - 1.0);
+                if (!(fabs(aicc) <= 1.7976931348623157e308)) aicc = __builtin_huge_val();
             }
+            const size_t ci = (size_t)s * AR_KEYS + key;
+            ws.cache_aicc[ci] = aicc;
+            ws.cache_evals[ci] = nm_evals;
+            for (int i = 0; i < AR_MAXDIM; i++) ws.cache_x[ci * AR_MAXDIM + i] = i < D ? L.sim(0, i) : 0.0;
+            atomicAdd(&a.passes[s], passes);
             ph = PH_NEXT;
         }
     }
-    if (valid) {
-        a.status[s] = (live && have) ? FIT_OK : FIT_SHORT;
-        a.aicc[s] = best_aicc;
-        a.order[(size_t)0 * ld + s] = best.p; a.order[(size_t)1 * ld + s] = best.q; a.order[(size_t)2 * ld + s] = best.P;
-        a.order[(size_t)3 * ld + s] = best.Q; a.order[(size_t)4 * ld + s] = best.c;
-        for (int i = 0; i < AR_MAXDIM; i++) a.xbest[(size_t)i * ld + s] = bestx[i];
-        a.evals[s] = evals; a.passes[s] = passes; a.models[s] = n_models;
+}
+
+// Speculative variant for short queues (fewer problems than a quarter of the resident lanes): four adjacent lanes share
+// one problem and evaluate the four possible trial points of a Nelder-Mead iteration (reflection, expansion, outside and
+// inside contraction) in ONE pass; the decision then replays the sequential rules, counting only the evaluations the
+// sequential method would have made, so iterates, evaluation counts and the stopping point are those of the sequential
+// fit.  An iteration costs one pass instead of ~1.7: the critical path of a sweep's slowest fit shortens accordingly.
+// The simplex lives in the group leader's LDS column; all four lanes run the same bookkeeping on it (identical values).
+__global__ __launch_bounds__(NM_BLOCK) void arima_fit_spec_kernel(const ArimaArgs a, const ArWs ws, const int total)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int m = a.m;
+    const int lane = threadIdx.x, g = lane & 3, leader = lane & ~3;
+    ArLds L{lds, ar_ring_slots(m), leader};
+    int qoff[8];
+    {
+        int acc = 0;
+        for (int dmn = AR_MAXDIM; dmn >= 0; dmn--) { qoff[dmn] = acc; acc += ws.counts[dmn]; }
+    }
+    bool fin = false;
+    int s = 0, key = 0, len = 0, D = 0;
+    ArOrd cur{0, 0, 0, 0, 0};
+    const double *wrow = ws.W;
+    int ph = PH_NEXT, vi = 0, nm_evals = 0, nm_iters = 1, passes = 0;
+
+    for (;;) {
+        if (!fin && ph == PH_NEXT) {
+            int item = 0;
+            if (g == 0) item = atomicAdd(&ws.counts[8], 1);
+            item = __shfl(item, leader);
+            if (item >= total) fin = true;
+            else {
+                int dmn = 0;
+                for (int k = AR_MAXDIM; k >= 0; k--)
+                    if (item >= qoff[k] && item < qoff[k] + ws.counts[k]) dmn = k;
+                const size_t qi = (size_t)dmn * ws.cap + (size_t)(item - qoff[dmn]);
+                s = ws.q_series[qi]; key = ws.q_key[qi];
+                cur = ar_unkey(key);
+                D = dmn;
+                len = a.wlen[s];
+                wrow = ws.W + (size_t)s * ws.tw;
+                const double wmean = a.wmean[s], wsd = a.wsd[s];
+                for (int i = 0; i < D; i++) L.sim(0, i) = 0.0;
+                if (cur.c) L.sim(0, D - 1) = wmean;
+                for (int k = 0; k < D; k++) {
+                    for (int i = 0; i < D; i++) L.sim(k + 1, i) = L.sim(0, i);
+                    const double step = (cur.c && k == D - 1) ? (wsd > 0.0 ? 0.1 * wsd : 1.0e-4) : 0.25;
+                    L.sim(k + 1, k) = L.sim(0, k) + step;
+                }
+                nm_evals = 0; nm_iters = 1; vi = 0; passes = 0;
+                if (D == 0) { ph = PH_FINAL; nm_evals = 1; }
+                else ph = PH_INIT;
+            }
+        }
+        // ---- trial point of this lane ---------------------------------------------------------------
+        double x[AR_MAXDIM] = {0, 0, 0, 0, 0, 0};
+        bool mine = false;                      // this lane's evaluation is a real one
+        if (!fin) {
+            if (ph == PH_ITER) {
+                bool stop = !(nm_evals < 200 * D && nm_iters < 200 * D);
+                if (!stop) {
+                    bool small = true;
+                    for (int k = 1; k <= D; k++) {
+                        for (int i = 0; i < D; i++)
+                            if (!(fabs(L.sim(k, i) - L.sim(0, i)) <= 1.0e-4)) small = false;
+                        if (!(fabs(L.fs(0) - L.fs(k)) <= 1.0e-8)) small = false;
+                    }
+                    stop = small;
+                }
+                if (stop) ph = PH_FINAL;
+            }
+            if (ph == PH_INIT) { mine = vi + g <= D; if (mine) for (int i = 0; i < D; i++) x[i] = L.sim(vi + g, i); }
+            else if (ph == PH_ITER) { mine = true; for (int i = 0; i < D; i++) x[i] = ar_trial(L, D, g, i); }
+            else if (ph == PH_SHRINK) { mine = 1 + vi + g <= D; if (mine) for (int i = 0; i < D; i++) x[i] = L.sim(1 + vi + g, i); }
+            else { mine = true; for (int i = 0; i < D; i++) x[i] = L.sim(0, i); }      // PH_FINAL
+        }
+        ArFac fac;
+        ar_factors(cur, m, x, fac);
+        if (__all(fin)) break;
+
+        const int wave_len = ar_wave_max(fin ? 0 : len);
+        const double css = ar_css_pass(wrow, len, wave_len, !fin, fac, m, L);
+        if (fin) continue;
+        passes++;
+        const int nu = len - fac.nc;
+        double v = css / (double)nu;
+        double f = __builtin_huge_val();
+        if (fabs(css) <= 1.7976931348623157e308) {
+            if (v < 1.0e-300) v = 1.0e-300;
+            f = 0.5 * dm_log(v);
+        }
+
+        if (ph == PH_INIT) {
+            if (mine) L.fs(vi + g) = f;
+            const int cnt = (D + 1 - vi) < 4 ? (D + 1 - vi) : 4;
+            vi += cnt; nm_evals += cnt;
+            if (vi == D + 1) { ar_sort(L, D); ph = PH_ITER; }
+        } else if (ph == PH_ITER) {
+            const double fr = __shfl(f, leader), fe = __shfl(f, leader + 1), foc = __shfl(f, leader + 2), fic = __shfl(f, leader + 3);
+            nm_evals++;
+            bool shrink = false;
+            if (fr < L.fs(0)) { nm_evals++; if (fe < fr) ar_accept(L, D, 1, fe); else ar_accept(L, D, 0, fr); }
+            else if (fr < L.fs(D - 1)) ar_accept(L, D, 0, fr);
+            else if (fr < L.fs(D)) { nm_evals++; if (foc <= fr) ar_accept(L, D, 2, foc); else shrink = true; }
+            else { nm_evals++; if (fic < L.fs(D)) ar_accept(L, D, 3, fic); else shrink = true; }
+            if (!shrink) nm_iters++;
+            else {
+                for (int k = 1; k <= D; k++)
+                    for (int i = 0; i < D; i++) L.sim(k, i) = L.sim(0, i) + 0.5 * (L.sim(k, i) - L.sim(0, i));
+                vi = 0; ph = PH_SHRINK;
+            }
+        } else if (ph == PH_SHRINK) {
+            if (mine) L.fs(1 + vi + g) = f;
+            const int cnt = (D - vi) < 4 ? (D - vi) : 4;
+            vi += cnt; nm_evals += cnt;
+            if (vi == D) { nm_iters++; ar_sort(L, D); ph = PH_ITER; }
+        } else { // PH_FINAL
+            double aicc = __builtin_huge_val();
+            if (fabs(css) <= 1.7976931348623157e308) {
+                const double dn = (double)len, dk = (double)(D + 1);
+                aicc = dn * dm_log(v) + 2.0 * dk + 2.0 * dk * (dk + 1.0) / (dn - dk - 1.0);
+                if (!(fabs(aicc) <= 1.7976931348623157e308)) aicc = __builtin_huge_val();
+            }
+            if (g == 0) {
+                const size_t ci = (size_t)s * AR_KEYS + key;
+                ws.cache_aicc[ci] = aicc;
+                ws.cache_evals[ci] = nm_evals;
+                for (int i = 0; i < AR_MAXDIM; i++) ws.cache_x[ci * AR_MAXDIM + i] = i < D ? L.sim(0, i) : 0.0;
+                atomicAdd(&a.passes[s], passes);
+            }
+            ph = PH_NEXT;
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // forecast of the differenced series with the selected model, then integration
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NM_BLOCK) void arima_forecast_kernel(const ArimaArgs a)
+__global__ __launch_bounds__(NM_BLOCK) void arima_forecast_kernel(const ArimaArgs a, const ArWs ws)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x;
@@ -606,8 +911,9 @@ __global__ __launch_bounds__(NM_BLOCK) void arima_forecast_kernel(const ArimaArg
     const int len = valid ? a.wlen[s] : 0;
     const bool live = valid && len >= 3 && a.status[s] == FIT_OK;
     const int m = a.m;
-    ArLds L{lds, AR_MAXP + AR_MAXSP * m + 1, ar_ring_slots(m)};
-    const double *w = a.w + (valid ? s : 0);
+    ArLds L{lds, ar_ring_slots(m), (int)threadIdx.x};
+    ArPolyLds PL{lds + (size_t)2 * L.R * NM_BLOCK, AR_MAXP + AR_MAXSP * m + 1};
+    const double *w = ws.W + (size_t)(valid ? s : 0) * ws.tw;
     const size_t ld = a.ld;
     const int wave_len = ar_wave_max(live ? len : 0);
     if (wave_len == 0) return;
@@ -622,8 +928,8 @@ __global__ __launch_bounds__(NM_BLOCK) void arima_forecast_kernel(const ArimaArg
     double mu = 0.0;
     ArFac fac;
     ar_factors(o, m, x, fac);
-    if (live) ar_build_poly(o, m, x, L, La, Lb, mu);
-    (void)ar_css_pass(w, ld, len, wave_len, live, fac, m, L);
+    if (live) ar_build_poly(o, m, x, PL, La, Lb, mu);
+    (void)ar_css_pass(w, len, wave_len, live, fac, m, L);
     if (!live) return;
     const int n = a.len[s], h = a.h;
     const int d = a.d[s], Dd = a.D[s];
@@ -633,11 +939,11 @@ __global__ __launch_bounds__(NM_BLOCK) void arima_forecast_kernel(const ArimaArg
         double acc = mu;
         for (int k = 1; k <= La; k++)
             if (t - k >= 0) {
-                const double wv = (t - k < len) ? w[(size_t)(t - k) * ld] : out[t - k - len];
-                acc = fma(L.a(k), wv - mu, acc);
+                const double wv = (t - k < len) ? w[t - k] : out[t - k - len];
+                acc = fma(PL.a(k), wv - mu, acc);
             }
         for (int k = 1; k <= Lb; k++)
-            if (t - k >= 0 && t - k < len) acc = fma(L.b(k), L.e_at(t - k), acc);
+            if (t - k >= 0 && t - k < len) acc = fma(PL.b(k), L.e_at(t - k), acc);
         out[j] = acc;
     }
     double last_d0 = a.last_d0[s], last_d1 = a.last_d1[s];
@@ -652,18 +958,59 @@ __global__ __launch_bounds__(NM_BLOCK) void arima_forecast_kernel(const ArimaArg
     a.model_code[s] = 1000000 + o.p * 100000 + d * 10000 + o.q * 1000 + o.P * 100 + Dd * 10 + o.Q;
 }
 
-void launch_arima(const ArimaArgs &a, hipStream_t stream)
+#define AR_HIPCHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) throw std::runtime_error(std::string("HIP: ") + hipGetErrorString(e_) + " at " #x); } while (0)
+
+int launch_arima(const ArimaArgs &a, hipStream_t stream)
 {
+    ArWs ws;
+    const size_t need = ws.carve((char *)a.ws, a.n_series, a.t_max);
+    if (!a.ws || need > a.ws_bytes) throw std::runtime_error("AutoARIMA workspace too small");
     const int grid = (a.n_series + NM_BLOCK - 1) / NM_BLOCK;
-    const size_t lds_bytes = ar_lds_bytes(a.m);
-    if (lds_bytes > 48 * 1024) {
-        (void)hipFuncSetAttribute((const void *)arima_search_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        (void)hipFuncSetAttribute((const void *)arima_forecast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    const int grid256 = (a.n_series + 255) / 256;
+    const size_t fit_lds = ar_lds_bytes(a.m);
+    const size_t fc_lds = sizeof(double) * (size_t)(2 * ar_ring_slots(a.m) + 2 * (AR_MAXP + AR_MAXSP * a.m + 1)) * NM_BLOCK;
+    if (fit_lds > 48 * 1024) {
+        AR_HIPCHECK(hipFuncSetAttribute((const void *)arima_fit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fit_lds));
+        AR_HIPCHECK(hipFuncSetAttribute((const void *)arima_fit_spec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fit_lds));
     }
+    if (fc_lds > 48 * 1024) AR_HIPCHECK(hipFuncSetAttribute((const void *)arima_forecast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fc_lds));
+    int dev = 0, cus = 256;
+    AR_HIPCHECK(hipGetDevice(&dev));
+    AR_HIPCHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    int per_cu = (int)((160 * 1024) / fit_lds);
+    per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);         // one wave per SIMD is enough: the pass is issue bound
+    const int max_waves = cus * per_cu;
+
     const size_t prep_lds = sizeof(double) * (size_t)(a.m > 1 ? a.m : 1) * NM_BLOCK;
-    hipLaunchKernelGGL(arima_prep_kernel, dim3(grid), dim3(NM_BLOCK), prep_lds, stream, a);
-    hipLaunchKernelGGL(arima_search_kernel, dim3(grid), dim3(NM_BLOCK), lds_bytes, stream, a);
-    hipLaunchKernelGGL(arima_forecast_kernel, dim3(grid), dim3(NM_BLOCK), lds_bytes, stream, a);
+    hipLaunchKernelGGL(arima_prep_kernel, dim3(grid), dim3(NM_BLOCK), prep_lds, stream, a, ws);
+    hipLaunchKernelGGL(arima_skip_kernel, dim3(grid256), dim3(256), 0, stream, a);
+    int launches = 2;
+    long prev_total = -1;
+    for (int sweep = 0; sweep < 4 * AR_MAXMODELS; sweep++) {
+        AR_HIPCHECK(hipMemsetAsync(ws.counts, 0, 16 * sizeof(int32_t), stream));
+        const int lookahead = (prev_total >= 0 && prev_total * (AR_SWEEP + 1) * 4 <= (long)max_waves * NM_BLOCK) ? 1 : 0;
+        hipLaunchKernelGGL(arima_advance_kernel, dim3(grid256), dim3(256), 0, stream, a, ws, lookahead);
+        int32_t counts[8];
+        AR_HIPCHECK(hipMemcpyAsync(counts, ws.counts, sizeof counts, hipMemcpyDeviceToHost, stream));
+        AR_HIPCHECK(hipStreamSynchronize(stream));
+        launches++;
+        long total = 0;
+        for (int i = 0; i <= AR_MAXDIM; i++) total += counts[i];
+        if (total == 0) break;
+        prev_total = total;
+        if (total * 4 <= (long)max_waves * NM_BLOCK) {
+            // short queue: four lanes per problem (one pass per Nelder-Mead iteration) -- the sweep is bound by its slowest fit
+            const long waves = (total * 4 + NM_BLOCK - 1) / NM_BLOCK;
+            hipLaunchKernelGGL(arima_fit_spec_kernel, dim3((int)waves), dim3(NM_BLOCK), fit_lds, stream, a, ws, (int)total);
+        } else {
+            const long waves = (total + NM_BLOCK - 1) / NM_BLOCK;
+            const int fit_grid = (int)(waves < max_waves ? waves : max_waves);
+            hipLaunchKernelGGL(arima_fit_kernel, dim3(fit_grid), dim3(NM_BLOCK), fit_lds, stream, a, ws, (int)total);
+        }
+        launches++;
+    }
+    hipLaunchKernelGGL(arima_forecast_kernel, dim3(grid), dim3(NM_BLOCK), fc_lds, stream, a, ws);
+    return launches + 1;
 }
 
 } // namespace anofox

@@ -79,6 +79,7 @@ struct AnofoxHipBatch {
     int32_t *d_len_group = nullptr;
     int32_t *d_count = nullptr;
     // AutoARIMA workspace
+    size_t ar_ws_bytes = 0;
     double *ar_w = nullptr, *ar_wmean = nullptr, *ar_wsd = nullptr, *ar_l0 = nullptr, *ar_l1 = nullptr, *ar_x = nullptr, *ar_aicc = nullptr;
     int32_t *ar_wlen = nullptr, *ar_d = nullptr, *ar_D = nullptr, *ar_order = nullptr, *ar_status = nullptr, *ar_evals = nullptr, *ar_passes = nullptr, *ar_models = nullptr;
     // streams / events
@@ -282,8 +283,9 @@ void alloc_common(AnofoxHipBatch *b)
     b->d_count = dalloc<int32_t>(2);
     if (b->plan.model == M_AutoARIMA) {
         const size_t T = std::max<size_t>(b->t_max, 1);
-        b->ar_w = dalloc<double>((T + 72) * ld);             // spare rows: the CSS pass prefetches whole 32-step blocks ahead
-        HIPCHECK(hipMemset(b->ar_w, 0, (T + 72) * ld * sizeof(double)));
+        b->ar_ws_bytes = arima_workspace_bytes((int)b->n, (int)T);
+        b->ar_w = (double *)dalloc<char>(b->ar_ws_bytes);     // search workspace: differenced rows, candidate cache, queues
+        HIPCHECK(hipMemset(b->ar_w, 0, b->ar_ws_bytes));
         b->ar_wmean = dalloc<double>(ld); b->ar_wsd = dalloc<double>(ld); b->ar_l0 = dalloc<double>(ld); b->ar_l1 = dalloc<double>(ld);
         b->ar_x = dalloc<double>(6 * ld); b->ar_aicc = dalloc<double>(ld);
         b->ar_wlen = dalloc<int32_t>(ld); b->ar_d = dalloc<int32_t>(ld); b->ar_D = dalloc<int32_t>(ld); b->ar_order = dalloc<int32_t>(5 * ld);
@@ -656,15 +658,14 @@ void run_group(AnofoxHipBatch *b, int period, const int32_t *d_len, hipStream_t 
         aa.y = b->d_y; aa.ld = ld; aa.len = d_len; aa.n_series = (int)n;
         aa.m = (period > 1 && period <= 24) ? period : 1;     // seasonal terms for m <= 24 (oracle ARIMA_MAX_PERIOD)
         aa.h = b->h;
-        aa.w = b->ar_w; aa.wlen = b->ar_wlen; aa.d = b->ar_d; aa.D = b->ar_D; aa.wmean = b->ar_wmean; aa.wsd = b->ar_wsd;
+        aa.ws = b->ar_w; aa.ws_bytes = b->ar_ws_bytes; aa.t_max = (int)std::max<size_t>(b->t_max, 1); aa.wlen = b->ar_wlen; aa.d = b->ar_d; aa.D = b->ar_D; aa.wmean = b->ar_wmean; aa.wsd = b->ar_wsd;
         aa.last_d0 = b->ar_l0; aa.last_d1 = b->ar_l1; aa.order = b->ar_order; aa.xbest = b->ar_x; aa.aicc = b->ar_aicc;
         aa.status = b->d_detail; aa.evals = b->d_evals_total; aa.passes = b->d_passes_total; aa.models = b->ar_models;
         aa.yhat = b->d_yhat; aa.model_code = b->d_model_code;
         HIPCHECK(hipEventRecord(b->ev_fit0, st));
-        launch_arima(aa, st);
+        b->fit_launches += launch_arima(aa, st);
         HIPCHECK(hipEventRecord(b->ev_fit1, st));
         b->timed_fit = true;
-        b->fit_launches += 3;
         b->n_problems += n;
         finish();
         break;

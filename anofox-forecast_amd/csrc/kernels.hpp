@@ -118,11 +118,12 @@ void launch_compact(const int32_t *series_prev, const int32_t *n_prev, int n_ser
 void launch_gather_columns(const double *y, size_t ld, const int32_t *series_of, const int32_t *n_active, int n_series,
                            int t_max, double *out, size_t ld_out, hipStream_t);
 
-// AutoARIMA (arima.hip): prep (D, d, differenced block), stepwise CSS search, forecast + integration
+// AutoARIMA (arima.hip): prep (D, d, differenced block), stepwise CSS search (advance / fit sweeps), forecast + integration
 struct ArimaArgs {
     const double *y; size_t ld; const int32_t *len; int n_series;
     int m, h;
-    double *w;                          // [t_max x ld] differenced block (scratch)
+    int t_max;                          // rows of y (longest series of the batch)
+    void *ws; size_t ws_bytes;          // search workspace, arima_workspace_bytes(n_series, t_max) bytes
     int32_t *wlen, *d, *D;              // [ld]
     double *wmean, *wsd, *last_d0, *last_d1;
     int32_t *order;                     // [5 x ld] p, q, P, Q, constant
@@ -132,7 +133,8 @@ struct ArimaArgs {
     double *yhat;                       // [n_series x h]
     int32_t *model_code;                // 1000000 + p*1e5 + d*1e4 + q*1e3 + P*100 + D*10 + Q
 };
-void launch_arima(const ArimaArgs &, hipStream_t);
+size_t arima_workspace_bytes(int n_series, int t_max);
+int launch_arima(const ArimaArgs &, hipStream_t);   // returns the number of kernel launches; synchronises the stream between sweeps
 
 void launch_prep(const PrepArgs &, hipStream_t);
 void launch_select(const SelectArgs &, hipStream_t);
