@@ -33,7 +33,8 @@ constexpr int AR_MAXP = 5, AR_MAXSP = 2, AR_MAXORDER = 5, AR_MAXDIM = 6, AR_MAXM
 constexpr int AR_KEYS = 6 * 6 * 3 * 3 * 2;            // order keys (p, q, P, Q, constant)
 constexpr int AR_KEYWORDS = (AR_KEYS + 31) / 32;      // bitmap words
 constexpr int AR_SWEEP = 17;                          // candidates of one sweep (8 seasonal, 8 non-seasonal, constant)
-constexpr int AR_S = 32;                              // steps per streamed block of the CSS pass
+constexpr int AR_S = 32;                              // steps per streamed block of the CSS pass (run-time period)
+constexpr int AR_SPARE = 96;                          // spare elements per row of W (two blocks of the longest block length)
 
 __device__ __forceinline__ int ar_wave_max(int v)
 {
@@ -70,10 +71,10 @@ __device__ __forceinline__ void ar_pacf(const double *u, int k, double *phi)
 // The ring holds e_t and v_t of step t side by side in slot t & (R - 1), R = the power of two >= 2 m + 6, so that one
 // 128-bit LDS access moves both and the slot index is a wave-uniform mask (no wrap arithmetic per lane).
 
-// LDS per wave (lane-minor): [ring: R slots x 64 lanes x {e, v}][simplex 42 + values 7]
+// LDS per wave (lane-minor): [ring: R slots x 64 lanes x {e, v}][simplex vertices 42]
 // The ring holds e_t and v_t of step t side by side in slot t mod R, R = 2 m + 6 (the two seasonal lags of a 4-step
 // sub-block plus the q + m Q residuals the forecast needs), so that one 128-bit LDS access moves both; slot indices are
-// wave-uniform and kept in scalar registers.
+// wave-uniform and kept in scalar registers.  (Forecast kernel: R = 2 m + 6; fit kernels: ar_fit_ring_slots.)
 typedef double ar_ev_t __attribute__((ext_vector_type(2)));
 __host__ __device__ inline int ar_ring_slots(int m) { return 2 * m + 6; }
 struct ArLds {
@@ -81,10 +82,30 @@ struct ArLds {
     int col;              // lane column holding this lane's simplex (its own, or its group leader's in the speculative fit)
     __device__ double *smp() const { return base + (size_t)2 * R * NM_BLOCK; }
     __device__ double &sim(int k, int i) const { return smp()[(k * AR_MAXDIM + i) * NM_BLOCK + col]; }
-    __device__ double &fs(int k) const { return smp()[((AR_MAXDIM + 1) * AR_MAXDIM + k) * NM_BLOCK + col]; }
     __device__ double e_at(int t) const { return base[((size_t)(t % R) * NM_BLOCK + threadIdx.x) * 2]; }
 };
-static size_t ar_lds_bytes(int m) { return sizeof(double) * (size_t)(2 * ar_ring_slots(m) + 49) * NM_BLOCK; }
+// the fit kernels need the two seasonal lags of a 4-step sub-block only: 2 m + 4 slots (39 KB per wave at m = 7 with the
+// 42 simplex coordinates: four waves per CU, one per SIMD); the function values of the simplex stay in registers
+__host__ __device__ inline int ar_fit_ring_slots(int m) { return 2 * m + 4 < 8 ? 8 : 2 * m + 4; }
+static size_t ar_lds_bytes(int m) { return sizeof(double) * (size_t)(2 * ar_fit_ring_slots(m) + (AR_MAXDIM + 1) * AR_MAXDIM) * NM_BLOCK; }
+
+// simplex function values in registers; run-time index by select chains (a handful of v_cndmask per access, against
+// tens of thousands of instructions per pass)
+struct ArFs {
+    double v[AR_MAXDIM + 1];
+    __device__ __forceinline__ double get(int k) const
+    {
+        double r = v[0];
+#pragma unroll
+        for (int j = 1; j <= AR_MAXDIM; j++) r = (k == j) ? v[j] : r;
+        return r;
+    }
+    __device__ __forceinline__ void set(int k, double x)
+    {
+#pragma unroll
+        for (int j = 0; j <= AR_MAXDIM; j++) v[j] = (k == j) ? x : v[j];
+    }
+};
 
 // the four factor polynomials of a trial point, zero padded (registers)
 struct ArFac { double phi[AR_MAXP], th[AR_MAXP], Phi[AR_MAXSP], Th[AR_MAXSP]; double mu; int nc; };
@@ -151,7 +172,14 @@ __device__ __forceinline__ void ar_build_poly(const ArOrd &o, int m, const doubl
 // in registers: the S values of the NEXT block are requested (eight 128-bit loads... per lane) before the S steps of the
 // current one run and are only touched afterwards, so the HBM/L2 latency sits behind S steps of recursion.  Rows carry
 // 2 S spare elements, so the loads are unconditional.
-template <int MODE>
+// M > 0: compile-time period with the fit kernels' ring of R = 2 M + 4 slots and a block length S that is a multiple of R,
+// so every ring slot of a block is a compile-time constant (LDS accesses with immediate offsets, no index arithmetic).
+template <int M>
+struct ArBlockLen { static constexpr int R = 2 * M + 4; static constexpr int value = (R >= 24 ? R : 2 * R); };
+template <>
+struct ArBlockLen<0> { static constexpr int R = 0; static constexpr int value = AR_S; };
+
+template <int MODE, int M>
 __device__ __noinline__ double ar_css_pass_impl(const double *wrow, int len, int wave_len_v, bool live, const ArFac &fin, int m_v,
                                                 const ArLds &L)
 {
@@ -166,8 +194,9 @@ __device__ __noinline__ double ar_css_pass_impl(const double *wrow, int len, int
     const int nc = fin.nc;
     // wave-uniform quantities in scalar registers
     const int wave_len = __builtin_amdgcn_readfirstlane(wave_len_v);
-    const int m = __builtin_amdgcn_readfirstlane(m_v);
-    const int R = __builtin_amdgcn_readfirstlane(L.R);
+    constexpr bool CT = M > 0;
+    const int m = CT ? M : __builtin_amdgcn_readfirstlane(m_v);
+    const int R = CT ? ArBlockLen<M>::R : __builtin_amdgcn_readfirstlane(L.R);
     const int lim = live ? len : 0;
     const int nc_max = __builtin_amdgcn_readfirstlane(ar_wave_max(live ? nc : 0));
     const int len_min = -__builtin_amdgcn_readfirstlane(ar_wave_max(live ? -len : -0x3fffffff));
@@ -180,7 +209,8 @@ __device__ __noinline__ double ar_css_pass_impl(const double *wrow, int len, int
     double css = 0.0;
     double wl[AR_MAXP] = {0, 0, 0, 0, 0}, ul[AR_MAXP] = {0, 0, 0, 0, 0};
     for (int k = 0; k < R; k++) ring[k * NM_BLOCK] = ar_ev_t{0.0, 0.0};
-    constexpr int S = AR_S;
+    constexpr int S = ArBlockLen<M>::value;
+    static_assert(S % 4 == 0 && 2 * S <= AR_SPARE, "block length");
     ar_ev_t cur[S / 2], nxt[S / 2];
 #pragma unroll
     for (int j = 0; j < S / 2; j++) cur[j] = wp_next[j];
@@ -188,6 +218,10 @@ __device__ __noinline__ double ar_css_pass_impl(const double *wrow, int len, int
     // ring slots of t0, t0 - m, t0 - 2m (scalar, advanced by 4 per sub-block)
     int s0 = 0, s1 = (R - m % R) % R, s2 = (R - (2 * m) % R) % R;
     auto wrap = [&](int x) __attribute__((always_inline)) { return x >= R ? x - R : x; };
+    // slot of step (sb + j) of a block and of its two seasonal lags: constants when the period is a template parameter
+    auto slot0 = [&](int sbj, int j) __attribute__((always_inline)) { return CT ? sbj % (CT ? ArBlockLen<M>::R : 1) : wrap(s0 + j); };
+    auto slot1 = [&](int sbj, int j) __attribute__((always_inline)) { return CT ? (sbj + 4 * (CT ? ArBlockLen<M>::R : 1) - M) % (CT ? ArBlockLen<M>::R : 1) : wrap(s1 + j); };
+    auto slot2 = [&](int sbj, int j) __attribute__((always_inline)) { return CT ? (sbj + 4 * (CT ? ArBlockLen<M>::R : 1) - 2 * M) % (CT ? ArBlockLen<M>::R : 1) : wrap(s2 + j); };
 
     auto block = [&](const int base, auto gated_tag) __attribute__((always_inline)) {
         constexpr bool GATED = decltype(gated_tag)::value;
@@ -199,8 +233,8 @@ __device__ __noinline__ double ar_css_pass_impl(const double *wrow, int len, int
             if (MODE == 1) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    l1[j] = ring[wrap(s1 + j) * NM_BLOCK];
-                    l2[j] = ring[wrap(s2 + j) * NM_BLOCK];
+                    l1[j] = ring[slot1(sb + j, j) * NM_BLOCK];
+                    l2[j] = ring[slot2(sb + j, j) * NM_BLOCK];
                 }
             }
 #pragma unroll
@@ -216,8 +250,8 @@ __device__ __noinline__ double ar_css_pass_impl(const double *wrow, int len, int
                 wl[0] = wp;
                 double z = vt;
                 if (MODE == 0) {
-                    l1[j] = ring[wrap(s1 + j) * NM_BLOCK];
-                    l2[j] = ring[wrap(s2 + j) * NM_BLOCK];
+                    l1[j] = ring[slot1(sb + j, j) * NM_BLOCK];
+                    l2[j] = ring[slot2(sb + j, j) * NM_BLOCK];
                 }
                 if (MODE != 2) {
                     z = fma(Phi[0], l1[j].y, z);
@@ -239,7 +273,7 @@ __device__ __noinline__ double ar_css_pass_impl(const double *wrow, int len, int
                     if (GATED) et = on ? et : 0.0;
                 }
                 if (MODE == 0) {
-                    if (!GATED || t < lim) ring[wrap(s0 + j) * NM_BLOCK] = ar_ev_t{et, vt};
+                    if (!GATED || t < lim) ring[slot0(sb + j, j) * NM_BLOCK] = ar_ev_t{et, vt};
                 }
                 vnew[j] = vt; enew[j] = et;
                 const double ec = (!GATED || t < lim) ? et : 0.0;
@@ -248,9 +282,9 @@ __device__ __noinline__ double ar_css_pass_impl(const double *wrow, int len, int
             if (MODE != 0) {
 #pragma unroll
                 for (int j = 0; j < 4; j++)
-                    if (!GATED || t0 + j < lim) ring[wrap(s0 + j) * NM_BLOCK] = ar_ev_t{enew[j], vnew[j]};
+                    if (!GATED || t0 + j < lim) ring[slot0(sb + j, j) * NM_BLOCK] = ar_ev_t{enew[j], vnew[j]};
             }
-            s0 = wrap(s0 + 4); s1 = wrap(s1 + 4); s2 = wrap(s2 + 4);
+            if (!CT) { s0 = wrap(s0 + 4); s1 = wrap(s1 + 4); s2 = wrap(s2 + 4); }
         }
     };
 
@@ -268,9 +302,14 @@ __device__ __noinline__ double ar_css_pass_impl(const double *wrow, int len, int
 
 __device__ __forceinline__ double ar_css_pass(const double *wrow, int len, int wave_len, bool live, const ArFac &f, int m, const ArLds &L)
 {
-    if (m >= 4) return ar_css_pass_impl<1>(wrow, len, wave_len, live, f, m, L);
-    if (m <= 1) return ar_css_pass_impl<2>(wrow, len, wave_len, live, f, m, L);
-    return ar_css_pass_impl<0>(wrow, len, wave_len, live, f, m, L);
+    if (L.R == 2 * m + 4) {      // fit kernels: common periods compiled in
+        if (m == 7) return ar_css_pass_impl<1, 7>(wrow, len, wave_len, live, f, m, L);
+        if (m == 12) return ar_css_pass_impl<1, 12>(wrow, len, wave_len, live, f, m, L);
+        if (m == 4) return ar_css_pass_impl<1, 4>(wrow, len, wave_len, live, f, m, L);
+    }
+    if (m >= 4) return ar_css_pass_impl<1, 0>(wrow, len, wave_len, live, f, m, L);
+    if (m <= 1) return ar_css_pass_impl<2, 0>(wrow, len, wave_len, live, f, m, L);
+    return ar_css_pass_impl<0, 0>(wrow, len, wave_len, live, f, m, L);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -292,7 +331,7 @@ struct ArWs {
     static size_t align(size_t x) { return (x + 255) & ~(size_t)255; }
     size_t carve(char *p, int n, int t_max)
     {
-        tw = (size_t)((t_max + AR_S - 1) / AR_S) * AR_S + 2 * AR_S;
+        tw = (size_t)((t_max + AR_S - 1) / AR_S) * AR_S + AR_SPARE;
         cap = (size_t)n * AR_SWEEP;
         size_t off = 0;
         auto take = [&](size_t bytes) { char *r = p ? p + off : nullptr; off += align(bytes); return r; };
@@ -604,33 +643,33 @@ __device__ __forceinline__ double ar_trial(const ArLds &L, int D, int which, int
     return which == 3 ? a * xb + b * xw : a * xb - b * xw;
 }
 
-__device__ __forceinline__ void ar_accept(const ArLds &L, int D, int which, double fnew)
+__device__ __forceinline__ void ar_accept(const ArLds &L, ArFs &F, int D, int which, double fnew)
 {
     double xn[AR_MAXDIM];
     for (int i = 0; i < D; i++) xn[i] = ar_trial(L, D, which, i);
     int j = D;
-    while (j > 0 && fnew < L.fs(j - 1)) {
-        L.fs(j) = L.fs(j - 1);
+    while (j > 0 && fnew < F.get(j - 1)) {
+        F.set(j, F.get(j - 1));
         for (int i = 0; i < D; i++) L.sim(j, i) = L.sim(j - 1, i);
         j--;
     }
-    L.fs(j) = fnew;
+    F.set(j, fnew);
     for (int i = 0; i < D; i++) L.sim(j, i) = xn[i];
 }
 
-__device__ __forceinline__ void ar_sort(const ArLds &L, int D)
+__device__ __forceinline__ void ar_sort(const ArLds &L, ArFs &F, int D)
 {
     for (int k = 1; k <= D; k++) {
-        const double fk = L.fs(k);
+        const double fk = F.get(k);
         double tmp[AR_MAXDIM];
         for (int i = 0; i < D; i++) tmp[i] = L.sim(k, i);
         int j = k;
-        while (j > 0 && fk < L.fs(j - 1)) {
-            L.fs(j) = L.fs(j - 1);
+        while (j > 0 && fk < F.get(j - 1)) {
+            F.set(j, F.get(j - 1));
             for (int i = 0; i < D; i++) L.sim(j, i) = L.sim(j - 1, i);
             j--;
         }
-        L.fs(j) = fk;
+        F.set(j, fk);
         for (int i = 0; i < D; i++) L.sim(j, i) = tmp[i];
     }
 }
@@ -639,7 +678,9 @@ __global__ __launch_bounds__(NM_BLOCK) void arima_fit_kernel(const ArimaArgs a, 
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int m = a.m;
-    ArLds L{lds, ar_ring_slots(m), (int)threadIdx.x};
+    ArLds L{lds, ar_fit_ring_slots(m), (int)threadIdx.x};
+    ArFs F;
+    for (int k = 0; k <= AR_MAXDIM; k++) F.v[k] = 0.0;
     // queue: dimension 6 first (longest fits first, so the tail of the launch is made of short ones)
     int qoff[8];
     {
@@ -692,7 +733,7 @@ __global__ __launch_bounds__(NM_BLOCK) void arima_fit_kernel(const ArimaArgs a, 
                     for (int k = 1; k <= D; k++) {
                         for (int i = 0; i < D; i++)
                             if (!(fabs(L.sim(k, i) - L.sim(0, i)) <= 1.0e-4)) small = false;
-                        if (!(fabs(L.fs(0) - L.fs(k)) <= 1.0e-8)) small = false;
+                        if (!(fabs(F.get(0) - F.get(k)) <= 1.0e-8)) small = false;
                     }
                     stop = small;
                 }
@@ -725,30 +766,30 @@ __global__ __launch_bounds__(NM_BLOCK) void arima_fit_kernel(const ArimaArgs a, 
 
         // ---- 4. consume -----------------------------------------------------------------------------
         if (ph == PH_INIT) {
-            L.fs(vi) = f; vi++; nm_evals++;
-            if (vi == D + 1) { ar_sort(L, D); ph = PH_ITER; }
+            F.set(vi, f); vi++; nm_evals++;
+            if (vi == D + 1) { ar_sort(L, F, D); ph = PH_ITER; }
         } else if (ph == PH_ITER) {
             fxr = f; nm_evals++;
-            if (fxr < L.fs(0)) ph = PH_E;
-            else if (fxr < L.fs(D - 1)) { ar_accept(L, D, 0, fxr); nm_iters++; }
-            else if (fxr < L.fs(D)) ph = PH_OC;
+            if (fxr < F.get(0)) ph = PH_E;
+            else if (fxr < F.get(D - 1)) { ar_accept(L, F, D, 0, fxr); nm_iters++; }
+            else if (fxr < F.get(D)) ph = PH_OC;
             else ph = PH_IC;
         } else if (ph == PH_E) {
             nm_evals++;
-            if (f < fxr) ar_accept(L, D, 1, f); else ar_accept(L, D, 0, fxr);
+            if (f < fxr) ar_accept(L, F, D, 1, f); else ar_accept(L, F, D, 0, fxr);
             nm_iters++; ph = PH_ITER;
         } else if (ph == PH_OC || ph == PH_IC) {
             nm_evals++;
-            const bool ok = (ph == PH_OC) ? (f <= fxr) : (f < L.fs(D));
-            if (ok) { ar_accept(L, D, ph == PH_OC ? 2 : 3, f); nm_iters++; ph = PH_ITER; }
+            const bool ok = (ph == PH_OC) ? (f <= fxr) : (f < F.get(D));
+            if (ok) { ar_accept(L, F, D, ph == PH_OC ? 2 : 3, f); nm_iters++; ph = PH_ITER; }
             else {
                 for (int k = 1; k <= D; k++)
                     for (int i = 0; i < D; i++) L.sim(k, i) = L.sim(0, i) + 0.5 * (L.sim(k, i) - L.sim(0, i));
                 vi = 0; ph = PH_SHRINK;
             }
         } else if (ph == PH_SHRINK) {
-            L.fs(1 + vi) = f; vi++; nm_evals++;
-            if (vi == D) { nm_iters++; ar_sort(L, D); ph = PH_ITER; }
+            F.set(1 + vi, f); vi++; nm_evals++;
+            if (vi == D) { nm_iters++; ar_sort(L, F, D); ph = PH_ITER; }
         } else { // PH_FINAL: information criterion of the fitted candidate -> cache
             double aicc = __builtin_huge_val();
             if (fabs(css) <= 1.7976931348623157e308) {
@@ -777,7 +818,9 @@ __global__ __launch_bounds__(NM_BLOCK) void arima_fit_spec_kernel(const ArimaArg
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int m = a.m;
     const int lane = threadIdx.x, g = lane & 3, leader = lane & ~3;
-    ArLds L{lds, ar_ring_slots(m), leader};
+    ArLds L{lds, ar_fit_ring_slots(m), leader};
+    ArFs F;
+    for (int k = 0; k <= AR_MAXDIM; k++) F.v[k] = 0.0;
     int qoff[8];
     {
         int acc = 0;
@@ -829,7 +872,7 @@ __global__ __launch_bounds__(NM_BLOCK) void arima_fit_spec_kernel(const ArimaArg
                     for (int k = 1; k <= D; k++) {
                         for (int i = 0; i < D; i++)
                             if (!(fabs(L.sim(k, i) - L.sim(0, i)) <= 1.0e-4)) small = false;
-                        if (!(fabs(L.fs(0) - L.fs(k)) <= 1.0e-8)) small = false;
+                        if (!(fabs(F.get(0) - F.get(k)) <= 1.0e-8)) small = false;
                     }
                     stop = small;
                 }
@@ -857,18 +900,18 @@ __global__ __launch_bounds__(NM_BLOCK) void arima_fit_spec_kernel(const ArimaArg
         }
 
         if (ph == PH_INIT) {
-            if (mine) L.fs(vi + g) = f;
+            for (int j = 0; j < 4; j++) { const double fj = __shfl(f, leader + j); if (vi + j <= D) F.set(vi + j, fj); }
             const int cnt = (D + 1 - vi) < 4 ? (D + 1 - vi) : 4;
             vi += cnt; nm_evals += cnt;
-            if (vi == D + 1) { ar_sort(L, D); ph = PH_ITER; }
+            if (vi == D + 1) { ar_sort(L, F, D); ph = PH_ITER; }
         } else if (ph == PH_ITER) {
             const double fr = __shfl(f, leader), fe = __shfl(f, leader + 1), foc = __shfl(f, leader + 2), fic = __shfl(f, leader + 3);
             nm_evals++;
             bool shrink = false;
-            if (fr < L.fs(0)) { nm_evals++; if (fe < fr) ar_accept(L, D, 1, fe); else ar_accept(L, D, 0, fr); }
-            else if (fr < L.fs(D - 1)) ar_accept(L, D, 0, fr);
-            else if (fr < L.fs(D)) { nm_evals++; if (foc <= fr) ar_accept(L, D, 2, foc); else shrink = true; }
-            else { nm_evals++; if (fic < L.fs(D)) ar_accept(L, D, 3, fic); else shrink = true; }
+            if (fr < F.get(0)) { nm_evals++; if (fe < fr) ar_accept(L, F, D, 1, fe); else ar_accept(L, F, D, 0, fr); }
+            else if (fr < F.get(D - 1)) ar_accept(L, F, D, 0, fr);
+            else if (fr < F.get(D)) { nm_evals++; if (foc <= fr) ar_accept(L, F, D, 2, foc); else shrink = true; }
+            else { nm_evals++; if (fic < F.get(D)) ar_accept(L, F, D, 3, fic); else shrink = true; }
             if (!shrink) nm_iters++;
             else {
                 for (int k = 1; k <= D; k++)
@@ -876,10 +919,10 @@ __global__ __launch_bounds__(NM_BLOCK) void arima_fit_spec_kernel(const ArimaArg
                 vi = 0; ph = PH_SHRINK;
             }
         } else if (ph == PH_SHRINK) {
-            if (mine) L.fs(1 + vi + g) = f;
+            for (int j = 0; j < 4; j++) { const double fj = __shfl(f, leader + j); if (1 + vi + j <= D) F.set(1 + vi + j, fj); }
             const int cnt = (D - vi) < 4 ? (D - vi) : 4;
             vi += cnt; nm_evals += cnt;
-            if (vi == D) { nm_iters++; ar_sort(L, D); ph = PH_ITER; }
+            if (vi == D) { nm_iters++; ar_sort(L, F, D); ph = PH_ITER; }
         } else { // PH_FINAL
             double aicc = __builtin_huge_val();
             if (fabs(css) <= 1.7976931348623157e308) {
@@ -998,9 +1041,11 @@ int launch_arima(const ArimaArgs &a, hipStream_t stream)
         for (int i = 0; i <= AR_MAXDIM; i++) total += counts[i];
         if (total == 0) break;
         prev_total = total;
-        if (total * 4 <= (long)max_waves * NM_BLOCK) {
-            // short queue: four lanes per problem (one pass per Nelder-Mead iteration) -- the sweep is bound by its slowest fit
-            const long waves = (total * 4 + NM_BLOCK - 1) / NM_BLOCK;
+        if (total <= 2L * max_waves * (NM_BLOCK / 4)) {
+            // short queue (up to two problems per resident 4-lane group): four lanes per problem, one pass per Nelder-Mead
+            // iteration -- such a sweep is bound by its slowest fit, not by throughput
+            long waves = (total * 4 + NM_BLOCK - 1) / NM_BLOCK;
+            if (waves > max_waves) waves = max_waves;
             hipLaunchKernelGGL(arima_fit_spec_kernel, dim3((int)waves), dim3(NM_BLOCK), fit_lds, stream, a, ws, (int)total);
         } else {
             const long waves = (total + NM_BLOCK - 1) / NM_BLOCK;
