@@ -137,7 +137,7 @@ def main():
         fit_ms_avg = float(np.mean(fit_ms))
         achieved = float(np.mean(alg_bytes)) / (fit_ms_avg * 1e-3) / 1e9 if fit_ms_avg > 0 else 0.0
         out = {
-            "metric": "series/sec fit+forecast, AutoETS h=28 on M5-shape batches",
+            "metric": f"series/sec fit+forecast, {'AutoETS' if model != 'AutoARIMA' else 'AutoARIMA'} h={h} on M5-shape batches",
             "value": round(value, 1), "unit": "series/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
@@ -150,7 +150,8 @@ def main():
                        "device_ms_per_step": round(float(np.mean(dev_ms)), 3), "datagen_s": round(gen_s, 1)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": "ets_fit_kernel<spec,period> (all spec launches of one step, concurrent streams)",
+                         "kernel": ("arima_fit_kernel + arima_fit_spec_kernel (all sweeps of one step)" if model == "AutoARIMA" else
+                                    "ets_round_kernel<spec,period,driver> + ets_final_kernel (all spec launches of one step, concurrent streams)"),
                          "kernel_ms": round(fit_ms_avg, 3), "algorithmic_bytes": int(np.mean(alg_bytes))},
         }
         # HBM traffic of the fit kernels comes from separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE,
