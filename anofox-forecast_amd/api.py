@@ -352,3 +352,94 @@ def ts_forecast_by(group, date, target, method, horizon, frequency, params=None,
 
 
 anofox_fcst_ts_forecast_by = ts_forecast_by  # alias registered by the reference (ts_macros.cpp:2191-2194)
+
+
+# --------------------------------------------------------------------------------------------
+# ts_cv_forecast_by: the same per-series call multiplied by folds
+# --------------------------------------------------------------------------------------------
+def cv_collect(fold_id, split, group, date, target):
+    """Collection step of `_ts_cv_forecast_native` (ts_cv_forecast_native.cpp:520-610, 640-665).
+
+    Rows with a NULL fold_id, split or date are dropped; a NULL target counts as 0.0 (no validity mask on this
+    path, `:709`); rows are keyed by (fold_id, group); 'train' and 'test' rows are kept apart (any other split value
+    is ignored) and each side is sorted by date.  Pairs without train rows or without test rows are dropped.
+    Returns (pairs, kind) with pairs = [{fold_id, group, train (f64), test_us (i64), test_y (f64)}] in
+    first-appearance order and kind the date column kind.
+    """
+    dates = np.asarray(date)
+    kind = _date_kind(dates)
+    us = _to_micros(dates, kind)
+    null_date = np.isnat(dates) if np.issubdtype(dates.dtype, np.datetime64) else np.zeros(len(dates), bool)
+    fold = np.asarray(fold_id, dtype=object)
+    spl = np.asarray(split, dtype=object)
+    grp = np.asarray(group, dtype=object)
+    tgt = np.asarray(target, dtype=object) if not np.ma.isMaskedArray(target) else np.ma.filled(np.ma.asarray(target, dtype=object), None)
+    order, members = [], {}
+    for i in range(len(grp)):
+        if fold[i] is None or spl[i] is None or null_date[i]:
+            continue
+        k = (int(fold[i]), "__NULL__" if grp[i] is None else grp[i])
+        if k not in members:
+            members[k] = {"train": [], "test": []}
+            order.append(k)
+        side = str(spl[i])
+        if side in ("train", "test"):
+            members[k][side].append(i)
+    def val(i):
+        v = tgt[i]
+        return 0.0 if v is None or (isinstance(v, float) and v != v) else float(v)
+    pairs = []
+    for k in order:
+        tr, te = members[k]["train"], members[k]["test"]
+        if not tr or not te:
+            continue
+        tr = np.array(tr)[np.argsort(us[np.array(tr)], kind="stable")]
+        te = np.array(te)[np.argsort(us[np.array(te)], kind="stable")]
+        pairs.append({"fold_id": k[0], "group": None if k[1] == "__NULL__" else k[1],
+                      "train": np.array([val(i) for i in tr], dtype=np.float64),
+                      "test_us": us[te].astype(np.int64), "test_y": np.array([val(i) for i in te], dtype=np.float64)})
+    return pairs, kind, dates.dtype
+
+
+def ts_cv_forecast_by(fold_id, split, group, date, target, method, params=None, group_name="id", date_name="date"):
+    """ts_cv_forecast_by(ml_folds, group_col, date_col, target_col, method, params := MAP{})
+    (ts_macros.cpp:731-747 -> _ts_cv_forecast_native, ts_cv_forecast_native.cpp).
+
+    `fold_id`, `split`, `group`, `date`, `target` are the equal-length columns of the fold table made by
+    ts_cv_folds_by (train AND test rows).  Every (fold, group) pair is one training series whose horizon is its number
+    of test rows (`:676-677`); forecasts are matched to the test rows by position (`:724-737`).  All pairs go to the
+    GPU in ONE batch call with per-series horizons (anofox_ts_forecast_batch) instead of the reference's serial loop.
+    Returns the columns fold_id, <group_name>, <date_name>, y, split, yhat, yhat_lower, yhat_upper, model_name ordered
+    by (fold_id, group, date) like the macro's ORDER BY 1, 2, 3.  Default confidence level 0.90 (`:45`).
+    """
+    b = bind(method, 1, "1d", params)
+    pairs, kind, date_dtype = cv_collect(fold_id, split, group, date, target)
+    cols = {"fold_id": [], group_name: [], date_name: [], "y": [], "split": [], "yhat": [], "yhat_lower": [], "yhat_upper": [],
+            "model_name": []}
+    if pairs:
+        opts = options_from_bind(b)
+        results, berr = forecast_batch([p["train"] for p in pairs], opts, None, [len(p["test_us"]) for p in pairs])
+        if not berr["ok"]:
+            raise InvalidInputException(berr["message"])
+        rows = []
+        for p, r in zip(pairs, results):
+            if not r["ok"]:
+                if r["code"] in (_lib.INVALID_MODEL, _lib.INVALID_INPUT):
+                    raise InvalidInputException(r["message"])
+                continue                      # computation / data errors: the pair yields no rows (`:718-721`)
+            for i in range(min(len(r["point"]), len(p["test_us"]))):
+                rows.append((p["fold_id"], p["group"], int(p["test_us"][i]), float(p["test_y"][i]), r["point"][i], r["lower"][i],
+                             r["upper"][i], r["model_name"]))
+        rows.sort(key=lambda t: (t[0], (t[1] is None, "" if t[1] is None else t[1]), t[2]))
+        for t in rows:
+            cols["fold_id"].append(t[0]); cols[group_name].append(t[1]); cols[date_name].append(t[2]); cols["y"].append(t[3])
+            cols["split"].append("test"); cols["yhat"].append(t[4]); cols["yhat_lower"].append(t[5]); cols["yhat_upper"].append(t[6])
+            cols["model_name"].append(t[7])
+    cols["fold_id"] = np.array(cols["fold_id"], dtype=np.int64)
+    cols[date_name] = _from_micros(np.array(cols[date_name], dtype=np.int64), kind, date_dtype)
+    for c in ("y", "yhat", "yhat_lower", "yhat_upper"):
+        cols[c] = np.array(cols[c], dtype=np.float64)
+    return cols
+
+
+anofox_fcst_ts_cv_forecast_by = ts_cv_forecast_by

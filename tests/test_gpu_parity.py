@@ -163,6 +163,61 @@ def test_ts_forecast_by_operator(env):
         api.ts_forecast_by(grp, ds, Y.reshape(-1), "Naive", 3, "1d", {"seasonal_period": "7"})
 
 
+def _cv_folds(series_id, n, n_folds, horizon):
+    """Expanding-window folds the way ts_cv_folds_by lays them out (ts_cv_forecast.test:20-37: 24 obs, 3 folds, h = 4
+    -> train 12 / 16 / 20, test 4 each)."""
+    rows = []
+    for k in range(1, n_folds + 1):
+        end = n - (n_folds - k + 1) * horizon
+        rows += [(k, "train", series_id, t) for t in range(end)]
+        rows += [(k, "test", series_id, t) for t in range(end, end + horizon)]
+    return rows
+
+
+def test_ts_cv_forecast_by_operator(env):
+    """every (fold, group) pair is an independent training series whose horizon is its number
+    of test rows; one batch call with per-series horizons; forecasts matched to the test rows by position."""
+    api, O, lib, synth = env
+    # the reference's own case (ts_cv_forecast.test): y = 10 + i, i = 1..24, Naive -> last training value
+    rows = _cv_folds("A", 24, 3, 4)
+    fold, split, grp, t = (np.array(c, dtype=object) for c in zip(*rows))
+    ds = np.array([int(x) + 1 for x in t], dtype=np.int32)
+    y = np.array([10.0 + d for d in ds])
+    out = api.ts_cv_forecast_by(fold, split, grp, ds, y, "Naive", {}, group_name="series_id", date_name="ds")
+    assert sorted(out.keys()) == sorted(["ds", "fold_id", "model_name", "series_id", "split", "y", "yhat", "yhat_lower", "yhat_upper"])
+    assert len(out["yhat"]) == 12 and list(out["fold_id"]) == [1] * 4 + [2] * 4 + [3] * 4 and set(out["split"]) == {"test"}
+    assert out["ds"].dtype == np.int32 and list(out["ds"][:4]) == [13, 14, 15, 16]
+    np.testing.assert_array_equal(out["yhat"], np.repeat([22.0, 26.0, 30.0], 4))
+    np.testing.assert_array_equal(out["y"], 10.0 + out["ds"])
+    # AutoETS over several groups, shuffled rows, ragged horizons; against the oracle pair by pair
+    Y = synth.gen_series(synth.SEED_M5, 300, 4, 90, 7, positive=True)
+    rows = []
+    for g in range(4):
+        rows += [(k, sp, f"g{g}", tt) for (k, sp, _, tt) in _cv_folds(g, 90, 3, 5 + g)]
+    perm = np.random.default_rng(3).permutation(len(rows))
+    fold, split, grp, t = (np.array(c, dtype=object)[perm] for c in zip(*rows))
+    ds = np.datetime64("2024-01-01") + np.array([int(x) for x in t]).astype("timedelta64[D]")
+    yv = np.array([Y[int(g[1:]), int(x)] for g, x in zip(grp, t)])
+    out = api.ts_cv_forecast_by(fold, split, grp, ds, yv, "AutoETS", {"seasonal_period": 7}, group_name="id", date_name="ds")
+    assert len(out["yhat"]) == 3 * (5 + 6 + 7 + 8)
+    pos = 0
+    for k in (1, 2, 3):
+        for g in range(4):
+            h = 5 + g
+            end = 90 - (3 - k + 1) * h
+            ref = O.forecast(Y[g, :end], O.make_options("AutoETS", h, seasonal_period=7, confidence_level=0.90))
+            sl = slice(pos, pos + h)
+            assert list(out["fold_id"][sl]) == [k] * h and list(out["id"][sl]) == [f"g{g}"] * h
+            np.testing.assert_allclose(out["yhat"][sl], ref["point"], rtol=REL_TOL)
+            np.testing.assert_allclose(out["yhat_lower"][sl], ref["lower"], rtol=REL_TOL)
+            np.testing.assert_array_equal(out["y"][sl], Y[g, end:end + h])
+            assert out["ds"][pos] == np.datetime64("2024-01-01") + np.timedelta64(end, "D")
+            assert out["model_name"][pos] == ref["model_name"]
+            pos += h
+    with pytest.raises(api.InvalidInputException, match="Unknown model"):
+        api.ts_cv_forecast_by(fold, split, grp, ds, yv, "NoSuchModel", {})
+
+
 @pytest.mark.parametrize("seq_rounds", ["0", "2", "6"])
 @pytest.mark.parametrize("gather", ["0", "1"])
 def test_schedule_variants_are_bit_identical(env, monkeypatch, seq_rounds, gather):

@@ -74,3 +74,22 @@ def test_synthetic_generator_is_shard_consistent():
     b = synth.gen_series(synth.SEED_M5, 1000, 1100, 64)
     assert np.array_equal(a[1000:], b) and 0.3 < (a == 0).mean() < 0.8
     assert synth.gen_series(synth.SEED_M5, 5, 3, 64, positive=True).min() >= 1.0
+
+
+def test_cv_collect_rules():
+    """Collection step of _ts_cv_forecast_native (ts_cv_forecast_native.cpp:520-665): NULL fold/split/date rows dropped,
+    NULL target -> 0.0, unknown split values ignored, both sides sorted by date, pairs lacking a side dropped."""
+    from anofox_forecast_amd import api
+    fold = np.array([1, 1, 1, 1, 1, 2, 2, None, 1, 3], dtype=object)
+    split = np.array(["train", "test", "train", "valid", "train", "train", "train", "train", None, "test"], dtype=object)
+    grp = np.array(["a"] * 10, dtype=object)
+    ds = np.array([3, 9, 1, 5, 2, 1, 2, 7, 8, 4], dtype=np.int64)
+    y = np.array([30.0, 90.0, 10.0, 50.0, None, 1.0, 2.0, 7.0, 8.0, 4.0], dtype=object)
+    pairs, kind, dtype = api.cv_collect(fold, split, grp, ds, y)
+    assert kind == "BIGINT" and dtype == np.int64
+    assert len(pairs) == 1                                   # fold 2 has no test rows, fold 3 no train rows
+    p = pairs[0]
+    assert p["fold_id"] == 1 and p["group"] == "a"
+    np.testing.assert_array_equal(p["train"], [10.0, 0.0, 30.0])     # sorted by date; NULL target counted as 0.0
+    np.testing.assert_array_equal(p["test_us"], [9])
+    np.testing.assert_array_equal(p["test_y"], [90.0])
