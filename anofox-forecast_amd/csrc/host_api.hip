@@ -427,8 +427,20 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
     const size_t n = b->n, ld = b->ld;
     // Round budgets (streamed passes per launch).  Geometric, so every round retires roughly half of the
     // still-running problems and the compaction + gather in between stays a few percent of the passes.
-    static const int BUDGET[] = {32, 32, 64, 128, 256, 1024};
-    const int n_rounds = (int)(sizeof BUDGET / sizeof BUDGET[0]);
+    // iteration budgets of the rounds (the last one runs everything left to completion); ANOFOX_HIP_BUDGETS overrides
+    std::vector<int> BUDGET = {24, 24, 24, 24, 24, 24, 48, 48, 96, 96, 192, 1024};   // measured best of five schedules (5-12 rounds)
+    if (const char *e = std::getenv("ANOFOX_HIP_BUDGETS")) {
+        std::vector<int> v;
+        for (const char *q = e; *q;) {
+            char *end = nullptr;
+            long x = std::strtol(q, &end, 10);
+            if (end == q) break;
+            if (x > 0) v.push_back((int)x);
+            q = (*end == ',') ? end + 1 : end;
+        }
+        if (!v.empty()) BUDGET = v;
+    }
+    const int n_rounds = (int)BUDGET.size();
     const int n_lanes = std::min<int>(N_AUX_STREAMS, b->n_slots_cap);
     // fork: aux streams wait for everything queued on `st` so far
     HIPCHECK(hipEventRecord(b->ev_fit0, st));

@@ -14,7 +14,7 @@ import os
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # measured best of 4/8/16/24/32 on MI355X
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libanofox_fcst_hip.so")
+LIB_PATH = os.environ.get("ANOFOX_HIP_LIB", os.path.join(_HERE, "libanofox_fcst_hip.so"))   # override: A/B builds only
 
 SUCCESS, NULL_POINTER, INVALID_INPUT, COMPUTATION_ERROR, ALLOCATION_ERROR, INVALID_MODEL = 0, 1, 2, 3, 4, 5
 INSUFFICIENT_DATA, INVALID_DATE_FORMAT, INVALID_FREQUENCY, PANIC_CAUGHT, INTERNAL_ERROR = 6, 7, 8, 9, 10
