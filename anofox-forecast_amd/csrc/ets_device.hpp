@@ -101,7 +101,12 @@ __device__ __forceinline__ void ets_step(const EtsPar &p, EtsState &st, double y
             q = st.l + phib;
         } else if constexpr (Cfg::T == C_MUL) {
             if (!(st.b > 0.0)) st.bad = 1;
-            phib = Cfg::D ? dm_pow_pos(st.b, p.phi) : st.b;
+            if constexpr (Cfg::D) {
+                // growth rates outside [2^-1000, 2^1000] reject the trial point (oracle/ets.c does the same), so the
+                // power below never meets a special case and runs without a branch
+                if (!(st.b >= 0x1p-1000 && st.b <= 0x1p+1000)) st.bad = 1;
+                phib = dm_pow_step(st.b, p.phi);
+            } else phib = st.b;
             q = st.l * phib;
         }
         double f = q;

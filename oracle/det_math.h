@@ -139,4 +139,54 @@ static inline double det_exp(double x)
 /* pow for a positive base (ETS multiplicative trend, b^phi): exp(y * log(x)). */
 static inline double det_pow_pos(double x, double y) { return det_exp(y * det_log(x)); }
 
+/*
+ * b^phi of the damped multiplicative trend, evaluated once per observation: x in [2^-1000, 2^1000], 0 < y <= 1 (ets.c
+ * rejects the trial point otherwise).  Same reductions as det_log / det_exp, but written for that domain only -- no
+ * special cases -- and with the polynomial and recombination steps fused (fma), because this one function is most of the
+ * arithmetic of the five damped multiplicative-trend specs.  csrc/det_math.hpp states the identical sequence.
+ */
+static inline double det_pow_step(double x, double y)
+{
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
+                 Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
+                 Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    const double invln2 = 1.44269504088896338700e+00;
+    const uint64_t u = det_bits(x);
+    uint32_t hx = (uint32_t)(u >> 32);
+    hx += 0x3ff00000u - 0x3fe6a09eu;
+    const int k = (int)(hx >> 20) - 0x3ff;
+    hx = (hx & 0x000fffffu) + 0x3fe6a09eu;
+    const double m = det_from_bits(((uint64_t)hx << 32) | (u & 0xffffffffull));
+    const double f = m - 1.0;
+    const double hfsq = 0.5 * f * f;
+    const double s = f / (2.0 + f);
+    const double z = s * s;
+    const double w = z * z;
+    const double t1 = w * fma(w, fma(w, Lg6, Lg4), Lg2);
+    const double t2 = z * fma(w, fma(w, fma(w, Lg7, Lg5), Lg3), Lg1);
+    const double R = t2 + t1;
+    const double dk = (double)k;
+    const double lg = fma(dk, ln2_hi, (fma(s, hfsq + R, dk * ln2_lo) - hfsq) + f);
+    const double t = y * lg;
+    const double dn = rint(invln2 * t);                 /* round to nearest even; |dn| <= 1000 */
+    const double r = fma(-dn, ln2_lo, fma(-dn, ln2_hi, t));
+    double p = 1.0 / 6227020800.0;
+    p = fma(p, r, 1.0 / 479001600.0);
+    p = fma(p, r, 1.0 / 39916800.0);
+    p = fma(p, r, 1.0 / 3628800.0);
+    p = fma(p, r, 1.0 / 362880.0);
+    p = fma(p, r, 1.0 / 40320.0);
+    p = fma(p, r, 1.0 / 5040.0);
+    p = fma(p, r, 1.0 / 720.0);
+    p = fma(p, r, 1.0 / 120.0);
+    p = fma(p, r, 1.0 / 24.0);
+    p = fma(p, r, 1.0 / 6.0);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    const double e = fma(p, r, 1.0);
+    return e * det_from_bits((uint64_t)(0x3ff + (int)dn) << 52);
+}
+
 #endif /* ORACLE_DET_MATH_H */

@@ -320,7 +320,10 @@ double ets_lik(const EtsSpec *spec, const double *y, int n, const double *par,
                 q = l + phib;
             } else if (spec->trend == ETS_MUL) {
                 if (!(b > 0.0)) { bad = 1; break; }
-                phib = spec->damped ? det_pow_pos(b, phi) : b;
+                /* a damped growth rate outside [2^-1000, 2^1000] is inadmissible (the trial point is rejected): keeps
+                 * phi * log(b) inside the range where exp needs no special cases, on the CPU and in the kernels alike */
+                if (spec->damped && !(b >= 0x1p-1000 && b <= 0x1p+1000)) { bad = 1; break; }
+                phib = spec->damped ? det_pow_step(b, phi) : b;
                 q = l * phib;
             }
             double f = q;
