@@ -78,6 +78,10 @@ struct AnofoxHipBatch {
     uint32_t *d_mask = nullptr;
     int32_t *d_len_group = nullptr;
     int32_t *d_count = nullptr;
+    // strictly positive series of the current group, dense: round 0 of the specs with a multiplicative component runs on it
+    int32_t *d_pos_map = nullptr, *d_pos_cnt = nullptr, *d_notpos = nullptr;
+    double *d_ypos = nullptr;
+    bool use_pos = false;
     // AutoARIMA workspace
     size_t ar_ws_bytes = 0;
     double *ar_w = nullptr, *ar_wmean = nullptr, *ar_wsd = nullptr, *ar_l0 = nullptr, *ar_l1 = nullptr, *ar_x = nullptr, *ar_aicc = nullptr;
@@ -244,7 +248,7 @@ void free_batch_buffers(AnofoxHipBatch *b)
     F(b->d_aicc); F(b->d_yhat_slots); F(b->d_status_slots); F(b->d_evals_slots); F(b->d_iters_slots);
     F(b->d_passes_slots); F(b->d_slot_spec);
     F(b->d_yhat); F(b->d_lo); F(b->d_hi); F(b->d_model_code); F(b->d_status); F(b->d_detail);
-    F(b->d_passes_total); F(b->d_evals_total); F(b->d_mask); F(b->d_len_group); F(b->d_count);
+    F(b->d_passes_total); F(b->d_evals_total); F(b->d_mask); F(b->d_len_group); F(b->d_count); F(b->d_pos_map); F(b->d_pos_cnt); F(b->d_notpos); F(b->d_ypos);
     F(b->ar_w); F(b->ar_wmean); F(b->ar_wsd); F(b->ar_l0); F(b->ar_l1); F(b->ar_x); F(b->ar_aicc); F(b->ar_wlen); F(b->ar_d); F(b->ar_D);
     F(b->ar_order); F(b->ar_status); F(b->ar_evals); F(b->ar_passes); F(b->ar_models);
     if (b->own_stream) (void)hipStreamDestroy(b->own_stream);
@@ -281,6 +285,9 @@ void alloc_common(AnofoxHipBatch *b)
     b->d_mask = dalloc<uint32_t>(ld);
     b->d_len_group = dalloc<int32_t>(ld);
     b->d_count = dalloc<int32_t>(2);
+    if (b->plan.model == M_AutoETS) {
+        b->d_pos_map = dalloc<int32_t>(ld); b->d_pos_cnt = dalloc<int32_t>(2); b->d_notpos = dalloc<int32_t>(ld);
+    }
     if (b->plan.model == M_AutoARIMA) {
         const size_t T = std::max<size_t>(b->t_max, 1);
         b->ar_ws_bytes = arima_workspace_bytes((int)b->n, (int)T);
@@ -410,6 +417,23 @@ __global__ void count_positive_kernel(int n, const int32_t *len, const uint32_t 
     if (threadIdx.x == 0) { count[0] = sp[0]; count[1] = su[0]; }
 }
 
+// notpos[s] = 1 unless series s is usable and strictly positive
+__global__ void mark_nonpositive_kernel(int n, const int32_t *len, const uint32_t *flags, int32_t *notpos)
+{
+    int s = blockIdx.x * 256 + threadIdx.x;
+    if (s < n) notpos[s] = (len[s] > 0 && (flags[s] & SF_POSITIVE)) ? 0 : 1;
+}
+
+// per (spec with a multiplicative component): the series the dense first round never visits are retired here
+__global__ void retire_nonpositive_kernel(int n, const int32_t *len, const int32_t *notpos, int32_t *status, int32_t *done, int32_t *passes,
+                                          int32_t *evals, int32_t *iters)
+{
+    int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= n || !notpos[s]) return;
+    status[s] = len[s] > 0 ? FIT_NONPOSITIVE : FIT_SKIPPED;
+    done[s] = 1; passes[s] = 0; evals[s] = 0; iters[s] = 0;
+}
+
 // AutoETS fallback plan (forecast.rs:1327-1336): 1 Holt-Winters, 2 Holt, 3 SES(0.3)
 __global__ void fallback_plan_kernel(int n, const int32_t *len, int period, uint32_t *mask, int32_t *detail)
 {
@@ -504,7 +528,15 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
             a.first_round = (r == 0);
             a.spec_below = -1;
             a.gathered = 0;
-            if (r == 0) {
+            if (r == 0 && b->use_pos && a.need_positive) {
+                // mixed batch: this spec is admissible for the strictly positive series only -- its first round runs on
+                // their dense list (built once per group) instead of sweeping every wave for a few live lanes
+                hipLaunchKernelGGL(retire_nonpositive_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, sq, (int)n, d_len, b->d_notpos,
+                                   a.status, lane.st.done, lane.st.passes, lane.st.evals, lane.st.iters);
+                a.series_of = b->d_pos_map; a.n_active = b->d_pos_cnt;
+                if (b->d_ypos) { a.y_round = b->d_ypos; a.ld_round = ld; a.gathered = 1; }
+                else { a.y_round = b->d_y; a.ld_round = ld; }
+            } else if (r == 0) {
                 a.y_round = b->d_y; a.ld_round = ld; a.series_of = nullptr; a.n_active = nullptr;
             } else {
                 const int32_t *prev_map = (r == 1) ? nullptr : lane.map[(r - 1) & 1];
@@ -647,6 +679,17 @@ void run_group(AnofoxHipBatch *b, int period, const int32_t *d_len, hipStream_t 
             for (int id : specs) if (!spec_has_mult(id)) n_add++;
             const double live = (double)cnt[0] * (double)specs.size() + (double)(cnt[1] - cnt[0]) * (double)n_add;
             b->seq_rounds = live >= 8.0 * 65536.0 ? 4 : 0;    // >= 8 problems per SIMD lane-slot: VALU-bound, go sequential
+            b->use_pos = cnt[0] > 0 && (double)cnt[0] < 0.7 * (double)cnt[1];
+        } else {
+            b->use_pos = false;
+        }
+        if (b->use_pos) {
+            hipLaunchKernelGGL(mark_nonpositive_kernel, dim3((unsigned)blocks256), dim3(256), 0, st, (int)n, d_len, b->d_flags, b->d_notpos);
+            launch_compact(nullptr, nullptr, (int)n, b->d_notpos, b->d_pos_map, b->d_pos_cnt, st);
+            if (b->use_gather) {
+                if (!b->d_ypos) b->d_ypos = dalloc<double>(std::max<size_t>(b->t_max, 1) * ld);
+                launch_gather_columns(b->d_y, ld, b->d_pos_map, b->d_pos_cnt, (int)n, (int)b->t_max, b->d_ypos, ld, st);
+            }
         }
         launch_fit_slots(b, specs, d_len, m, true, st);
         SelectArgs sa{};
