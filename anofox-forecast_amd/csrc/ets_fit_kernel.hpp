@@ -89,8 +89,11 @@ __global__ __launch_bounds__(NM_BLOCK, ANOFOX_ROUND_WAVES) void ets_round_kernel
         r.done = !active;
     }
 
-    if constexpr (SPEC) nm_advance_spec(mdl, lds, r, a.budget);
-    else nm_advance_seq(mdl, lds, r, a.budget);
+    // few problems left (they no longer fill the chip): run them to completion now instead of paying a compaction +
+    // gather + launch gap per remaining round -- the later rounds then find nothing to do
+    const int budget = (n_act <= a.tail_below) ? (1 << 30) : a.budget;
+    if constexpr (SPEC) nm_advance_spec(mdl, lds, r, budget);
+    else nm_advance_seq(mdl, lds, r, budget);
 
     if (active && (lane % LPP) == 0) {
 #pragma unroll

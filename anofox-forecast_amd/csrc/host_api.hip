@@ -104,6 +104,7 @@ struct AnofoxHipBatch {
     uint64_t n_problems = 0;
     int seq_rounds = 3;      // rounds run by the sequential Nelder-Mead driver before switching to the speculative one
     int seq_rounds_env = -1; // ANOFOX_HIP_SEQ_ROUNDS override (-1 = decide from the number of live problems)
+    int tail_below = 0;      // per spec: run the remaining problems to completion once this few are left (measured: rounds + compaction win at every threshold, 0 = off)
     int spec_below = 8192;   // per spec: switch to the speculative driver once this few problems are still running
     bool use_gather = false; // rebuild a dense block of the running problems between rounds (else index y by series)
 };
@@ -527,6 +528,7 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
             const bool spec_mode = r >= b->seq_rounds;
             a.first_round = (r == 0);
             a.spec_below = -1;
+            a.tail_below = (r == 0) ? 0 : b->tail_below;
             a.gathered = 0;
             if (r == 0 && b->use_pos && a.need_positive) {
                 // mixed batch: this spec is admissible for the strictly positive series only -- its first round runs on
@@ -859,6 +861,7 @@ bool anofox_hip_batch_create(size_t n_series, size_t t_max, const ForecastOption
         b->use_gather = (double)max_slots_for(plan) * (double)std::max<size_t>(t_max, 1) * (double)b->ld * 8.0 <= 24.0 * 1073741824.0;
         if (const char *e = std::getenv("ANOFOX_HIP_GATHER")) b->use_gather = std::atoi(e) != 0;
         if (const char *e = std::getenv("ANOFOX_HIP_SPEC_BELOW")) b->spec_below = std::atoi(e);
+        if (const char *e = std::getenv("ANOFOX_HIP_TAIL_BELOW")) b->tail_below = std::atoi(e);
         alloc_common(b);
     } catch (const HipFail &f) {
         set_error(out_error, INTERNAL_ERROR, "Internal error: " + f.msg);

@@ -41,6 +41,7 @@ struct FitArgs {
     int budget, first_round;
     int spec_below;              // device-side driver choice: the speculative kernel runs iff n_active <= spec_below,
                                  // the sequential one iff n_active > spec_below (both are enqueued; -1 = unconditional)
+    int tail_below;              // run to completion once this few problems are still running (0 = never)
     int gathered;                // y_round holds the running problems' columns densely (column p), else index by series
     NmStateBuf st;
     int m, h;
