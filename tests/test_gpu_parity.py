@@ -274,3 +274,51 @@ def test_auto_arima_matches_oracle(env):
     _compare(api, O, lib, series, "AutoARIMA", 10)                        # auto-detected periods (host packer)
     r = api.forecast_series(KAT_SERIES, lib.make_options("AutoARIMA", 3, auto_detect=False))
     assert r["ok"] and r["model_name"].startswith("AutoARIMA(") and abs(r["point"][0] - 18.014537) / 18.014537 < 2e-3
+
+
+def _run_device_batch(lib, Y, model, h, m, dev="cuda:0"):
+    import torch
+    from anofox_forecast_amd.device import DeviceBatch, pack_time_major
+    n, T = Y.shape
+    b = DeviceBatch(n, T, lib.make_options(model, h, seasonal_period=m), dev)
+    y = torch.from_numpy(pack_time_major(Y, b.ld)).to(dev)
+    ln = torch.full((b.ld,), T, dtype=torch.int32, device=dev)
+    ln[n:] = 0
+    b.set_block(y, ln)
+    b.run()
+    torch.cuda.synchronize()
+    out = {k: v.cpu().numpy().copy() for k, v in b.results().items()}
+    b.run()                                   # a second step over the same resident block
+    torch.cuda.synchronize()
+    again = {k: v.cpu().numpy().copy() for k, v in b.results().items()}
+    names = [b.model_name(int(c)) for c in out["model_code"][:n]]
+    b.close()
+    return out, again, names
+
+
+@pytest.mark.parametrize("model,positive", [("AutoETS", False), ("AutoETS", True), ("AutoARIMA", False)])
+def test_full_size_m5_properties(env, model, positive):
+    """BASELINE.json's full M5 shape (30,490 series x 1,913 observations, h = 28, m = 7), checked through properties that
+    do not need the oracle at that size: a second run over the resident block reproduces every bit; a series' result does
+    not depend on the batch it is in nor on its position (a shuffled 96-series sub-batch reproduces the full batch bit
+    for bit); that sub-batch equals the CPU oracle; intervals bracket the point forecast; every series gets a forecast and
+    a model name of the right family."""
+    api, O, lib, synth = env
+    n, T, h, m = 30490, 1913, 28, 7
+    Y = synth.gen_series(synth.SEED_M5, 0, n, T, m, positive)
+    full, again, names = _run_device_batch(lib, Y, model, h, m)
+    for k in ("yhat", "lower", "upper", "model_code", "status"):
+        assert np.array_equal(full[k], again[k], equal_nan=True), f"{k}: second run differs"
+    assert np.all(full["status"][:n] == 0)
+    yh, lo, hi = full["yhat"][:n], full["lower"][:n], full["upper"][:n]
+    assert np.all(np.isfinite(yh)) and np.all(lo <= yh) and np.all(yh <= hi)
+    assert all(nm.startswith(model + "(") or nm == model for nm in names)
+    pick = np.random.default_rng(5).choice(n, 96, replace=False)          # arbitrary series, arbitrary order
+    sub, _, sub_names = _run_device_batch(lib, Y[pick], model, h, m)
+    for k in ("yhat", "lower", "upper", "model_code"):
+        assert np.array_equal(sub[k][:96], full[k][pick], equal_nan=True), f"{k}: result depends on the batch"
+    oo = O.make_options(model, h, seasonal_period=m)
+    n_ref = 96 if model == "AutoETS" and not positive else 24              # the oracle needs seconds per series otherwise
+    for j in range(n_ref):
+        ref = O.forecast(Y[pick[j]], oo)
+        assert _rel(sub["yhat"][j], ref["point"]) <= REL_TOL and sub_names[j] == ref["model_name"]
