@@ -20,6 +20,7 @@
 // (scalar recursions); the pass is VALU-issue bound.
 #include <hip/hip_runtime.h>
 #include <type_traits>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 
@@ -1031,7 +1032,10 @@ int launch_arima(const ArimaArgs &a, hipStream_t stream)
     long prev_total = -1;
     for (int sweep = 0; sweep < 4 * AR_MAXMODELS; sweep++) {
         AR_HIPCHECK(hipMemsetAsync(ws.counts, 0, 16 * sizeof(int32_t), stream));
-        const int lookahead = (prev_total >= 0 && prev_total * (AR_SWEEP + 1) * 4 <= (long)max_waves * NM_BLOCK) ? 1 : 0;
+        // look one sweep ahead once the previous sweep's queue times the fan-out (~18 candidates per series) fits the
+        // resident lanes `la_factor` times over: the extra fits cost idle lanes, the saved sweeps cost ~0.1-0.2 s each
+        static const double la_factor = [] { const char *e = std::getenv("ANOFOX_HIP_ARIMA_LOOKAHEAD"); return e ? std::atof(e) : 4.0; }();   // measured 0 / 0.25 / 1 / 4 / 16: 2.16 / 2.03 / 1.93 / 1.92 / 1.90 s on the M5 batch
+        const int lookahead = (prev_total >= 0 && (double)prev_total * (AR_SWEEP + 1) <= la_factor * (double)max_waves * NM_BLOCK) ? 1 : 0;
         hipLaunchKernelGGL(arima_advance_kernel, dim3(grid256), dim3(256), 0, stream, a, ws, lookahead);
         int32_t counts[8];
         AR_HIPCHECK(hipMemcpyAsync(counts, ws.counts, sizeof counts, hipMemcpyDeviceToHost, stream));
