@@ -327,7 +327,6 @@ struct ArWs {
     int32_t *state;       // [n x 8] stage, idx, base key, best key, have, improved, n_models, fin
     int32_t *q_series, *q_key;   // [7 x cap] problem queues by dimension
     int32_t *counts;      // [16] 0..6 queue lengths, 8 fetch cursor
-    double *simplex;      // unused (simplex lives in LDS)
     size_t tw, cap;
     static size_t align(size_t x) { return (x + 255) & ~(size_t)255; }
     size_t carve(char *p, int n, int t_max)
@@ -347,7 +346,6 @@ struct ArWs {
         q_series = (int32_t *)take(sizeof(int32_t) * 7 * cap);
         q_key = (int32_t *)take(sizeof(int32_t) * 7 * cap);
         counts = (int32_t *)take(sizeof(int32_t) * 16);
-        simplex = nullptr;
         return off;
     }
 };

@@ -81,10 +81,7 @@ __device__ __forceinline__ double dm_scalbn(double x, int n)
 __device__ __forceinline__ double dm_exp(double x)
 {
     const double ln2hi = 6.93147180369123816490e-01, ln2lo = 1.90821492927058770002e-10,
-                 invln2 = 1.44269504088896338700e+00,
-                 P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03,
-                 P3 = 6.61375632143793436117e-05, P4 = -1.65339022054652515390e-06,
-                 P5 = 4.13813679705723846039e-08;
+                 invln2 = 1.44269504088896338700e+00;
     if (x != x) return x;
     if (x > 709.782712893383973096) return __builtin_huge_val();
     if (x < -745.13321910194110842) return 0.0;
@@ -104,7 +101,7 @@ __device__ __forceinline__ double dm_exp(double x)
     }
     // division-free: Taylor polynomial of e^r, degree 13, Horner with fused multiply-adds
     // (|r| <= 0.35: remainder < 5e-18).  Same coefficients and order as the CPU checker.
-    (void)P1; (void)P2; (void)P3; (void)P4; (void)P5; (void)hi; (void)lo;
+    (void)hi; (void)lo;
     double p = 1.0 / 6227020800.0;
     p = fma(p, x, 1.0 / 479001600.0);
     p = fma(p, x, 1.0 / 39916800.0);

@@ -720,7 +720,8 @@ void run_group(AnofoxHipBatch *b, int period, const int32_t *d_len, hipStream_t 
         aa.status = b->d_detail; aa.evals = b->d_evals_total; aa.passes = b->d_passes_total; aa.models = b->ar_models;
         aa.yhat = b->d_yhat; aa.model_code = b->d_model_code;
         HIPCHECK(hipEventRecord(b->ev_fit0, st));
-        b->fit_launches += launch_arima(aa, st);
+        try { b->fit_launches += launch_arima(aa, st); }
+        catch (const std::exception &e) { throw HipFail{e.what()}; }
         HIPCHECK(hipEventRecord(b->ev_fit1, st));
         b->timed_fit = true;
         b->n_problems += n;
@@ -868,6 +869,11 @@ bool anofox_hip_batch_create(size_t n_series, size_t t_max, const ForecastOption
         free_batch_buffers(b);
         delete b;
         return false;
+    } catch (const std::exception &e) {
+        set_error(out_error, INTERNAL_ERROR, std::string("Internal error: ") + e.what());
+        free_batch_buffers(b);
+        delete b;
+        return false;
     }
     *out_batch = b;
     return true;
@@ -916,6 +922,9 @@ bool anofox_hip_batch_pack_host(AnofoxHipBatch *b, const double *const *values, 
     } catch (const HipFail &f) {
         set_error(out_error, INTERNAL_ERROR, "Internal error: " + f.msg);
         return false;
+    } catch (const std::exception &e) {
+        set_error(out_error, INTERNAL_ERROR, std::string("Internal error: ") + e.what());
+        return false;
     }
     return true;
 }
@@ -941,6 +950,9 @@ bool anofox_hip_batch_set_device_block(AnofoxHipBatch *b, const void *d_y, size_
     } catch (const HipFail &f) {
         set_error(out_error, INTERNAL_ERROR, "Internal error: " + f.msg);
         return false;
+    } catch (const std::exception &e) {
+        set_error(out_error, INTERNAL_ERROR, std::string("Internal error: ") + e.what());
+        return false;
     }
     return true;
 }
@@ -953,6 +965,9 @@ bool anofox_hip_batch_run(AnofoxHipBatch *b, void *stream, AnofoxError *out_erro
         run_batch(b, stream ? (hipStream_t)stream : b->own_stream);
     } catch (const HipFail &f) {
         set_error(out_error, INTERNAL_ERROR, "Internal error: " + f.msg);
+        return false;
+    } catch (const std::exception &e) {
+        set_error(out_error, INTERNAL_ERROR, std::string("Internal error: ") + e.what());
         return false;
     }
     return true;
