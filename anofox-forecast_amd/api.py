@@ -355,6 +355,96 @@ anofox_fcst_ts_forecast_by = ts_forecast_by  # alias registered by the reference
 
 
 # --------------------------------------------------------------------------------------------
+# columnar ingest: the collection side of route B through the C-ABI
+# --------------------------------------------------------------------------------------------
+class Ingest:
+    """ctypes face of anofox_hip_ingest_* (include/anofox_fcst_hip.h block 4): chunks of rows in, series out.
+
+    Replaces ts_forecast_native.cpp:476-610.  `group_key` values are int64 dictionary ids of the group values."""
+
+    def __init__(self):
+        self._L = _lib.load()
+        self._h = self._L.anofox_hip_ingest_create()
+        if not self._h:
+            raise MemoryError("anofox_hip_ingest_create failed")
+        self.n_groups = self.t_max = None
+
+    def append(self, group_key, date, value, date_valid=None, value_valid=None):
+        gk = np.ascontiguousarray(group_key, dtype=np.int64)
+        dt = np.ascontiguousarray(date, dtype=np.int64)
+        vl = np.ascontiguousarray(value, dtype=np.float64)
+        dm = validity_mask(date_valid) if date_valid is not None else None
+        vm = validity_mask(value_valid) if value_valid is not None else None
+        err = _lib.AnofoxError()
+        ok = self._L.anofox_hip_ingest_append(self._h, gk.ctypes.data, dt.ctypes.data, dm.ctypes.data if dm is not None else None,
+                                              vl.ctypes.data, vm.ctypes.data if vm is not None else None, len(gk), C.byref(err))
+        if not ok:
+            raise InvalidInputException(err.message.decode(errors="replace"))
+
+    def finish(self):
+        ng, tm, err = C.c_size_t(), C.c_size_t(), _lib.AnofoxError()
+        if not self._L.anofox_hip_ingest_finish(self._h, C.byref(ng), C.byref(tm), C.byref(err)):
+            raise InvalidInputException(err.message.decode(errors="replace"))
+        self.n_groups, self.t_max = int(ng.value), int(tm.value)
+        return self.n_groups, self.t_max
+
+    def _arr(self, fn, n):
+        p = getattr(self._L, "anofox_hip_ingest_" + fn)(self._h)
+        return np.array([p[i] for i in range(n)]) if p else np.array([])
+
+    def group_keys(self): return self._arr("group_keys", self.n_groups)
+    def last_dates(self): return self._arr("last_dates", self.n_groups)
+    def lengths(self): return self._arr("lengths", self.n_groups)
+
+    def series(self):
+        """[(values f64[len], valid bool[len])] per group, in output order (for inspection and tests)."""
+        L, V, M = self.lengths(), self._L.anofox_hip_ingest_values(self._h), self._L.anofox_hip_ingest_validity(self._h)
+        out = []
+        for g in range(self.n_groups):
+            n = int(L[g])
+            vals = np.array([V[g][i] for i in range(n)], dtype=np.float64)
+            ok = np.array([(M[g][i >> 6] >> (i & 63)) & 1 for i in range(n)], dtype=bool)
+            out.append((vals, ok))
+        return out
+
+    def forecast(self, opts):
+        """create a batch of (n_groups, t_max), pack the ingested series, run, fetch: [(result dict)] per group."""
+        L = self._L
+        n = self.n_groups
+        hb, err = C.c_void_p(), _lib.AnofoxError()
+        if not L.anofox_hip_batch_create(n, self.t_max, C.byref(opts), C.byref(hb), C.byref(err)):
+            raise InvalidInputException(err.message.decode(errors="replace"))
+        try:
+            if not L.anofox_hip_batch_pack_ingest(hb, self._h, C.byref(err)) or not L.anofox_hip_batch_run(hb, None, C.byref(err)):
+                raise InvalidInputException(err.message.decode(errors="replace"))
+            results = (_lib.ForecastResult * n)()
+            errors = (_lib.AnofoxError * n)()
+            L.anofox_hip_batch_fetch(hb, results, errors)
+            lens = self.lengths()
+            out = []
+            for i in range(n):
+                d = {"ok": errors[i].code == 0, "code": int(errors[i].code), "message": errors[i].message.decode(errors="replace")}
+                if d["ok"]:
+                    d.update(_result_dict(results[i], int(lens[i])))
+                    L.anofox_free_forecast_result(C.byref(results[i]))
+                out.append(d)
+            return out
+        finally:
+            L.anofox_hip_batch_destroy(hb)
+
+    def close(self):
+        if self._h:
+            self._L.anofox_hip_ingest_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# --------------------------------------------------------------------------------------------
 # ts_cv_forecast_by (SURVEY.md section 8f rank 1): the same per-series call multiplied by folds
 # --------------------------------------------------------------------------------------------
 def cv_collect(fold_id, split, group, date, target):

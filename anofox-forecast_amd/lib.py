@@ -82,6 +82,9 @@ EXPORTED_SYMBOLS = [
     "anofox_hip_device_count", "anofox_hip_set_device", "anofox_hip_batch_create", "anofox_hip_batch_destroy",
     "anofox_hip_batch_ld", "anofox_hip_batch_pack_host", "anofox_hip_batch_set_device_block", "anofox_hip_batch_run",
     "anofox_hip_batch_stats", "anofox_hip_batch_device_results", "anofox_hip_batch_fetch", "anofox_hip_model_name",
+    "anofox_hip_ingest_create", "anofox_hip_ingest_destroy", "anofox_hip_ingest_append", "anofox_hip_ingest_finish",
+    "anofox_hip_ingest_group_keys", "anofox_hip_ingest_last_dates", "anofox_hip_ingest_lengths", "anofox_hip_ingest_values",
+    "anofox_hip_ingest_validity", "anofox_hip_batch_pack_ingest",
 ]
 
 _lib = None
@@ -131,6 +134,20 @@ def load():
     L.anofox_hip_batch_fetch.restype = C.c_bool
     L.anofox_hip_batch_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.anofox_hip_model_name.argtypes = [P(ForecastOptions), C.c_int32, C.c_char * 64]
+    # block 4: columnar ingest (host side only; usable without a GPU up to pack_ingest)
+    L.anofox_hip_ingest_create.restype = C.c_void_p
+    L.anofox_hip_ingest_destroy.argtypes = [C.c_void_p]
+    L.anofox_hip_ingest_append.restype = C.c_bool
+    L.anofox_hip_ingest_append.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, P(AnofoxError)]
+    L.anofox_hip_ingest_finish.restype = C.c_bool
+    L.anofox_hip_ingest_finish.argtypes = [C.c_void_p, P(C.c_size_t), P(C.c_size_t), P(AnofoxError)]
+    for fn, rt in (("group_keys", P(C.c_int64)), ("last_dates", P(C.c_int64)), ("lengths", P(C.c_size_t)),
+                   ("values", P(P(C.c_double))), ("validity", P(P(C.c_uint64)))):
+        f = getattr(L, "anofox_hip_ingest_" + fn)
+        f.restype = rt
+        f.argtypes = [C.c_void_p]
+    L.anofox_hip_batch_pack_ingest.restype = C.c_bool
+    L.anofox_hip_batch_pack_ingest.argtypes = [C.c_void_p, C.c_void_p, P(AnofoxError)]
     _lib = L
     return L
 

@@ -210,6 +210,41 @@ bool anofox_hip_batch_fetch(AnofoxHipBatch *batch,
 void anofox_hip_model_name(const struct ForecastOptions *options, int32_t model_code,
                            char out_name[64]);
 
+/* ------------------------------------------------------------------------- */
+/* Block 4: columnar ingest for the table-in-out caller (route B)              */
+/* ------------------------------------------------------------------------- */
+/*
+ * Replaces the collection loop of _ts_forecast_native
+ * (src/table_functions/ts_forecast_native.cpp:476-610: per-row GetValue into a
+ * std::map<string, GroupData> under a mutex, per-group sort at finalize).
+ * The binding appends each DataChunk as plain columns; `group_key` is the
+ * dictionary id (or hash) of the group value -- the binding keeps id -> Value.
+ * Rules kept: rows with a NULL date are dropped (:505); a NULL target is an
+ * invalid slot (interpolated by the packer, imputation.rs:61-114); groups come
+ * out in first-appearance order (:586); rows of a group are stably sorted by date.
+ * append is thread-safe; validity bitmasks use DuckDB's layout (bit i%64 of word
+ * i/64, 1 = valid) and may be NULL (= all valid).
+ */
+typedef struct AnofoxHipIngest AnofoxHipIngest;
+AnofoxHipIngest *anofox_hip_ingest_create(void);
+void anofox_hip_ingest_destroy(AnofoxHipIngest *ingest);
+bool anofox_hip_ingest_append(AnofoxHipIngest *ingest,
+                              const int64_t *group_key, const int64_t *date,
+                              const uint64_t *date_valid,
+                              const double *value, const uint64_t *value_valid,
+                              size_t n_rows, struct AnofoxError *out_error);
+bool anofox_hip_ingest_finish(AnofoxHipIngest *ingest, size_t *n_groups, size_t *t_max,
+                              struct AnofoxError *out_error);
+/* Valid after finish, owned by the ingest: [n_groups] each. */
+const int64_t *anofox_hip_ingest_group_keys(const AnofoxHipIngest *ingest);
+const int64_t *anofox_hip_ingest_last_dates(const AnofoxHipIngest *ingest);
+const size_t *anofox_hip_ingest_lengths(const AnofoxHipIngest *ingest);
+const double *const *anofox_hip_ingest_values(const AnofoxHipIngest *ingest);
+const uint64_t *const *anofox_hip_ingest_validity(const AnofoxHipIngest *ingest);
+/* Series of a finished ingest -> the batch's HBM block (batch created with n_groups, t_max). */
+bool anofox_hip_batch_pack_ingest(AnofoxHipBatch *batch, const AnofoxHipIngest *ingest,
+                                  struct AnofoxError *out_error);
+
 #ifdef __cplusplus
 } /* extern "C" */
 #endif

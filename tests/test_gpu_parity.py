@@ -163,6 +163,34 @@ def test_ts_forecast_by_operator(env):
         api.ts_forecast_by(grp, ds, Y.reshape(-1), "Naive", 3, "1d", {"seasonal_period": "7"})
 
 
+def test_columnar_ingest_feeds_the_batch(env):
+    """rows appended chunk by chunk through the C-ABI ingest (block 4) give the same forecasts as
+    the operator mirror that groups and sorts in Python -- NULL targets, shuffled rows, ragged groups included."""
+    api, O, lib, synth = env
+    Y = synth.gen_series(synth.SEED_M5, 40, 6, 80, 7, positive=True)
+    rows = [(100 + g, t, Y[g, t]) for g in range(6) for t in range(80 - 5 * g)]
+    perm = np.random.default_rng(4).permutation(len(rows))
+    gk, dt, val = (np.array(c)[perm] for c in zip(*rows))
+    vok = np.random.default_rng(5).random(len(rows)) > 0.03
+    ing = api.Ingest()
+    for lo in range(0, len(rows), 97):
+        sl = slice(lo, lo + 97)
+        ing.append(gk[sl].astype(np.int64), dt[sl].astype(np.int64), val[sl], None, vok[sl])
+    ng, tmax = ing.finish()
+    assert ng == 6 and tmax == 80
+    got = ing.forecast(lib.make_options("AutoETS", 12, seasonal_period=7))
+    ref = api.ts_forecast_by([f"k{int(k)}" for k in gk], dt.astype(np.int64), np.ma.array(val, mask=~vok), "AutoETS", 12, 1,
+                             {"seasonal_period": 7})
+    keys = list(dict.fromkeys(f"k{int(k)}" for k in gk))
+    assert [f"k{int(k)}" for k in ing.group_keys()] == keys
+    for i, k in enumerate(keys):
+        assert got[i]["ok"]
+        sel = [j for j, g in enumerate(ref["id"]) if g == k]
+        np.testing.assert_array_equal(got[i]["point"], ref["yhat"][sel])
+        assert got[i]["model_name"] == ref["model_name"][sel[0]]
+    ing.close()
+
+
 def _cv_folds(series_id, n, n_folds, horizon):
     """Expanding-window folds the way ts_cv_folds_by lays them out (ts_cv_forecast.test:20-37: 24 obs, 3 folds, h = 4
     -> train 12 / 16 / 20, test 4 each)."""

@@ -93,3 +93,39 @@ def test_cv_collect_rules():
     np.testing.assert_array_equal(p["train"], [10.0, 0.0, 30.0])     # sorted by date; NULL target counted as 0.0
     np.testing.assert_array_equal(p["test_us"], [9])
     np.testing.assert_array_equal(p["test_y"], [90.0])
+
+
+def test_columnar_ingest_rules(hiplib):
+    """anofox_hip_ingest_* (header block 4) against the collection rules of ts_forecast_native.cpp:476-610: NULL-date rows
+    dropped, NULL targets kept as invalid slots, groups in first-appearance order, rows of a group stably sorted by date,
+    chunked appends equivalent to one append.  Host code only: runs without a GPU."""
+    from anofox_forecast_amd import api
+    rng = np.random.default_rng(9)
+    n = 5000
+    gk = rng.integers(100, 140, n)
+    dt = rng.integers(0, 400, n)                           # duplicates on purpose: equal dates keep arrival order
+    val = rng.normal(size=n)
+    dok = rng.random(n) > 0.02
+    vok = rng.random(n) > 0.05
+    ing = api.Ingest()
+    for lo in range(0, n, 777):                            # DataChunk-like appends
+        sl = slice(lo, min(lo + 777, n))
+        ing.append(gk[sl], dt[sl], val[sl], dok[sl], vok[sl])
+    ng, tmax = ing.finish()
+    keep = np.nonzero(dok)[0]
+    first = {}
+    for i in keep:
+        first.setdefault(int(gk[i]), len(first))
+    assert ng == len(first) and list(ing.group_keys()) == list(first.keys())
+    series = ing.series()
+    lens = ing.lengths()
+    assert tmax == max(lens)
+    for g, key in enumerate(first):
+        rows = keep[gk[keep] == key]
+        rows = rows[np.argsort(dt[rows], kind="stable")]
+        assert lens[g] == len(rows) and ing.last_dates()[g] == dt[rows[-1]]
+        v, ok = series[g]
+        np.testing.assert_array_equal(ok, vok[rows])
+        np.testing.assert_array_equal(v[ok], val[rows][vok[rows]])
+        assert np.all(v[~ok] == 0.0)
+    ing.close()
