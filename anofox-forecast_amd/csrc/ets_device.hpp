@@ -205,7 +205,16 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
     constexpr int S_TARGET = Cfg::ADDITIVE ? 32 : ((Cfg::T == C_MUL && Cfg::D) ? 8 : 16);
     constexpr int S = (MS > 0) ? ((S_TARGET / MS > 0 ? S_TARGET / MS : 1) * MS) : S_TARGET;
     double cur[S], nxt[S];
-    auto load_rows = [&](double (&buf)[S], const int row0) __attribute__((always_inline)) {
+    // two loaders: `load_fast` for a block that lies entirely inside the allocation (one 64-bit row address per block,
+    // then a constant stride per load) and `load_clamped` for the last block or two of a pass (row index clamped to the
+    // last row; ~10 scalar instructions per load, which is why it is kept out of the main loop).  Neither holds a
+    // branch: a conditional load in the loop makes the compiler wait for every outstanding load at once.
+    auto load_fast = [&](double (&buf)[S], const int row0) __attribute__((always_inline)) {
+        const double *pb = yp + (size_t)row0 * ld;
+#pragma unroll
+        for (int j = 0; j < S; j++) buf[j] = pb[(size_t)j * ld];
+    };
+    auto load_clamped = [&](double (&buf)[S], const int row0) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < S; j++) {
             int r = row0 + j;
@@ -213,7 +222,9 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
             buf[j] = yp[(size_t)r * ld];
         }
     };
-    load_rows(cur, 0);
+    // main loop while the NEXT block is entirely in range, epilogue (predicated steps only) for what is left
+    const int fast_end = row_max + 1 - 2 * S;          // largest base whose successor block is in range
+    load_clamped(cur, 0);
 
     if constexpr (MS >= 0) {
         constexpr int MR = MS > 0 ? MS : 1;
@@ -229,8 +240,9 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
 #pragma unroll
             for (int k = 0; k < K; k++) s[k][0] = 0.0;
         }
-        for (int base = 0; base < wave_len; base += S) {
-            load_rows(nxt, base + S);
+        int base = 0;
+        for (; base < wave_len && base <= fast_end; base += S) {
+            load_fast(nxt, base + S);
             if (base + S <= wave_min_len) {
 #pragma unroll
                 for (int j = 0; j < S; j++)
@@ -244,6 +256,17 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
                         for (int k = 0; k < K; k++) ets_step<Cfg>(par[k], st[k], cur[j], s[k][MS > 0 ? j % MR : 0]);
                     }
             }
+#pragma unroll
+            for (int j = 0; j < S; j++) cur[j] = nxt[j];
+        }
+        for (; base < wave_len; base += S) {
+            load_clamped(nxt, base + S);
+#pragma unroll
+            for (int j = 0; j < S; j++)
+                if (base + j < v.len) {
+#pragma unroll
+                    for (int k = 0; k < K; k++) ets_step<Cfg>(par[k], st[k], cur[j], s[k][MS > 0 ? j % MR : 0]);
+                }
 #pragma unroll
             for (int j = 0; j < S; j++) cur[j] = nxt[j];
         }
@@ -275,9 +298,7 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
             for (int k = 0; k < K; k++) ring[(k * m + j) * NM_BLOCK + lane] = f0;
         }
         int j = 0;
-        for (int base = 0; base < wave_len; base += S) {
-            load_rows(nxt, base + S);
-            const bool full = base + S <= wave_min_len;
+        auto ring_block = [&](const int base, const bool full) __attribute__((always_inline)) {
 #pragma unroll
             for (int i = 0; i < S; i++) {
                 if (full || base + i < v.len) {
@@ -290,6 +311,17 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
                 }
                 j = (j + 1 == m) ? 0 : j + 1;
             }
+        };
+        int base = 0;
+        for (; base < wave_len && base <= fast_end; base += S) {
+            load_fast(nxt, base + S);
+            ring_block(base, base + S <= wave_min_len);
+#pragma unroll
+            for (int i = 0; i < S; i++) cur[i] = nxt[i];
+        }
+        for (; base < wave_len; base += S) {
+            load_clamped(nxt, base + S);
+            ring_block(base, false);
 #pragma unroll
             for (int i = 0; i < S; i++) cur[i] = nxt[i];
         }
