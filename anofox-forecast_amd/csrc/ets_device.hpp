@@ -36,6 +36,8 @@ struct SeriesView {
     int wave_len;      // max len over the wave (uniform)
     int wave_min_len;  // min len over the wave's active lanes (uniform)
     int rows;          // rows the block holds (row indices are clamped to rows - 1 by the streaming loads)
+    const double *yb;  // the block itself (wave-uniform) and this lane's column: y == yb + col.  The streaming loads
+    int col;           // address rows from the scalar base so the per-load address work stays on the scalar unit
 };
 
 __device__ __forceinline__ int wave_max_i32(int v)
@@ -188,7 +190,8 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
         ets_unpack<Cfg>(cand[k], par[k]);
         st[k].l = in.l0; st[k].b = in.b0; st[k].sse = 0.0; st[k].mant = 1.0; st[k].eacc = 0; st[k].bad = 0;
     }
-    const double *yp = v.y;
+    const double *yp = v.yb;            // wave-uniform base; the lane's column is added as a 32-bit offset
+    const unsigned col_bytes = (unsigned)v.col * 8u;     // ld < 2^29 columns: the byte offset of a column fits 32 bits
     const size_t ld = v.ld;
 
     // y is streamed through two register buffers of S steps: the S rows of the NEXT block are requested before the S
@@ -205,26 +208,27 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
     constexpr int S_TARGET = Cfg::ADDITIVE ? 32 : ((Cfg::T == C_MUL && Cfg::D) ? 8 : 16);
     constexpr int S = (MS > 0) ? ((S_TARGET / MS > 0 ? S_TARGET / MS : 1) * MS) : S_TARGET;
     double cur[S], nxt[S];
-    // two loaders: `load_fast` for a block that lies entirely inside the allocation (one 64-bit row address per block,
-    // then a constant stride per load) and `load_clamped` for the last block or two of a pass (row index clamped to the
-    // last row; ~10 scalar instructions per load, which is why it is kept out of the main loop).  Neither holds a
-    // branch: a conditional load in the loop makes the compiler wait for every outstanding load at once.
-    auto load_fast = [&](double (&buf)[S], const int row0) __attribute__((always_inline)) {
-        const double *pb = yp + (size_t)row0 * ld;
-#pragma unroll
-        for (int j = 0; j < S; j++) buf[j] = pb[(size_t)j * ld];
-    };
-    auto load_clamped = [&](double (&buf)[S], const int row0) __attribute__((always_inline)) {
+    // One loader, no branch (a conditional load in the loop makes the compiler wait for every outstanding load at once)
+    // and no per-load address arithmetic on the vector unit: the rows of a block are fetched with buffer loads whose
+    // descriptor is rebuilt once per block from scalars (base = first row of the block, range = what is left of the
+    // allocation), the row stride goes in the scalar offset operand and the lane's column in the 32-bit vector offset.
+    // The hardware range check returns zeros for rows past the allocation, so the prefetch of the block after the last
+    // one needs no clamp (those values are never used).
+    typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+    const size_t row_bytes = ld * 8;
+    const size_t total_bytes = (size_t)(row_max + 1) * row_bytes;
+    auto load_block = [&](double (&buf)[S], const int row0) __attribute__((always_inline)) {
+        const size_t off = (size_t)row0 * row_bytes;
+        const size_t rem = off < total_bytes ? total_bytes - off : 0;
+        const unsigned nrec = rem > 0xffffffffull ? 0xffffffffu : (unsigned)rem;
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)yp + (rem ? off : 0)), 0, nrec, 0x00020000);
 #pragma unroll
         for (int j = 0; j < S; j++) {
-            int r = row0 + j;
-            r = r < row_max ? r : row_max;
-            buf[j] = yp[(size_t)r * ld];
+            const u32x2_t w = __builtin_amdgcn_raw_buffer_load_b64(rsrc, col_bytes, (unsigned)(j * row_bytes), 0);
+            buf[j] = __builtin_bit_cast(double, w);
         }
     };
-    // main loop while the NEXT block is entirely in range, epilogue (predicated steps only) for what is left
-    const int fast_end = row_max + 1 - 2 * S;          // largest base whose successor block is in range
-    load_clamped(cur, 0);
+    load_block(cur, 0);
 
     if constexpr (MS >= 0) {
         constexpr int MR = MS > 0 ? MS : 1;
@@ -241,8 +245,24 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
             for (int k = 0; k < K; k++) s[k][0] = 0.0;
         }
         int base = 0;
-        for (; base < wave_len && base <= fast_end; base += S) {
-            load_fast(nxt, base + S);
+        if constexpr (Cfg::ADDITIVE) {
+            // cheap steps: two blocks per iteration on alternating buffers, so the copy between the buffers (one of the
+            // ~11 instructions of a step) disappears while every wave-uniform full block remains
+            for (; base + 2 * S <= wave_min_len; base += 2 * S) {
+                load_block(nxt, base + S);
+#pragma unroll
+                for (int j = 0; j < S; j++)
+#pragma unroll
+                    for (int k = 0; k < K; k++) ets_step<Cfg>(par[k], st[k], cur[j], s[k][MS > 0 ? j % MR : 0]);
+                load_block(cur, base + 2 * S);
+#pragma unroll
+                for (int j = 0; j < S; j++)
+#pragma unroll
+                    for (int k = 0; k < K; k++) ets_step<Cfg>(par[k], st[k], nxt[j], s[k][MS > 0 ? j % MR : 0]);
+            }
+        }
+        for (; base < wave_len; base += S) {
+            load_block(nxt, base + S);
             if (base + S <= wave_min_len) {
 #pragma unroll
                 for (int j = 0; j < S; j++)
@@ -256,17 +276,6 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
                         for (int k = 0; k < K; k++) ets_step<Cfg>(par[k], st[k], cur[j], s[k][MS > 0 ? j % MR : 0]);
                     }
             }
-#pragma unroll
-            for (int j = 0; j < S; j++) cur[j] = nxt[j];
-        }
-        for (; base < wave_len; base += S) {
-            load_clamped(nxt, base + S);
-#pragma unroll
-            for (int j = 0; j < S; j++)
-                if (base + j < v.len) {
-#pragma unroll
-                    for (int k = 0; k < K; k++) ets_step<Cfg>(par[k], st[k], cur[j], s[k][MS > 0 ? j % MR : 0]);
-                }
 #pragma unroll
             for (int j = 0; j < S; j++) cur[j] = nxt[j];
         }
@@ -313,15 +322,9 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
             }
         };
         int base = 0;
-        for (; base < wave_len && base <= fast_end; base += S) {
-            load_fast(nxt, base + S);
-            ring_block(base, base + S <= wave_min_len);
-#pragma unroll
-            for (int i = 0; i < S; i++) cur[i] = nxt[i];
-        }
         for (; base < wave_len; base += S) {
-            load_clamped(nxt, base + S);
-            ring_block(base, false);
+            load_block(nxt, base + S);
+            ring_block(base, base + S <= wave_min_len);
 #pragma unroll
             for (int i = 0; i < S; i++) cur[i] = nxt[i];
         }

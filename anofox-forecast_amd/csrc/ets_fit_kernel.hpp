@@ -55,7 +55,9 @@ __global__ __launch_bounds__(NM_BLOCK, ANOFOX_ROUND_WAVES) void ets_round_kernel
     }
 
     SeriesView v;
-    v.y = a.y_round + (valid ? (a.gathered ? p : s) : 0);
+    v.col = valid ? (a.gathered ? p : s) : 0;
+    v.yb = a.y_round;
+    v.y = a.y_round + v.col;
     v.ld = a.ld_round;
     v.len = active ? len : 0;
     v.wave_len = wave_max_i32(v.len);
@@ -123,7 +125,9 @@ __global__ __launch_bounds__(NM_BLOCK) void ets_final_kernel(const FitArgs a)
     const bool active = valid && len > 0 && st == FIT_OK;
 
     SeriesView v;
-    v.y = a.y + (valid ? s : 0);
+    v.col = valid ? s : 0;
+    v.yb = a.y;
+    v.y = a.y + v.col;
     v.ld = a.ld;
     v.len = active ? len : 0;
     v.wave_len = wave_max_i32(v.len);
