@@ -209,9 +209,16 @@ __device__ __noinline__ double ar_css_pass_impl(const double *wrow, int len, int
     const lptr_t ring = (lptr_t)(L.base) + threadIdx.x;        // slot k of this lane: ring[k * NM_BLOCK]
     double css = 0.0;
     double wl[AR_MAXP] = {0, 0, 0, 0, 0}, ul[AR_MAXP] = {0, 0, 0, 0, 0};
-    for (int k = 0; k < R; k++) ring[k * NM_BLOCK] = ar_ev_t{0.0, 0.0};
-    constexpr int S = ArBlockLen<M>::value;
+    if (MODE != 3)
+        for (int k = 0; k < R; k++) ring[k * NM_BLOCK] = ar_ev_t{0.0, 0.0};
+    // MODE 3: compile-time period with BOTH seasonal lags in registers (shift rings of 2 M values of e and of v, block =
+    // two revolutions so every ring index is a constant): no LDS traffic in the pass at all
+    constexpr int S = (MODE == 3) ? 4 * M : ArBlockLen<M>::value;
+    constexpr int RR = (MODE == 3) ? 2 * M : 1;
     static_assert(S % 4 == 0 && 2 * S <= AR_SPARE, "block length");
+    double er[RR], vr[RR];
+#pragma unroll
+    for (int k = 0; k < RR; k++) { er[k] = 0.0; vr[k] = 0.0; }
     ar_ev_t cur[S / 2], nxt[S / 2];
 #pragma unroll
     for (int j = 0; j < S / 2; j++) cur[j] = wp_next[j];
@@ -254,6 +261,10 @@ __device__ __noinline__ double ar_css_pass_impl(const double *wrow, int len, int
                     l1[j] = ring[slot1(sb + j, j) * NM_BLOCK];
                     l2[j] = ring[slot2(sb + j, j) * NM_BLOCK];
                 }
+                if (MODE == 3) {
+                    l2[j] = ar_ev_t{er[(sb + j) % RR], vr[(sb + j) % RR]};
+                    l1[j] = ar_ev_t{er[(sb + j + M) % RR], vr[(sb + j + M) % RR]};
+                }
                 if (MODE != 2) {
                     z = fma(Phi[0], l1[j].y, z);
                     z = fma(Phi[1], l2[j].y, z);
@@ -276,11 +287,16 @@ __device__ __noinline__ double ar_css_pass_impl(const double *wrow, int len, int
                 if (MODE == 0) {
                     if (!GATED || t < lim) ring[slot0(sb + j, j) * NM_BLOCK] = ar_ev_t{et, vt};
                 }
+                if (MODE == 3) {
+                    const bool keep = GATED && !(t < lim);
+                    er[(sb + j) % RR] = keep ? er[(sb + j) % RR] : et;
+                    vr[(sb + j) % RR] = keep ? vr[(sb + j) % RR] : vt;
+                }
                 vnew[j] = vt; enew[j] = et;
                 const double ec = (!GATED || t < lim) ? et : 0.0;
                 css = fma(ec, ec, css);
             }
-            if (MODE != 0) {
+            if (MODE == 1 || MODE == 2) {
 #pragma unroll
                 for (int j = 0; j < 4; j++)
                     if (!GATED || t0 + j < lim) ring[slot0(sb + j, j) * NM_BLOCK] = ar_ev_t{enew[j], vnew[j]};
@@ -304,7 +320,7 @@ __device__ __noinline__ double ar_css_pass_impl(const double *wrow, int len, int
 __device__ __forceinline__ double ar_css_pass(const double *wrow, int len, int wave_len, bool live, const ArFac &f, int m, const ArLds &L)
 {
     if (L.R == 2 * m + 4) {      // fit kernels: common periods compiled in
-        if (m == 7) return ar_css_pass_impl<1, 7>(wrow, len, wave_len, live, f, m, L);
+        if (m == 7) return ar_css_pass_impl<3, 7>(wrow, len, wave_len, live, f, m, L);
         if (m == 12) return ar_css_pass_impl<1, 12>(wrow, len, wave_len, live, f, m, L);
         if (m == 4) return ar_css_pass_impl<1, 4>(wrow, len, wave_len, live, f, m, L);
     }
