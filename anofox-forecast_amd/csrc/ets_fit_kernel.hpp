@@ -55,9 +55,10 @@ __global__ __launch_bounds__(NM_BLOCK, ANOFOX_ROUND_WAVES) void ets_round_kernel
     }
 
     SeriesView v;
-    v.col = valid ? (a.gathered ? p : s) : 0;
-    v.yb = a.y_round;
-    v.y = a.y_round + v.col;
+    const bool gathered = a.gathered && n_act > a.gather_min;      // below the threshold the gather kernel did nothing
+    v.col = valid ? (gathered ? p : s) : 0;
+    v.yb = gathered ? a.y_round : a.y;
+    v.y = v.yb + v.col;
     v.ld = a.ld_round;
     v.len = active ? len : 0;
     v.wave_len = wave_max_i32(v.len);

@@ -104,6 +104,7 @@ struct AnofoxHipBatch {
     uint64_t n_problems = 0;
     int seq_rounds = 3;      // rounds run by the sequential Nelder-Mead driver before switching to the speculative one
     int seq_rounds_env = -1; // ANOFOX_HIP_SEQ_ROUNDS override (-1 = decide from the number of live problems)
+    int gather_min = 0;      // per spec: stop gathering columns once this few problems are still running (measured: the gather pays at every count, 0 = always gather)
     int tail_below = 0;      // per spec: run the remaining problems to completion once this few are left (measured: rounds + compaction win at every threshold, 0 = off)
     int spec_below = 8192;   // per spec: switch to the speculative driver once this few problems are still running
     bool use_gather = false; // rebuild a dense block of the running problems between rounds (else index y by series)
@@ -324,7 +325,7 @@ void alloc_common(AnofoxHipBatch *b)
             if (b->use_gather) l.ybuf = dalloc<double>(T * ld);
             l.map[0] = dalloc<int32_t>(ld);
             l.map[1] = dalloc<int32_t>(ld);
-            l.cnt = dalloc<int32_t>(2);
+            l.cnt = dalloc<int32_t>(3);
             l.st.sim = dalloc<double>(20 * ld);
             l.st.fs = dalloc<double>(5 * ld);
             l.st.phase = dalloc<int32_t>(ld);
@@ -542,12 +543,13 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
                 a.y_round = b->d_y; a.ld_round = ld; a.series_of = nullptr; a.n_active = nullptr;
             } else {
                 const int32_t *prev_map = (r == 1) ? nullptr : lane.map[(r - 1) & 1];
-                const int32_t *prev_cnt = (r == 1) ? nullptr : lane.cnt + ((r - 1) & 1);
-                launch_compact(prev_map, prev_cnt, (int)n, lane.st.done, lane.map[r & 1], lane.cnt + (r & 1), sq);
-                a.series_of = lane.map[r & 1]; a.n_active = lane.cnt + (r & 1);
+                const int32_t *prev_cnt = (r == 1) ? nullptr : lane.cnt + ((r - 1) % 3);
+                if (r == 1) HIPCHECK(hipMemsetAsync(lane.cnt, 0, 3 * sizeof(int32_t), sq));      // then the counters rotate: no more memsets
+                launch_compact(prev_map, prev_cnt, (int)n, lane.st.done, lane.map[r & 1], lane.cnt + (r % 3), sq, lane.cnt + ((r + 1) % 3));
+                a.series_of = lane.map[r & 1]; a.n_active = lane.cnt + (r % 3);
                 if (b->use_gather && lane.ybuf) {
-                    launch_gather_columns(b->d_y, ld, lane.map[r & 1], lane.cnt + (r & 1), (int)n, (int)b->t_max, lane.ybuf, ld, sq);
-                    a.y_round = lane.ybuf; a.ld_round = ld; a.gathered = 1;
+                    launch_gather_columns(b->d_y, ld, lane.map[r & 1], lane.cnt + (r % 3), (int)n, (int)b->t_max, lane.ybuf, ld, sq, b->gather_min);
+                    a.y_round = lane.ybuf; a.ld_round = ld; a.gathered = 1; a.gather_min = b->gather_min;
                 } else {
                     a.y_round = b->d_y; a.ld_round = ld;
                 }
@@ -863,6 +865,7 @@ bool anofox_hip_batch_create(size_t n_series, size_t t_max, const ForecastOption
         if (const char *e = std::getenv("ANOFOX_HIP_GATHER")) b->use_gather = std::atoi(e) != 0;
         if (const char *e = std::getenv("ANOFOX_HIP_SPEC_BELOW")) b->spec_below = std::atoi(e);
         if (const char *e = std::getenv("ANOFOX_HIP_TAIL_BELOW")) b->tail_below = std::atoi(e);
+        if (const char *e = std::getenv("ANOFOX_HIP_GATHER_MIN")) b->gather_min = std::atoi(e);
         alloc_common(b);
     } catch (const HipFail &f) {
         set_error(out_error, INTERNAL_ERROR, "Internal error: " + f.msg);

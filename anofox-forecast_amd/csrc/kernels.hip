@@ -232,8 +232,10 @@ FitLaunchers ets_fit_launcher(int spec_id, int m)
 // wave.  The order of the waves' ranges is not deterministic -- it only decides which column a problem
 // occupies in the next round, never a result (every problem is independent of its position).
 __global__ __launch_bounds__(NM_BLOCK) void compact_kernel(const int32_t *series_prev, const int32_t *n_prev_ptr, int n_series,
-                                                           const int32_t *done, int32_t *series_next, int32_t *n_next_ptr)
+                                                           const int32_t *done, int32_t *series_next, int32_t *n_next_ptr, int32_t *n_clear)
 {
+    // the counter of the round after next is cleared here (three counters rotate), so no memset sits between the rounds
+    if (n_clear && blockIdx.x == 0 && threadIdx.x == 0) *n_clear = 0;
     const int n_prev = n_prev_ptr ? *n_prev_ptr : n_series;
     if ((int)blockIdx.x * NM_BLOCK >= n_prev) return;
     const int lane = threadIdx.x;
@@ -255,11 +257,11 @@ __global__ __launch_bounds__(NM_BLOCK) void compact_kernel(const int32_t *series
 }
 
 void launch_compact(const int32_t *series_prev, const int32_t *n_prev, int n_series, const int32_t *done,
-                    int32_t *series_next, int32_t *n_next, hipStream_t stream)
+                    int32_t *series_next, int32_t *n_next, hipStream_t stream, int32_t *n_clear)
 {
-    (void)hipMemsetAsync(n_next, 0, sizeof(int32_t), stream);
+    if (!n_clear) (void)hipMemsetAsync(n_next, 0, sizeof(int32_t), stream);   // stand-alone use: clear the output counter here
     const int grid = (n_series + NM_BLOCK - 1) / NM_BLOCK;
-    hipLaunchKernelGGL(compact_kernel, dim3(grid), dim3(NM_BLOCK), 0, stream, series_prev, n_prev, n_series, done, series_next, n_next);
+    hipLaunchKernelGGL(compact_kernel, dim3(grid), dim3(NM_BLOCK), 0, stream, series_prev, n_prev, n_series, done, series_next, n_next, n_clear);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -268,10 +270,10 @@ void launch_compact(const int32_t *series_prev, const int32_t *n_prev, int n_ser
 // ------------------------------------------------------------------------------------------
 constexpr int GATHER_TB = 32;
 __global__ __launch_bounds__(NM_BLOCK) void gather_columns_kernel(const double *y, size_t ld, const int32_t *series_of,
-                                                                  const int32_t *n_active, int t_max, double *out, size_t ld_out)
+                                                                  const int32_t *n_active, int t_max, double *out, size_t ld_out, int min_active)
 {
     const int n_act = *n_active;
-    if ((int)blockIdx.x * NM_BLOCK >= n_act) return;
+    if ((int)blockIdx.x * NM_BLOCK >= n_act || n_act <= min_active) return;     // few problems left: the round reads y in place
     const int p = blockIdx.x * NM_BLOCK + threadIdx.x;
     const int s = series_of[p < n_act ? p : n_act - 1];
     const int t0 = blockIdx.y * GATHER_TB;
@@ -280,10 +282,10 @@ __global__ __launch_bounds__(NM_BLOCK) void gather_columns_kernel(const double *
 }
 
 void launch_gather_columns(const double *y, size_t ld, const int32_t *series_of, const int32_t *n_active, int n_series,
-                           int t_max, double *out, size_t ld_out, hipStream_t stream)
+                           int t_max, double *out, size_t ld_out, hipStream_t stream, int min_active)
 {
     dim3 grid((n_series + NM_BLOCK - 1) / NM_BLOCK, (t_max + GATHER_TB - 1) / GATHER_TB);
-    hipLaunchKernelGGL(gather_columns_kernel, grid, dim3(NM_BLOCK), 0, stream, y, ld, series_of, n_active, t_max, out, ld_out);
+    hipLaunchKernelGGL(gather_columns_kernel, grid, dim3(NM_BLOCK), 0, stream, y, ld, series_of, n_active, t_max, out, ld_out, min_active);
 }
 
 } // namespace anofox

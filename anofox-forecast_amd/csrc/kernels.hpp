@@ -42,6 +42,7 @@ struct FitArgs {
     int spec_below;              // device-side driver choice: the speculative kernel runs iff n_active <= spec_below,
                                  // the sequential one iff n_active > spec_below (both are enqueued; -1 = unconditional)
     int tail_below;              // run to completion once this few problems are still running (0 = never)
+    int gather_min;              // the gather (and the gathered view) only applies while more than this many problems run
     int gathered;                // y_round holds the running problems' columns densely (column p), else index by series
     NmStateBuf st;
     int m, h;
@@ -114,10 +115,10 @@ FitLaunchers ets_fit_launcher(int spec_id, int m);
 // compaction of the unfinished problems: series_next[0..n_next) = the series of the previous map whose done flag
 // is 0 (one ballot + one atomic per wave; the order of the survivors is not preserved, results do not depend on it)
 void launch_compact(const int32_t *series_prev, const int32_t *n_prev, int n_series, const int32_t *done,
-                    int32_t *series_next, int32_t *n_next, hipStream_t);
+                    int32_t *series_next, int32_t *n_next, hipStream_t, int32_t *n_clear = nullptr);
 // out[t * ld_out + p] = y[t * ld + series_of[p]] for p < *n_active, t < t_max
 void launch_gather_columns(const double *y, size_t ld, const int32_t *series_of, const int32_t *n_active, int n_series,
-                           int t_max, double *out, size_t ld_out, hipStream_t);
+                           int t_max, double *out, size_t ld_out, hipStream_t, int min_active = 0);
 
 // AutoARIMA (arima.hip): prep (D, d, differenced block), stepwise CSS search (advance / fit sweeps), forecast + integration
 struct ArimaArgs {
