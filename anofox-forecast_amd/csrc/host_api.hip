@@ -82,6 +82,7 @@ struct AnofoxHipBatch {
     int32_t *d_pos_map = nullptr, *d_pos_cnt = nullptr, *d_notpos = nullptr;
     double *d_ypos = nullptr;
     bool use_pos = false;
+    int32_t live_pos = -1, live_all = -1;   // usable strictly positive / usable series of the current group (-1: not counted)
     // AutoARIMA workspace
     size_t ar_ws_bytes = 0;
     double *ar_w = nullptr, *ar_wmean = nullptr, *ar_wsd = nullptr, *ar_l0 = nullptr, *ar_l1 = nullptr, *ar_x = nullptr, *ar_aicc = nullptr;
@@ -484,7 +485,16 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
         if (ti == 4) c += 20;       // b^phi every step
         return c;
     };
-    std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return cost(specs[x]) > cost(specs[y]); });
+    // expected work of a spec on THIS batch: a spec with a multiplicative component only runs on the strictly positive series
+    auto work = [&](int id) {
+        const double live = (b->live_all >= 0 && spec_has_mult(id)) ? (double)b->live_pos : (b->live_all >= 0 ? (double)b->live_all : 1.0);
+        return (double)cost(id) * (live + 1.0);
+    };
+    std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return work(specs[x]) > work(specs[y]); });
+    // one stream per spec (the runtime maps them onto the hardware queues; two explicit pairing schemes -- dedicated
+    // queues for the heaviest specs, heaviest-with-lightest -- both measured 14 % slower on the 30-spec batch)
+    std::vector<int> stream_of(order.size());
+    for (size_t oi = 0; oi < order.size(); oi++) stream_of[oi] = (int)(oi % (size_t)n_lanes);
     std::vector<FitArgs> args(order.size());
     std::vector<FitLaunchers> fns(order.size());
     for (size_t oi = 0; oi < order.size(); oi++) {
@@ -524,7 +534,7 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
         for (size_t oi = 0; oi < order.size(); oi++) {
             const int q = (int)(oi % (size_t)n_lanes);
             auto &lane = b->lanes[q];
-            hipStream_t sq = b->aux[q];
+            hipStream_t sq = b->aux[stream_of[oi]];
             FitArgs &a = args[oi];
             const bool spec_mode = r >= b->seq_rounds;
             a.first_round = (r == 0);
@@ -570,7 +580,7 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
             b->fit_launches++;
         }
     }
-    for (size_t oi = 0; oi < order.size(); oi++) fns[oi].final(args[oi], b->aux[oi % (size_t)n_lanes]);
+    for (size_t oi = 0; oi < order.size(); oi++) fns[oi].final(args[oi], b->aux[stream_of[oi]]);
     for (int i = 0; i < n_lanes; i++) {
         HIPCHECK(hipEventRecord(b->ev_join[i], b->aux[i]));
         HIPCHECK(hipStreamWaitEvent(st, b->ev_join[i], 0));
@@ -684,8 +694,10 @@ void run_group(AnofoxHipBatch *b, int period, const int32_t *d_len, hipStream_t 
             const double live = (double)cnt[0] * (double)specs.size() + (double)(cnt[1] - cnt[0]) * (double)n_add;
             b->seq_rounds = live >= 8.0 * 65536.0 ? 4 : 0;    // >= 8 problems per SIMD lane-slot: VALU-bound, go sequential
             b->use_pos = cnt[0] > 0 && (double)cnt[0] < 0.7 * (double)cnt[1];
+            b->live_pos = cnt[0]; b->live_all = cnt[1];
         } else {
             b->use_pos = false;
+            b->live_pos = b->live_all = -1;
         }
         if (b->use_pos) {
             hipLaunchKernelGGL(mark_nonpositive_kernel, dim3((unsigned)blocks256), dim3(256), 0, st, (int)n, d_len, b->d_flags, b->d_notpos);
