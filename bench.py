@@ -73,11 +73,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP backend has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # ANOFOX_BENCH_ONE_GPU=1 (debug only): every rank uses GPU 0 and the gather runs over gloo -- exercises the N > 1 code
+    # path on a single-GPU box; RCCL refuses two ranks on one device
+    one_gpu = os.environ.get("ANOFOX_BENCH_ONE_GPU") == "1"
+    dev_index = 0 if one_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)     # "nccl" is RCCL on ROCm
+        if one_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)     # "nccl" is RCCL on ROCm
 
     model, ets_model, n_def, T_def, m, positive, seed, cpu_def = WORKLOADS[args.workload]
     n = args.n_series or n_def
