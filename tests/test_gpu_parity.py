@@ -91,6 +91,17 @@ def test_ets_specs_match_oracle(env, spec, period):
     _compare(api, O, lib, list(Y), "ETS", 10, ets_model=spec, seasonal_period=period)
 
 
+@pytest.mark.parametrize("period", [2, 12, 24, 64])
+def test_autoets_other_periods(env, period):
+    """The compile-time m = 12 ring (additive class only), the LDS ring at its smallest, a long and the maximum period, with
+    ragged lengths that end inside a streamed block: AutoETS over the whole grid against the oracle."""
+    api, O, lib, synth = env
+    T = 5 * period + 37
+    Y = synth.gen_series(synth.SEED_M5, 3000 + period, 40, T, period, positive=True)
+    series = [Y[s, : T - (s % 7) * 3] for s in range(40)]
+    _compare(api, O, lib, series, "AutoETS", period + 3, seasonal_period=period)
+
+
 def test_autoets_full_grid_positive(env):
     api, O, lib, synth = env
     Y = synth.gen_series(synth.SEED_M5, 2000, 64, 100, 7, positive=True)
@@ -322,6 +333,20 @@ def _run_device_batch(lib, Y, model, h, m, dev="cuda:0"):
     names = [b.model_name(int(c)) for c in out["model_code"][:n]]
     b.close()
     return out, again, names
+
+
+@pytest.mark.parametrize("m", [2, 3, 4, 12, 24, 30])
+def test_auto_arima_other_periods(env, m):
+    """Every variant of the CSS pass: per-step ring access (m = 2, 3), compile-time ring slots (m = 4, 12), the generic
+    run-time ring (m = 24) and the non-seasonal fallback for m > 24 -- each against the oracle."""
+    api, O, lib, synth = env
+    rng = np.random.default_rng(100 + m)
+    T = 8 * m + 40
+    t = np.arange(T)
+    series = [10 + 3 * np.sin(2 * np.pi * t / m + k) + 0.02 * k * t + rng.normal(0, 0.5 + 0.1 * k, T) for k in range(12)]
+    series += [np.cumsum(rng.normal(0.05, 1.0, T)) for _ in range(6)]
+    series = [s[: T - 3 * (i % 5)] for i, s in enumerate(series)]                    # ragged
+    _compare(api, O, lib, series, "AutoARIMA", 2 * m + 1, seasonal_period=m)
 
 
 @pytest.mark.parametrize("model,positive", [("AutoETS", False), ("AutoETS", True), ("AutoARIMA", False)])
