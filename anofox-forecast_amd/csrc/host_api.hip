@@ -107,6 +107,7 @@ struct AnofoxHipBatch {
     int seq_rounds_env = -1; // ANOFOX_HIP_SEQ_ROUNDS override (-1 = decide from the number of live problems)
     int gather_min = 0;      // per spec: stop gathering columns once this few problems are still running (measured: the gather pays at every count, 0 = always gather)
     int tail_below = 0;      // per spec: run the remaining problems to completion once this few are left (measured: rounds + compaction win at every threshold, 0 = off)
+    int spec_below_md = 8192; // same, for the damped multiplicative-trend specs (their pass is ~10x longer: the stragglers matter more)
     int spec_below = 8192;   // per spec: switch to the speculative driver once this few problems are still running
     bool use_gather = false; // rebuild a dense block of the running problems between rounds (else index y by series)
 };
@@ -571,7 +572,7 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
             } else {
                 // later rounds: enqueue both drivers, the device-side count of running problems picks one --
                 // sequential (least arithmetic) while this spec still fills >= 1/8 of the chip, else speculative
-                a.spec_below = b->spec_below;
+                a.spec_below = (spec_trend_idx(specs[order[oi]]) == 4) ? b->spec_below_md : b->spec_below;
                 a.budget = (BUDGET[r] * 7) / 4;
                 fns[oi].round_seq(a, sq);
                 a.budget = BUDGET[r];
@@ -875,7 +876,8 @@ bool anofox_hip_batch_create(size_t n_series, size_t t_max, const ForecastOption
         // candidate spec: on by default while that stays under 24 GiB of the 288 GB HBM
         b->use_gather = (double)max_slots_for(plan) * (double)std::max<size_t>(t_max, 1) * (double)b->ld * 8.0 <= 24.0 * 1073741824.0;
         if (const char *e = std::getenv("ANOFOX_HIP_GATHER")) b->use_gather = std::atoi(e) != 0;
-        if (const char *e = std::getenv("ANOFOX_HIP_SPEC_BELOW")) b->spec_below = std::atoi(e);
+        if (const char *e = std::getenv("ANOFOX_HIP_SPEC_BELOW")) b->spec_below = b->spec_below_md = std::atoi(e);
+        if (const char *e = std::getenv("ANOFOX_HIP_SPEC_BELOW_MD")) b->spec_below_md = std::atoi(e);
         if (const char *e = std::getenv("ANOFOX_HIP_TAIL_BELOW")) b->tail_below = std::atoi(e);
         if (const char *e = std::getenv("ANOFOX_HIP_GATHER_MIN")) b->gather_min = std::atoi(e);
         alloc_common(b);

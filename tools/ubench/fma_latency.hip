@@ -20,12 +20,11 @@ __global__ void k(double *out, int iters, double a, double b)
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 template <int CHAINS>
-void run(int waves_per_simd)
+void run(int waves_per_simd, int iters = 20000)
 {
     int dev; hipGetDevice(&dev); hipDeviceProp_t p; hipGetDeviceProperties(&p, dev);
     const int grid = p.multiProcessorCount * 4 * waves_per_simd;   // one-wave workgroups
     double *d; hipMalloc(&d, sizeof(double) * grid * 64);
-    const int iters = 20000;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     k<CHAINS><<<grid, 64>>>(d, 100, 0.999, 1e-3);
     hipEventRecord(e0);
@@ -42,5 +41,7 @@ int main()
 {
     run<1>(1); run<2>(1); run<4>(1); run<8>(1);
     run<1>(2); run<1>(4); run<4>(2);
+    run<4>(2, 2000000);      // ~0.5 s of sustained fp64 FMA issue: does the clock hold?
+    run<4>(2, 8000000);      // ~2 s
     return 0;
 }
