@@ -315,6 +315,32 @@ def test_auto_arima_matches_oracle(env):
     assert r["ok"] and r["model_name"].startswith("AutoARIMA(") and abs(r["point"][0] - 18.014537) / 18.014537 < 2e-3
 
 
+@pytest.mark.parametrize("model,kw", [("AutoETS", dict(seasonal_period=7)), ("AutoETS", dict(seasonal_period=1)),
+                                      ("AutoARIMA", dict(seasonal_period=7)), ("HoltWinters", dict(seasonal_period=7)),
+                                      ("ETS", dict(ets_model="MMdM", seasonal_period=7)), ("SESOptimized", dict())])
+def test_hostile_inputs_match_oracle(env, model, kw):
+    """Non-finite, huge, tiny, negative, all-zero, step and alternating series, lengths around every admissibility
+    threshold, horizons 0 / 5 / 200: the same error code or the same bits as the oracle, series by series."""
+    api, O, lib, synth = env
+    base = np.abs(np.random.default_rng(0).normal(50, 10, 120)) + 5
+    cases = {"inf": np.r_[base[:60], np.inf, base[61:]], "nan": np.r_[base[:60], np.nan, base[61:]], "huge": base * 1e300,
+             "tiny": base * 1e-300, "neg": base - 60, "zeros": np.zeros(80), "step": np.r_[np.full(60, 5.0), np.full(60, 9.0)],
+             "len3": base[:3], "len4": base[:4], "len14": base[:14], "len15": base[:15], "alt": np.tile([1.0, 1e6], 60)}
+    for h in (0, 5, 200):
+        got, berr = api.forecast_batch(list(cases.values()), lib.make_options(model, h, **kw))
+        assert berr["ok"]
+        oo = O.make_options(model, h, **kw)
+        for (name, y), r in zip(cases.items(), got):
+            ref = O.forecast(y, oo)
+            assert r["ok"] == ref["ok"], (name, h, r.get("code"), ref.get("code"))
+            if not r["ok"]:
+                assert r["code"] == ref["code"], (name, h)
+            else:
+                assert r["model_name"] == ref["model_name"], (name, h)
+                assert np.array_equal(np.asarray(r["point"]), np.asarray(ref["point"]), equal_nan=True), (name, h)
+                assert np.array_equal(np.asarray(r["lower"]), np.asarray(ref["lower"]), equal_nan=True), (name, h)
+
+
 def _run_device_batch(lib, Y, model, h, m, dev="cuda:0"):
     import torch
     from anofox_forecast_amd.device import DeviceBatch, pack_time_major
