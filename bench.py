@@ -56,6 +56,9 @@ WORKLOADS = {
     "ets_aaa_m5": ("ETS", "AAA", 30490, 1913, 7, False, 20260101, 8192),
     "autoets_stress": ("AutoETS", "", 125000, 1024, 7, False, 20260102, 8192),
     "autoarima_m5": ("AutoARIMA", "", 30490, 1913, 7, False, 20260101, 512),
+    # single-spec probes (kernel efficiency without cross-kernel effects)
+    "ets_amdn_stress": ("ETS", "AMdN", 125000, 1024, 7, True, 20260102, 256),
+    "ets_mam_stress": ("ETS", "MAM", 125000, 1024, 7, True, 20260102, 256),
 }
 
 
