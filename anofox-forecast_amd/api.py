@@ -355,6 +355,67 @@ anofox_fcst_ts_forecast_by = ts_forecast_by  # alias registered by the reference
 
 
 # --------------------------------------------------------------------------------------------
+# ts_forecast_agg: the GROUP BY aggregate caller
+# --------------------------------------------------------------------------------------------
+def ts_forecast_agg(group, date, value, method="auto", horizon=12, params=None):
+    """ts_forecast_agg(date, value, method, horizon, params) ... GROUP BY group
+    (src/aggregate_functions/ts_forecast_agg.cpp:247-560).
+
+    Rows with a NULL timestamp or a NULL value are skipped (`:278`); a group's pairs are ordered by (timestamp, value)
+    (`std::sort` of pairs, `:341`); options: the method (default "auto"), `params['model']` as the ETS notation, horizon
+    (default 12), confidence 0.90, fitted values on, seasonal period 0 with detection off (the block is memset, `:355`).
+    Forecast timestamps advance by the MEDIAN step of the group's timestamps (`:393-404`; one day if there is a single
+    row).  A failed group returns its error message and empty lists instead of aborting the statement (`:374-391`).
+    Returns {group: struct} with the reference's field names (lower_90 / upper_90 for the fixed 0.90 level).
+    All groups go to the GPU as one batch.
+    """
+    dates = np.asarray(date)
+    kind = _date_kind(dates)
+    us = _to_micros(dates, kind)
+    null_date = np.isnat(dates) if np.issubdtype(dates.dtype, np.datetime64) else np.zeros(len(dates), bool)
+    grp = np.asarray(group, dtype=object)
+    val = np.asarray(value, dtype=object)
+    order, rows = [], {}
+    for i in range(len(grp)):
+        v = val[i]
+        if null_date[i] or v is None or (isinstance(v, float) and v != v):
+            continue
+        if grp[i] not in rows:
+            rows[grp[i]] = []
+            order.append(grp[i])
+        rows[grp[i]].append((int(us[i]), float(v)))
+    series, stamps = [], []
+    for k in order:
+        pairs = sorted(rows[k])
+        stamps.append([p[0] for p in pairs])
+        series.append(np.array([p[1] for p in pairs], dtype=np.float64))
+    ets_model = str((params or {}).get("model") or "")
+    opts = _lib.make_options(str(method) if method is not None else "auto", int(horizon) if horizon is not None else 12,
+                             ets_model=ets_model, seasonal_period=0, confidence_level=0.90, auto_detect=False, include_fitted=True)
+    out = {}
+    if not series:
+        return out
+    results, berr = forecast_batch(series, opts)
+    for k, ts, r in zip(order, stamps, results):
+        ok = berr["ok"] and r["ok"]
+        if not ok:
+            out[k] = {"forecast_step": [], "forecast_timestamp": [], "point_forecast": [], "lower_90": [], "upper_90": [],
+                      "model_name": "", "insample_fitted": [], "date_col_name": "date",
+                      "error_message": r["message"] if berr["ok"] else berr["message"]}
+            continue
+        if len(ts) >= 2:
+            steps = sorted(ts[j] - ts[j - 1] for j in range(1, len(ts)))
+            step = steps[len(steps) // 2]
+        else:
+            step = 86400000000
+        h = len(r["point"])
+        out[k] = {"forecast_step": list(range(1, h + 1)), "forecast_timestamp": [ts[-1] + (j + 1) * step for j in range(h)],
+                  "point_forecast": r["point"], "lower_90": r["lower"], "upper_90": r["upper"], "model_name": r["model_name"],
+                  "insample_fitted": r.get("fitted", np.array([])), "date_col_name": "date", "error_message": None}
+    return out
+
+
+# --------------------------------------------------------------------------------------------
 # columnar ingest (SURVEY.md section 8f rank 2): the collection side of route B through the C-ABI
 # --------------------------------------------------------------------------------------------
 class Ingest:

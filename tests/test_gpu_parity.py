@@ -174,6 +174,34 @@ def test_ts_forecast_by_operator(env):
         api.ts_forecast_by(grp, ds, Y.reshape(-1), "Naive", 3, "1d", {"seasonal_period": "7"})
 
 
+def test_ts_forecast_agg_caller(env):
+    """the aggregate caller -- NULL rows skipped, (timestamp, value) order, median-step forecast
+    timestamps, fitted values on, a failing group reports its message instead of aborting."""
+    api, O, lib, synth = env
+    Y = synth.gen_series(synth.SEED_M5, 70, 3, 40, 7, positive=True)
+    grp, ds, val = [], [], []
+    for g in range(3):
+        for t in range(40):
+            grp.append(f"s{g}"); ds.append(1000 + 5 * t); val.append(Y[g, t] if (t + g) % 13 else None)   # a few NULL values
+    grp += ["tiny", "tiny"]; ds += [1, 2]; val += [1.0, 2.0]                                           # too short: error row
+    perm = np.random.default_rng(8).permutation(len(grp))
+    out = api.ts_forecast_agg(np.array(grp, dtype=object)[perm], np.array(ds, dtype=np.int64)[perm],
+                              np.array(val, dtype=object)[perm], "AutoETS", 6, {})
+    assert set(out) == {"s0", "s1", "s2", "tiny"}
+    assert out["tiny"]["point_forecast"] == [] and "Insufficient data" in out["tiny"]["error_message"]
+    oo = O.make_options("AutoETS", 6, seasonal_period=0, confidence_level=0.90, auto_detect=False, include_fitted=True)
+    for g in range(3):
+        keep = [t for t in range(40) if (t + g) % 13]
+        ref = O.forecast(Y[g, keep], oo)
+        r = out[f"s{g}"]
+        assert r["model_name"] == ref["model_name"] and r["forecast_step"] == [1, 2, 3, 4, 5, 6]
+        np.testing.assert_allclose(r["point_forecast"], ref["point"], rtol=REL_TOL)
+        np.testing.assert_allclose(r["lower_90"], ref["lower"], rtol=REL_TOL)
+        np.testing.assert_allclose(r["insample_fitted"], ref["fitted"], rtol=REL_TOL)
+        last = 1000 + 5 * keep[-1]
+        assert r["forecast_timestamp"] == [last + 5 * (j + 1) for j in range(6)]                      # median step = 5
+
+
 def test_columnar_ingest_feeds_the_batch(env):
     """rows appended chunk by chunk through the C-ABI ingest (block 4) give the same forecasts as
     the operator mirror that groups and sorts in Python -- NULL targets, shuffled rows, ragged groups included."""
