@@ -174,6 +174,35 @@ def test_ts_forecast_by_operator(env):
         api.ts_forecast_by(grp, ds, Y.reshape(-1), "Naive", 3, "1d", {"seasonal_period": "7"})
 
 
+def test_concurrent_single_series_calls(env):
+    """Route A calls anofox_ts_forecast from every DuckDB worker thread at once (threading): concurrent calls
+    from 8 host threads give the results of the serial calls."""
+    import threading
+    api, O, lib, synth = env
+    Y = synth.gen_series(synth.SEED_M5, 500, 48, 70, 7, positive=True)
+    models = [("AutoETS", dict(seasonal_period=7)), ("HoltWinters", dict(seasonal_period=7)), ("AutoARIMA", dict()), ("Naive", dict())]
+    jobs = [(i, models[i % 4]) for i in range(48)]
+    serial = [api.forecast_series(Y[i], lib.make_options(m, 9, **kw)) for i, (m, kw) in jobs]
+    got = [None] * len(jobs)
+    errs = []
+
+    def work(tid):
+        try:
+            for j in range(tid, len(jobs), 8):
+                i, (m, kw) = jobs[j]
+                got[j] = api.forecast_series(Y[i], lib.make_options(m, 9, **kw))
+        except Exception as e:          # noqa: BLE001
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(8)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    for a, b in zip(serial, got):
+        assert a["ok"] and b["ok"] and a["model_name"] == b["model_name"]
+        assert np.array_equal(a["point"], b["point"]) and np.array_equal(a["upper"], b["upper"])
+
+
 def test_ts_forecast_agg_caller(env):
     """the aggregate caller -- NULL rows skipped, (timestamp, value) order, median-step forecast
     timestamps, fitted values on, a failing group reports its message instead of aborting."""
