@@ -1059,8 +1059,9 @@ int launch_arima(const ArimaArgs &a, hipStream_t stream)
         for (int i = 0; i <= AR_MAXDIM; i++) total += counts[i];
         if (total == 0) break;
         prev_total = total;
-        if (total <= 2L * max_waves * (NM_BLOCK / 4)) {
-            // short queue (up to two problems per resident 4-lane group): four lanes per problem, one pass per Nelder-Mead
+        static const double spec_factor = [] { const char *e = std::getenv("ANOFOX_HIP_ARIMA_SPEC_FACTOR"); return e ? std::atof(e) : 3.0; }();   // measured 1 / 2 / 2.5 / 3 / 4: 1.83 / 1.83 / 1.74 / 1.74 / 1.73 s
+        if ((double)total <= spec_factor * (double)max_waves * (NM_BLOCK / 4)) {
+            // short queue (up to three problems per resident 4-lane group): four lanes per problem, one pass per Nelder-Mead
             // iteration -- such a sweep is bound by its slowest fit, not by throughput
             long waves = (total * 4 + NM_BLOCK - 1) / NM_BLOCK;
             if (waves > max_waves) waves = max_waves;
