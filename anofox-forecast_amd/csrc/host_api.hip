@@ -12,6 +12,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "classic_device.hpp"
@@ -62,6 +63,8 @@ struct AnofoxHipBatch {
     std::vector<int32_t> h_period;     // per-series period
     std::vector<int32_t> h_base_status;
     std::vector<int32_t> h_slot_spec;
+    double *h_stage = nullptr;         // pinned staging copy of the time-major block (packer output, H2D source)
+    size_t h_stage_elems = 0;
     std::vector<double> h_clean;       // interpolated host copy (only when fitted values requested)
     std::vector<size_t> h_clean_off;
     // prep outputs
@@ -247,6 +250,7 @@ void free_batch_buffers(AnofoxHipBatch *b)
 {
     auto F = [](void *p) { if (p) (void)hipFree(p); };
     if (b->owns_y) F(b->d_y);
+    if (b->h_stage) (void)hipHostFree(b->h_stage);
     if (b->owns_len) F(b->d_len);
     F(b->d_mean); F(b->d_sd); F(b->d_fig_add); F(b->d_fig_mul); F(b->d_l0); F(b->d_b0); F(b->d_flags);
     F(b->d_aicc); F(b->d_yhat_slots); F(b->d_status_slots); F(b->d_evals_slots); F(b->d_iters_slots);
@@ -912,28 +916,73 @@ bool anofox_hip_batch_pack_host(AnofoxHipBatch *b, const double *const *values, 
     if (!b || !values || !lengths) { set_error(out_error, NULL_POINTER, "Null pointer argument"); return false; }
     try {
         const size_t n = b->n, ld = b->ld, T = std::max<size_t>(b->t_max, 1);
-        std::vector<double> block(T * ld, 0.0);
-        std::vector<double> clean;
+        for (size_t s = 0; s < n; s++)
+            if (lengths[s] > b->t_max) throw HipFail{"series longer than the plan's t_max"};
+        // The packer is the host half of the batch entry and easily costs more than the fit: it runs on all host threads,
+        // 64 series (one 512-byte row segment of the time-major block) per tile, straight into a pinned staging block that
+        // is allocated once per batch, so the H2D copy that follows is a single DMA at link speed.
+        if (b->h_stage_elems < T * ld) {
+            if (b->h_stage) (void)hipHostFree(b->h_stage);
+            b->h_stage = nullptr; b->h_stage_elems = 0;
+            HIPCHECK(hipHostMalloc((void **)&b->h_stage, T * ld * sizeof(double), hipHostMallocDefault));
+            b->h_stage_elems = T * ld;
+        }
+        double *block = b->h_stage;
         b->h_len.assign(n, 0);
         b->h_period.assign(n, 1);
         const bool keep = b->opt.include_fitted || b->opt.include_residuals;
-        if (keep) { b->h_clean.clear(); b->h_clean_off.assign(n + 1, 0); }
+        if (keep) {
+            b->h_clean_off.assign(n + 1, 0);
+            for (size_t s = 0; s < n; s++) b->h_clean_off[s + 1] = b->h_clean_off[s] + lengths[s];
+            b->h_clean.assign(b->h_clean_off[n], 0.0);
+        }
         const bool detect = b->opt.auto_detect_seasonality && b->opt.seasonal_period == 0;
-        for (size_t s = 0; s < n; s++) {
-            const size_t len = lengths[s];
-            if (len > b->t_max) throw HipFail{"series longer than the plan's t_max"};
-            b->h_len[s] = (int32_t)len;
-            clean.resize(len);
-            if (len) fill_nulls_interpolate(values[s], validity ? validity[s] : nullptr, len, clean.data());
-            for (size_t t = 0; t < len; t++) block[t * ld + s] = clean[t];
-            int period = 1;
-            if (detect) { int p = len >= 3 ? detect_seasonality_first(clean.data(), len) : 0; period = p > 0 ? p : 1; }
-            else if (b->opt.seasonal_period > 0) period = b->opt.seasonal_period;
-            b->h_period[s] = period;
-            if (keep) { b->h_clean.insert(b->h_clean.end(), clean.begin(), clean.end()); b->h_clean_off[s + 1] = b->h_clean.size(); }
+        constexpr size_t TILE = 64;
+        const size_t n_tiles = ld / TILE;
+        auto do_tiles = [&](size_t tile0, size_t tile1) {
+            std::vector<double> clean(TILE * T);
+            for (size_t tile = tile0; tile < tile1; tile++) {
+                const size_t s0 = tile * TILE;
+                size_t len_of[TILE];
+                for (size_t j = 0; j < TILE; j++) {
+                    const size_t s = s0 + j;
+                    const size_t len = s < n ? lengths[s] : 0;
+                    len_of[j] = len;
+                    double *c = clean.data() + j * T;
+                    if (len) fill_nulls_interpolate(values[s], validity ? validity[s] : nullptr, len, c);
+                    if (s < n) {
+                        b->h_len[s] = (int32_t)len;
+                        int period = 1;
+                        if (detect) { int p = len >= 3 ? detect_seasonality_first(c, len) : 0; period = p > 0 ? p : 1; }
+                        else if (b->opt.seasonal_period > 0) period = b->opt.seasonal_period;
+                        b->h_period[s] = period;
+                        if (keep && len) std::memcpy(b->h_clean.data() + b->h_clean_off[s], c, len * sizeof(double));
+                    }
+                }
+                for (size_t t = 0; t < T; t++) {
+                    double *row = block + t * ld + s0;
+                    for (size_t j = 0; j < TILE; j++) row[j] = t < len_of[j] ? clean[j * T + t] : 0.0;
+                }
+            }
+        };
+        unsigned n_thr = std::thread::hardware_concurrency();
+        if (const char *e = std::getenv("ANOFOX_HIP_PACK_THREADS")) n_thr = (unsigned)std::max(1, std::atoi(e));
+        n_thr = (unsigned)std::min<size_t>(std::max(1u, std::min(n_thr, 32u)), std::max<size_t>(n_tiles, 1));
+        if (n_thr <= 1 || n_tiles < 8) do_tiles(0, n_tiles);
+        else {
+            std::vector<std::thread> pool;
+            std::vector<std::string> fails(n_thr);
+            for (unsigned k = 0; k < n_thr; k++)
+                pool.emplace_back([&, k] {
+                    try { do_tiles(n_tiles * k / n_thr, n_tiles * (k + 1) / n_thr); }
+                    catch (const std::exception &e) { fails[k] = e.what(); }
+                    catch (...) { fails[k] = "packer thread failed"; }
+                });
+            for (auto &th : pool) th.join();
+            for (auto &f : fails) if (!f.empty()) throw HipFail{f};
         }
         if (!b->d_y || !b->owns_y) { b->d_y = dalloc<double>(T * ld); b->owns_y = true; }
-        HIPCHECK(hipMemcpy(b->d_y, block.data(), T * ld * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHECK(hipMemcpy(b->d_y, block, T * ld * sizeof(double), hipMemcpyHostToDevice));
         finalize_lengths(b);
         b->has_block = true;
     } catch (const HipFail &f) {
