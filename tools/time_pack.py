@@ -22,3 +22,8 @@ print(f"run: {(t1 - t0) * 1e3:.1f} ms")
 res = (lib.ForecastResult * n)(); errs = (lib.AnofoxError * n)()
 t0 = time.perf_counter(); L.anofox_hip_batch_fetch(hb, res, errs); t1 = time.perf_counter()
 print(f"fetch (D2H + {n} x 3 mallocs): {(t1 - t0) * 1e3:.1f} ms")
+L.anofox_hip_batch_destroy(hb)
+for rep in range(3):
+    t0 = time.perf_counter(); hb = C.c_void_p(); assert L.anofox_hip_batch_create(n, T, C.byref(opts), C.byref(hb), C.byref(err)); t1 = time.perf_counter()
+    L.anofox_hip_batch_destroy(hb); t2 = time.perf_counter()
+    print(f"batch_create: {(t1 - t0) * 1e3:.1f} ms, destroy {(t2 - t1) * 1e3:.1f} ms")
