@@ -1180,6 +1180,19 @@ bool anofox_ts_forecast_batch(const double *const *values, const uint64_t *const
     AnofoxHipBatch *b = nullptr;
     AnofoxError e;
     if (!anofox_hip_batch_create(n_series, t_max, &opt, &b, &e)) {
+        if (e.code == INVALID_INPUT) {
+            // an option block the core rejects (seasonal_period on a non-seasonal model, bad ETS notation or pool) is a
+            // PER-SERIES error there, raised after the length checks (forecast.rs:516-565): a series that is too short
+            // reports InsufficientData first, and a batch made only of such series does not abort the statement
+            if (out_errors)
+                for (size_t s = 0; s < n_series; s++) {
+                    if (lengths[s] == 0) set_error(&out_errors[s], INSUFFICIENT_DATA, "Insufficient data: need at least 1 observations, got 0");
+                    else if (lengths[s] < 3)
+                        set_error(&out_errors[s], INSUFFICIENT_DATA, "Insufficient data: need at least 3 observations, got " + std::to_string(lengths[s]));
+                    else out_errors[s] = e;
+                }
+            return true;
+        }
         if (out_batch_error) *out_batch_error = e;
         if (out_errors) for (size_t s = 0; s < n_series; s++) out_errors[s] = e;
         return false;
