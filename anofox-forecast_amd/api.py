@@ -416,6 +416,158 @@ def ts_forecast_agg(group, date, value, method="auto", horizon=12, params=None):
 
 
 # --------------------------------------------------------------------------------------------
+# ts_forecast_inspect_by / ts_forecast_explain_by
+# --------------------------------------------------------------------------------------------
+INSPECTABLE = ("AutoETS", "AutoARIMA", "AutoTheta", "AutoTBATS", "MFLES", "AutoMFLES", "MSTL", "AutoMSTL", "Laplace")
+EXPLAINABLE = ("ETS", "MSTL", "AutoMSTL", "Theta")
+_ETS_LETTER = {"Additive": "A", "Multiplicative": "M", "None": "N", "AdditiveDamped": "Ad", "MultiplicativeDamped": "Md"}
+
+
+def inspect_batch(series, opts, valids=None):
+    """Fit the batch and read the fit state back (anofox_hip_batch_inspect): per series a dict with the model name, the
+    parameters in model terms, AIC/AICc/BIC, SSE, final level/growth/seasonal states and the one-step fitted values."""
+    L = _lib.load()
+    n = len(series)
+    arrs = [np.ascontiguousarray(s, dtype=np.float64) for s in series]
+    t_max = max((len(a) for a in arrs), default=0)
+    hb, err = C.c_void_p(), _lib.AnofoxError()
+    if not L.anofox_hip_batch_create(n, t_max, C.byref(opts), C.byref(hb), C.byref(err)):
+        raise InvalidInputException(err.message.decode(errors="replace"))
+    try:
+        masks = [validity_mask(v) for v in valids] if valids is not None else None
+        vptr = (C.c_void_p * n)(*[a.ctypes.data if len(a) else C.addressof(C.c_double()) for a in arrs])
+        mptr = (C.c_void_p * n)(*[m.ctypes.data if len(m) else None for m in masks]) if masks is not None else None
+        lens = (C.c_size_t * n)(*[len(a) for a in arrs])
+        if not L.anofox_hip_batch_pack_host(hb, vptr, mptr, lens, C.byref(err)) or not L.anofox_hip_batch_run(hb, None, C.byref(err)):
+            raise InvalidInputException(err.message.decode(errors="replace"))
+        results = (_lib.ForecastResult * n)()
+        errors = (_lib.AnofoxError * n)()
+        L.anofox_hip_batch_fetch(hb, results, errors)
+        m = max(int(opts.seasonal_period), 1)
+        insp = (_lib.AnofoxHipInspection * n)()
+        fitted = np.full((n, max(t_max, 1)), np.nan)
+        seas = np.full((n, m), np.nan)
+        if not L.anofox_hip_batch_inspect(hb, insp, fitted.ctypes.data, seas.ctypes.data, m, C.byref(err)):
+            raise InvalidInputException(err.message.decode(errors="replace"))
+        out = []
+        for i in range(n):
+            d = {"ok": errors[i].code == 0, "code": int(errors[i].code), "message": errors[i].message.decode(errors="replace")}
+            if d["ok"]:
+                d.update(_result_dict(results[i], len(arrs[i])))
+                L.anofox_free_forecast_result(C.byref(results[i]))
+                x = insp[i]
+                d.update({k: getattr(x, k) for k in ("model_code", "alpha", "beta", "gamma", "phi", "aic", "aicc", "bic", "sse", "level", "trend")})
+                d["has_constant"] = bool(x.reserved)
+                d["fitted_values"] = fitted[i, :len(arrs[i])].copy()
+                d["seasonal_states"] = seas[i].copy()
+            out.append(d)
+        return out
+    finally:
+        L.anofox_hip_batch_destroy(hb)
+
+
+def _collect_groups(group, date, target):
+    """Groups in first-appearance order, rows by date, NULL targets as invalid slots (the LIST(... ORDER BY date) of the macros)."""
+    dates = np.asarray(date)
+    us = _to_micros(dates, _date_kind(dates))
+    grp = np.asarray(group, dtype=object)
+    tgt = np.asarray(target, dtype=object)
+    order, rows = [], {}
+    for i in range(len(grp)):
+        if grp[i] not in rows:
+            rows[grp[i]] = []
+            order.append(grp[i])
+        rows[grp[i]].append(i)
+    series, valids = [], []
+    for k in order:
+        idx = np.array(rows[k])
+        idx = idx[np.argsort(us[idx], kind="stable")]
+        ok = np.array([tgt[i] is not None and not (isinstance(tgt[i], float) and tgt[i] != tgt[i]) for i in idx])
+        series.append(np.array([float(tgt[i]) if o else 0.0 for i, o in zip(idx, ok)]))
+        valids.append(ok)
+    return order, series, valids
+
+
+def ts_forecast_inspect_by(group, date, target, method, params=None):
+    """ts_forecast_inspect_by(source, group_col, date_col, target_col, method, params := MAP{}) (ts_macros.cpp:596-672,
+    forecast.rs:1739-1885).  Supported here: AutoETS (model_family 'Ets') and AutoARIMA ('Arima'); a method outside the
+    reference's Inspectable list is rejected with its message.  Returns {group: inspection struct} with the macro's field
+    names (unused fields None).  Unpinned: the field VALUES come from the un-vendored crate's `Explanation` types."""
+    b = bind(method, 1, "1d", params)
+    if b.method not in INSPECTABLE:
+        raise InvalidInputException(f"Invalid model: Model '{b.method}' does not implement Inspectable. Supported models: "
+                                    "AutoETS, AutoARIMA, AutoTheta, AutoTBATS, MFLES, AutoMFLES, MSTL, AutoMSTL, Laplace.")
+    if b.method not in ("AutoETS", "AutoARIMA"):
+        raise InvalidInputException(f"Internal error: inspection of '{b.method}' is not implemented by the HIP backend")
+    order, series, valids = _collect_groups(group, date, target)
+    res = inspect_batch(series, options_from_bind(b), valids)
+    out = {}
+    for k, y, v, r in zip(order, series, valids, res):
+        if not r["ok"]:
+            if r["code"] in (_lib.INVALID_MODEL, _lib.INVALID_INPUT):
+                raise InvalidInputException(r["message"])
+            continue
+        fam = "Ets" if b.method == "AutoETS" else "Arima"
+        d = {"model_family": fam, "spec": None, "alpha": None, "beta": None, "gamma": None, "phi": None, "aic": None, "bic": None,
+             "seasonal_period": max(b.seasonal_period, 1), "order_p": None, "order_d": None, "order_q": None, "seasonal_order_P": None,
+             "seasonal_order_D": None, "seasonal_order_Q": None, "seasonal_order_s": None, "fitted_values": None, "residuals": None,
+             "model_name": r["model_name"]}
+        nn = lambda x: None if x != x else float(x)          # noqa: E731
+        if fam == "Ets":
+            inner = r["model_name"][r["model_name"].find("(") + 1:-1].split(",") if "(" in r["model_name"] else []
+            d["spec"] = "".join(_ETS_LETTER.get(p, "?") for p in inner) if inner else None
+            d.update(alpha=nn(r["alpha"]), beta=nn(r["beta"]), gamma=nn(r["gamma"]), phi=nn(r["phi"]), aic=nn(r["aic"]), bic=nn(r["bic"]))
+            if not np.all(np.isnan(r["fitted_values"])):
+                d["fitted_values"] = r["fitted_values"]
+                d["residuals"] = np.where(v, y, np.nan) - r["fitted_values"]
+        else:
+            c = int(r["model_code"]) - 1000000
+            d.update(order_p=c // 100000, order_d=c // 10000 % 10, order_q=c // 1000 % 10, seasonal_order_P=c // 100 % 10,
+                     seasonal_order_D=c // 10 % 10, seasonal_order_Q=c % 10, seasonal_order_s=max(b.seasonal_period, 1),
+                     aic=nn(r["aic"]), bic=nn(r["bic"]))
+        out[k] = d
+    return out
+
+
+def ts_forecast_explain_by(group, date, target, method, horizon, params=None):
+    """ts_forecast_explain_by(source, group_col, date_col, target_col, method, horizon, params := MAP{}) (ts_macros.cpp:674-716,
+    forecast.rs:1899-2017).  Supported here: ETS with a fixed spec.  Per group: horizon and the level / trend / seasonal
+    contribution of every forecast step from the final states of the fit (additive components add up to yhat,
+    multiplicative ones multiply up to it).  Unpinned like the inspection."""
+    b = bind(method, horizon, "1d", params)
+    if b.method not in EXPLAINABLE:
+        raise InvalidInputException(f"Invalid model: Model '{b.method}' does not implement Explainable. Supported models: ETS, MSTL, Theta.")
+    if b.method != "ETS" or not b.model_spec:
+        raise InvalidInputException(f"Internal error: explanation of '{b.method}' is not implemented by the HIP backend")
+    order, series, valids = _collect_groups(group, date, target)
+    res = inspect_batch(series, options_from_bind(b), valids)
+    spec = b.model_spec
+    trend_t = spec[1:-1]                       # N | A | Ad | M | Md
+    seas_t = spec[-1]
+    m = max(b.seasonal_period, 1)
+    out = {}
+    for k, y, r in zip(order, series, res):
+        if not r["ok"]:
+            if r["code"] in (_lib.INVALID_MODEL, _lib.INVALID_INPUT):
+                raise InvalidInputException(r["message"])
+            continue
+        h = int(horizon)
+        phi = r["phi"] if r["phi"] == r["phi"] else 1.0
+        damp = np.cumsum(phi ** np.arange(1, h + 1))                 # phi + phi^2 + ... (= 1, 2, 3, ... undamped)
+        level = np.full(h, r["level"])
+        if trend_t.startswith("A"):
+            trend = damp * r["trend"]
+        elif trend_t.startswith("M"):
+            trend = r["trend"] ** damp
+        else:
+            trend = None
+        seasonal = np.array([r["seasonal_states"][(len(y) + i) % m] for i in range(h)]) if seas_t != "N" else None
+        out[k] = {"horizon": h, "level": level, "trend": trend, "seasonal": seasonal, "residual": None, "yhat": r["point"],
+                  "model_name": r["model_name"]}
+    return out
+
+
+# --------------------------------------------------------------------------------------------
 # columnar ingest (SURVEY.md section 8f rank 2): the collection side of route B through the C-ABI
 # --------------------------------------------------------------------------------------------
 class Ingest:

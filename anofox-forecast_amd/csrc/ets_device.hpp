@@ -62,7 +62,7 @@ struct EtsCfg {
 };
 
 struct EtsPar { double alpha, bstar, phi, beta, gamma; };
-struct EtsState { double l, b, sse, mant; int eacc; int bad; };
+struct EtsState { double l, b, sse, mant; int eacc; int bad; double f; };   // f: last one-step forecast (inspection only)
 
 template <class Cfg>
 __device__ __forceinline__ void ets_unpack(const double (&x)[Cfg::DIM], EtsPar &p)
@@ -94,6 +94,7 @@ __device__ __forceinline__ void ets_step(const EtsPar &p, EtsState &st, double y
         double e = y - f;
         st.sse = fma(e, e, st.sse);
         st.l = fma(p.alpha, e, q);
+        st.f = f;
         if constexpr (Cfg::T == C_ADD) st.b = fma(p.beta, e, phib);
         if constexpr (Cfg::S == C_ADD) s = fma(p.gamma, e, s);
     } else {
@@ -149,6 +150,7 @@ __device__ __forceinline__ void ets_step(const EtsPar &p, EtsState &st, double y
             s = fma(p.gamma, tt - s, s);
         }
         st.l = lnew;
+        st.f = f;
     }
 }
 
@@ -172,7 +174,12 @@ struct EtsInit {
 };
 
 // Final pass output target (candidate 0 only)
-struct EtsFinalOut { double *yhat; int h; double *sse_out; };
+struct EtsFinalOut {
+    double *yhat; int h; double *sse_out;
+    // inspection (NULL otherwise): one-step fitted values of this lane's series at fitted[t * fitted_ld], final states at
+    // states[r * states_ld] with r = 0 level, 1 growth, 2 + j seasonal state of phase j
+    double *fitted; size_t fitted_ld; double *states; size_t states_ld;
+};
 
 // The pass.  MS > 0: compile-time period, ring in VGPRs.  MS == 0: no seasonality.
 // MS == -1: run-time period, ring in LDS (`ring`, K * m * 64 doubles).
@@ -229,6 +236,9 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
         }
     };
     load_block(cur, 0);
+    auto keep_fit = [&](const int t) __attribute__((always_inline)) {
+        if constexpr (FINAL) { if (fin->fitted && t < v.len) fin->fitted[(size_t)t * fin->fitted_ld] = st[0].f; }
+    };
 
     if constexpr (MS >= 0) {
         constexpr int MR = MS > 0 ? MS : 1;
@@ -252,13 +262,11 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
                 load_block(nxt, base + S);
 #pragma unroll
                 for (int j = 0; j < S; j++)
-#pragma unroll
-                    for (int k = 0; k < K; k++) ets_step<Cfg>(par[k], st[k], cur[j], s[k][MS > 0 ? j % MR : 0]);
+                    { _Pragma("unroll") for (int k = 0; k < K; k++) ets_step<Cfg>(par[k], st[k], cur[j], s[k][MS > 0 ? j % MR : 0]); keep_fit(base + j); }
                 load_block(cur, base + 2 * S);
 #pragma unroll
                 for (int j = 0; j < S; j++)
-#pragma unroll
-                    for (int k = 0; k < K; k++) ets_step<Cfg>(par[k], st[k], nxt[j], s[k][MS > 0 ? j % MR : 0]);
+                    { _Pragma("unroll") for (int k = 0; k < K; k++) ets_step<Cfg>(par[k], st[k], nxt[j], s[k][MS > 0 ? j % MR : 0]); keep_fit(base + S + j); }
             }
         }
         for (; base < wave_len; base += S) {
@@ -266,20 +274,26 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
             if (base + S <= wave_min_len) {
 #pragma unroll
                 for (int j = 0; j < S; j++)
-#pragma unroll
-                    for (int k = 0; k < K; k++) ets_step<Cfg>(par[k], st[k], cur[j], s[k][MS > 0 ? j % MR : 0]);
+                    { _Pragma("unroll") for (int k = 0; k < K; k++) ets_step<Cfg>(par[k], st[k], cur[j], s[k][MS > 0 ? j % MR : 0]); keep_fit(base + j); }
             } else {
 #pragma unroll
                 for (int j = 0; j < S; j++)
                     if (base + j < v.len) {
 #pragma unroll
                         for (int k = 0; k < K; k++) ets_step<Cfg>(par[k], st[k], cur[j], s[k][MS > 0 ? j % MR : 0]);
+                        keep_fit(base + j);
                     }
             }
 #pragma unroll
             for (int j = 0; j < S; j++) cur[j] = nxt[j];
         }
         if constexpr (FINAL) {
+            if constexpr (MS > 0) {
+                if (fin->states && v.len > 0) {
+#pragma unroll
+                    for (int jj = 0; jj < MS; jj++) fin->states[(size_t)(2 + jj) * fin->states_ld] = s[0][jj];
+                }
+            }
             double pp = par[0].phi, phistar = par[0].phi;
             for (int i = 0; i < fin->h; i++) {
                 double f;
@@ -317,6 +331,7 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
                         ets_step<Cfg>(par[k], st[k], cur[i], sv);
                         ring[(k * m + j) * NM_BLOCK + lane] = sv;
                     }
+                    keep_fit(base + i);
                 }
                 j = (j + 1 == m) ? 0 : j + 1;
             }
@@ -329,6 +344,8 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
             for (int i = 0; i < S; i++) cur[i] = nxt[i];
         }
         if constexpr (FINAL) {
+            if (fin->states && v.len > 0)
+                for (int jj = 0; jj < m; jj++) fin->states[(size_t)(2 + jj) * fin->states_ld] = ring[(0 * m + jj) * NM_BLOCK + lane];
             double pp = par[0].phi, phistar = par[0].phi;
             for (int i = 0; i < fin->h; i++) {
                 double f;
@@ -346,7 +363,10 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
     }
 #pragma unroll
     for (int k = 0; k < K; k++) fout[k] = ets_objective_value<Cfg>(st[k], v.len);
-    if constexpr (FINAL) { if (fin->sse_out && v.len > 0) *fin->sse_out = st[0].sse; }
+    if constexpr (FINAL) {
+        if (fin->sse_out && v.len > 0) *fin->sse_out = st[0].sse;
+        if (fin->states && v.len > 0) { fin->states[0] = st[0].l; fin->states[fin->states_ld] = st[0].b; }
+    }
 }
 
 // Nelder-Mead model adaptor.  CPL = candidates per lane: 4 -> one lane evaluates all four trial points

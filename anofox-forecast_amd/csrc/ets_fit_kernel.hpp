@@ -123,7 +123,8 @@ __global__ __launch_bounds__(NM_BLOCK) void ets_final_kernel(const FitArgs a)
     const bool valid = s < a.n_series;
     const int len = valid ? a.len[s] : 0;
     int st = valid ? a.status[s] : FIT_SKIPPED;
-    const bool active = valid && len > 0 && st == FIT_OK;
+    const bool inspect = a.insp_sel != nullptr;
+    const bool active = valid && len > 0 && st == FIT_OK && (!inspect || a.insp_sel[s] == a.insp_code);
 
     SeriesView v;
     v.col = valid ? s : 0;
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(NM_BLOCK) void ets_final_kernel(const FitArgs a)
     v.wave_min_len = wave_min_i32(active ? len : 0x7fffffff);
     v.rows = a.t_rows;
     if (v.wave_len == 0) {
-        if (valid && len > 0) { a.aicc[s] = __builtin_huge_val(); a.evals[s] = 0; a.iters[s] = 0; a.passes[s] = 0; }
+        if (!inspect && valid && len > 0) { a.aicc[s] = __builtin_huge_val(); a.evals[s] = 0; a.iters[s] = 0; a.passes[s] = 0; }
         return;
     }
     EtsInit in;
@@ -152,7 +153,32 @@ __global__ __launch_bounds__(NM_BLOCK) void ets_final_kernel(const FitArgs a)
     fin.h = a.h;
     fin.yhat = a.yhat + (size_t)(valid ? s : 0) * a.h;
     fin.sse_out = nullptr;
+    fin.fitted = nullptr; fin.states = nullptr; fin.fitted_ld = 0; fin.states_ld = 0;
+    double sse = 0.0;
+    if (inspect) {
+        fin.fitted = a.insp_fitted + (valid ? s : 0); fin.fitted_ld = a.ld;
+        fin.states = a.insp_states + (valid ? s : 0); fin.states_ld = a.ld;
+        fin.sse_out = &sse;
+        fin.h = 0;                                   // the forecasts of the run stay as they are
+    }
     ets_pass<Cfg, MS, 1, true>(v, in, cand, f, lds, &fin);
+    if (inspect) {
+        if (active && fabs(f[0]) <= 1.7976931348623157e308) {
+            EtsPar par;
+            ets_unpack<Cfg>(cand[0], par);
+            const double dk = (double)a.n_param, dn = (double)len, aic = f[0] + 2.0 * dk;
+            double *o = a.insp_info + s;
+            o[0 * a.ld] = par.alpha;
+            o[1 * a.ld] = Cfg::T != C_NONE ? par.beta : __builtin_nan("");
+            o[2 * a.ld] = Cfg::S != C_NONE ? par.gamma : __builtin_nan("");
+            o[3 * a.ld] = Cfg::D ? par.phi : __builtin_nan("");
+            o[4 * a.ld] = aic;
+            o[5 * a.ld] = aic + 2.0 * dk * (dk + 1.0) / (dn - dk - 1.0);
+            o[6 * a.ld] = f[0] + dk * dm_log(dn);
+            o[7 * a.ld] = sse;
+        }
+        return;
+    }
 
     if (valid && len > 0) {
         double aicc = __builtin_huge_val();

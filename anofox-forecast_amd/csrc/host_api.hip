@@ -85,6 +85,12 @@ struct AnofoxHipBatch {
     int32_t *d_pos_map = nullptr, *d_pos_cnt = nullptr, *d_notpos = nullptr;
     double *d_ypos = nullptr;
     bool use_pos = false;
+    // what the inspection pass needs from the last fit: the final-kernel arguments of every spec, in launch order
+    std::vector<anofox::FitArgs> insp_args;
+    std::vector<anofox::FitLaunchers> insp_fns;
+    std::vector<int> insp_spec, insp_stream;
+    bool insp_ok = false;
+    int insp_m = 1;
     int32_t live_pos = -1, live_all = -1;   // usable strictly positive / usable series of the current group (-1: not counted)
     // AutoARIMA workspace
     size_t ar_ws_bytes = 0;
@@ -593,6 +599,10 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
     HIPCHECK(hipEventRecord(b->ev_fit1, st));
     b->timed_fit = true;
     b->n_problems += (uint64_t)specs.size() * n;
+    b->insp_args = args; b->insp_fns = fns; b->insp_stream = stream_of; b->insp_m = m;
+    b->insp_spec.resize(order.size());
+    for (size_t oi = 0; oi < order.size(); oi++) b->insp_spec[oi] = specs[order[oi]];
+    b->insp_ok = true;
 }
 
 void run_group(AnofoxHipBatch *b, int period, const int32_t *d_len, hipStream_t st)
@@ -757,6 +767,7 @@ void run_batch(AnofoxHipBatch *b, hipStream_t st)
     b->fit_launches = 0;
     b->n_problems = 0;
     b->timed_fit = false;
+    b->insp_ok = false;
     HIPCHECK(hipEventRecord(b->ev_start, st));
     HIPCHECK(hipMemcpyAsync(b->d_status, b->h_base_status.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, st));
     HIPCHECK(hipMemsetAsync(b->d_passes_total, 0, ld * sizeof(int32_t), st));
@@ -1159,6 +1170,82 @@ void anofox_free_forecast_result(ForecastResult *r)
     std::free(r->upper_bounds); r->upper_bounds = nullptr;
     std::free(r->fitted_values); r->fitted_values = nullptr;
     std::free(r->residuals); r->residuals = nullptr;
+}
+
+bool anofox_hip_batch_inspect(AnofoxHipBatch *b, AnofoxHipInspection *out, double *fitted, double *seasonal, size_t seasonal_stride,
+                              AnofoxError *out_error)
+{
+    if (!b || !out) { set_error(out_error, NULL_POINTER, "Null pointer argument"); return false; }
+    if (!b->ran) { set_error(out_error, INVALID_INPUT, "Invalid input: the batch has not been run"); return false; }
+    const size_t n = b->n, ld = b->ld, T = std::max<size_t>(b->t_max, 1);
+    try {
+        HIPCHECK(hipStreamSynchronize(b->last_stream));
+        std::vector<int32_t> code(n), status(n);
+        HIPCHECK(hipMemcpy(code.data(), b->d_model_code, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+        HIPCHECK(hipMemcpy(status.data(), b->d_status, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+        for (size_t s = 0; s < n; s++) {
+            AnofoxHipInspection &o = out[s];
+            o.model_code = code[s]; o.status = status[s]; o.seasonal_period = b->h_period.empty() ? 1 : b->h_period[s];
+            o.alpha = o.beta = o.gamma = o.phi = o.aic = o.aicc = o.bic = o.sse = o.level = o.trend = std::nan("");
+        }
+        if (fitted) for (size_t i = 0; i < n * T; i++) fitted[i] = std::nan("");
+        const bool ets = (b->plan.model == M_AutoETS || (b->plan.model == M_ETS && b->plan.ets_spec_id >= 0)) && b->insp_ok;
+        if (ets) {
+            for (size_t s = 1; s < n; s++)
+                if (b->h_period[s] != b->h_period[0]) throw HipFail{"inspection needs one seasonal period for the whole batch"};
+            const int m = b->insp_m;
+            const size_t rows = (size_t)(2 + std::max(m, 1));
+            double *d_fit = dalloc<double>(T * ld), *d_states = dalloc<double>(rows * ld), *d_info = dalloc<double>(8 * ld);
+            std::vector<double> nanv(std::max(T, rows) * ld, std::nan(""));
+            HIPCHECK(hipMemcpy(d_fit, nanv.data(), T * ld * sizeof(double), hipMemcpyHostToDevice));
+            HIPCHECK(hipMemcpy(d_states, nanv.data(), rows * ld * sizeof(double), hipMemcpyHostToDevice));
+            HIPCHECK(hipMemcpy(d_info, nanv.data(), 8 * ld * sizeof(double), hipMemcpyHostToDevice));
+            hipStream_t st = b->last_stream;
+            for (size_t oi = 0; oi < b->insp_args.size(); oi++) {
+                FitArgs a = b->insp_args[oi];
+                a.insp_sel = b->d_model_code;
+                a.insp_code = b->plan.model == M_AutoETS ? 100 + b->insp_spec[oi] : 0;
+                a.insp_fitted = d_fit; a.insp_states = d_states; a.insp_info = d_info;
+                b->insp_fns[oi].final(a, st);
+            }
+            HIPCHECK(hipStreamSynchronize(st));
+            std::vector<double> info(8 * ld), states(rows * ld), fit;
+            HIPCHECK(hipMemcpy(info.data(), d_info, 8 * ld * sizeof(double), hipMemcpyDeviceToHost));
+            HIPCHECK(hipMemcpy(states.data(), d_states, rows * ld * sizeof(double), hipMemcpyDeviceToHost));
+            if (fitted) { fit.resize(T * ld); HIPCHECK(hipMemcpy(fit.data(), d_fit, T * ld * sizeof(double), hipMemcpyDeviceToHost)); }
+            (void)hipFree(d_fit); (void)hipFree(d_states); (void)hipFree(d_info);
+            for (size_t s = 0; s < n; s++) {
+                AnofoxHipInspection &o = out[s];
+                o.alpha = info[0 * ld + s]; o.beta = info[1 * ld + s]; o.gamma = info[2 * ld + s]; o.phi = info[3 * ld + s];
+                o.aic = info[4 * ld + s]; o.aicc = info[5 * ld + s]; o.bic = info[6 * ld + s]; o.sse = info[7 * ld + s];
+                o.level = states[0 * ld + s]; o.trend = states[1 * ld + s];
+                if (seasonal) for (int j = 0; j < m && (size_t)j < seasonal_stride; j++) seasonal[s * seasonal_stride + j] = states[(size_t)(2 + j) * ld + s];
+                if (fitted) { const size_t len = (size_t)std::max(b->h_len[s], 0); for (size_t t = 0; t < len; t++) fitted[s * T + t] = fit[t * ld + s]; }
+            }
+        } else if (b->plan.model == M_AutoARIMA) {
+            std::vector<double> aicc(n);
+            std::vector<int32_t> ord(5 * ld), wlen(n);
+            HIPCHECK(hipMemcpy(aicc.data(), b->ar_aicc, n * sizeof(double), hipMemcpyDeviceToHost));
+            HIPCHECK(hipMemcpy(ord.data(), b->ar_order, 5 * ld * sizeof(int32_t), hipMemcpyDeviceToHost));
+            HIPCHECK(hipMemcpy(wlen.data(), b->ar_wlen, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+            for (size_t s = 0; s < n; s++)
+                if (code[s] >= 1000000) {
+                    const double k = 1.0 + ord[0 * ld + s] + ord[1 * ld + s] + ord[2 * ld + s] + ord[3 * ld + s] + ord[4 * ld + s];
+                    const double nn = (double)wlen[s];
+                    out[s].aicc = aicc[s];
+                    out[s].aic = aicc[s] - 2.0 * k * (k + 1.0) / (nn - k - 1.0);
+                    out[s].bic = out[s].aic - 2.0 * k + k * std::log(nn);
+                    out[s].reserved = ord[4 * ld + s];          // 1: the model has a constant
+                }
+        }
+    } catch (const HipFail &f) {
+        set_error(out_error, INTERNAL_ERROR, "Internal error: " + f.msg);
+        return false;
+    } catch (const std::exception &e) {
+        set_error(out_error, INTERNAL_ERROR, std::string("Internal error: ") + e.what());
+        return false;
+    }
+    return true;
 }
 
 bool anofox_ts_forecast_batch(const double *const *values, const uint64_t *const *validity, const size_t *lengths, size_t n_series,

@@ -56,6 +56,12 @@ struct FitArgs {
     double *yhat;                // [n_series x h] for this spec
     int32_t *status;             // [ld]
     int32_t *evals, *iters, *passes; // [ld]
+    // inspection pass of the final kernel (all NULL in a normal run): only series whose selected model is `insp_code` take part
+    const int32_t *insp_sel;     // [n_series] selected model code
+    int32_t insp_code;
+    double *insp_fitted;         // [t_rows x ld] one-step fitted values (time-major)
+    double *insp_states;         // [(2 + m) x ld] final level, growth, seasonal states by phase
+    double *insp_info;           // [8 x ld] alpha, beta, gamma, phi, aic, aicc, bic, sse
 };
 
 struct SelectArgs {

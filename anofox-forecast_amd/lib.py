@@ -77,6 +77,13 @@ class AnofoxHipStats(C.Structure):
 assert C.sizeof(ForecastOptions) == 184 and C.sizeof(ForecastResult) == 144 and C.sizeof(AnofoxError) == 260
 
 # every symbol include/anofox_fcst_hip.h declares
+class AnofoxHipInspection(C.Structure):
+    _fields_ = [("model_code", C.c_int32), ("status", C.c_int32), ("seasonal_period", C.c_int32), ("reserved", C.c_int32),
+                ("alpha", C.c_double), ("beta", C.c_double), ("gamma", C.c_double), ("phi", C.c_double),
+                ("aic", C.c_double), ("aicc", C.c_double), ("bic", C.c_double), ("sse", C.c_double),
+                ("level", C.c_double), ("trend", C.c_double)]
+
+
 EXPORTED_SYMBOLS = [
     "anofox_ts_forecast", "anofox_free_forecast_result", "anofox_fcst_version", "anofox_ts_forecast_batch",
     "anofox_hip_device_count", "anofox_hip_set_device", "anofox_hip_batch_create", "anofox_hip_batch_destroy",
@@ -84,7 +91,7 @@ EXPORTED_SYMBOLS = [
     "anofox_hip_batch_stats", "anofox_hip_batch_device_results", "anofox_hip_batch_fetch", "anofox_hip_model_name",
     "anofox_hip_ingest_create", "anofox_hip_ingest_destroy", "anofox_hip_ingest_append", "anofox_hip_ingest_finish",
     "anofox_hip_ingest_group_keys", "anofox_hip_ingest_last_dates", "anofox_hip_ingest_lengths", "anofox_hip_ingest_values",
-    "anofox_hip_ingest_validity", "anofox_hip_batch_pack_ingest",
+    "anofox_hip_ingest_validity", "anofox_hip_batch_pack_ingest", "anofox_hip_batch_inspect",
 ]
 
 _lib = None
@@ -134,6 +141,8 @@ def load():
     L.anofox_hip_batch_fetch.restype = C.c_bool
     L.anofox_hip_batch_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.anofox_hip_model_name.argtypes = [P(ForecastOptions), C.c_int32, C.c_char * 64]
+    L.anofox_hip_batch_inspect.restype = C.c_bool
+    L.anofox_hip_batch_inspect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, P(AnofoxError)]
     # block 4: columnar ingest (host side only; usable without a GPU up to pack_ingest)
     L.anofox_hip_ingest_create.restype = C.c_void_p
     L.anofox_hip_ingest_destroy.argtypes = [C.c_void_p]

@@ -206,6 +206,29 @@ bool anofox_hip_batch_fetch(AnofoxHipBatch *batch,
                             struct ForecastResult *out_results,
                             struct AnofoxError *out_errors);
 
+/*
+ * Fit-state snapshot of a batch that has been run (what ts_forecast_inspect_by /
+ * ts_forecast_explain_by read out of a fitted model, forecast.rs:1739-1885, 1899-2017).  For AutoETS and ETS(spec):
+ * the smoothing parameters in the model's own terms (beta = alpha beta*, gamma = gamma* (1 - alpha); NaN where the
+ * spec has no such component), AIC / AICc / BIC, SSE, the final level and growth, optionally the final seasonal states
+ * by phase (`seasonal`, row stride `seasonal_stride` >= period) and the one-step fitted values (`fitted`, [n_series x
+ * t_max] row-major, NaN past a series' length).  A second streamed pass per candidate spec on the device produces
+ * them; series that took the fallback chain, and every other model, report NaN (AutoARIMA reports its AICc; its orders
+ * are in model_code).  The batch must have one seasonal period.
+ */
+typedef struct AnofoxHipInspection {
+    int32_t model_code;      /* as in anofox_hip_batch_device_results */
+    int32_t status;          /* ErrorCode of the series */
+    int32_t seasonal_period;
+    int32_t reserved;
+    double alpha, beta, gamma, phi;
+    double aic, aicc, bic, sse;
+    double level, trend;     /* final states l_T, b_T */
+} AnofoxHipInspection;
+bool anofox_hip_batch_inspect(AnofoxHipBatch *batch, AnofoxHipInspection *out,
+                              double *fitted, double *seasonal, size_t seasonal_stride,
+                              struct AnofoxError *out_error);
+
 /* Render a device model_code to the reference's model_name text (<= 63 chars). */
 void anofox_hip_model_name(const struct ForecastOptions *options, int32_t model_code,
                            char out_name[64]);

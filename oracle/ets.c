@@ -279,6 +279,9 @@ static void ets_unpack(const EtsSpec *spec, const double *par,
  * every other spec -- the general form of Hyndman's etscalc (forecast R package /
  *     StatsForecast ets.py `update`), with beta/alpha = beta*, gamma = gamma*(1-alpha).
  */
+/* test hook (oracle_ets_inspect): when set, every pass also stores its one-step forecasts here */
+double *ets_fitted_sink = NULL;
+
 double ets_lik(const EtsSpec *spec, const double *y, int n, const double *par,
                double l0, double b0, const double *s0,
                double *sse_out, double *l_out, double *b_out, double *s_out)
@@ -304,6 +307,7 @@ double ets_lik(const EtsSpec *spec, const double *y, int n, const double *par,
             }
             double f = q;
             if (spec->season == ETS_ADD) f = q + sbuf[j];
+            if (ets_fitted_sink) ets_fitted_sink[t] = f;
             double e = y[t] - f;
             sse = fma(e, e, sse);
             l = fma(alpha, e, q);
@@ -335,6 +339,7 @@ double ets_lik(const EtsSpec *spec, const double *y, int n, const double *par,
              * so this is the single largest saving of the general recursion; the quotients differ
              * from y/s, y/q, l'/l by an ulp or two.  A zero denominator gives inf/NaN, the SSE
              * becomes non-finite and the candidate is rejected (no HUGEN clamps needed). */
+            if (ets_fitted_sink) ets_fitted_sink[t] = f;
             const int need_f = (spec->error == ETS_MUL) || (spec->season == ETS_MUL);
             double rf = 0.0, rl = 0.0;
             if (need_f && spec->trend == ETS_MUL) { double R = 1.0 / (f * l); rf = R * l; rl = R * f; }

@@ -782,6 +782,48 @@ int oracle_ets_fit_spec(const double *y, int n, int spec_id, int m, int *iters, 
     return st;
 }
 
+/* test hook for the inspection outputs: fit spec `spec_id` -- or, when it is negative, the spec AutoETS
+ * selects from `pool` -- and report the parameters in model terms, the criteria, the final states and the one-step fitted
+ * values.  Returns the spec id, -1 when no spec can be fitted. */
+extern double *ets_fitted_sink;
+int oracle_ets_inspect(const double *y, int n, int period, int pool, int spec_id, double *par8, double *states, double *fitted)
+{
+    int best = spec_id;
+    if (spec_id < 0) {
+        int positive = 1, constant = 1;
+        for (int i = 0; i < n; i++) { if (!(y[i] > 0.0)) positive = 0; if (y[i] != y[0]) constant = 0; }
+        if (constant) return -1;
+        double best_aicc = INFINITY;
+        for (int id = 0; id < 30; id++) {
+            EtsSpec sp = spec_from_id(id, period);
+            if (sp.season != ETS_NONE && period <= 1) continue;
+            if (!spec_is_valid(&sp) || !pool_allows(pool, &sp)) continue;
+            if (!positive && (sp.error == ETS_MUL || sp.trend == ETS_MUL || sp.season == ETS_MUL)) continue;
+            EtsFit fit;
+            double sfin[ETS_MAX_PERIOD];
+            if (ets_fit(&sp, y, n, &fit, sfin) != ETS_OK) continue;
+            if (fit.aicc < best_aicc) { best_aicc = fit.aicc; best = id; }
+        }
+        if (best < 0) return -1;
+    }
+    EtsSpec sp = spec_from_id(best, period);
+    EtsFit fit;
+    double sfin[ETS_MAX_PERIOD], s0[ETS_MAX_PERIOD];
+    if (ets_fit(&sp, y, n, &fit, sfin) != ETS_OK) return -1;
+    ets_init_states(&sp, y, n, &fit.l0, &fit.b0, s0);
+    ets_fitted_sink = fitted;
+    ets_lik(&sp, y, n, fit.par, fit.l0, fit.b0, s0, NULL, NULL, NULL, NULL);
+    ets_fitted_sink = NULL;
+    par8[0] = fit.alpha;
+    par8[1] = sp.trend != ETS_NONE ? fit.alpha * fit.beta_star : NAN;
+    par8[2] = sp.season != ETS_NONE ? fit.gamma_star * (1.0 - fit.alpha) : NAN;
+    par8[3] = sp.damped ? fit.phi : NAN;
+    par8[4] = fit.aic; par8[5] = fit.aicc; par8[6] = fit.bic; par8[7] = fit.sse;
+    states[0] = fit.l; states[1] = fit.b;
+    if (sp.season != ETS_NONE) for (int j = 0; j < sp.m; j++) states[2 + j] = sfin[j];
+    return best;
+}
+
 /* test hooks */
 double oracle_det_log(double x) { return det_log(x); }
 double oracle_det_exp(double x) { return det_exp(x); }

@@ -168,3 +168,22 @@ def forecast_batch(values_concat, offsets, opts, n_threads=0):
                                        int(n_threads))
     name_list = [bytes(r).split(b"\0", 1)[0].decode() for r in names]
     return {"yhat": yhat, "lower": lo, "upper": hi, "status": status, "names": name_list, "threads": used}
+
+
+def ets_inspect(values, period, spec_id=-1, pool=0):
+    """Test hook: parameters, criteria, final states and one-step fitted values of spec `spec_id`, or of
+    the spec AutoETS selects when it is negative.  Returns None when nothing can be fitted."""
+    y = np.ascontiguousarray(values, dtype=np.float64)
+    L = lib()
+    L.oracle_ets_inspect.restype = C.c_int
+    L.oracle_ets_inspect.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    par = np.zeros(8)
+    states = np.full(2 + 64, np.nan)
+    fitted = np.full(len(y), np.nan)
+    sid = L.oracle_ets_inspect(y.ctypes.data, len(y), int(period), int(pool), int(spec_id), par.ctypes.data, states.ctypes.data, fitted.ctypes.data)
+    if sid < 0:
+        return None
+    keys = ("alpha", "beta", "gamma", "phi", "aic", "aicc", "bic", "sse")
+    out = dict(zip(keys, par))
+    out.update(spec_id=sid, level=states[0], trend=states[1], seasonal_states=states[2:2 + max(period, 1)], fitted_values=fitted)
+    return out

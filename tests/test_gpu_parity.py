@@ -177,6 +177,53 @@ def test_ts_forecast_by_operator(env):
         api.ts_forecast_by(grp, ds, Y.reshape(-1), "Naive", 3, "1d", {"seasonal_period": "7"})
 
 
+def test_inspect_and_explain_callers(env):
+    """the fit state read back from the device (parameters, criteria, final states, one-step fitted
+    values) equals the oracle's for AutoETS and for a fixed ETS spec; the caller mirrors shape it like the macros."""
+    api, O, lib, synth = env
+    Y = synth.gen_series(synth.SEED_M5, 900, 6, 84, 7, positive=True)
+    res = api.inspect_batch(list(Y), lib.make_options("AutoETS", 5, seasonal_period=7))
+    for y, r in zip(Y, res):
+        ref = O.ets_inspect(y, 7)
+        assert r["ok"] and ref is not None and r["model_code"] == 100 + ref["spec_id"]
+        for k in ("alpha", "beta", "gamma", "phi", "aic", "aicc", "bic", "sse", "level", "trend"):
+            assert _rel(np.array([r[k]]), np.array([ref[k]])) <= REL_TOL, (k, r[k], ref[k])
+        assert _rel(r["fitted_values"], ref["fitted_values"]) <= REL_TOL
+        if ref["gamma"] == ref["gamma"]:
+            assert _rel(r["seasonal_states"], ref["seasonal_states"]) <= REL_TOL
+    res = api.inspect_batch(list(Y), lib.make_options("ETS", 5, ets_model="AAdA", seasonal_period=7))
+    for y, r in zip(Y, res):
+        ref = O.ets_inspect(y, 7, spec_id=_spec_id_of(O, "AAdA"))
+        assert _rel(r["fitted_values"], ref["fitted_values"]) <= REL_TOL and _rel(np.array([r["phi"]]), np.array([ref["phi"]])) <= REL_TOL
+    # caller mirrors
+    grp = np.repeat(np.array([f"g{i}" for i in range(6)], dtype=object), 84)
+    ds = np.tile(np.arange(84), 6)
+    insp = api.ts_forecast_inspect_by(grp, ds, Y.reshape(-1), "AutoETS", {"seasonal_period": 7})
+    assert set(insp) == {f"g{i}" for i in range(6)}
+    g0 = insp["g0"]
+    assert g0["model_family"] == "Ets" and g0["seasonal_period"] == 7 and len(g0["fitted_values"]) == 84 and g0["order_p"] is None
+    assert g0["spec"] and set(g0["spec"]) <= set("AMNd") and g0["aic"] is not None
+    ar = api.ts_forecast_inspect_by(grp, ds, Y.reshape(-1), "AutoARIMA", {"seasonal_period": 7})["g0"]
+    assert ar["model_family"] == "Arima" and ar["spec"] is None and ar["order_p"] is not None and ar["aic"] is not None
+    with pytest.raises(api.InvalidInputException, match="does not implement Inspectable"):
+        api.ts_forecast_inspect_by(grp, ds, Y.reshape(-1), "Naive", {})
+    ex = api.ts_forecast_explain_by(grp, ds, Y.reshape(-1), "ETS", 12, {"model": "AAdA", "seasonal_period": 7})["g1"]
+    assert ex["horizon"] == 12 and len(ex["level"]) == 12 and len(ex["trend"]) == 12 and len(ex["seasonal"]) == 12
+    np.testing.assert_allclose(ex["level"] + ex["trend"] + ex["seasonal"], ex["yhat"], rtol=1e-12)
+    exm = api.ts_forecast_explain_by(grp, ds, Y.reshape(-1), "ETS", 9, {"model": "MAM", "seasonal_period": 7})["g2"]
+    np.testing.assert_allclose((exm["level"] + exm["trend"]) * exm["seasonal"], exm["yhat"], rtol=1e-12)
+    with pytest.raises(api.InvalidInputException, match="does not implement Explainable"):
+        api.ts_forecast_explain_by(grp, ds, Y.reshape(-1), "AutoETS", 3, {})
+
+
+def _spec_id_of(O, notation):
+    """spec id = error * 15 + trend index * 3 + season (oracle/forecast.c spec_from_id)."""
+    err = {"A": 0, "M": 1}[notation[0]]
+    trend = {"N": 0, "A": 1, "Ad": 2, "M": 3, "Md": 4}[notation[1:-1]]
+    seas = {"N": 0, "A": 1, "M": 2}[notation[-1]]
+    return err * 15 + trend * 3 + seas
+
+
 def test_concurrent_single_series_calls(env):
     """Route A calls anofox_ts_forecast from every DuckDB worker thread at once (threading): concurrent calls
     from 8 host threads give the results of the serial calls."""
