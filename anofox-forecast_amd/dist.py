@@ -17,6 +17,27 @@ def shard_range(n_total: int, rank: int, world: int) -> tuple[int, int]:
     return lo, min(lo + per, n_total)
 
 
+def shard_ranges_balanced(lengths, world: int) -> list[tuple[int, int]]:
+    """Contiguous series-id ranges with (nearly) equal total length per rank -- the cost-aware variant of SURVEY.md 8e for
+    ragged batches (the fit streams 8 T_s bytes per pass, so a rank's work is proportional to the sum of its lengths).
+    Boundaries sit where the running sum of lengths crosses k / world of the total; every rank gets a (possibly empty) range."""
+    import numpy as np
+    lens = np.asarray(lengths, dtype=np.int64)
+    n = len(lens)
+    csum = np.concatenate([[0], np.cumsum(lens)])
+    total = int(csum[-1])
+    cuts = [0]
+    for k in range(1, world):
+        target = total * k / world
+        i = int(np.searchsorted(csum, target, side="left"))
+        i = min(max(i, cuts[-1]), n)
+        if i > cuts[-1] and abs(csum[i - 1] - target) <= abs(csum[i] - target):
+            i -= 1 if i - 1 >= cuts[-1] else 0
+        cuts.append(i)
+    cuts.append(n)
+    return [(cuts[k], cuts[k + 1]) for k in range(world)]
+
+
 def gather_forecasts(local: dict, n_total: int, rank: int, world: int, dst: int = 0):
     """Gather {'yhat','lower','upper' [n_local,h] f64, 'model_code','status' [n_local] i32} to `dst`.
 

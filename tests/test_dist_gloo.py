@@ -44,3 +44,16 @@ def test_gather_world2_gloo():
     ids = np.arange(n_total, dtype=np.float64)
     np.testing.assert_array_equal(ret["yhat"], ids[:, None] * 10 + np.arange(h)[None, :])
     np.testing.assert_array_equal(ret["code"], (100 + ids % 30).astype(np.int32))
+
+
+def test_balanced_shards_cover_and_balance():
+    import numpy as np
+    from anofox_forecast_amd.dist import shard_ranges_balanced
+    rng = np.random.default_rng(2)
+    lens = rng.integers(3, 2000, 5000)
+    for world in (1, 2, 3, 8):
+        r = shard_ranges_balanced(lens, world)
+        assert r[0][0] == 0 and r[-1][1] == len(lens) and all(r[k][1] == r[k + 1][0] for k in range(world - 1))
+        work = np.array([lens[a:b].sum() for a, b in r], dtype=float)
+        assert work.max() <= work.mean() * 1.01 + 2000            # within one series of the ideal share
+    assert shard_ranges_balanced([5, 5], 4) and sum(b - a for a, b in shard_ranges_balanced([5, 5], 4)) == 2
