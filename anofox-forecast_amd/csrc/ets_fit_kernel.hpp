@@ -30,8 +30,11 @@ __global__ __launch_bounds__(NM_BLOCK, ANOFOX_ROUND_WAVES) void ets_round_kernel
     constexpr int PPB = NM_BLOCK / LPP;          // problems per workgroup
     const int lane = threadIdx.x;
     const int n_act = a.n_active ? *a.n_active : a.n_series;
-    if ((int)blockIdx.x * PPB >= n_act) return;
     if (a.spec_below >= 0 && SPEC != (n_act <= a.spec_below)) return;   // the other driver owns this round
+    // fused compaction: this round appends its unfinished problems to the next round's list; the counter of the round
+    // after that is cleared here (three counters rotate), by the round's owner even when nothing is left to run
+    if (a.clear_cnt && blockIdx.x == 0 && lane == 0) *a.clear_cnt = 0;
+    if ((int)blockIdx.x * PPB >= n_act) return;
     const int p = blockIdx.x * PPB + lane / LPP;
     const bool valid = p < n_act;
     const int s = valid ? (a.series_of ? a.series_of[p] : p) : 0;
@@ -110,6 +113,29 @@ __global__ __launch_bounds__(NM_BLOCK, ANOFOX_ROUND_WAVES) void ets_round_kernel
         a.st.iters[s] = r.iters;
         a.st.passes[s] = r.passes;
         a.st.done[s] = r.done ? 1 : 0;
+    }
+    if (a.next_map) {
+        // Fused compaction + gather: every problem that is still running reserves a column of the next round's dense block
+        // (one ballot + one atomic per wave, consecutive columns within the wave) and copies its series there -- reads of
+        // this round's column, writes of 512 contiguous bytes per row and wave -- so no compaction or gather kernel sits
+        // between two rounds of a spec.
+        const bool push = active && !r.done;
+        const bool lead = push && (lane % LPP) == 0;
+        const unsigned long long bal = __ballot(lead);
+        const int cnt = __popcll(bal);
+        if (cnt) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(a.next_cnt, cnt);
+            base = __shfl(base, 0);
+            int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+            if constexpr (SPEC) pos = __shfl(pos, lane & ~(LPP - 1));
+            if (lead) a.next_map[pos] = s;
+            if (push && a.next_y) {
+                const double *src = v.y;
+                double *dst = a.next_y + pos;
+                for (int t = lane % LPP; t < len; t += LPP) dst[(size_t)t * a.ld] = src[(size_t)t * v.ld];
+            }
+        }
     }
 }
 

@@ -104,6 +104,7 @@ struct AnofoxHipBatch {
     // per aux stream: gathered block of the running problems, ping-pong column maps + counts, parked NM state
     struct Lane {
         double *ybuf = nullptr;
+        double *ybuf2 = nullptr;         // fused compaction: the rounds alternate between the two dense blocks
         int32_t *map[2] = {nullptr, nullptr};
         int32_t *cnt = nullptr;          // [2]
         anofox::NmStateBuf st{};
@@ -114,6 +115,8 @@ struct AnofoxHipBatch {
     uint64_t n_problems = 0;
     int seq_rounds = 3;      // rounds run by the sequential Nelder-Mead driver before switching to the speculative one
     int seq_rounds_env = -1; // ANOFOX_HIP_SEQ_ROUNDS override (-1 = decide from the number of live problems)
+    bool fused = false;      // ANOFOX_HIP_FUSED=1: compaction + gather fused into the end of every round kernel (measured 3-8 % slower
+                             // than the separate kernels: the gaps between a spec's rounds are queueing, not those kernels)
     int gather_min = 0;      // per spec: stop gathering columns once this few problems are still running (measured: the gather pays at every count, 0 = always gather)
     int tail_below = 0;      // per spec: run the remaining problems to completion once this few are left (measured: rounds + compaction win at every threshold, 0 = off)
     int spec_below_md = 8192; // same, for the damped multiplicative-trend specs (their pass is ~10x longer: the stragglers matter more)
@@ -270,7 +273,7 @@ void free_batch_buffers(AnofoxHipBatch *b)
     for (hipEvent_t e : {b->ev_start, b->ev_stop, b->ev_fit0, b->ev_fit1, b->ev_fork}) if (e) (void)hipEventDestroy(e);
     for (auto &e : b->ev_join) if (e) (void)hipEventDestroy(e);
     for (auto &l : b->lanes) {
-        F(l.ybuf); F(l.map[0]); F(l.map[1]); F(l.cnt);
+        F(l.ybuf); F(l.ybuf2); F(l.map[0]); F(l.map[1]); F(l.cnt);
         F(l.st.sim); F(l.st.fs); F(l.st.phase); F(l.st.evals); F(l.st.iters); F(l.st.passes); F(l.st.done);
     }
 }
@@ -335,6 +338,7 @@ void alloc_common(AnofoxHipBatch *b)
         for (int q = 0; q < n_lanes; q++) {
             auto &l = b->lanes[q];
             if (b->use_gather) l.ybuf = dalloc<double>(T * ld);
+            if (b->use_gather && b->fused) l.ybuf2 = dalloc<double>(T * ld);
             l.map[0] = dalloc<int32_t>(ld);
             l.map[1] = dalloc<int32_t>(ld);
             l.cnt = dalloc<int32_t>(3);
@@ -562,6 +566,10 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
                 else { a.y_round = b->d_y; a.ld_round = ld; }
             } else if (r == 0) {
                 a.y_round = b->d_y; a.ld_round = ld; a.series_of = nullptr; a.n_active = nullptr;
+            } else if (b->fused) {
+                // the previous round left its unfinished problems, densely, in map / ybuf [r & 1] with their count in cnt[r % 3]
+                a.series_of = lane.map[r & 1]; a.n_active = lane.cnt + (r % 3);
+                a.y_round = (r & 1) ? lane.ybuf2 : lane.ybuf; a.ld_round = ld; a.gathered = 1; a.gather_min = 0;
             } else {
                 const int32_t *prev_map = (r == 1) ? nullptr : lane.map[(r - 1) & 1];
                 const int32_t *prev_cnt = (r == 1) ? nullptr : lane.cnt + ((r - 1) % 3);
@@ -574,6 +582,12 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
                 } else {
                     a.y_round = b->d_y; a.ld_round = ld;
                 }
+            }
+            a.next_map = nullptr; a.next_cnt = nullptr; a.clear_cnt = nullptr; a.next_y = nullptr;
+            if (b->fused && r + 1 < n_rounds) {
+                if (r == 0) HIPCHECK(hipMemsetAsync(lane.cnt, 0, 3 * sizeof(int32_t), sq));      // once; afterwards the counters rotate
+                a.next_map = lane.map[(r + 1) & 1]; a.next_cnt = lane.cnt + ((r + 1) % 3); a.clear_cnt = lane.cnt + ((r + 2) % 3);
+                a.next_y = ((r + 1) & 1) ? lane.ybuf2 : lane.ybuf;
             }
             if (r == 0 || b->seq_rounds_env >= 0 || b->seq_rounds == 0) {
                 // first round (no device count yet) or a forced schedule: the host picks the driver
@@ -887,14 +901,16 @@ bool anofox_hip_batch_create(size_t n_series, size_t t_max, const ForecastOption
         b->opt = *options;
         b->plan = plan;
         if (const char *e = std::getenv("ANOFOX_HIP_SEQ_ROUNDS")) { b->seq_rounds_env = std::atoi(e); b->seq_rounds = b->seq_rounds_env; }
-        // dense re-gather of the running problems between rounds (+10% throughput) costs one block copy per
-        // candidate spec: on by default while that stays under 24 GiB of the 288 GB HBM
-        b->use_gather = (double)max_slots_for(plan) * (double)std::max<size_t>(t_max, 1) * (double)b->ld * 8.0 <= 24.0 * 1073741824.0;
+        // dense re-gather of the running problems between rounds (up to 2x on a large batch) costs one block copy per
+        // candidate spec: on by default while that stays under 96 GiB of the 288 GB HBM
+        b->use_gather = (double)max_slots_for(plan) * (double)std::max<size_t>(t_max, 1) * (double)b->ld * 8.0 <= 96.0 * 1073741824.0;
         if (const char *e = std::getenv("ANOFOX_HIP_GATHER")) b->use_gather = std::atoi(e) != 0;
         if (const char *e = std::getenv("ANOFOX_HIP_SPEC_BELOW")) b->spec_below = b->spec_below_md = std::atoi(e);
         if (const char *e = std::getenv("ANOFOX_HIP_SPEC_BELOW_MD")) b->spec_below_md = std::atoi(e);
         if (const char *e = std::getenv("ANOFOX_HIP_TAIL_BELOW")) b->tail_below = std::atoi(e);
         if (const char *e = std::getenv("ANOFOX_HIP_GATHER_MIN")) b->gather_min = std::atoi(e);
+        if (const char *e = std::getenv("ANOFOX_HIP_FUSED")) b->fused = std::atoi(e) != 0;
+        if (!b->use_gather) b->fused = false;
         alloc_common(b);
     } catch (const HipFail &f) {
         set_error(out_error, INTERNAL_ERROR, "Internal error: " + f.msg);

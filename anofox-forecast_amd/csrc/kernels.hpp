@@ -44,6 +44,9 @@ struct FitArgs {
     int tail_below;              // run to completion once this few problems are still running (0 = never)
     int gather_min;              // the gather (and the gathered view) only applies while more than this many problems run
     int gathered;                // y_round holds the running problems' columns densely (column p), else index by series
+    // fused compaction + gather at the end of a round (NULL: the host runs compact / gather kernels instead)
+    int32_t *next_map, *next_cnt, *clear_cnt;
+    double *next_y;              // next round's dense block [t_rows x ld] (NULL: the next round reads y in place)
     NmStateBuf st;
     int m, h;
     const double *l0, *b0;       // [ld] for this spec's (season, trend) class
