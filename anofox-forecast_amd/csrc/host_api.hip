@@ -897,6 +897,8 @@ bool anofox_hip_batch_create(size_t n_series, size_t t_max, const ForecastOption
         b->t_max = t_max;
         b->ld = (n_series + 63) / 64 * 64;
         if (b->ld == 0) b->ld = 64;
+        // the streamed loads address a block of <= 32 rows with 32-bit offsets (buffer loads): 33 rows must stay under 4 GiB
+        if ((double)b->ld * 8.0 * 33.0 >= 4294967296.0) throw HipFail{"batch too wide for one launch (more than ~16 million series): shard it"};
         b->h = options->horizon;
         b->opt = *options;
         b->plan = plan;
