@@ -509,7 +509,9 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
     // one stream per spec (the runtime maps them onto the hardware queues; two explicit pairing schemes -- dedicated
     // queues for the heaviest specs, heaviest-with-lightest -- both measured 14 % slower on the 30-spec batch)
     std::vector<int> stream_of(order.size());
-    for (size_t oi = 0; oi < order.size(); oi++) stream_of[oi] = (int)(oi % (size_t)n_lanes);
+    int n_streams = n_lanes;
+    if (const char *e = std::getenv("ANOFOX_HIP_STREAMS")) { const int v = std::atoi(e); if (v > 0) n_streams = std::min(v, n_lanes); }
+    for (size_t oi = 0; oi < order.size(); oi++) stream_of[oi] = (int)(oi % (size_t)n_streams);
     std::vector<FitArgs> args(order.size());
     std::vector<FitLaunchers> fns(order.size());
     for (size_t oi = 0; oi < order.size(); oi++) {
