@@ -364,6 +364,19 @@ def test_ts_cv_forecast_by_operator(env):
         api.ts_cv_forecast_by(fold, split, grp, ds, yv, "NoSuchModel", {})
 
 
+def test_fused_compaction_variant_is_bit_identical(env, monkeypatch):
+    """ANOFOX_HIP_FUSED=1 (compaction + gather fused into the end of every round kernel) and the 6-round schedule walk the
+    same trajectories as the default schedule."""
+    api, O, lib, synth = env
+    monkeypatch.setenv("ANOFOX_HIP_FUSED", "1")
+    monkeypatch.setenv("ANOFOX_HIP_BUDGETS", "32,32,64,128,256,1024")
+    Y = synth.gen_series(synth.SEED_M5, 5200, 130, 160, 7, positive=True)
+    series = [Y[s, : 160 - (s % 5) * 9] for s in range(130)]
+    _compare(api, O, lib, series, "AutoETS", 14, seasonal_period=7)
+    Yi = synth.gen_series(synth.SEED_M5, 5400, 130, 160, 7)
+    _compare(api, O, lib, list(Yi), "AutoETS", 14, seasonal_period=7)
+
+
 @pytest.mark.parametrize("seq_rounds", ["0", "2", "6"])
 @pytest.mark.parametrize("gather", ["0", "1"])
 def test_schedule_variants_are_bit_identical(env, monkeypatch, seq_rounds, gather):
