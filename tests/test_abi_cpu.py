@@ -77,3 +77,27 @@ def test_product_never_imports_oracle():
                 assert '#include "../../oracle' not in txt and "oracle/" not in txt.replace("oracle/ets.c", "").replace("oracle/", "oracle/") or True
     out = subprocess.check_output(["ldd", os.path.join(pkg, "libanofox_fcst_hip.so")]).decode() if os.path.exists(os.path.join(pkg, "libanofox_fcst_hip.so")) else ""
     assert "liboracle" not in out
+
+
+def build_c_caller(out_dir):
+    """Compile tests/c_abi/caller.c against include/ and the in-tree shared library; returns the binary path."""
+    exe = os.path.join(out_dir, "caller")
+    pkg = os.path.join(ROOT, "anofox-forecast_amd")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c_abi", "caller.c"), "-L", pkg, "-lanofox_fcst_hip",
+                           "-Wl,-rpath," + pkg, "-o", exe])
+    return exe
+
+
+def test_plain_c_caller_links_and_reports_errors(hiplib):
+    """A C program written like the reference's binding links against the library with nothing but the
+    header; without a GPU it gets INTERNAL_ERROR (no fallback), and argument errors still come first."""
+    import torch
+    hiplib.load()
+    with tempfile.TemporaryDirectory() as d:
+        exe = build_c_caller(d)
+        out = subprocess.run([exe, "NoSuchModel"], capture_output=True, text=True, timeout=120).stdout
+        assert out.startswith("ERR %d " % hiplib.INVALID_MODEL) and "Unknown model" in out, out
+        if not torch.cuda.is_available():
+            out = subprocess.run([exe, "Naive", "0"], capture_output=True, text=True, timeout=120).stdout
+            assert out.startswith("ERR %d" % hiplib.INTERNAL_ERROR) and "no CPU fallback" in out, out

@@ -521,3 +521,27 @@ def test_full_size_m5_properties(env, model, positive):
     for j in range(n_ref):
         ref = O.forecast(Y[pick[j]], oo)
         assert _rel(sub["yhat"][j], ref["point"]) <= REL_TOL and sub_names[j] == ref["model_name"]
+
+
+def test_plain_c_caller_matches_oracle(env):
+    """tests/c_abi/caller.c: a C program using only include/anofox_fcst_hip.h, filling the structs the way
+    the reference's binding does; its printed model name and first forecast must be the oracle's."""
+    import subprocess, tempfile
+    from test_abi_cpu import build_c_caller
+    api, O, lib, synth = env
+    y = np.array([20.0 + 0.5 * i + (6.0 if i % 7 == 0 else 0.0) for i in range(48)])
+    y[10] = 0.0
+    valid = np.ones(48, dtype=bool)
+    valid[10] = False
+    with tempfile.TemporaryDirectory() as d:
+        exe = build_c_caller(d)
+        for model, period in (("AutoETS", 7), ("Naive", 0), ("AutoARIMA", 7), ("HoltWinters", 12), ("Holt", 0), ("SeasonalNaive", 7)):
+            out = subprocess.run([exe, model, str(period)], capture_output=True, text=True, timeout=300).stdout.split("\n")
+            oo = O.make_options(model, 5, confidence_level=0.90, seasonal_period=period, auto_detect=False)
+            ref = O.forecast(y, oo, valid)
+            assert ref["ok"], ref
+            tag, rest = out[0].split(" ", 1)
+            name, first, n, inside = rest.rsplit(" ", 3)
+            assert tag == "OK" and name == ref["model_name"] and int(n) == 5 and inside == "1", (model, out)
+            assert abs(float(first) - ref["point"][0]) <= 1e-9 * max(1.0, abs(ref["point"][0])), (model, out, ref["point"][0])
+            assert out[1].startswith("VERSION 0.1.0"), out
