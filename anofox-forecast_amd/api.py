@@ -746,3 +746,166 @@ def ts_cv_forecast_by(fold_id, split, group, date, target, method, params=None, 
 
 
 anofox_fcst_ts_cv_forecast_by = ts_cv_forecast_by
+
+
+# --------------------------------------------------------------------------------------------
+# _ts_backtest_native (second caller): walk-forward folds cut by position
+# --------------------------------------------------------------------------------------------
+def backtest_fold_bounds(n_dates, horizon, folds, window_type="expanding", min_train_size=1, gap=0, embargo=0,
+                         initial_train_size=-1, skip_length=-1, clip_horizon=False):
+    """ComputeFoldBoundaries (ts_backtest_native.cpp:623-711): position-based fold boundaries over the number of
+    distinct dates of the whole input.  Returns [(fold_id, train_start, train_end, test_start, test_end)], all inclusive.
+    Unsigned arithmetic of the reference is kept where it matters (no fold can start before index 0)."""
+    out = []
+    if n_dates < 2:
+        return out
+    if initial_train_size > 0:
+        init = int(initial_train_size)
+    else:
+        needed = int(horizon) * int(folds)
+        init = n_dates - needed if n_dates > needed else 1
+    skip = int(skip_length) if skip_length > 0 else int(horizon)
+    for fold in range(int(folds)):
+        train_end = init - 1 + fold * skip
+        test_start = train_end + 1 + int(gap)
+        test_end = test_start + int(horizon) - 1
+        if clip_horizon and test_end >= n_dates:
+            test_end = n_dates - 1
+        if not (test_start < n_dates if clip_horizon else test_end < n_dates):
+            break
+        if window_type == "expanding":
+            train_start = 0
+        else:
+            train_start = train_end + 1 - int(min_train_size) if train_end + 1 >= int(min_train_size) else 0
+        if fold > 0 and embargo > 0 and out:
+            train_start = max(train_start, out[-1][4] + 1 + int(embargo))
+        out.append((fold + 1, train_start, train_end, test_start, test_end))
+    return out
+
+
+def backtest_metric(metric, actual, forecast, lower, upper):
+    """ComputeMetric (ts_backtest_native.cpp:280-373): sums run in row order like the reference's loops."""
+    a, f = np.asarray(actual, dtype=np.float64), np.asarray(forecast, dtype=np.float64)
+    n = len(a)
+    if n == 0 or len(f) == 0:
+        return float("nan")
+    seq = lambda x: float(np.cumsum(x)[-1]) if len(x) else 0.0      # sequential accumulation, not pairwise
+    with np.errstate(all="ignore"):
+        if metric == "mae":
+            return seq(np.abs(a - f)) / n
+        if metric == "mse":
+            return seq((a - f) * (a - f)) / n
+        if metric == "mape":
+            k = a != 0
+            return seq(np.abs((a[k] - f[k]) / a[k])) / int(k.sum()) * 100.0 if k.any() else float("nan")
+        if metric == "smape":
+            d = np.abs(a) + np.abs(f)
+            k = d > 0
+            return seq(np.abs(a[k] - f[k]) / d[k]) / int(k.sum()) * 200.0 if k.any() else float("nan")
+        if metric == "bias":
+            return seq(f - a) / n
+        if metric == "r2":
+            mean = seq(a) / n
+            res, tot = seq((a - f) * (a - f)), seq((a - mean) * (a - mean))
+            return 1.0 - res / tot if tot > 0 else float("nan")
+        if metric == "coverage":
+            lo, hi = np.asarray(lower), np.asarray(upper)
+            if len(lo) != n or len(hi) != n:
+                return float("nan")
+            return int(((a >= lo) & (a <= hi)).sum()) / n
+        return float(np.sqrt(seq((a - f) * (a - f)) / n))           # "rmse" and every unknown name
+
+
+def ts_backtest_native(group, date, value, horizon=7, folds=5, params=None, metric="rmse", group_name="id", date_name="date"):
+    """_ts_backtest_native(TABLE(group, date, value), horizon, folds, params, metric) (ts_backtest_native.cpp:379-972).
+
+    Rows with a NULL date or value are dropped (`:534`); TIMESTAMP dates are truncated to seconds (`:546-550`); fold
+    boundaries are positions over the distinct dates of the whole input (`backtest_fold_bounds`); for every fold each
+    group whose sorted rows reach the fold's train end and test start is fitted on rows [train_start..train_end] with
+    the options the reference zero-initialises (`:768-776`: only horizon and "method[:model]" set, so period 1 and
+    the default interval width) and its forecasts are matched to its test rows by position.  Failing groups are
+    skipped (`:791-794`).  All (fold, group) pairs go to the GPU in ONE batch call instead of the serial loop of
+    `:873-880`.  Returns columns fold_id, <group>, <date>, yhat, actual, error, abs_error, yhat_lower, yhat_upper,
+    model_name, fold_metric_score in (fold, first-appearance group, position) order.
+    """
+    p = params or {}
+
+    def as_int(key, default):
+        try:
+            return int(str(p[key])) if p.get(key) is not None else default
+        except ValueError:
+            return default
+    method = str(p["method"]) if p.get("method") is not None else "AutoETS"
+    spec = str(p["model"]) if p.get("model") is not None else ""
+    window_type = str(p["window_type"]) if p.get("window_type") is not None else "expanding"
+    clip = str(p.get("clip_horizon", "false")).lower() in ("true", "1", "yes")
+    dates = np.asarray(date)
+    kind = _date_kind(dates)
+    us = _to_micros(dates, kind)
+    if kind == "TIMESTAMP":
+        us = (us // 1_000_000) * 1_000_000
+    null_date = np.isnat(dates) if np.issubdtype(dates.dtype, np.datetime64) else np.zeros(len(dates), bool)
+    grp = np.asarray(group, dtype=object)
+    val = np.ma.filled(np.ma.asarray(value, dtype=object), None) if np.ma.isMaskedArray(value) else np.asarray(value, dtype=object)
+    order, rows = [], {}
+    for i in range(len(grp)):
+        if null_date[i] or val[i] is None:
+            continue
+        k = "__NULL__" if grp[i] is None else grp[i]
+        if k not in rows:
+            rows[k] = []
+            order.append(k)
+        rows[k].append(i)
+    kept = np.array([i for k in order for i in rows[k]], dtype=np.int64)
+    bounds = backtest_fold_bounds(len(np.unique(us[kept])) if len(kept) else 0, horizon, folds, window_type,
+                                  as_int("min_train_size", 1), as_int("gap", 0), as_int("embargo", 0),
+                                  as_int("initial_train_size", -1), as_int("skip_length", -1), clip)
+    sorted_rows = {}
+    for k in order:
+        idx = np.array(rows[k])
+        sorted_rows[k] = idx[np.argsort(us[idx], kind="stable")]
+    pairs = []
+    for (fid, tr0, tr1, te0, te1) in bounds:
+        for k in order:
+            idx = sorted_rows[k]
+            n = len(idx)
+            if tr1 >= n or te0 >= n or tr0 > tr1:
+                continue
+            te = idx[te0:min(te1, n - 1) + 1]
+            if len(te) == 0:
+                continue
+            pairs.append((fid, k, np.array([float(val[i]) for i in idx[tr0:tr1 + 1]], dtype=np.float64), te))
+    cols = {c: [] for c in ("fold_id", group_name, date_name, "yhat", "actual", "error", "abs_error", "yhat_lower", "yhat_upper",
+                            "model_name", "fold_metric_score")}
+    if pairs:
+        opts = _lib.make_options(method + (":" + spec if spec else ""), int(horizon), confidence_level=0.0, auto_detect=False)
+        results, berr = forecast_batch([pr[2] for pr in pairs], opts)
+        fold_of_row = []
+        for (fid, k, _, te), r in zip(pairs, results):
+            if not berr["ok"] or not r["ok"]:
+                continue
+            for hh in range(min(len(r["point"]), len(te))):
+                actual = float(val[te[hh]])
+                cols["fold_id"].append(fid); cols[group_name].append(None if k == "__NULL__" else k)
+                cols[date_name].append(int(us[te[hh]])); cols["yhat"].append(r["point"][hh]); cols["actual"].append(actual)
+                cols["error"].append(r["point"][hh] - actual); cols["abs_error"].append(abs(r["point"][hh] - actual))
+                cols["yhat_lower"].append(r["lower"][hh]); cols["yhat_upper"].append(r["upper"][hh])
+                cols["model_name"].append(r["model_name"] if r["model_name"] else method)
+                fold_of_row.append(fid)
+        fold_of_row = np.array(fold_of_row, dtype=np.int64)
+        score = np.full(len(fold_of_row), np.nan)
+        for (fid, *_rest) in bounds:
+            k = fold_of_row == fid
+            if k.any():
+                score[k] = backtest_metric(metric, np.array(cols["actual"])[k], np.array(cols["yhat"])[k],
+                                           np.array(cols["yhat_lower"])[k], np.array(cols["yhat_upper"])[k])
+        cols["fold_metric_score"] = score
+    cols["fold_id"] = np.array(cols["fold_id"], dtype=np.int64)
+    cols[date_name] = _from_micros(np.array(cols[date_name], dtype=np.int64), kind, dates.dtype)
+    for c in ("yhat", "actual", "error", "abs_error", "yhat_lower", "yhat_upper", "fold_metric_score"):
+        cols[c] = np.array(cols[c], dtype=np.float64)
+    return cols
+
+
+_ts_backtest_native = ts_backtest_native
+_anofox_fcst_ts_backtest_native = ts_backtest_native

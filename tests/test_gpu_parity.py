@@ -545,3 +545,72 @@ def test_plain_c_caller_matches_oracle(env):
             assert tag == "OK" and name == ref["model_name"] and int(n) == 5 and inside == "1", (model, out)
             assert abs(float(first) - ref["point"][0]) <= 1e-9 * max(1.0, abs(ref["point"][0])), (model, out, ref["point"][0])
             assert out[1].startswith("VERSION 0.1.0"), out
+
+
+def test_ts_backtest_native_caller(env):
+    """SURVEY section 8f rank 1, second caller (_ts_backtest_native, ts_backtest_native.cpp): position-based walk-forward
+    folds over the distinct dates of the whole input; every (fold, group) pair is one training series fitted with the
+    zero-initialised options of `:768-776`; one batch call; against the oracle pair by pair."""
+    api, O, lib, synth = env
+    # the equivalence test's data (ts_backtest_equivalence.test:11-19): 60 days, two series, 2 folds x horizon 7, Naive
+    i = np.arange(60)
+    grp = np.array(["A"] * 60 + ["B"] * 60, dtype=object)
+    ds = np.concatenate([np.datetime64("2024-01-01") + i.astype("timedelta64[D]")] * 2)
+    val = np.concatenate([100.0 + i * 2.0 + 50 + (i % 7) * 3.0, 100.0 + i * 2.0 + (i % 7) * 3.0])
+    out = api.ts_backtest_native(grp, ds, val, 7, 2, {"method": "Naive"}, "mae", group_name="series_id", date_name="date")
+    assert list(out.keys()) == ["fold_id", "series_id", "date", "yhat", "actual", "error", "abs_error", "yhat_lower", "yhat_upper",
+                                "model_name", "fold_metric_score"]
+    assert len(out["yhat"]) == 28 and list(out["fold_id"]) == [1] * 14 + [2] * 14 and list(out["series_id"][:14]) == ["A"] * 7 + ["B"] * 7
+    np.testing.assert_array_equal(out["yhat"][:7], np.full(7, val[45]))          # fold 1: train ends at day 45
+    np.testing.assert_array_equal(out["yhat"][21:], np.full(7, val[60 + 52]))    # fold 2, series B: train ends at day 52
+    np.testing.assert_array_equal(out["actual"][:7], val[46:53])
+    assert out["date"][0] == np.datetime64("2024-02-16") and out["date"].dtype == ds.dtype
+    np.testing.assert_array_equal(out["error"], out["yhat"] - out["actual"])
+    np.testing.assert_array_equal(out["abs_error"], np.abs(out["error"]))
+    assert out["fold_metric_score"][0] == api.backtest_metric("mae", out["actual"][:14], out["yhat"][:14], [], [])
+    assert set(out["model_name"]) == {"Naive"}
+    # ragged groups, shuffled rows, a NULL value, AutoETS and AutoARIMA: pair by pair against the oracle
+    Y = synth.gen_series(synth.SEED_M5, 310, 5, 120, 7, positive=True)
+    lens = [120, 120, 104, 90, 120]
+    rows = [(f"g{g}", t, Y[g, t]) for g in range(5) for t in range(lens[g])]
+    perm = np.random.default_rng(5).permutation(len(rows))
+    grp = np.array([rows[k][0] for k in perm], dtype=object)
+    t = np.array([rows[k][1] for k in perm], dtype=np.int64)
+    v = np.array([rows[k][2] for k in perm], dtype=object)
+    drop = int(np.flatnonzero((grp == "g4") & (t == 17))[0])
+    v[drop] = None                                                  # dropped row: g4 is one point shorter and shifted
+    series = {f"g{g}": Y[g, :lens[g]] for g in range(5)}
+    series["g4"] = np.delete(Y[4], 17)
+    tt = {f"g{g}": np.arange(lens[g]) for g in range(5)}
+    tt["g4"] = np.delete(np.arange(120), 17)
+    first_seen = list(dict.fromkeys(g for k, g in enumerate(grp) if k != drop))      # group_order: first appearance (`:596-600`)
+    for method, params in (("AutoETS", {}), ("AutoARIMA", {"window_type": "fixed", "min_train_size": 80, "gap": 1})):
+        params = dict(params, method=method)
+        out = api.ts_backtest_native(grp, t, v, 6, 3, params, "rmse")
+        bounds = api.backtest_fold_bounds(120, 6, 3, params.get("window_type", "expanding"), params.get("min_train_size", 1), params.get("gap", 0))
+        assert len(bounds) == (3 if method == "AutoETS" else 2)        # gap 1 pushes the third test window past the data
+        pos = 0
+        for (fid, tr0, tr1, te0, te1) in bounds:
+            start = pos
+            for g in first_seen:
+                yy = series[g]
+                if tr1 >= len(yy) or te0 >= len(yy):
+                    continue
+                ref = O.forecast(yy[tr0:tr1 + 1], O.make_options(method, 6, confidence_level=0.0, auto_detect=False))
+                assert ref["ok"], ref
+                n = min(6, min(te1, len(yy) - 1) - te0 + 1)
+                sl = slice(pos, pos + n)
+                assert list(out["fold_id"][sl]) == [fid] * n and list(out["id"][sl]) == [g] * n, (method, fid, g)
+                np.testing.assert_allclose(out["yhat"][sl], ref["point"][:n], rtol=REL_TOL)
+                np.testing.assert_allclose(out["yhat_lower"][sl], ref["lower"][:n], rtol=REL_TOL)
+                np.testing.assert_allclose(out["yhat_upper"][sl], ref["upper"][:n], rtol=REL_TOL)
+                np.testing.assert_array_equal(out["actual"][sl], yy[te0:te0 + n])
+                np.testing.assert_array_equal(out["date"][sl], tt[g][te0:te0 + n])
+                assert out["model_name"][pos] == ref["model_name"]
+                pos += n
+            want = api.backtest_metric("rmse", out["actual"][start:pos], out["yhat"][start:pos], [], [])
+            assert np.all(out["fold_metric_score"][start:pos] == want)
+        assert pos == len(out["yhat"]) and pos > 0
+    # failing fits are skipped, not raised (`:791-794`): an unknown method gives no rows
+    out = api.ts_backtest_native(grp, t, v, 6, 3, {"method": "NoSuchModel"}, "rmse")
+    assert len(out["yhat"]) == 0 and out["date"].dtype == np.int64

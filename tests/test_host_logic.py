@@ -129,3 +129,35 @@ def test_columnar_ingest_rules(hiplib):
         np.testing.assert_array_equal(v[ok], val[rows][vok[rows]])
         assert np.all(v[~ok] == 0.0)
     ing.close()
+
+
+def test_backtest_fold_bounds_and_metric():
+    """ComputeFoldBoundaries / ComputeMetric (ts_backtest_native.cpp:623-711, 280-373), incl. the worked example of `:645-646`."""
+    from anofox_forecast_amd import api
+    assert api.backtest_fold_bounds(36, 12, 1) == [(1, 0, 23, 24, 35)]
+    # 60 dates, 2 folds, horizon 7 (ts_backtest_equivalence.test:47-49): trains end at 45 and 52
+    assert api.backtest_fold_bounds(60, 7, 2) == [(1, 0, 45, 46, 52), (2, 0, 52, 53, 59)]
+    assert api.backtest_fold_bounds(1, 7, 2) == []
+    # not enough dates: initial train of one point, folds stop at the data end
+    assert api.backtest_fold_bounds(10, 4, 5) == [(1, 0, 0, 1, 4), (2, 0, 4, 5, 8)]
+    assert api.backtest_fold_bounds(10, 4, 5, clip_horizon=True) == [(1, 0, 0, 1, 4), (2, 0, 4, 5, 8), (3, 0, 8, 9, 9)]
+    # fixed window of 10 points, gap 2, embargo pushes the next train start past the previous test
+    b = api.backtest_fold_bounds(60, 5, 3, window_type="fixed", min_train_size=10, gap=2)
+    assert b == [(1, 35, 44, 47, 51), (2, 40, 49, 52, 56), (3, 45, 54, 57, 61)][:2]
+    b = api.backtest_fold_bounds(60, 5, 2, window_type="expanding", embargo=3, initial_train_size=30, skip_length=10)
+    assert b == [(1, 0, 29, 30, 34), (2, 38, 39, 40, 44)]
+    a, f = np.array([1.0, 2.0, 0.0, 4.0]), np.array([1.5, 1.0, 1.0, 4.0])
+    lo, hi = f - 0.75, f + 0.75
+    assert api.backtest_metric("mae", a, f, lo, hi) == (0.5 + 1.0 + 1.0 + 0.0) / 4
+    assert api.backtest_metric("mse", a, f, lo, hi) == (0.25 + 1.0 + 1.0) / 4
+    assert api.backtest_metric("rmse", a, f, lo, hi) == np.sqrt((0.25 + 1.0 + 1.0) / 4)
+    assert api.backtest_metric("nonsense", a, f, lo, hi) == api.backtest_metric("rmse", a, f, lo, hi)
+    assert api.backtest_metric("mape", a, f, lo, hi) == (0.5 + 0.5 + 0.0) / 3 * 100.0
+    assert api.backtest_metric("smape", a, f, lo, hi) == ((0.5 / 2.5 + 1.0 / 3.0) + 1.0 / 1.0 + 0.0) / 4 * 200.0
+    assert api.backtest_metric("bias", a, f, lo, hi) == (0.5 - 1.0 + 1.0 + 0.0) / 4
+    assert api.backtest_metric("coverage", a, f, lo, hi) == 2 / 4
+    mean = 7.0 / 4
+    tot = sum((x - mean) ** 2 for x in a)
+    assert abs(api.backtest_metric("r2", a, f, lo, hi) - (1.0 - 2.25 / tot)) < 1e-15
+    assert np.isnan(api.backtest_metric("r2", np.ones(3), np.ones(3), [], []))
+    assert np.isnan(api.backtest_metric("mae", [], [], [], []))
