@@ -101,3 +101,15 @@ def test_plain_c_caller_links_and_reports_errors(hiplib):
         if not torch.cuda.is_available():
             out = subprocess.run([exe, "Naive", "0"], capture_output=True, text=True, timeout=120).stdout
             assert out.startswith("ERR %d" % hiplib.INTERNAL_ERROR) and "no CPU fallback" in out, out
+
+
+def test_ingest_under_address_and_ub_sanitizers():
+    """csrc/ingest.hip is host-only C++: build it with g++ ASan+UBSan together with tests/c_abi/ingest_san.cpp, which
+    replays random chunked appends against the reference's collection rule (ts_forecast_native.cpp:502-600)."""
+    with tempfile.TemporaryDirectory() as d:
+        exe = os.path.join(d, "ingest_san")
+        subprocess.check_call(["g++", "-std=c++17", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                               "-x", "c++", os.path.join(ROOT, "anofox-forecast_amd", "csrc", "ingest.hip"),
+                               "-x", "c++", os.path.join(ROOT, "tests", "c_abi", "ingest_san.cpp"), "-o", exe])
+        r = subprocess.run([exe, "150"], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and r.stdout.startswith("OK 150 rounds"), (r.stdout, r.stderr[-2000:])
