@@ -25,11 +25,16 @@ namespace {
 
 constexpr int N_AUX_STREAMS = 32;   // one stream per candidate ETS spec (the hardware multiplexes them onto GPU_MAX_HW_QUEUES queues)
 
-struct HipFail { std::string msg; };
+struct HipFail { std::string msg; bool oom = false; };      // oom: the device or pinned-host allocator refused (reported as ALLOCATION_ERROR)
+void report_hip_failure(AnofoxError *out_error, const HipFail &f)
+{
+    if (f.oom) anofox::set_error(out_error, ALLOCATION_ERROR, "Allocation error: " + f.msg);      // error.rs:20-21, code 4
+    else anofox::set_error(out_error, INTERNAL_ERROR, "Internal error: " + f.msg);
+}
 #define HIPCHECK(expr)                                                                             \
     do {                                                                                           \
         hipError_t _e = (expr);                                                                    \
-        if (_e != hipSuccess) throw HipFail{std::string(#expr) + ": " + hipGetErrorString(_e)};    \
+        if (_e != hipSuccess) throw HipFail{std::string(#expr) + ": " + hipGetErrorString(_e), _e == hipErrorOutOfMemory};    \
     } while (0)
 
 template <class T> T *dalloc(size_t n)
@@ -917,7 +922,7 @@ bool anofox_hip_batch_create(size_t n_series, size_t t_max, const ForecastOption
         if (!b->use_gather) b->fused = false;
         alloc_common(b);
     } catch (const HipFail &f) {
-        set_error(out_error, INTERNAL_ERROR, "Internal error: " + f.msg);
+        report_hip_failure(out_error, f);
         free_batch_buffers(b);
         delete b;
         return false;
@@ -1017,7 +1022,7 @@ bool anofox_hip_batch_pack_host(AnofoxHipBatch *b, const double *const *values, 
         finalize_lengths(b);
         b->has_block = true;
     } catch (const HipFail &f) {
-        set_error(out_error, INTERNAL_ERROR, "Internal error: " + f.msg);
+        report_hip_failure(out_error, f);
         return false;
     } catch (const std::exception &e) {
         set_error(out_error, INTERNAL_ERROR, std::string("Internal error: ") + e.what());
@@ -1045,7 +1050,7 @@ bool anofox_hip_batch_set_device_block(AnofoxHipBatch *b, const void *d_y, size_
         finalize_lengths(b);
         b->has_block = true;
     } catch (const HipFail &f) {
-        set_error(out_error, INTERNAL_ERROR, "Internal error: " + f.msg);
+        report_hip_failure(out_error, f);
         return false;
     } catch (const std::exception &e) {
         set_error(out_error, INTERNAL_ERROR, std::string("Internal error: ") + e.what());
@@ -1061,7 +1066,7 @@ bool anofox_hip_batch_run(AnofoxHipBatch *b, void *stream, AnofoxError *out_erro
     try {
         run_batch(b, stream ? (hipStream_t)stream : b->own_stream);
     } catch (const HipFail &f) {
-        set_error(out_error, INTERNAL_ERROR, "Internal error: " + f.msg);
+        report_hip_failure(out_error, f);
         return false;
     } catch (const std::exception &e) {
         set_error(out_error, INTERNAL_ERROR, std::string("Internal error: ") + e.what());
@@ -1259,7 +1264,7 @@ bool anofox_hip_batch_inspect(AnofoxHipBatch *b, AnofoxHipInspection *out, doubl
                 }
         }
     } catch (const HipFail &f) {
-        set_error(out_error, INTERNAL_ERROR, "Internal error: " + f.msg);
+        report_hip_failure(out_error, f);
         return false;
     } catch (const std::exception &e) {
         set_error(out_error, INTERNAL_ERROR, std::string("Internal error: ") + e.what());

@@ -614,3 +614,20 @@ def test_ts_backtest_native_caller(env):
     # failing fits are skipped, not raised (`:791-794`): an unknown method gives no rows
     out = api.ts_backtest_native(grp, t, v, 6, 3, {"method": "NoSuchModel"}, "rmse")
     assert len(out["yhat"]) == 0 and out["date"].dtype == np.int64
+
+
+def test_refused_allocation_is_reported_and_recoverable(env):
+    """A plan that cannot fit the HBM (8M series x 10k-step horizon: 640 GB per forecast block) fails with ALLOCATION_ERROR (error.rs:20-21, code 4) before
+    anything is launched, leaves nothing behind, and the next ordinary call gives the oracle's numbers."""
+    import ctypes as C
+    api, O, lib, synth = env
+    L = lib.load()
+    hb, err = C.c_void_p(), lib.AnofoxError()
+    opts = lib.make_options("AutoETS", 10_000, seasonal_period=7)
+    ok = L.anofox_hip_batch_create(8_000_000, 64, C.byref(opts), C.byref(hb), C.byref(err))
+    assert not ok and err.code == lib.ALLOCATION_ERROR and err.message.startswith(b"Allocation error:"), (err.code, err.message)
+    assert not hb.value
+    ok = L.anofox_hip_batch_create(40_000_000, 16, C.byref(opts), C.byref(hb), C.byref(err))      # too wide for one launch
+    assert not ok and err.code == lib.INTERNAL_ERROR and b"shard it" in err.message
+    Y = synth.gen_series(synth.SEED_M5, 520, 8, 60, 7, positive=True)
+    assert _compare(api, O, lib, list(Y), "AutoETS", 7, seasonal_period=7) <= REL_TOL
