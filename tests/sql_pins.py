@@ -1,0 +1,64 @@
+"""Evaluator for tests/golden/reference_sql_pins.json (made by tests/golden/make_sql_pins.py): the pins the reference's
+sqllogictest files hold on `_ts_forecast(values, horizon, model)`, replayed against any forecast function with the
+C-ABI's result fields.  SQL semantics kept: lists are 1-indexed, an index past the end is NULL, NaN orders above
+every number."""
+import json
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PINS = json.load(open(os.path.join(HERE, "golden", "reference_sql_pins.json")))
+
+
+def pin_id(case):
+    return f'{case["calls"][0]["model"]}-{case["check"]}@{case["source"].split("/")[-1]}'
+
+
+def _cmp(a, op, b):
+    if a is None or b is None:
+        return None
+    ka, kb = (1, 0.0) if a != a else (0, a), (1, 0.0) if b != b else (0, b)          # NaN sorts last
+    return {"<": ka < kb, ">": ka > kb, "<=": ka <= kb, ">=": ka >= kb, "=": ka == kb}[op]
+
+
+def _at(res, field, k):
+    key = {"point": "point", "lower": "lower", "upper": "upper"}[field]
+    v = res[key]
+    return float(v[k - 1]) if 1 <= k <= len(v) else None
+
+
+def check_pin(case, run):
+    """`run(values, valid, horizon, model)` -> result dict (ok, point, lower, upper, fitted, residuals, model_name, aic, bic, mse)."""
+    res = []
+    for c in case["calls"]:
+        vals = np.array([0.0 if v is None else v for v in c["values"]], dtype=np.float64)
+        valid = np.array([v is not None for v in c["values"]], dtype=bool)
+        r = run(vals, None if valid.all() else valid, c["horizon"], c["model"])
+        assert r["ok"], (case["source"], r)
+        res.append(r)
+    r0, kind, exp = res[0], case["check"], case["expected"]
+    if kind == "model_name":
+        got = r0["model_name"]
+    elif kind == "length":
+        key = case["field"]
+        got = float(len(r0[key])) if key in r0 else None
+    elif kind == "cmp_const":
+        got = _cmp(_at(r0, case["field"], case["k"]), case["op"], case["c"])
+    elif kind == "near_const":
+        got = _cmp(abs(_at(r0, case["field"], case["k"]) - case["c"]), case["op"], case["tol"])
+    elif kind == "cmp_fields":
+        got = _cmp(_at(r0, case["field"], case["k"]), case["op"], _at(res[case["rhs_call"]], case["rhs_field"], case["rhs_k"]))
+    elif kind == "near_fields":
+        got = _cmp(abs(_at(r0, case["field"], case["k"]) - _at(res[case["rhs_call"]], case["rhs_field"], case["rhs_k"])), case["op"], case["tol"])
+    elif kind == "not_null":
+        got = _at(r0, case["field"], case["k"]) is not None
+    elif kind == "scalar_not_null":
+        got = True                                   # a DOUBLE / VARCHAR struct field of a successful call is never NULL (ts_forecast.cpp:160-170)
+    elif kind == "mse_not_negative":
+        got = _cmp(float(r0["mse"]), ">=", 0.0)
+    elif kind == "round":
+        got = round(_at(r0, case["field"], case["k"]), case["digits"])
+    else:
+        raise AssertionError(f"unknown check {kind}")
+    assert got == exp, (case["source"], kind, got, exp)

@@ -631,3 +631,19 @@ def test_refused_allocation_is_reported_and_recoverable(env):
     assert not ok and err.code == lib.INTERNAL_ERROR and b"shard it" in err.message
     Y = synth.gen_series(synth.SEED_M5, 520, 8, 60, 7, positive=True)
     assert _compare(api, O, lib, list(Y), "AutoETS", 7, seasonal_period=7) <= REL_TOL
+
+
+def test_reference_sql_pins_on_the_hip_path(env):
+    """The 178 pins the reference's sqllogictest files hold on `_ts_forecast(values, horizon, model)` for the models on the
+    path (tests/golden/reference_sql_pins.json; model names, lengths, orderings, tolerances), replayed through
+    anofox_ts_forecast with the scalar's options (ts_forecast.cpp:406-411)."""
+    import sql_pins
+    api, O, lib, synth = env
+    o = sql_pins.PINS["options"]
+
+    def run(values, valid, horizon, model):
+        opts = lib.make_options(model, horizon, seasonal_period=o["seasonal_period"], confidence_level=o["confidence_level"],
+                                auto_detect=o["auto_detect"], include_fitted=o["include_fitted"], include_residuals=o["include_residuals"])
+        return api.forecast_series(values, opts, valid)
+    for case in sql_pins.PINS["cases"]:
+        sql_pins.check_pin(case, run)

@@ -136,3 +136,16 @@ def test_auto_arima_pieces(oracle):
     assert r["ok"] and r["model_name"].split(",")[1] == "0" and abs(r["point"][-1] - 5.0) < 0.5
     r = oracle.forecast([1.0, 2.0], oracle.make_options("AutoARIMA", 2))
     assert not r["ok"] and r["code"] == 6
+
+
+# ---- the scalar pins of the reference's sqllogictest files (tests/golden/make_sql_pins.py) ----
+import sql_pins  # noqa: E402
+
+
+@pytest.mark.parametrize("case", sql_pins.PINS["cases"], ids=[sql_pins.pin_id(c) for c in sql_pins.PINS["cases"]])
+def test_reference_sql_pins(oracle, case):
+    o = sql_pins.PINS["options"]
+
+    def run(values, valid, horizon, model):
+        return oracle.forecast(values, _opts(oracle, model, horizon, o), valid)
+    sql_pins.check_pin(case, run)
