@@ -647,3 +647,76 @@ def test_reference_sql_pins_on_the_hip_path(env):
         return api.forecast_series(values, opts, valid)
     for case in sql_pins.PINS["cases"]:
         sql_pins.check_pin(case, run)
+
+
+def _model_name_tables():
+    """The two groups of test/sql/ts_native_model_names.test:14-27 and its single-fold CV table (`:45-53`)."""
+    i = np.arange(60)
+    y = np.concatenate([10.0 + i * 0.5 + np.sin(i * 3.14159 / 7) * 3, 20.0 + i * 0.3 + np.cos(i * 3.14159 / 7) * 2])
+    grp = np.array(["G1"] * 60 + ["G2"] * 60, dtype=object)
+    ds = np.concatenate([np.datetime64("2024-01-01T00:00:00", "us") + i.astype("timedelta64[D]")] * 2)
+    return grp, ds, y, np.concatenate([i, i])
+
+
+def test_native_model_names_replay(env):
+    """test/sql/ts_native_model_names.test: the model_name column of _ts_forecast_native and _ts_cv_forecast_native for
+    every model on the path with an empty params MAP (so the period is auto-detected), and the unknown-model errors."""
+    api, O, lib, synth = env
+    grp, ds, y, i = _model_name_tables()
+    exact = ["Naive", "SMA", "SeasonalNaive", "SES", "SESOptimized", "RandomWalkDrift", "Holt", "HoltWinters", "SeasonalES",
+             "SeasonalESOptimized", "ETS", "ARIMA"]
+    for model in exact + ["AutoETS", "AutoARIMA"]:
+        out = api.ts_forecast_by(grp, ds, y, model, 3, "1d", {})
+        assert len(out["yhat"]) == 6, model
+        names = set(out["model_name"])
+        if model in exact:
+            assert names == {model}, (model, names)
+        else:
+            assert all(n.startswith(model) for n in names), (model, names)
+        for g in ("G1", "G2"):                                       # and the oracle agrees on names and numbers
+            ref = O.forecast(y[grp == g], O.make_options(model, 3))
+            sel = np.array(out["id"], dtype=object) == g
+            assert ref["ok"] and set(np.array(out["model_name"], dtype=object)[sel]) == {ref["model_name"]}
+            np.testing.assert_allclose(np.asarray(out["yhat"])[sel], ref["point"], rtol=REL_TOL)
+    keep = i < 48                                                    # train: ds < 2024-02-15 (i < 45), test: the next three days
+    split = np.where(i[keep] < 45, "train", "test").astype(object)
+    fold = np.ones(int(keep.sum()), dtype=np.int64)
+    for model in ["Naive", "SESOptimized", "RandomWalkDrift", "HoltWinters", "SeasonalESOptimized", "ETS", "ARIMA", "AutoARIMA"]:
+        out = api.ts_cv_forecast_by(fold, split, grp[keep], ds[keep], y[keep], model, {})
+        assert len(out["yhat"]) == 6 and set(out["split"]) == {"test"}
+        names = set(out["model_name"])
+        assert names == {model} if model != "AutoARIMA" else all(n.startswith("AutoARIMA") for n in names), (model, names)
+    for bad in ("AIDA", "NotAModel"):
+        with pytest.raises(api.InvalidInputException, match=f"Unknown model: '{bad}'"):
+            api.ts_forecast_by(grp, ds, y, bad, 3, "1d", {})
+        with pytest.raises(api.InvalidInputException, match=f"Unknown model: '{bad}'"):
+            api.ts_cv_forecast_by(fold, split, grp[keep], ds[keep], y[keep], bad, {})
+
+
+def test_ets_model_parameter_replay(env):
+    """test/sql/ts_forecast_ets_model.test: ETS with and without a `model` parameter through ts_forecast_by (two groups of 84
+    days, horizon 7 -> 14 rows), the four rejected notations and the two parameter errors."""
+    api, O, lib, synth = env
+    i = np.arange(84)
+    y = np.concatenate([100.0 + i * 0.5 + np.sin(i * 2 * 3.14159 / 7) * 10, 200.0 + i * 0.3 + np.cos(i * 2 * 3.14159 / 7) * 15])
+    grp = np.array(["A"] * 84 + ["B"] * 84, dtype=object)
+    ds = np.concatenate([np.datetime64("2024-01-01T00:00:00", "us") + i.astype("timedelta64[D]")] * 2)
+    for params in ({}, {"model": "AAA"}, {"model": "ANN"}, {"confidence_level": "0.95"}):
+        out = api.ts_forecast_by(grp, ds, y, "ETS", 7, "1d", params)
+        assert len(out["yhat"]) == 14 and np.all(np.asarray(out["yhat"]) > 0), params
+        assert out["ds"][0] == np.datetime64("2024-03-25T00:00:00", "us")
+        for g in ("A", "B"):
+            oo = O.make_options("ETS", 7, ets_model=params.get("model", ""), confidence_level=float(params.get("confidence_level", 0.90)))
+            ref = O.forecast(y[grp == g], oo)
+            sel = np.array(out["id"], dtype=object) == g
+            np.testing.assert_allclose(np.asarray(out["yhat"])[sel], ref["point"], rtol=REL_TOL)
+            np.testing.assert_allclose(np.asarray(out["yhat_upper"])[sel], ref["upper"], rtol=REL_TOL)
+    for spec, msg in (("XYZ", "Invalid ETS model specification"), ("123", "Invalid ETS model specification"), ("MAA", "unstable"), ("MAdA", "unstable")):
+        with pytest.raises(api.InvalidInputException, match=msg):
+            api.ts_forecast_by(grp, ds, y, "ETS", 7, "1d", {"model": spec})
+    with pytest.raises(api.InvalidInputException, match="only valid when method='ETS'"):
+        api.ts_forecast_by(grp, ds, y, "Naive", 7, "1d", {"model": "AAA"})
+    with pytest.raises(api.InvalidInputException, match="Unknown parameter"):
+        api.ts_forecast_by(grp, ds, y, "ETS", 7, "1d", {"methd": "AAA"})
+    agg = api.ts_forecast_agg(grp, ds, y, "ETS", 7, {})
+    assert len(agg) == 2
