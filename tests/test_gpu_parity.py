@@ -720,3 +720,46 @@ def test_ets_model_parameter_replay(env):
         api.ts_forecast_by(grp, ds, y, "ETS", 7, "1d", {"methd": "AAA"})
     agg = api.ts_forecast_agg(grp, ds, y, "ETS", 7, {})
     assert len(agg) == 2
+
+
+def test_ts_forecast_by_sql_replay(env):
+    """test/sql/ts_forecast_by.test for the models on the path: row counts, distinct steps and ids, model names, forecast
+    dates after the data, parameter maps (typed values), frequency spellings, interval ordering, horizons 1 and 30."""
+    api, O, lib, synth = env
+    i = np.arange(60)
+    g_grp = np.array(["A"] * 60 + ["B"] * 60, dtype=object)
+    g_ds = np.concatenate([np.datetime64("2024-01-01T00:00:00", "us") + i.astype("timedelta64[D]")] * 2)
+    g_y = np.concatenate([10.0 + i * 0.5 + np.sin(i * 3.14159 / 7) * 2, 20.0 + i * 0.3 + np.cos(i * 3.14159 / 7) * 3])
+    j = np.arange(84)
+    s_grp = np.array(["S1"] * 84 + ["S2"] * 84, dtype=object)
+    s_ds = np.concatenate([np.datetime64("2024-01-01T00:00:00", "us") + j.astype("timedelta64[D]")] * 2)
+    s_y = np.concatenate([100 + np.sin(j * 2 * 3.14159 / 7) * 20 + j * 0.1, 200 + np.cos(j * 2 * 3.14159 / 7) * 30 + j * 0.2])
+    G, S = (g_grp, g_ds, g_y), (s_grp, s_ds, s_y)
+    out = api.ts_forecast_by(*G, "Naive", 5, "1d", {})
+    assert len(out["yhat"]) == 10 and list(out.keys()) == ["id", "forecast_step", "ds", "yhat", "yhat_lower", "yhat_upper", "model_name"]
+    out = api.ts_forecast_by(*G, "Naive", 7, "1d", {})
+    assert len(set(out["forecast_step"])) == 7
+    out = api.ts_forecast_by(*G, "Naive", 3, "1d", {})
+    assert len(set(out["id"])) == 2 and len(out["yhat"]) == 6
+    assert int(np.sum(out["ds"] > np.datetime64("2024-02-29T00:00:00", "us"))) == 6          # forecasts lie after the data
+    assert int(np.sum((out["yhat_lower"] <= out["yhat"]) & (out["yhat"] <= out["yhat_upper"]))) == 6
+    for table, model, h, rows in ((G, "Naive", 3, 6), (G, "SMA", 3, 6), (S, "SeasonalNaive", 7, 14), (G, "SES", 3, 6), (G, "SESOptimized", 3, 6),
+                                  (G, "RandomWalkDrift", 3, 6), (G, "Holt", 3, 6), (S, "HoltWinters", 7, 14), (S, "SeasonalES", 7, 14),
+                                  (S, "SeasonalESOptimized", 7, 14), (G, "ETS", 3, 6), (G, "ARIMA", 3, 6)):
+        out = api.ts_forecast_by(*table, model, h, "1d", {})
+        assert len(out["yhat"]) == rows and out["model_name"][0] == model, model
+    for model in ("AutoETS", "AutoARIMA"):
+        out = api.ts_forecast_by(*G, model, 3, "1d", {})
+        assert len(out["yhat"]) == 6 and out["model_name"][0]
+    assert len(api.ts_forecast_by(*G, "Naive", 3, "1d", {"confidence_level": 0.80})["yhat"]) == 6          # typed MAP values
+    assert len(api.ts_forecast_by(*S, "SeasonalNaive", 7, "1d", {"seasonal_period": 7})["yhat"]) == 14
+    assert len(api.ts_forecast_by(*S, "HoltWinters", 7, "1d", {"confidence_level": 0.95, "seasonal_period": 7})["yhat"]) == 14
+    for freq in ("1d", "1 day", "1w"):
+        assert len(api.ts_forecast_by(*G, "Naive", 3, freq, {})["yhat"]) == 6
+    out = api.ts_forecast_by(*G, "Naive", 3, "1w", {})
+    assert out["ds"][0] == np.datetime64("2024-03-07T00:00:00", "us")                          # last day 2024-02-29 + one week
+    out = api.ts_forecast_by(*G, "Naive", 5, "1d", {})
+    assert min(out["forecast_step"]) == 1 and max(out["forecast_step"]) == 5
+    assert len(api.ts_forecast_by(*G, "Naive", 1, "1d", {})["yhat"]) == 2
+    assert len(api.ts_forecast_by(*G, "Naive", 30, "1d", {})["yhat"]) == 60
+    assert len(api.ts_forecast_by(*G, "ETS", 5, "1d", {"model": "AAA"})["yhat"]) == 10
