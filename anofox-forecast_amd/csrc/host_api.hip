@@ -468,6 +468,16 @@ __global__ void fallback_plan_kernel(int n, const int32_t *len, int period, uint
     mask[s] = (period > 1 && L >= 2 * period) ? 1u : (L >= 10 ? 2u : 3u);
 }
 
+// HoltWinters: 1 = two full seasons or more (seasonal fit), 2 = shorter (Holt); an unsupported period fails the long series
+__global__ void holt_winters_plan_kernel(int n, const int32_t *len, int m, uint32_t *mask, int32_t *detail)
+{
+    int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= n) return;
+    const int L = len[s];
+    mask[s] = L <= 0 ? 0u : (L >= 2 * m ? 1u : 2u);
+    if (L > 0) detail[s] = FIT_PERIOD;        // overwritten by the stage that fits the series
+}
+
 void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const int32_t *d_len, int m, bool skip_constant,
                       hipStream_t st)
 {
@@ -662,9 +672,11 @@ void run_group(AnofoxHipBatch *b, int period, const int32_t *d_len, hipStream_t 
     case M_HoltWinters: {
         int m = std::max(period, 2);
         prep(1, false);
-        if (m > ETS_MAX_PERIOD) { // every series fails like a too-short one
-            HIPCHECK(hipMemsetAsync(b->d_detail, 0xff, ld * sizeof(int32_t), st));
-        } else run_classic(b, CK_HW, d_len, m, 1, 0.0, 2 * m, nullptr, 0, 0, false, st);
+        // fewer than two seasons -> Holt's linear trend under the same name (the crate's fallback, pinned by
+        // test/sql/ts_forecast_exp_smoothing.test:498-503 and ts_forecast_params.test:203-207)
+        hipLaunchKernelGGL(holt_winters_plan_kernel, dim3(blocks256), dim3(256), 0, st, (int)n, d_len, m, b->d_mask, b->d_detail);
+        if (m <= ETS_MAX_PERIOD) run_classic(b, CK_HW, d_len, m, 1, 0.0, 2 * m, b->d_mask, 1u, 0, false, st);
+        run_classic(b, CK_HOLT, d_len, 1, 1, 0.0, 0, b->d_mask, 2u, 0, false, st);
         finish();
         break;
     }

@@ -340,8 +340,12 @@ static int m_holt(const double *y, size_t n, int h, double *out, Err *err)
 static int m_holt_winters(const double *y, size_t n, int h, size_t period, double *out, Err *err)
 {
     size_t m = period < 2 ? 2 : period;
-    if (m > ETS_MAX_PERIOD || n < 2 * m)
-        FAIL(err, COMPUTATION_ERROR, "Computation error: HoltWinters fit failed: need at least %zu observations for period %zu, got %zu", 2 * m, m, n);
+    /* fewer than two seasons: the crate's Holt-Winters falls back to Holt's linear trend (pinned by
+     * test/sql/ts_forecast_exp_smoothing.test:498-503 and test/sql/ts_forecast_params.test:203-207: 10 observations,
+     * seasonal_period 7, rows are returned); the caller still names the result "HoltWinters" */
+    if (n < 2 * m) return m_holt(y, n, h, out, err);
+    if (m > ETS_MAX_PERIOD)
+        FAIL(err, COMPUTATION_ERROR, "Computation error: HoltWinters fit failed: unsupported seasonal period");
     SeriesCtx c = { y, n, m };
     double x0[3] = { 0.3, 0.1, 0.1 };
     NmResult r;

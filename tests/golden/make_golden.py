@@ -57,6 +57,12 @@ cases += [
      "options": SCALAR_OPTS, "check": "abs_all", "tol": 0.01, "expected": [5.0, 5.0, 5.0]},
     {"source": "test/sql/ts_forecast_auto.test:98", "model": "AutoETS", "values": [42.0] * 30, "horizon": 5,
      "options": SCALAR_OPTS, "check": "abs_all", "tol": 1.0, "expected": [42.0] * 5},
+    # ts_forecast_by(grouped_data, ..., 'HoltWinters', 3, '1d', MAP{confidence_level: 0.95, seasonal_period: 7}) returns 3 rows per
+    # group although a group has 10 observations (< 2 seasons): the fit does not fail (exp_smoothing.test:498-503 says why)
+    {"source": "test/sql/ts_forecast_params.test:203-207", "model": "HoltWinters", "values": [10.0 + 2.0 * i for i in range(10)], "horizon": 3,
+     "options": {"confidence_level": 0.95, "seasonal_period": 7, "auto_detect": False}, "check": "n_points", "expected": 3},
+    {"source": "test/sql/ts_forecast_params.test:203-207", "model": "HoltWinters", "values": [100.0 + 5.0 * i for i in range(10)], "horizon": 3,
+     "options": {"confidence_level": 0.95, "seasonal_period": 7, "auto_detect": False}, "check": "n_points", "expected": 3},
     {"source": "crates/anofox-fcst-ffi/tests/core_ffi_parity.rs:680-704", "model": "ARIMA", "values": seasonal_data(), "horizon": 5,
      "options": {"confidence_level": 0.95, "seasonal_period": 0, "auto_detect": False}, "check": "bits_all",
      "expected": toy_arima_expected(seasonal_data(), 5)},

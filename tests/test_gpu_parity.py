@@ -763,3 +763,44 @@ def test_ts_forecast_by_sql_replay(env):
     assert len(api.ts_forecast_by(*G, "Naive", 1, "1d", {})["yhat"]) == 2
     assert len(api.ts_forecast_by(*G, "Naive", 30, "1d", {})["yhat"]) == 60
     assert len(api.ts_forecast_by(*G, "ETS", 5, "1d", {"model": "AAA"})["yhat"]) == 10
+
+
+def test_ts_forecast_params_sql_replay(env):
+    """test/sql/ts_forecast_params.test: interval shape, SeasonalNaive / auto aliases on the LIST form, parameter maps and
+    every frequency spelling through ts_forecast_by on DATE columns, the aggregate with and without params, horizons 0 / 1 / 24,
+    and Holt-Winters on 10 observations with seasonal_period 7 (falls back to Holt: rows are returned)."""
+    api, O, lib, synth = env
+    trend = np.arange(10.0, 34.0, 2.0)
+    seasonal = np.array([10.0, 20.0, 30.0] * 6)
+    scalar = dict(seasonal_period=0, confidence_level=0.95, auto_detect=False, include_fitted=True, include_residuals=True)
+    f = lambda v, h, model: api.forecast_series(v, lib.make_options(model, h, **scalar))
+    r = f(trend, 3, "Naive")
+    assert len(r["lower"]) == 3 and len(r["upper"]) == 3 and r["lower"][0] < r["point"][0] < r["upper"][0]
+    r = f(seasonal, 3, "SeasonalNaive")
+    assert r["model_name"] == "SeasonalNaive" and np.all(np.abs(r["point"] - 30.0) < 0.01) and len(f(seasonal, 6, "SeasonalNaive")["point"]) == 6
+    for model in ("auto", "AutoETS", "AutoARIMA"):
+        r = f(trend, 3, model)
+        assert r["ok"] and len(r["point"]) == 3 and len(r["model_name"]) > 0
+    for model, v, h in (("SESOptimized", trend, 3), ("Holt", trend, 3), ("HoltWinters", seasonal, 6), ("Naive", trend, 24), ("Naive", trend, 1)):
+        assert len(f(v, h, model)["point"]) == h
+    r = f(trend, 0, "Naive")
+    assert r["ok"] and len(r["point"]) == 0
+    assert len(f(np.array([10.0, 20.0, 30.0]), 1, "Naive")["point"]) == 1
+    assert len(f(np.array([10.0, 20.0, 10.0, 20.0]), 2, "SeasonalNaive")["point"]) == 2
+    r = f(trend, 3, "Naive")
+    assert r["mse"] >= 0
+    grp = np.array(["A"] * 10 + ["B"] * 10, dtype=object)
+    ds = np.concatenate([np.datetime64("2024-01-01", "D") + np.arange(10).astype("timedelta64[D]")] * 2)
+    y = np.concatenate([10.0 + 2.0 * np.arange(10), 100.0 + 5.0 * np.arange(10)])
+    for model, params in (("Naive", {"confidence_level": 0.80}), ("SeasonalNaive", {"seasonal_period": 7}),
+                          ("HoltWinters", {"confidence_level": 0.95, "seasonal_period": 7}), ("Naive", {})):
+        out = api.ts_forecast_by(grp, ds, y, model, 3, "1d", params)
+        assert len(out["yhat"]) == 6 and set(out["model_name"]) == {model}, (model, params)
+        assert out["ds"].dtype == ds.dtype and out["ds"][0] == np.datetime64("2024-01-11", "D")
+    hw = api.ts_forecast_by(grp, ds, y, "HoltWinters", 3, "1d", {"confidence_level": 0.95, "seasonal_period": 7})
+    holt = api.ts_forecast_by(grp, ds, y, "Holt", 3, "1d", {"confidence_level": 0.95})
+    np.testing.assert_array_equal(hw["yhat"], holt["yhat"])          # fewer than two seasons: Holt's numbers under the HoltWinters name
+    for freq in ("1d", "1 day", "1w", "1h", "30m", "1mo", "1q", "1y"):
+        assert len(api.ts_forecast_by(grp, ds, y, "Naive", 3, freq, {})["yhat"]) == 6, freq
+    for params in ({"confidence_level": 0.80}, {}):
+        assert len(api.ts_forecast_agg(grp, ds, y, "Naive", 3, params)) == 2

@@ -41,6 +41,8 @@ def test_known_answers(oracle, case):
             assert round(got, 6) == exp, (got, exp)
     elif case["check"] == "abs_all":
         assert np.all(np.abs(r["point"] - np.array(case["expected"])) < case["tol"])
+    elif case["check"] == "n_points":
+        assert len(r["point"]) == case["expected"] and np.all(np.isfinite(r["point"])) and r["model_name"] == case["model"]
     elif case["check"] == "bits_all":
         assert list(r["point"]) == case["expected"]
 
