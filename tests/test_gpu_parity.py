@@ -804,3 +804,31 @@ def test_ts_forecast_params_sql_replay(env):
         assert len(api.ts_forecast_by(grp, ds, y, "Naive", 3, freq, {})["yhat"]) == 6, freq
     for params in ({"confidence_level": 0.80}, {}):
         assert len(api.ts_forecast_agg(grp, ds, y, "Naive", 3, params)) == 2
+
+
+def test_param_grid_sql_replay(env):
+    """test/sql/ts_forecast_param_grid.test for the models on the path: every row non-NULL for SMA windows, seasonal periods,
+    five ETS notations and horizons 1..20 (values arrive as strings like the SQL MAP does), and the three
+    "different parameter -> different forecast" checks; each configuration also against the oracle."""
+    api, O, lib, synth = env
+    grp, ds, y, _ = _model_name_tables()
+
+    def run(model, h, params):
+        out = api.ts_forecast_by(grp, ds, y, model, h, "1d", params)
+        assert len(out["yhat"]) == 2 * h and np.all(np.isfinite(out["yhat"])), (model, params)
+        oo = O.make_options(model, h, ets_model=params.get("model", ""), seasonal_period=int(params.get("seasonal_period", 0)),
+                            window=int(params.get("window", 0)))
+        for g in ("G1", "G2"):
+            ref = O.forecast(y[grp == g], oo)
+            np.testing.assert_allclose(np.asarray(out["yhat"])[np.array(out["id"], dtype=object) == g], ref["point"], rtol=REL_TOL)
+        return round(float(np.sum(out["yhat"])), 4)
+    sums = {w: run("SMA", 3, {"window": str(w)}) for w in (3, 5, 12, 30)}
+    assert sums[3] != sums[30]
+    sums = {p: run("SeasonalNaive", 3, {"seasonal_period": str(p)}) for p in (4, 7, 12)}
+    assert sums[4] != sums[12]
+    for model in ("HoltWinters", "SeasonalES", "SeasonalESOptimized", "AutoETS", "AutoARIMA"):
+        run(model, 3, {"seasonal_period": "7"})
+    sums = {spec: run("ETS", 3, {"model": spec, "seasonal_period": "7"}) for spec in ("AAA", "ANA", "MNM", "AAdA", "MAdM")}
+    assert sums["AAA"] != sums["ANA"]
+    for h in (1, 3, 10, 20):
+        run("Naive", h, {})
