@@ -411,7 +411,7 @@ def ts_forecast_agg(group, date, value, method="auto", horizon=12, params=None):
         h = len(r["point"])
         out[k] = {"forecast_step": list(range(1, h + 1)), "forecast_timestamp": [ts[-1] + (j + 1) * step for j in range(h)],
                   "point_forecast": r["point"], "lower_90": r["lower"], "upper_90": r["upper"], "model_name": r["model_name"],
-                  "insample_fitted": r.get("fitted", np.array([])), "date_col_name": "date", "error_message": None}
+                  "insample_fitted": r.get("fitted", np.array([])), "date_col_name": "date", "error_message": ""}      # '' on success (`:534-536`)
     return out
 
 

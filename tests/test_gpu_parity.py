@@ -832,3 +832,38 @@ def test_param_grid_sql_replay(env):
     assert sums["AAA"] != sums["ANA"]
     for h in (1, 3, 10, 20):
         run("Naive", h, {})
+
+
+def test_ts_forecast_agg_sql_replay(env):
+    """test/sql/ts_forecast_agg.test for the models on the path: one struct per group, the nine fields and their lengths,
+    steps 1..h, timestamps after the data, '' as the success message, model names, interval ordering, the Naive value."""
+    api, O, lib, synth = env
+    i = np.arange(30)
+    t0 = np.datetime64("2024-01-01T00:00:00", "us")
+    sales = (np.array(["A"] * 30 + ["B"] * 30, dtype=object), np.concatenate([t0 + i.astype("timedelta64[D]")] * 2),
+             np.concatenate([10.0 + i * 0.5, 20.0 + i * 0.3]))
+    k = np.arange(40)
+    single = (np.array(["only"] * 40, dtype=object), t0 + k.astype("timedelta64[D]"), 50.0 + k * 0.2)
+    j = np.arange(56)
+    s1 = (np.array(["S1"] * 56, dtype=object), t0 + j.astype("timedelta64[D]"), 100 + np.sin(j * 2 * 3.14159 / 7) * 20 + j * 0.1)
+    out = api.ts_forecast_agg(*sales, "Naive", 5, {})
+    assert len(out) == 2 and [len(out[g]["point_forecast"]) for g in ("A", "B")] == [5, 5]
+    assert out["A"]["point_forecast"][0] != out["B"]["point_forecast"][0]
+    f = api.ts_forecast_agg(*single, "Naive", 5, {})["only"]
+    assert list(f.keys()) == ["forecast_step", "forecast_timestamp", "point_forecast", "lower_90", "upper_90", "model_name", "insample_fitted",
+                              "date_col_name", "error_message"]
+    assert [len(f[c]) for c in ("forecast_step", "forecast_timestamp", "point_forecast", "lower_90", "upper_90")] == [5] * 5
+    assert f["model_name"] == "Naive" and len(f["insample_fitted"]) == 40 and f["date_col_name"] is not None and f["error_message"] == ""
+    assert f["forecast_step"][0] == 1 and f["forecast_step"][4] == 5
+    assert f["forecast_timestamp"][0] > (np.datetime64("2024-02-09T00:00:00", "us") - np.datetime64(0, "us")).astype(np.int64)
+    assert np.all((f["lower_90"] <= f["point_forecast"]) & (f["point_forecast"] <= f["upper_90"]))
+    for model in ("Naive", "SMA", "SES", "SESOptimized", "RandomWalkDrift", "Holt", "ETS", "ARIMA"):
+        assert api.ts_forecast_agg(*single, model, 3, {})["only"]["model_name"] == model
+    for model in ("AutoETS", "AutoARIMA"):
+        assert api.ts_forecast_agg(*single, model, 3, {})["only"]["model_name"]
+    assert api.ts_forecast_agg(*s1, "HoltWinters", 7, {})["S1"]["model_name"] == "HoltWinters"
+    assert [api.ts_forecast_agg(*sales, "SES", 3, {})[g]["model_name"] for g in ("A", "B")] == ["SES", "SES"]
+    assert [len(api.ts_forecast_agg(*sales, "SES", 3, {})[g]["insample_fitted"]) for g in ("A", "B")] == [30, 30]
+    for h in (1, 12, 24):
+        assert len(api.ts_forecast_agg(*single, "Naive", h, {})["only"]["point_forecast"]) == h
+    assert abs(api.ts_forecast_agg(*single, "Naive", 1, {})["only"]["point_forecast"][0] - 57.8) < 0.1
