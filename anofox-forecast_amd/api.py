@@ -531,14 +531,16 @@ def ts_forecast_inspect_by(group, date, target, method, params=None):
 
 def ts_forecast_explain_by(group, date, target, method, horizon, params=None):
     """ts_forecast_explain_by(source, group_col, date_col, target_col, method, horizon, params := MAP{}) (ts_macros.cpp:674-716,
-    forecast.rs:1899-2017).  Supported here: ETS with a fixed spec.  Per group: horizon and the level / trend / seasonal
+    forecast.rs:1899-2017).  Supported here: ETS (spec from params['model'], "AAA" when absent).  Per group: horizon and the level / trend / seasonal
     contribution of every forecast step from the final states of the fit (additive components add up to yhat,
     multiplicative ones multiply up to it).  Unpinned like the inspection."""
     b = bind(method, horizon, "1d", params)
     if b.method not in EXPLAINABLE:
-        raise InvalidInputException(f"Invalid model: Model '{b.method}' does not implement Explainable. Supported models: ETS, MSTL, Theta.")
-    if b.method != "ETS" or not b.model_spec:
+        raise InvalidInputException(f"Invalid model: Model '{b.method}' does not implement Explainable. Supported models: ETS, MSTL, AutoMSTL, Theta.")
+    if b.method != "ETS":
         raise InvalidInputException(f"Internal error: explanation of '{b.method}' is not implemented by the HIP backend")
+    if not b.model_spec:
+        b.model_spec = "AAA"                   # forecast.rs:1932: `options.ets_spec.as_deref().unwrap_or("AAA")`
     order, series, valids = _collect_groups(group, date, target)
     res = inspect_batch(series, options_from_bind(b), valids)
     spec = b.model_spec

@@ -867,3 +867,35 @@ def test_ts_forecast_agg_sql_replay(env):
     for h in (1, 12, 24):
         assert len(api.ts_forecast_agg(*single, "Naive", h, {})["only"]["point_forecast"]) == h
     assert abs(api.ts_forecast_agg(*single, "Naive", 1, {})["only"]["point_forecast"][0] - 57.8) < 0.1
+
+
+def test_inspect_explain_sql_replay(env):
+    """test/sql/ts_forecast_inspect_explain.test for the models on the path: the three-product monthly panel (`:13-19`), the
+    inspection fields of AutoETS / AutoARIMA (incl. the pinned order_p = 0), the ETS decomposition lengths for horizons
+    12 / 8, and the four "does not implement" errors."""
+    api, O, lib, synth = env
+    k = np.arange(60)
+    one = 10.0 + 3.0 * np.sin(2 * np.pi * (k % 12) / 12.0) + 0.05 * k
+    grp = np.repeat(np.array(["A", "B", "C"], dtype=object), 60)
+    months = np.datetime64("2024-01", "M") + k.astype("timedelta64[M]")
+    ds = np.tile(months.astype("datetime64[D]"), 3)
+    y = np.tile(one, 3)
+    insp = api.ts_forecast_inspect_by(grp, ds, y, "AutoETS", {"seasonal_period": 12})
+    assert sorted(insp) == ["A", "B", "C"]
+    for g in "ABC":
+        assert insp[g]["model_family"] == "Ets" and insp[g]["seasonal_period"] == 12 and len(insp[g]["fitted_values"]) == 60
+    assert insp["A"]["spec"] is not None and insp["A"]["order_p"] is None
+    ar = api.ts_forecast_inspect_by(grp, ds, y, "AutoARIMA", {"seasonal_period": 12})
+    for g in "ABC":
+        assert ar[g]["model_family"] == "Arima" and ar[g]["aic"] is not None
+    assert ar["A"]["spec"] is None and ar["A"]["order_p"] == 0
+    for model, params in (("Naive", {}), ("SeasonalNaive", {"seasonal_period": 12})):
+        with pytest.raises(api.InvalidInputException, match="does not implement Inspectable"):
+            api.ts_forecast_inspect_by(grp, ds, y, model, params)
+    for h in (12, 8):
+        ex = api.ts_forecast_explain_by(grp, ds, y, "ETS", h, {"seasonal_period": 12})
+        for g in "ABC":
+            assert ex[g]["horizon"] == h and len(ex[g]["level"]) == h and len(ex[g]["trend"]) == h and len(ex[g]["seasonal"]) == h
+    for model, params in (("AutoETS", {"seasonal_period": 12}), ("Naive", {})):
+        with pytest.raises(api.InvalidInputException, match="does not implement Explainable"):
+            api.ts_forecast_explain_by(grp, ds, y, model, 12, params)
