@@ -60,11 +60,11 @@ def take_calls(sql):
                     break
             q += 1
         args = out[p + len("_ts_forecast("):q]
-        m = re.fullmatch(r"\s*\[([^\]]*)\]\s*,\s*(\d+)\s*,\s*'([^']*)'\s*", args)
+        m = re.fullmatch(r"\s*\[([^\]]*)\](?:::DOUBLE\[\])?\s*,\s*(\d+)\s*(?:,\s*'([^']*)'\s*)?", args)
         if not m:
             return None
         vals = []
-        for tok in m.group(1).split(","):
+        for tok in ([] if not m.group(1).strip() else m.group(1).split(",")):
             tok = tok.strip().replace("::DOUBLE", "")
             if tok.upper() == "NULL":
                 vals.append(None)
@@ -72,7 +72,7 @@ def take_calls(sql):
                 vals.append(float(tok))
             else:
                 return None
-        key = (tuple(vals), int(m.group(2)), m.group(3))
+        key = (tuple(vals), int(m.group(2)), m.group(3) if m.group(3) is not None else "auto")      # ts_forecast.cpp:380: default "auto"
         if key not in calls:
             calls.append(key)
         name = f"F{calls.index(key)}"
@@ -95,6 +95,9 @@ PATTERNS = [
     (rf"SELECT F0\.(point|lower|upper)\[(\d+)\] IS NOT NULL;?", lambda m: ("not_null", {"field": m.group(1), "k": int(m.group(2))})),
     (rf"SELECT F0\.(model|aic|bic|mse) IS NOT NULL;?", lambda m: ("scalar_not_null", {"field": m.group(1)})),
     (rf"SELECT F0\.mse >= 0;?", lambda m: ("mse_not_negative", {})),
+    (rf"SELECT F0 IS (NOT )?NULL;?", lambda m: ("struct_is_null", {"negated": m.group(1) is not None})),
+    (rf"SELECT isnan\(F0\.(point|lower|upper)\[(\d+)\]\);?", lambda m: ("is_nan", {"field": m.group(1), "k": int(m.group(2))})),
+    (rf"SELECT ABS\(F0\.(point|lower|upper)\[(\d+)\]\) (<|>) ({NUM});?", lambda m: ("near_const", {"field": m.group(1), "k": int(m.group(2)), "c": 0.0, "op": m.group(3), "tol": float(m.group(4))})),
     (rf"SELECT ROUND\(F0\.(point|lower|upper)\[(\d+)\], (\d+)\);?", lambda m: ("round", {"field": m.group(1), "k": int(m.group(2)), "digits": int(m.group(3))})),
 ]
 

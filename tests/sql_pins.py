@@ -35,9 +35,17 @@ def check_pin(case, run):
         vals = np.array([0.0 if v is None else v for v in c["values"]], dtype=np.float64)
         valid = np.array([v is not None for v in c["values"]], dtype=bool)
         r = run(vals, None if valid.all() else valid, c["horizon"], c["model"])
-        assert r["ok"], (case["source"], r)
         res.append(r)
     r0, kind, exp = res[0], case["check"], case["expected"]
+    if kind == "struct_is_null":
+        # the scalar returns a NULL struct for every failure except INVALID_INPUT (2) / INVALID_MODEL (5), which raise
+        # (src/table_functions/ts_forecast.cpp:425-432)
+        assert r0["ok"] or r0["code"] not in (2, 5), (case["source"], r0)
+        got = (not r0["ok"]) != case["negated"]
+        assert got == exp, (case["source"], kind, r0.get("code"), exp)
+        return
+    for r in res:
+        assert r["ok"], (case["source"], r)
     if kind == "model_name":
         got = r0["model_name"]
     elif kind == "length":
@@ -51,6 +59,9 @@ def check_pin(case, run):
         got = _cmp(_at(r0, case["field"], case["k"]), case["op"], _at(res[case["rhs_call"]], case["rhs_field"], case["rhs_k"]))
     elif kind == "near_fields":
         got = _cmp(abs(_at(r0, case["field"], case["k"]) - _at(res[case["rhs_call"]], case["rhs_field"], case["rhs_k"])), case["op"], case["tol"])
+    elif kind == "is_nan":
+        v = _at(r0, case["field"], case["k"])
+        got = v is not None and v != v
     elif kind == "not_null":
         got = _at(r0, case["field"], case["k"]) is not None
     elif kind == "scalar_not_null":

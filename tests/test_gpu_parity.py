@@ -634,7 +634,7 @@ def test_refused_allocation_is_reported_and_recoverable(env):
 
 
 def test_reference_sql_pins_on_the_hip_path(env):
-    """The 178 pins the reference's sqllogictest files hold on `_ts_forecast(values, horizon, model)` for the models on the
+    """The 251 pins the reference's sqllogictest files hold on `_ts_forecast(values, horizon, model)` for the models on the
     path (tests/golden/reference_sql_pins.json; model names, lengths, orderings, tolerances), replayed through
     anofox_ts_forecast with the scalar's options (ts_forecast.cpp:406-411)."""
     import sql_pins
