@@ -899,3 +899,53 @@ def test_inspect_explain_sql_replay(env):
     for model, params in (("AutoETS", {"seasonal_period": 12}), ("Naive", {})):
         with pytest.raises(api.InvalidInputException, match="does not implement Explainable"):
             api.ts_forecast_explain_by(grp, ds, y, model, 12, params)
+
+
+def test_error_isolation_batches_sql_replay(env):
+    """test/sql/ts_forecast_error_isolation.test, the table-driven parts: the 100-series mixed batch (`:218-280`: 85 structs,
+    80 three-point forecasts), the 1000-series scale batch (`:287-355`: 960 five-point forecasts) and the consecutive-error
+    rows (`:371-395`), each as ONE call of the batch entry with the scalar's default model and options."""
+    api, O, lib, synth = env
+    opts = lambda h: lib.make_options("auto", h, seasonal_period=0, confidence_level=0.95, auto_detect=False, include_fitted=True,
+                                      include_residuals=True)
+    series, valids = [], []
+    for i in range(1, 101):
+        if i % 10 == 0:
+            v, ok = [], []
+        elif i % 20 == 5:
+            v, ok = [1.0], [True]
+        elif i % 20 == 15:
+            v, ok = [0.0] * 5, [False] * 5
+        else:
+            v, ok = [float(i + k) for k in range(10)], [True] * 10
+        series.append(np.array(v)); valids.append(np.array(ok, dtype=bool))
+    got, berr = api.forecast_batch(series, opts(3), valids)
+    assert berr["ok"]
+    assert sum(r["ok"] for r in got) == 85
+    assert all(not r["ok"] and r["code"] == lib.INSUFFICIENT_DATA for r, s in zip(got, series) if len(s) <= 1)
+    assert sum(r["ok"] and len(r["point"]) == 3 for r, s in zip(got, series) if len(s) == 10) == 80
+    assert all(r["ok"] and np.all(np.isnan(r["point"])) for r, s in zip(got, series) if len(s) == 5)      # all-NULL: NaN forecasts, not an error
+    for idx in (0, 14, 98):                                                                                # and the oracle agrees
+        ref = O.forecast(series[idx], O.make_options("auto", 3, seasonal_period=0, confidence_level=0.95, auto_detect=False), valids[idx])
+        assert ref["ok"] == got[idx]["ok"] and np.array_equal(ref["point"], got[idx]["point"], equal_nan=True)
+    series = []
+    for i in range(1, 1001):
+        if i % 50 == 0:
+            v = []
+        elif i % 50 == 25:
+            v = [42.0]
+        elif i % 100 == 50:
+            v = [1.0, 2.0]
+        elif i % 20 == 10:
+            v = [1.0, 2.0, 3.0]
+        else:
+            v = [float(np.sin(i + k) * 10) for k in range(10)]
+        series.append(np.array(v))
+    got, berr = api.forecast_batch(series, opts(5))
+    assert berr["ok"] and sum(r["ok"] and len(r["point"]) == 5 for r in got) == 960
+    assert got[0]["ok"] and got[998]["ok"]
+    ten = np.arange(1.0, 11.0)
+    rows = [ten, np.array([]), np.array([]), np.array([]), ten, np.array([1.0]), ten]
+    got, berr = api.forecast_batch(rows, opts(3))
+    assert [r["ok"] for r in got] == [True, False, False, False, True, False, True]
+    assert [len(r["point"]) for r in got if r["ok"]] == [3, 3, 3]
