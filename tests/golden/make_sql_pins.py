@@ -96,6 +96,7 @@ PATTERNS = [
     (rf"SELECT F0\.(model|aic|bic|mse) IS NOT NULL;?", lambda m: ("scalar_not_null", {"field": m.group(1)})),
     (rf"SELECT F0\.mse >= 0;?", lambda m: ("mse_not_negative", {})),
     (rf"SELECT F0 IS (NOT )?NULL;?", lambda m: ("struct_is_null", {"negated": m.group(1) is not None})),
+    (rf"SELECT F0\.upper\[(\d+)\] - F0\.lower\[(\d+)\] (<|>) ({NUM});?", lambda m: ("width_cmp", {"k": int(m.group(1)), "k_lower": int(m.group(2)), "op": m.group(3), "c": float(m.group(4))})),
     (rf"SELECT isnan\(F0\.(point|lower|upper)\[(\d+)\]\);?", lambda m: ("is_nan", {"field": m.group(1), "k": int(m.group(2))})),
     (rf"SELECT ABS\(F0\.(point|lower|upper)\[(\d+)\]\) (<|>) ({NUM});?", lambda m: ("near_const", {"field": m.group(1), "k": int(m.group(2)), "c": 0.0, "op": m.group(3), "tol": float(m.group(4))})),
     (rf"SELECT ROUND\(F0\.(point|lower|upper)\[(\d+)\], (\d+)\);?", lambda m: ("round", {"field": m.group(1), "k": int(m.group(2)), "digits": int(m.group(3))})),

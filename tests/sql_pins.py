@@ -59,6 +59,8 @@ def check_pin(case, run):
         got = _cmp(_at(r0, case["field"], case["k"]), case["op"], _at(res[case["rhs_call"]], case["rhs_field"], case["rhs_k"]))
     elif kind == "near_fields":
         got = _cmp(abs(_at(r0, case["field"], case["k"]) - _at(res[case["rhs_call"]], case["rhs_field"], case["rhs_k"])), case["op"], case["tol"])
+    elif kind == "width_cmp":
+        got = _cmp(_at(r0, "upper", case["k"]) - _at(r0, "lower", case["k_lower"]), case["op"], case["c"])
     elif kind == "is_nan":
         v = _at(r0, case["field"], case["k"])
         got = v is not None and v != v

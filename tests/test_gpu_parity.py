@@ -634,7 +634,7 @@ def test_refused_allocation_is_reported_and_recoverable(env):
 
 
 def test_reference_sql_pins_on_the_hip_path(env):
-    """The 251 pins the reference's sqllogictest files hold on `_ts_forecast(values, horizon, model)` for the models on the
+    """The 252 pins the reference's sqllogictest files hold on `_ts_forecast(values, horizon, model)` for the models on the
     path (tests/golden/reference_sql_pins.json; model names, lengths, orderings, tolerances), replayed through
     anofox_ts_forecast with the scalar's options (ts_forecast.cpp:406-411)."""
     import sql_pins
@@ -949,3 +949,18 @@ def test_error_isolation_batches_sql_replay(env):
     got, berr = api.forecast_batch(rows, opts(3))
     assert [r["ok"] for r in got] == [True, False, False, False, True, False, True]
     assert [len(r["point"]) for r in got if r["ok"]] == [3, 3, 3]
+    # the five-row table of `:787-793` under every model on the path (`:795-895`), and the seasonal one of `:899-906` (`:909-918`)
+    table = [ten, np.array([]), ten[::-1].copy(), np.array([1.0]), np.full(10, 5.0)]
+    for model in ("NAIVE", "SMA", "SES", "RandomWalkDrift", "Holt", "AutoETS", "AutoARIMA"):
+        o = lib.make_options(model, 3, seasonal_period=0, confidence_level=0.95, auto_detect=False, include_fitted=True, include_residuals=True)
+        got, berr = api.forecast_batch(table, o)
+        assert berr["ok"] and [r["ok"] for r in got] == [True, False, True, False, True], model
+    seasonal = [np.array([1.0, 2.0, 3.0, 4.0] * 3), np.array([]), np.array([4.0, 3.0, 2.0, 1.0] * 3), np.array([1.0, 2.0]), np.full(12, 5.0)]
+    o = lib.make_options("HoltWinters", 4, seasonal_period=0, confidence_level=0.95, auto_detect=False, include_fitted=True, include_residuals=True)
+    got, berr = api.forecast_batch(seasonal, o)
+    assert berr["ok"] and [r["ok"] for r in got] == [True, False, True, False, True]
+    scen = {"empty": ([], []), "single": ([1.0], [1]), "double": ([1.0, 2.0], [1, 1]), "triple": ([1.0, 2.0, 3.0], [1, 1, 1]),
+            "all_null": ([0.0] * 5, [0] * 5), "mostly_null": ([0, 0, 5.0, 0, 0], [0, 0, 1, 0, 0]), "constant_zero": ([0.0] * 5, [1] * 5),
+            "constant_pos": ([5.0] * 5, [1] * 5), "constant_neg": ([-5.0] * 5, [1] * 5), "valid_trend": (list(ten), [1] * 10)}      # `:741-753`
+    got, berr = api.forecast_batch([np.array(v, dtype=float) for v, _ in scen.values()], opts(3), [np.array(k, dtype=bool) for _, k in scen.values()])
+    assert sorted(name for name, r in zip(scen, got) if not r["ok"]) == ["double", "empty", "single"]
