@@ -964,3 +964,32 @@ def test_error_isolation_batches_sql_replay(env):
             "constant_pos": ([5.0] * 5, [1] * 5), "constant_neg": ([-5.0] * 5, [1] * 5), "valid_trend": (list(ten), [1] * 10)}      # `:741-753`
     got, berr = api.forecast_batch([np.array(v, dtype=float) for v, _ in scen.values()], opts(3), [np.array(k, dtype=bool) for _, k in scen.values()])
     assert sorted(name for name, r in zip(scen, got) if not r["ok"]) == ["double", "empty", "single"]
+
+
+def test_native_param_validation_sql_replay(env):
+    """test/sql/ts_native_param_validation.test for the models on the path: the bind-time and model-time errors (tested
+    substrings) of _ts_forecast_native and _ts_cv_forecast_native, and the configurations that must return all 6 rows."""
+    api, O, lib, synth = env
+    grp, ds, y, i = _model_name_tables()
+    keep = i < 48
+    split = np.where(i[keep] < 45, "train", "test").astype(object)
+    fold = np.ones(int(keep.sum()), dtype=np.int64)
+    fb = lambda model, params: api.ts_forecast_by(grp, ds, y, model, 3, "1d", params)
+    cv = lambda model, params: api.ts_cv_forecast_by(fold, split, grp[keep], ds[keep], y[keep], model, params)
+    bad = [(fb, "AutoETS", {"methd": "ETS"}, "Unknown parameter"), (fb, "AutoETS", {"foo": "1", "bar": "2"}, "Unknown parameter"),
+           (cv, "AutoETS", {"methd": "ETS"}, "Unknown parameter"),
+           (fb, "AutoETS", {"confidence_level": "0.0"}, "Invalid confidence_level"), (fb, "AutoETS", {"confidence_level": "-0.5"}, "Invalid confidence_level"),
+           (fb, "AutoETS", {"confidence_level": "1.0"}, "Invalid confidence_level"), (fb, "AutoETS", {"confidence_level": "5.0"}, "Invalid confidence_level"),
+           (cv, "AutoETS", {"confidence_level": "1.5"}, "Invalid confidence_level"),
+           (fb, "Naive", {"model": "AAA"}, "only valid when method='ETS'"), (cv, "Holt", {"model": "ANA"}, "only valid when method='ETS'"),
+           (fb, "ETS", {"model": "XYZ"}, "Invalid ETS model specification"), (fb, "ETS", {"model": "AAAAA"}, "Invalid ETS model specification"),
+           (fb, "ETS", {"model": "MAA"}, "unstable"), (fb, "ETS", {"model": "MAdA"}, "unstable"),
+           (fb, "Naive", {"seasonal_period": "7"}, "does not use seasonal_period"), (fb, "SES", {"seasonal_period": "7"}, "does not use seasonal_period"),
+           (fb, "SMA", {"window": "-1"}, "must be a positive integer"), (fb, "Naive", {"window": "5"}, "only valid when method='SMA'"),
+           (fb, "Naive", {"seasonal_periods": "[7]"}, "only valid for multi-seasonal models")]
+    for call, model, params, msg in bad:
+        with pytest.raises(api.InvalidInputException, match=msg):
+            call(model, params)
+    for model, params in (("ETS", {"model": "AAA"}), ("ETS", {}), ("SeasonalNaive", {"seasonal_period": "7"}), ("HoltWinters", {"seasonal_period": "7"}),
+                          ("AutoETS", {"confidence_level": "0.95"}), ("AutoETS", {}), ("SMA", {"window": "12"})):
+        assert len(fb(model, params)["yhat"]) == 6, (model, params)
