@@ -993,3 +993,42 @@ def test_native_param_validation_sql_replay(env):
     for model, params in (("ETS", {"model": "AAA"}), ("ETS", {}), ("SeasonalNaive", {"seasonal_period": "7"}), ("HoltWinters", {"seasonal_period": "7"}),
                           ("AutoETS", {"confidence_level": "0.95"}), ("AutoETS", {}), ("SMA", {"window": "12"})):
         assert len(fb(model, params)["yhat"]) == 6, (model, params)
+
+
+def test_cv_forecast_sql_replay_rest(env):
+    """The remaining pins of test/sql/ts_cv_forecast.test: DATE dates keep their type (`:118-131`), the Drift alias names its
+    model and differs from Naive (`:139-163`), two series of different length (`:169-190`), one fold, horizon 1, and
+    SeasonalNaive with a STRUCT-style typed parameter (`:243`)."""
+    api, O, lib, synth = env
+    rows = _cv_folds("A", 24, 3, 4)
+    fold, split, grp, t = (np.array(c, dtype=object) for c in zip(*rows))
+    ds = np.array([int(x) + 1 for x in t], dtype=np.int32)
+    y = 10.0 + ds
+    naive = api.ts_cv_forecast_by(fold, split, grp, ds, y, "Naive", {}, group_name="series_id", date_name="ds")
+    drift = api.ts_cv_forecast_by(fold, split, grp, ds, y, "Drift", {}, group_name="series_id", date_name="ds")
+    assert set(drift["model_name"]) == {"RandomWalkDrift"} and np.any(np.abs(naive["yhat"] - drift["yhat"]) > 1e-4)
+    assert np.mean(np.abs(naive["yhat"] - naive["y"])) > 0 and not np.any(np.isnan(naive["yhat"]))
+    sn = api.ts_cv_forecast_by(fold, split, grp, ds, y, "SeasonalNaive", {"seasonal_period": 4})
+    assert len(sn["yhat"]) == 12
+    rows = _cv_folds("A", 18, 2, 3)
+    fold_d, split_d, grp_d, t_d = (np.array(c, dtype=object) for c in zip(*rows))
+    dates = np.datetime64("2023-01-02", "D") + np.array([int(x) for x in t_d]).astype("timedelta64[D]")
+    out = api.ts_cv_forecast_by(fold_d, split_d, grp_d, dates, np.array([float(x) + 1 for x in t_d]), "Naive", {})
+    assert out["date"].dtype == np.dtype("datetime64[D]") and len(out["yhat"]) == 6
+    rows = _cv_folds("A", 20, 2, 3) + _cv_folds("B", 25, 2, 3)
+    f2, s2, g2, t2 = (np.array(c, dtype=object) for c in zip(*rows))
+    d2 = np.array([int(x) + 1 for x in t2], dtype=np.int32)
+    out = api.ts_cv_forecast_by(f2, s2, g2, d2, 10.0 + d2, "Naive", {}, group_name="series_id")
+    counts = {}
+    for g, k in zip(out["series_id"], out["fold_id"]):
+        counts[(g, int(k))] = counts.get((g, int(k)), 0) + 1
+    assert counts == {("A", 1): 3, ("A", 2): 3, ("B", 1): 3, ("B", 2): 3}
+    for n_folds, h, want in ((1, 6, {1: 6}), (3, 1, {1: 1, 2: 1, 3: 1})):
+        rows = _cv_folds("A", 24, n_folds, h)
+        f3, s3, g3, t3 = (np.array(c, dtype=object) for c in zip(*rows))
+        d3 = np.array([int(x) + 1 for x in t3], dtype=np.int32)
+        out = api.ts_cv_forecast_by(f3, s3, g3, d3, 10.0 + d3, "Naive", {})
+        got = {}
+        for k in out["fold_id"]:
+            got[int(k)] = got.get(int(k), 0) + 1
+        assert got == want
