@@ -68,6 +68,42 @@ cases += [
      "expected": toy_arima_expected(seasonal_data(), 5)},
 ]
 
+# the wrapper's own unit tests (crates/anofox-fcst-core/src/forecast.rs, `mod tests`): inputs, options over the Rust default
+# (`:349-366`: AutoETS, confidence 0.95, seasonal_period 0, auto_detect on) and what each test asserts
+RUST_DEFAULT = {"confidence_level": 0.95, "seasonal_period": 0, "auto_detect": True}
+unit = [
+    {"source": "forecast.rs:2702-2713", "model": "Naive", "values": [1.0, 2.0, 3.0, 4.0, 5.0], "horizon": 3, "options": RUST_DEFAULT,
+     "expect": {"n_points": 3, "first": 5.0}},
+    {"source": "forecast.rs:2716-2726", "model": "SES", "values": [float(i) for i in range(20)], "horizon": 5, "options": RUST_DEFAULT,
+     "expect": {"n_points": 5}},
+    {"source": "forecast.rs:2729-2752", "model": "HoltWinters", "values": [100.0 + i * 0.5 + (i % 12) * 2.0 for i in range(48)], "horizon": 12,
+     "options": dict(RUST_DEFAULT, seasonal_period=12, auto_detect=False), "expect": {"n_points": 12, "name": "HoltWinters", "finite": True, "positive": True}},
+    {"source": "forecast.rs:2755-2772", "model": "ARIMA", "values": [100.0 + i * 2.0 + (i % 3) for i in range(30)], "horizon": 5, "options": RUST_DEFAULT,
+     "expect": {"n_points": 5, "name": "ARIMA", "finite": True}},
+    {"source": "forecast.rs:3095-3108", "model": "AutoETS", "values": [50.0 + (i % 7) * 3.0 for i in range(30)], "horizon": 7, "options": RUST_DEFAULT,
+     "expect": {"n_points": 7, "finite": True}},
+    {"source": "forecast.rs:3111-3131", "model": "AutoETS", "values": [42.0] * 30, "horizon": 5, "options": RUST_DEFAULT,
+     "expect": {"n_points": 5, "finite": True, "near": [42.0, 1.0]}},
+    {"source": "forecast.rs:3203-3224", "model": "Naive", "values": [1.0, 2.0, None, 4.0, 5.0, None, 7.0], "horizon": 3, "options": RUST_DEFAULT,
+     "expect": {"n_points": 3, "finite": True}},
+    {"source": "forecast.rs:3227-3244", "model": "SES", "values": [i * 2.0 for i in range(15)], "horizon": 3,
+     "options": dict(RUST_DEFAULT, include_fitted=True, include_residuals=True), "expect": {"n_fitted": 15, "n_residuals": 15, "mse": True}},
+    {"source": "forecast.rs:3247-3253", "model": "AutoETS", "values": [1.0, 2.0], "horizon": 12, "options": RUST_DEFAULT, "expect": {"fails": True}},
+    {"source": "forecast.rs:3345-3362", "model": "ETS", "values": [100.0 + i for i in range(60)], "horizon": 5, "options": RUST_DEFAULT,
+     "expect": {"n_points": 5}},
+    {"source": "forecast.rs:3365-3395", "model": "AutoARIMA", "values": [100.0 + i * 0.5 + 10.0 * math.sin(i * 0.1) for i in range(60)], "horizon": 5,
+     "options": dict(RUST_DEFAULT, seasonal_period=12), "expect": {"n_points": 5, "name_prefix": "AutoARIMA", "finite": True}},
+    {"source": "forecast.rs:3398-3434", "model": "AutoETS", "values": [100.0 + i * 0.5 + 10.0 * math.sin(2.0 * math.pi * i / 12.0) for i in range(48)],
+     "horizon": 5, "options": dict(RUST_DEFAULT, seasonal_period=12), "expect": {"n_points": 5, "name_prefix": "AutoETS", "finite": True}},
+    {"source": "forecast.rs:3437-3468", "model": "AutoARIMA", "values": [100.0 + i * 2.0 + 5.0 * math.sin(i * 0.2) for i in range(50)], "horizon": 5,
+     "options": RUST_DEFAULT, "expect": {"n_points": 5, "name_prefix": "AutoARIMA"}},
+    {"source": "forecast.rs:3437-3468", "model": "ARIMA", "values": [100.0 + i * 2.0 + 5.0 * math.sin(i * 0.2) for i in range(50)], "horizon": 5,
+     "options": RUST_DEFAULT, "expect": {"n_points": 5, "name": "ARIMA"}},
+    # calculate_confidence_intervals (`:3156-3172`) through a model whose forecast is known: bounds strictly around, widening
+    {"source": "forecast.rs:3156-3172", "model": "Naive", "values": [50.0 + i for i in range(20)], "horizon": 3, "options": RUST_DEFAULT,
+     "expect": {"n_points": 3, "interval_strict": True, "interval_widens": True}},
+]
+
 errors = [
     # (source, model, options, expected code, message substring) -- test/sql/ts_native_param_validation.test:126-198
     {"source": "ts_native_param_validation.test:126-139", "model": "ETS", "options": {"ets_model": "XYZ"}, "code": 2, "substr": "Invalid ETS model specification"},
@@ -95,5 +131,5 @@ names = {
 
 here = os.path.dirname(os.path.abspath(__file__))
 with open(os.path.join(here, "reference_kats.json"), "w") as f:
-    json.dump({"cases": cases, "errors": errors, "interpolation": interp, "names": names}, f, indent=1)
+    json.dump({"cases": cases, "errors": errors, "interpolation": interp, "names": names, "unit": unit}, f, indent=1)
 print("wrote", len(cases), "cases,", len(errors), "error cases")

@@ -75,3 +75,35 @@ def check_pin(case, run):
     else:
         raise AssertionError(f"unknown check {kind}")
     assert got == exp, (case["source"], kind, got, exp)
+
+
+def check_unit_case(case, run):
+    """One of the wrapper's own unit tests (reference_kats.json, key "unit"): `run(values, valid, horizon, model, options)`."""
+    vals = np.array([0.0 if v is None else v for v in case["values"]], dtype=np.float64)
+    valid = np.array([v is not None for v in case["values"]], dtype=bool)
+    r = run(vals, None if valid.all() else valid, case["horizon"], case["model"], case["options"])
+    e = case["expect"]
+    if e.get("fails"):
+        assert not r["ok"], (case["source"], r)
+        return
+    assert r["ok"], (case["source"], r)
+    if "n_points" in e:
+        assert len(r["point"]) == e["n_points"]
+    if "first" in e:
+        assert r["point"][0] == e["first"]
+    if "name" in e:
+        assert r["model_name"] == e["name"]
+    if "name_prefix" in e:
+        assert r["model_name"].startswith(e["name_prefix"]), r["model_name"]
+    if e.get("finite"):
+        assert np.all(np.isfinite(r["point"]))
+    if e.get("positive"):
+        assert np.all(r["point"] > 0)
+    if "near" in e:
+        assert np.all(np.abs(r["point"] - e["near"][0]) < e["near"][1])
+    if "n_fitted" in e:
+        assert len(r["fitted"]) == e["n_fitted"] and len(r["residuals"]) == e["n_residuals"] and r["mse"] == r["mse"]
+    if e.get("interval_strict"):
+        assert np.all(r["lower"] < r["point"]) and np.all(r["upper"] > r["point"])
+    if e.get("interval_widens"):
+        assert r["upper"][-1] - r["lower"][-1] > r["upper"][0] - r["lower"][0]

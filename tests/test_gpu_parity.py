@@ -1032,3 +1032,20 @@ def test_cv_forecast_sql_replay_rest(env):
         for k in out["fold_id"]:
             got[int(k)] = got.get(int(k), 0) + 1
         assert got == want
+
+
+def test_wrapper_unit_tests_on_the_hip_path(env):
+    """The assertions of the reference wrapper's own unit tests (forecast.rs `mod tests`, transcribed in
+    tests/golden/reference_kats.json under "unit") through anofox_ts_forecast."""
+    import json, os, sql_pins
+    api, O, lib, synth = env
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_kats.json")))
+
+    def run(values, valid, horizon, model, o):
+        opts = lib.make_options(model, horizon, seasonal_period=o.get("seasonal_period", 0), confidence_level=o.get("confidence_level", 0.90),
+                                auto_detect=o.get("auto_detect"), include_fitted=o.get("include_fitted", False),
+                                include_residuals=o.get("include_residuals", False))
+        return api.forecast_series(values, opts, valid)
+    assert len(gold["unit"]) >= 15
+    for case in gold["unit"]:
+        sql_pins.check_unit_case(case, run)

@@ -151,3 +151,9 @@ def test_reference_sql_pins(oracle, case):
     def run(values, valid, horizon, model):
         return oracle.forecast(values, _opts(oracle, model, horizon, o), valid)
     sql_pins.check_pin(case, run)
+
+
+@pytest.mark.parametrize("case", GOLD.get("unit", []), ids=[f'{c["model"]}@{c["source"]}' for c in GOLD.get("unit", [])])
+def test_wrapper_unit_tests(oracle, case):
+    """The assertions of the reference wrapper's own `mod tests` (crates/anofox-fcst-core/src/forecast.rs) on the oracle."""
+    sql_pins.check_unit_case(case, lambda v, valid, h, model, o: oracle.forecast(v, _opts(oracle, model, h, o), valid))
