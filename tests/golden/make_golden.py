@@ -104,6 +104,31 @@ unit = [
      "expect": {"n_points": 3, "interval_strict": True, "interval_widens": True}},
 ]
 
+# crates/anofox-fcst-ffi/tests/core_ffi_parity.rs: every configuration that file sends through the FFI on seasonal_data()
+# (60 points, `:55-65`; options of `:84-100`: confidence 0.95, detection off) must succeed with HORIZON = 5 points
+FFI = {"confidence_level": 0.95, "auto_detect": False}
+for model, period, line in [("SES", 0, 239), ("SESOptimized", 0, 252), ("Holt", 0, 265), ("HoltWinters", 12, 278), ("SeasonalES", 12, 294),
+                            ("SeasonalESOptimized", 12, 307), ("AutoETS", 12, 393), ("AutoARIMA", 12, 407), ("Naive", 0, 584),
+                            ("SeasonalNaive", 12, 596), ("SMA", 12, 608), ("RandomWalkDrift", 0, 621), ("ETS", 12, 659)]:
+    unit.append({"source": f"core_ffi_parity.rs:{line}", "model": model, "values": seasonal_data(), "horizon": 5,
+                 "options": dict(FFI, seasonal_period=period), "expect": {"n_points": 5, "finite": True}})
+for window in (3, 5, 12, 30, 60):
+    unit.append({"source": "core_ffi_parity.rs:715-728", "model": "SMA", "values": seasonal_data(), "horizon": 5,
+                 "options": dict(FFI, seasonal_period=0, window=window), "expect": {"n_points": 5, "sma_window": window}})
+for period in (4, 6, 12):
+    for model in ("HoltWinters", "SeasonalES", "SeasonalESOptimized", "SeasonalNaive"):
+        unit.append({"source": "core_ffi_parity.rs:731-790", "model": model, "values": seasonal_data(), "horizon": 5,
+                     "options": dict(FFI, seasonal_period=period), "expect": {"n_points": 5, "finite": True}})
+for spec in ("AAA", "ANA", "MNM", "MAM", "AAdA", "MAdM"):
+    unit.append({"source": "core_ffi_parity.rs:858-878", "model": "ETS", "values": seasonal_data(), "horizon": 5,
+                 "options": dict(FFI, seasonal_period=12, ets_model=spec), "expect": {"n_points": 5, "finite": True}})
+for horizon in (1, 3, 10, 20):
+    unit.append({"source": "core_ffi_parity.rs:924-946", "model": "SES", "values": seasonal_data(), "horizon": horizon,
+                 "options": dict(FFI, seasonal_period=0), "expect": {"n_points": horizon, "finite": True}})
+# `:659-677`: ETS without a spec on this series IS Holt-Winters(12, additive)
+unit.append({"source": "core_ffi_parity.rs:659-677", "model": "ETS", "values": seasonal_data(), "horizon": 5, "options": dict(FFI, seasonal_period=12),
+             "expect": {"n_points": 5, "same_as_model": "HoltWinters"}})
+
 errors = [
     # (source, model, options, expected code, message substring) -- test/sql/ts_native_param_validation.test:126-198
     {"source": "ts_native_param_validation.test:126-139", "model": "ETS", "options": {"ets_model": "XYZ"}, "code": 2, "substr": "Invalid ETS model specification"},

@@ -103,6 +103,12 @@ def check_unit_case(case, run):
         assert np.all(np.abs(r["point"] - e["near"][0]) < e["near"][1])
     if "n_fitted" in e:
         assert len(r["fitted"]) == e["n_fitted"] and len(r["residuals"]) == e["n_residuals"] and r["mse"] == r["mse"]
+    if "sma_window" in e:
+        w = e["sma_window"]
+        np.testing.assert_allclose(r["point"], np.full(len(r["point"]), np.mean(vals[-w:])), rtol=1e-14)
+    if "same_as_model" in e:
+        other = run(vals, None, case["horizon"], e["same_as_model"], case["options"])
+        assert other["ok"] and np.array_equal(other["point"], r["point"])
     if e.get("interval_strict"):
         assert np.all(r["lower"] < r["point"]) and np.all(r["upper"] > r["point"])
     if e.get("interval_widens"):

@@ -1044,7 +1044,7 @@ def test_wrapper_unit_tests_on_the_hip_path(env):
     def run(values, valid, horizon, model, o):
         opts = lib.make_options(model, horizon, seasonal_period=o.get("seasonal_period", 0), confidence_level=o.get("confidence_level", 0.90),
                                 auto_detect=o.get("auto_detect"), include_fitted=o.get("include_fitted", False),
-                                include_residuals=o.get("include_residuals", False))
+                                include_residuals=o.get("include_residuals", False), ets_model=o.get("ets_model", ""), window=o.get("window", 0))
         return api.forecast_series(values, opts, valid)
     assert len(gold["unit"]) >= 15
     for case in gold["unit"]:

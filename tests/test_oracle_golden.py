@@ -24,7 +24,8 @@ UNPINNED = {"AutoARIMA": 2e-3}                      # restated, but the crate's 
 def _opts(O, model, horizon, o):
     return O.make_options(model, horizon, ets_model=o.get("ets_model", ""), seasonal_period=o.get("seasonal_period", 0),
                           confidence_level=o.get("confidence_level", 0.90), auto_detect=o.get("auto_detect"),
-                          include_fitted=o.get("include_fitted", False), include_residuals=o.get("include_residuals", False))
+                          include_fitted=o.get("include_fitted", False), include_residuals=o.get("include_residuals", False),
+                          window=o.get("window", 0))
 
 
 @pytest.mark.parametrize("case", GOLD["cases"], ids=[f'{c["model"]}@{c["source"].split("/")[-1]}' for c in GOLD["cases"]])
