@@ -415,6 +415,9 @@ def ts_forecast_agg(group, date, value, method="auto", horizon=12, params=None):
     return out
 
 
+anofox_fcst_ts_forecast_agg = ts_forecast_agg     # alias registered next to the aggregate (ts_forecast_agg.cpp, tested in ts_forecast_params.test:217)
+
+
 # --------------------------------------------------------------------------------------------
 # ts_forecast_inspect_by / ts_forecast_explain_by
 # --------------------------------------------------------------------------------------------
@@ -567,6 +570,10 @@ def ts_forecast_explain_by(group, date, target, method, horizon, params=None):
         out[k] = {"horizon": h, "level": level, "trend": trend, "seasonal": seasonal, "residual": None, "yhat": r["point"],
                   "model_name": r["model_name"]}
     return out
+
+
+anofox_fcst_ts_forecast_inspect_by = ts_forecast_inspect_by     # ts_forecast_inspect_explain.test:146-158
+anofox_fcst_ts_forecast_explain_by = ts_forecast_explain_by
 
 
 # --------------------------------------------------------------------------------------------

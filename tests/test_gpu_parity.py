@@ -1049,3 +1049,27 @@ def test_wrapper_unit_tests_on_the_hip_path(env):
     assert len(gold["unit"]) >= 15
     for case in gold["unit"]:
         sql_pins.check_unit_case(case, run)
+
+
+def test_frequency_varchar_and_alias_sql_replay(env):
+    """test/sql/ts_integer_frequency.test:120-139 (DATE column with a gap, lower-case method, frequency given as '1d', '1 day'
+    or the integer 1), ts_varchar_edge_cases.test:56-70 (VARCHAR target column: the macro's ::DOUBLE cast) and
+    ts_table_macro_aliases.test:23-27 (the anofox_fcst_ aliases)."""
+    api, O, lib, synth = env
+    grp = np.array(["A"] * 4, dtype=object)
+    ds = np.array(["2023-01-01", "2023-01-02", "2023-01-04", "2023-01-05"], dtype="datetime64[D]")
+    val = np.array([10.0, 20.0, 30.0, 40.0])
+    for freq in ("1d", "1 day", 1):
+        out = api.ts_forecast_by(grp, ds, val, "naive", 2, freq, {})
+        assert len(out["yhat"]) == 2 and list(out["ds"]) == [np.datetime64("2023-01-06"), np.datetime64("2023-01-07")] and set(out["model_name"]) == {"Naive"}
+    i = np.arange(60)
+    g2 = np.array(["A"] * 60 + ["B"] * 60, dtype=object)
+    d2 = np.concatenate([np.datetime64("2024-01-01T00:00:00", "us") + i.astype("timedelta64[D]")] * 2)
+    y_num = np.concatenate([100.0 + i * 0.5, 200.0 + i * 0.25])
+    y_txt = np.array([repr(float(v)) for v in y_num], dtype=object)                      # the VARCHAR column
+    a = api.ts_forecast_by(g2, d2, y_txt, "Naive", 5, "1d", {})
+    b = api.ts_forecast_by(g2, d2, y_num, "Naive", 5, "1d", {})
+    assert len(a["yhat"]) == 10 and a["yhat"].dtype == np.float64 and np.array_equal(a["yhat"], b["yhat"])
+    assert len(api.anofox_fcst_ts_forecast_by(grp, ds, val, "Naive", 3, "1d")["yhat"]) == 3
+    assert api.anofox_fcst_ts_forecast_agg is api.ts_forecast_agg and api.anofox_fcst_ts_cv_forecast_by is api.ts_cv_forecast_by
+    assert api.anofox_fcst_ts_forecast_inspect_by is api.ts_forecast_inspect_by and api.anofox_fcst_ts_forecast_explain_by is api.ts_forecast_explain_by
