@@ -1073,3 +1073,32 @@ def test_frequency_varchar_and_alias_sql_replay(env):
     assert len(api.anofox_fcst_ts_forecast_by(grp, ds, val, "Naive", 3, "1d")["yhat"]) == 3
     assert api.anofox_fcst_ts_forecast_agg is api.ts_forecast_agg and api.anofox_fcst_ts_cv_forecast_by is api.ts_cv_forecast_by
     assert api.anofox_fcst_ts_forecast_inspect_by is api.ts_forecast_inspect_by and api.anofox_fcst_ts_forecast_explain_by is api.ts_forecast_explain_by
+
+
+def test_parallel_correctness_sql_replay(env, monkeypatch):
+    """test/sql/ts_parallel_correctness.test:13-52: 50 series x 60 days through ts_forecast_by give the same 350 rows whatever
+    the degree of parallelism.  Here: all host packer threads vs one, the whole batch vs one series at a time, and shuffled
+    input rows vs ordered ones -- bit-identical for Naive and for AutoETS."""
+    api, O, lib, synth = env
+    day = np.tile(np.arange(60), 50)
+    num = np.repeat(np.arange(1, 51), 60)
+    grp = np.array([f"series_{k:03d}" for k in num], dtype=object)
+    ds = np.datetime64("2024-01-01", "D") + day.astype("timedelta64[D]")
+    y = 100.0 + num * 10.0 + day * 0.5 + (day % 7) * 3.0
+    for model, params in (("Naive", {}), ("AutoETS", {"seasonal_period": 7})):
+        monkeypatch.delenv("ANOFOX_HIP_PACK_THREADS", raising=False)
+        many = api.ts_forecast_by(grp, ds, y, model, 7, "1d", params, group_name="unique_id")
+        assert len(many["yhat"]) == 350 and len(set(many["unique_id"])) == 50
+        monkeypatch.setenv("ANOFOX_HIP_PACK_THREADS", "1")
+        one = api.ts_forecast_by(grp, ds, y, model, 7, "1d", params, group_name="unique_id")
+        for c in ("yhat", "yhat_lower", "yhat_upper"):
+            assert np.array_equal(many[c], one[c]), (model, c)
+        assert list(many["model_name"]) == list(one["model_name"]) and np.array_equal(many["ds"], one["ds"])
+        perm = np.random.default_rng(11).permutation(len(y))
+        shuf = api.ts_forecast_by(grp[perm], ds[perm], y[perm], model, 7, "1d", params, group_name="unique_id")
+        key = lambda o: sorted(zip(o["unique_id"], o["forecast_step"], o["yhat"], o["model_name"]))
+        assert key(shuf) == key(many)
+        for k in (1, 25, 50):                                                   # a series does not see its neighbours
+            sel = num == k
+            solo = api.ts_forecast_by(grp[sel], ds[sel], y[sel], model, 7, "1d", params, group_name="unique_id")
+            assert np.array_equal(solo["yhat"], np.asarray(many["yhat"])[np.array(many["unique_id"], dtype=object) == f"series_{k:03d}"])
