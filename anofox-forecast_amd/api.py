@@ -724,6 +724,11 @@ def ts_cv_forecast_by(fold_id, split, group, date, target, method, params=None, 
     Returns the columns fold_id, <group_name>, <date_name>, y, split, yhat, yhat_lower, yhat_upper, model_name ordered
     by (fold_id, group, date) like the macro's ORDER BY 1, 2, 3.  Default confidence level 0.90 (`:45`).
     """
+    if fold_id is None or split is None:       # a source table without the fold columns (ts_cv_forecast_native.cpp:326-332)
+        raise InvalidInputException(
+            "ts_cv_forecast_by: Input table is missing required columns 'fold_id' and/or 'split'. Create folds first:\n"
+            "  CREATE TABLE folds AS SELECT * FROM ts_cv_folds_by('your_table', group, date, value, n_folds, horizon, MAP{});\n"
+            "  SELECT * FROM ts_cv_forecast_by('folds', group, date, value, 'Naive', MAP{});")
     b = bind(method, 1, "1d", params)
     pairs, kind, date_dtype = cv_collect(fold_id, split, group, date, target)
     cols = {"fold_id": [], group_name: [], date_name: [], "y": [], "split": [], "yhat": [], "yhat_lower": [], "yhat_upper": [],

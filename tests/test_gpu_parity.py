@@ -1102,3 +1102,23 @@ def test_parallel_correctness_sql_replay(env, monkeypatch):
             sel = num == k
             solo = api.ts_forecast_by(grp[sel], ds[sel], y[sel], model, 7, "1d", params, group_name="unique_id")
             assert np.array_equal(solo["yhat"], np.asarray(many["yhat"])[np.array(many["unique_id"], dtype=object) == f"series_{k:03d}"])
+
+
+def test_cv_backtest_sql_replay(env):
+    """test/sql/ts_cv_backtest.test: a table without fold columns is rejected with the reference's message; 3 folds x horizon 7
+    over two 84-day series give 42 rows, 3 folds, 2 series per fold, for Naive and for AutoETS."""
+    api, O, lib, synth = env
+    i = np.arange(84)
+    val = {"A": 100.0 + i * 0.5 + np.sin(i * 2 * 3.14159 / 7) * 10, "B": 200.0 + i * 0.3 + np.cos(i * 2 * 3.14159 / 7) * 5}
+    t0 = np.datetime64("2024-01-01T00:00:00", "us")
+    with pytest.raises(api.InvalidInputException, match="missing required columns 'fold_id' and/or 'split'"):
+        api.ts_cv_forecast_by(None, None, np.array(["A"] * 84, dtype=object), t0 + i.astype("timedelta64[D]"), val["A"], "Naive", {})
+    rows = _cv_folds("A", 84, 3, 7) + _cv_folds("B", 84, 3, 7)
+    fold, split, grp, t = (np.array(c, dtype=object) for c in zip(*rows))
+    ds = t0 + np.array([int(x) for x in t]).astype("timedelta64[D]")
+    y = np.array([val[g][int(x)] for g, x in zip(grp, t)])
+    for model in ("Naive", "AutoETS"):
+        out = api.ts_cv_forecast_by(fold, split, grp, ds, y, model, {})
+        assert len(out) == 9 and len(out["yhat"]) == 42 and not np.any(np.isnan(out["yhat"]))
+        assert sorted(set(int(k) for k in out["fold_id"])) == [1, 2, 3]
+        assert all(len(set(g for g, k in zip(out["id"], out["fold_id"]) if k == f)) == 2 for f in (1, 2, 3))
