@@ -614,6 +614,11 @@ def test_ts_backtest_native_caller(env):
     # failing fits are skipped, not raised (`:791-794`): an unknown method gives no rows
     out = api.ts_backtest_native(grp, t, v, 6, 3, {"method": "NoSuchModel"}, "rmse")
     assert len(out["yhat"]) == 0 and out["date"].dtype == np.int64
+    # the binding glues "method:model" into the model field (`:776-781`), which the core's parser does not know: no rows either
+    out = api.ts_backtest_native(grp, t, v, 6, 3, {"method": "ETS", "model": "AAA"}, "rmse")
+    assert len(out["yhat"]) == 0
+    r = api.forecast_series(series["g0"], lib.make_options("ETS:AAA", 3))
+    assert not r["ok"] and r["code"] == lib.INVALID_MODEL and "Unknown model: 'ETS:AAA'" in r["message"]
 
 
 def test_refused_allocation_is_reported_and_recoverable(env):
