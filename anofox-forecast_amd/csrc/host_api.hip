@@ -873,6 +873,16 @@ void fitted_values_host(const double *y, size_t n, ModelType model, size_t perio
     }
 }
 
+// The candidate specs of a batch run on concurrent streams; ROCm maps streams onto GPU_MAX_HW_QUEUES hardware queues
+// (default 4: the 25-spec grid then runs ~2x slower).  A caller that has not chosen a value gets the measured best one
+// (16; 8 / 24 / 32 are slower) -- set when the library is loaded, which is before the HIP runtime reads it at its first call.
+// An explicit value in the environment is left alone.
+__attribute__((constructor)) void anofox_default_hw_queues()
+{
+    const char *cur = std::getenv("GPU_MAX_HW_QUEUES");
+    if (!cur || !*cur) (void)setenv("GPU_MAX_HW_QUEUES", "16", 1);
+}
+
 bool device_ready(AnofoxError *err)
 {
     int cnt = 0;
