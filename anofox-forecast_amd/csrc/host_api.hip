@@ -806,13 +806,22 @@ void run_batch(AnofoxHipBatch *b, hipStream_t st)
     HIPCHECK(hipMemsetAsync(b->d_passes_total, 0, ld * sizeof(int32_t), st));
     HIPCHECK(hipMemsetAsync(b->d_evals_total, 0, ld * sizeof(int32_t), st));
     HIPCHECK(hipMemsetAsync(b->d_model_code, 0, ld * sizeof(int32_t), st));
-    // group series by seasonal period (all equal unless auto-detection ran)
+    // group series by seasonal period (all equal unless auto-detection ran).  Detection gives ~140 distinct periods per
+    // thousand M5-like series and every group is one run of the whole pipeline, so series are grouped by the period the
+    // model actually USES: none for the non-seasonal models, 1 for every AutoARIMA period outside 2..24 (no seasonal terms).
+    auto used_period = [&](int period) {
+        switch (b->plan.model) {
+        case M_Naive: case M_RandomWalkDrift: case M_ARIMA: case M_SES: case M_SESOptimized: case M_Holt: return 1;
+        case M_AutoARIMA: return (period > 1 && period <= 24) ? period : 1;
+        default: return period;
+        }
+    };
     std::map<int, std::vector<size_t>> groups;
     bool uniform = true;
-    for (size_t s = 1; s < n; s++) if (b->h_period[s] != b->h_period[0]) { uniform = false; break; }
-    if (uniform) run_group(b, n ? b->h_period[0] : 1, b->d_len, st);
+    for (size_t s = 1; s < n; s++) if (used_period(b->h_period[s]) != used_period(b->h_period[0])) { uniform = false; break; }
+    if (uniform) run_group(b, n ? used_period(b->h_period[0]) : 1, b->d_len, st);
     else {
-        for (size_t s = 0; s < n; s++) groups[b->h_period[s]].push_back(s);
+        for (size_t s = 0; s < n; s++) groups[used_period(b->h_period[s])].push_back(s);
         std::vector<int32_t> eff(ld);
         for (auto &g : groups) {
             std::fill(eff.begin(), eff.end(), 0);
