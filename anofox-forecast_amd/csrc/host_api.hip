@@ -7,7 +7,10 @@
 // fails with INTERNAL_ERROR.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <mutex>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -466,6 +469,7 @@ __global__ void fallback_plan_kernel(int n, const int32_t *len, int period, uint
     if (L <= 0) { mask[s] = 0; return; }
     if (mask[s] == 0) { detail[s] = FIT_OK; return; }
     mask[s] = (period > 1 && L >= 2 * period) ? 1u : (L >= 10 ? 2u : 3u);
+    detail[s] = FIT_PERIOD;      // until the planned stage fits the series (Holt-Winters with a period above ETS_MAX_PERIOD never runs)
 }
 
 // HoltWinters: 1 = two full seasons or more (seasonal fit), 2 = shorter (Holt); an unsupported period fails the long series
@@ -970,7 +974,10 @@ bool anofox_hip_batch_create(size_t n_series, size_t t_max, const ForecastOption
 void anofox_hip_batch_destroy(AnofoxHipBatch *b)
 {
     if (!b) return;
-    if (b->last_stream || b->own_stream) (void)hipDeviceSynchronize();
+    // wait for this batch's own work only (other batches may be running from other host threads)
+    if (b->last_stream) (void)hipStreamSynchronize(b->last_stream);
+    if (b->own_stream) (void)hipStreamSynchronize(b->own_stream);
+    for (auto &q : b->aux) if (q) (void)hipStreamSynchronize(q);
     free_batch_buffers(b);
     delete b;
 }
@@ -1304,16 +1311,11 @@ bool anofox_hip_batch_inspect(AnofoxHipBatch *b, AnofoxHipInspection *out, doubl
     return true;
 }
 
-bool anofox_ts_forecast_batch(const double *const *values, const uint64_t *const *validity, const size_t *lengths, size_t n_series,
-                              const ForecastOptions *options, const int *horizons, ForecastResult *out_results,
-                              AnofoxError *out_errors, AnofoxError *out_batch_error)
+// one plan, one device batch: create, pack, run, fetch (the whole of the batch entry unless periods are auto-detected)
+static bool forecast_batch_uniform(const double *const *values, const uint64_t *const *validity, const size_t *lengths, size_t n_series,
+                                   const ForecastOptions *options, const int *horizons, ForecastResult *out_results,
+                                   AnofoxError *out_errors, AnofoxError *out_batch_error)
 {
-    if (out_batch_error) { out_batch_error->code = SUCCESS; std::memset(out_batch_error->message, 0, sizeof out_batch_error->message); }
-    if (!values || !lengths || !options || !out_results) { set_error(out_batch_error, NULL_POINTER, "Null pointer argument"); return false; }
-    for (size_t s = 0; s < n_series; s++) {
-        std::memset(&out_results[s], 0, sizeof(ForecastResult));
-        if (!values[s]) { set_error(out_batch_error, NULL_POINTER, "Null pointer argument"); return false; }
-    }
     ForecastOptions opt = *options;
     int hmax = options->horizon;
     if (horizons) for (size_t s = 0; s < n_series; s++) hmax = std::max(hmax, horizons[s]);
@@ -1358,6 +1360,166 @@ bool anofox_ts_forecast_batch(const double *const *values, const uint64_t *const
     }
     anofox_hip_batch_destroy(b);
     return ok;
+}
+
+bool anofox_ts_forecast_batch(const double *const *values, const uint64_t *const *validity, const size_t *lengths, size_t n_series,
+                              const ForecastOptions *options, const int *horizons, ForecastResult *out_results,
+                              AnofoxError *out_errors, AnofoxError *out_batch_error)
+{
+    if (out_batch_error) { out_batch_error->code = SUCCESS; std::memset(out_batch_error->message, 0, sizeof out_batch_error->message); }
+    if (!values || !lengths || !options || !out_results) { set_error(out_batch_error, NULL_POINTER, "Null pointer argument"); return false; }
+    for (size_t s = 0; s < n_series; s++) {
+        std::memset(&out_results[s], 0, sizeof(ForecastResult));
+        if (!values[s]) { set_error(out_batch_error, NULL_POINTER, "Null pointer argument"); return false; }
+    }
+    // Per-series period detection (params := MAP{}): every distinct period a model uses is its own run of the pipeline,
+    // latency bound and tiny (~140 distinct periods per thousand M5-like series).  Detect the periods here, split the batch
+    // by used period and run the parts side by side from a few host threads, each part as an ordinary batch that names
+    // its period -- forecast() sees the same period either way (forecast.rs:527-539), so the results are unchanged.
+    Plan plan;
+    AnofoxError pe;
+    const bool detect = options->auto_detect_seasonality && options->seasonal_period == 0 && n_series >= 2;
+    if (!detect || !make_plan(options, plan, &pe))
+        return forecast_batch_uniform(values, validity, lengths, n_series, options, horizons, out_results, out_errors, out_batch_error);
+    try {
+        auto used_period = [&](int period) {
+            switch (plan.model) {
+            case M_Naive: case M_RandomWalkDrift: case M_ARIMA: case M_SES: case M_SESOptimized: case M_Holt: return 1;
+            case M_AutoARIMA: return (period > 1 && period <= 24) ? period : 1;
+            default: return period;
+            }
+        };
+        std::vector<int> period(n_series, 1);
+        {
+            std::atomic<size_t> next{0};
+            auto work = [&]() {
+                std::vector<double> clean;
+                for (size_t s = next.fetch_add(1); s < n_series; s = next.fetch_add(1)) {
+                    if (lengths[s] < 3) continue;
+                    clean.resize(lengths[s]);
+                    fill_nulls_interpolate(values[s], validity ? validity[s] : nullptr, lengths[s], clean.data());
+                    const int p = detect_seasonality_first(clean.data(), lengths[s]);
+                    period[s] = used_period(p > 0 ? p : 1);
+                }
+            };
+            unsigned n_thr = std::max(1u, std::min({std::thread::hardware_concurrency(), 32u, (unsigned)((n_series + 15) / 16)}));
+            std::vector<std::thread> pool;
+            for (unsigned i = 1; i < n_thr; i++) pool.emplace_back(work);
+            work();
+            for (auto &t : pool) t.join();
+        }
+        std::map<int, std::vector<size_t>> groups;
+        for (size_t s = 0; s < n_series; s++) groups[period[s]].push_back(s);
+        std::vector<std::pair<int, std::vector<size_t>>> parts(groups.begin(), groups.end());
+        std::sort(parts.begin(), parts.end(), [](const auto &x, const auto &y) { return x.second.size() > y.second.size(); });
+        std::mutex err_mu;
+        bool all_ok = true;
+        AnofoxError first_err;
+        first_err.code = SUCCESS;
+        auto run_part = [&](const std::pair<int, std::vector<size_t>> &part) {
+            const std::vector<size_t> &idx = part.second;
+            const size_t k = idx.size();
+            std::vector<const double *> v(k);
+            std::vector<const uint64_t *> m(k);
+            std::vector<size_t> len(k);
+            std::vector<int> hz(k);
+            for (size_t j = 0; j < k; j++) {
+                v[j] = values[idx[j]]; m[j] = validity ? validity[idx[j]] : nullptr; len[j] = lengths[idx[j]];
+                if (horizons) hz[j] = horizons[idx[j]];
+            }
+            ForecastOptions o = *options;
+            o.auto_detect_seasonality = false;
+            o.seasonal_period = part.first > 1 ? part.first : 0;           // 0 with detection off: period 1
+            std::vector<ForecastResult> res(k);
+            std::vector<AnofoxError> errs(k);
+            for (auto &e : errs) { e.code = SUCCESS; e.message[0] = 0; }
+            AnofoxError be;
+            const bool ok = forecast_batch_uniform(v.data(), validity ? m.data() : nullptr, len.data(), k, &o, horizons ? hz.data() : nullptr,
+                                                   res.data(), errs.data(), &be);
+            for (size_t j = 0; j < k; j++) {
+                out_results[idx[j]] = res[j];
+                if (out_errors) out_errors[idx[j]] = errs[j];
+            }
+            if (!ok) {
+                std::lock_guard<std::mutex> lock(err_mu);
+                if (all_ok) first_err = be;
+                all_ok = false;
+            }
+        };
+        // the big parts fill the chip on their own and hold the most memory: one at a time; the small ones side by side
+        size_t first_small = 0;
+        while (first_small < parts.size() && parts[first_small].second.size() >= 2048) run_part(parts[first_small++]);
+        // A worker keeps ONE device batch for all its parts (creating and destroying a batch costs ~30 ms of allocator calls
+        // that serialise across threads -- as much as the part's own run): capacity = the largest small part, short parts are
+        // padded with empty series, the period is set before every pack.
+        const size_t cap = first_small < parts.size() ? parts[first_small].second.size() : 0;
+        size_t t_cap = 0;
+        int h_cap = options->horizon;
+        for (size_t s = 0; s < n_series; s++) { t_cap = std::max(t_cap, lengths[s]); if (horizons) h_cap = std::max(h_cap, horizons[s]); }
+        std::atomic<size_t> next{first_small};
+        auto work = [&]() {
+            AnofoxHipBatch *wb = nullptr;
+            static const double dummy = 0.0;
+            std::vector<const double *> v(cap, &dummy);
+            std::vector<const uint64_t *> m(cap, nullptr);
+            std::vector<size_t> len(cap, 0);
+            std::vector<ForecastResult> res(cap);
+            std::vector<AnofoxError> errs(cap);
+            for (size_t g = next.fetch_add(1); g < parts.size(); g = next.fetch_add(1)) {
+                const std::vector<size_t> &idx = parts[g].second;
+                const size_t k = idx.size();
+                AnofoxError be;
+                be.code = SUCCESS; be.message[0] = 0;
+                if (!wb) {
+                    ForecastOptions o = *options;
+                    o.auto_detect_seasonality = false;
+                    o.seasonal_period = parts[g].first > 1 ? parts[g].first : 0;
+                    o.horizon = h_cap;
+                    if (!anofox_hip_batch_create(cap, t_cap, &o, &wb, &be)) { wb = nullptr; run_part(parts[g]); continue; }   // the plain path reports it
+                }
+                wb->opt.seasonal_period = parts[g].first > 1 ? parts[g].first : 0;
+                for (size_t j = 0; j < cap; j++) {
+                    if (j < k) { v[j] = values[idx[j]]; m[j] = validity ? validity[idx[j]] : nullptr; len[j] = lengths[idx[j]]; }
+                    else { v[j] = &dummy; m[j] = nullptr; len[j] = 0; }
+                    std::memset(&res[j], 0, sizeof(ForecastResult));
+                    errs[j].code = SUCCESS; errs[j].message[0] = 0;
+                }
+                const bool ok = anofox_hip_batch_pack_host(wb, v.data(), validity ? m.data() : nullptr, len.data(), &be) &&
+                                anofox_hip_batch_run(wb, nullptr, &be) && anofox_hip_batch_fetch(wb, res.data(), errs.data());
+                if (!ok) {
+                    if (be.code == SUCCESS) set_error(&be, INTERNAL_ERROR, "Internal error: device batch failed");
+                    std::lock_guard<std::mutex> lock(err_mu);
+                    if (all_ok) first_err = be;
+                    all_ok = false;
+                    continue;
+                }
+                for (size_t j = 0; j < k; j++) {
+                    ForecastResult &r = res[j];
+                    const int hs = horizons ? horizons[idx[j]] : options->horizon;      // forecasts are prefix-consistent: truncate
+                    if (r.point_forecasts && hs >= 0 && (size_t)hs < r.n_forecasts) {
+                        r.n_forecasts = (size_t)hs;
+                        if (hs == 0) {
+                            std::free(r.point_forecasts); std::free(r.lower_bounds); std::free(r.upper_bounds);
+                            r.point_forecasts = r.lower_bounds = r.upper_bounds = nullptr;
+                        }
+                    }
+                    out_results[idx[j]] = r;
+                    if (out_errors) out_errors[idx[j]] = errs[j];
+                }
+            }
+            if (wb) anofox_hip_batch_destroy(wb);
+        };
+        const unsigned n_thr = (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)std::thread::hardware_concurrency(), 16, parts.size() - first_small}));
+        std::vector<std::thread> pool;
+        for (unsigned i = 1; i < n_thr; i++) pool.emplace_back(work);
+        work();
+        for (auto &t : pool) t.join();
+        if (!all_ok && out_batch_error) *out_batch_error = first_err;
+        return all_ok;
+    } catch (const std::exception &e) {
+        set_error(out_batch_error, INTERNAL_ERROR, std::string("Internal error: ") + e.what());
+        return false;
+    }
 }
 
 bool anofox_ts_forecast(const double *values, const uint64_t *validity, size_t length, const ForecastOptions *options,

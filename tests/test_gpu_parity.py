@@ -1127,3 +1127,27 @@ def test_cv_backtest_sql_replay(env):
         assert len(out) == 9 and len(out["yhat"]) == 42 and not np.any(np.isnan(out["yhat"]))
         assert sorted(set(int(k) for k in out["fold_id"])) == [1, 2, 3]
         assert all(len(set(g for g, k in zip(out["id"], out["fold_id"]) if k == f)) == 2 for f in (1, 2, 3))
+
+
+def test_default_chain_with_unsupported_detected_period(env):
+    """Found by the fuzz: `ETS` without a spec (and the AutoETS fallback) plan Holt-Winters when two seasons fit
+    (forecast.rs:1327-1336); with a detected period above the 64 the kernels support nothing ran and the series reported
+    success with an empty forecast.  It fails like the oracle now, alone and inside a batch whose other periods are fine."""
+    api, O, lib, synth = env
+    t = np.arange(150)
+    long_period = 50.0 + 10.0 * np.sin(2 * np.pi * t / 70.0) + 0.01 * t            # detected period 70: two seasons fit into 150
+    weekly = 20.0 + 5.0 * np.sin(2 * np.pi * t / 7.0) + 0.02 * t
+    for model in ("ETS", "AutoETS"):
+        opts = lib.make_options(model, 6)                                            # seasonal_period 0: detection on
+        got, berr = api.forecast_batch([weekly, long_period, weekly[::-1].copy(), long_period * 2.0], opts)
+        assert berr["ok"]
+        for y, r in zip([weekly, long_period, weekly[::-1].copy(), long_period * 2.0], got):
+            ref = O.forecast(y, O.make_options(model, 6))
+            assert r["ok"] == ref["ok"], (model, r, ref)
+            if ref["ok"]:
+                assert r["model_name"] == ref["model_name"] and np.array_equal(r["point"], ref["point"])
+            else:
+                assert r["code"] == ref["code"]
+        single = api.forecast_series(long_period, opts)
+        ref = O.forecast(long_period, O.make_options(model, 6))
+        assert single["ok"] == ref["ok"] and (single["ok"] or single["code"] == ref["code"])
