@@ -1457,7 +1457,10 @@ bool anofox_ts_forecast_batch(const double *const *values, const uint64_t *const
         int h_cap = options->horizon;
         for (size_t s = 0; s < n_series; s++) { t_cap = std::max(t_cap, lengths[s]); if (horizons) h_cap = std::max(h_cap, horizons[s]); }
         std::atomic<size_t> next{first_small};
+        int cur_dev = 0;
+        (void)hipGetDevice(&cur_dev);                      // the device is a per-thread setting: the workers inherit the caller's
         auto work = [&]() {
+            (void)hipSetDevice(cur_dev);
             AnofoxHipBatch *wb = nullptr;
             static const double dummy = 0.0;
             std::vector<const double *> v(cap, &dummy);
