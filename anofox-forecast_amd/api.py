@@ -220,17 +220,18 @@ def validity_mask(valid) -> np.ndarray:
 
 def _result_dict(res: _lib.ForecastResult, n_values: int) -> dict:
     h = res.n_forecasts
+
+    def arr(ptr, n):                       # copy out of the callee's malloc'ed block (released right after by the caller)
+        return np.ctypeslib.as_array(ptr, shape=(n,)).copy() if n and ptr else np.empty(0, dtype=np.float64)
     out = {
-        "point": np.array(res.point_forecasts[:h], dtype=np.float64),
-        "lower": np.array(res.lower_bounds[:h], dtype=np.float64),
-        "upper": np.array(res.upper_bounds[:h], dtype=np.float64),
+        "point": arr(res.point_forecasts, h), "lower": arr(res.lower_bounds, h), "upper": arr(res.upper_bounds, h),
         "model_name": res.model_name.decode(),
         "aic": res.aic, "bic": res.bic, "mse": res.mse, "n_fitted": res.n_fitted,
     }
     if res.fitted_values:
-        out["fitted"] = np.array(res.fitted_values[:res.n_fitted])
+        out["fitted"] = arr(res.fitted_values, res.n_fitted)
     if res.residuals:
-        out["residuals"] = np.array(res.residuals[:n_values])
+        out["residuals"] = arr(res.residuals, n_values)
     return out
 
 
