@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <vector>
@@ -1392,21 +1393,25 @@ bool anofox_ts_forecast_batch(const double *const *values, const uint64_t *const
         std::vector<int> period(n_series, 1);
         {
             std::atomic<size_t> next{0};
+            std::atomic<bool> failed{false};
             auto work = [&]() {
-                std::vector<double> clean;
-                for (size_t s = next.fetch_add(1); s < n_series; s = next.fetch_add(1)) {
-                    if (lengths[s] < 3) continue;
-                    clean.resize(lengths[s]);
-                    fill_nulls_interpolate(values[s], validity ? validity[s] : nullptr, lengths[s], clean.data());
-                    const int p = detect_seasonality_first(clean.data(), lengths[s]);
-                    period[s] = used_period(p > 0 ? p : 1);
-                }
+                try {                                   // nothing may leave a worker thread
+                    std::vector<double> clean;
+                    for (size_t s = next.fetch_add(1); s < n_series; s = next.fetch_add(1)) {
+                        if (lengths[s] < 3) continue;
+                        clean.resize(lengths[s]);
+                        fill_nulls_interpolate(values[s], validity ? validity[s] : nullptr, lengths[s], clean.data());
+                        const int p = detect_seasonality_first(clean.data(), lengths[s]);
+                        period[s] = used_period(p > 0 ? p : 1);
+                    }
+                } catch (...) { failed = true; }
             };
             unsigned n_thr = std::max(1u, std::min({std::thread::hardware_concurrency(), 32u, (unsigned)((n_series + 15) / 16)}));
             std::vector<std::thread> pool;
             for (unsigned i = 1; i < n_thr; i++) pool.emplace_back(work);
             work();
             for (auto &t : pool) t.join();
+            if (failed) throw std::runtime_error("period detection failed (out of host memory)");
         }
         std::map<int, std::vector<size_t>> groups;
         for (size_t s = 0; s < n_series; s++) groups[period[s]].push_back(s);
@@ -1459,7 +1464,7 @@ bool anofox_ts_forecast_batch(const double *const *values, const uint64_t *const
         std::atomic<size_t> next{first_small};
         int cur_dev = 0;
         (void)hipGetDevice(&cur_dev);                      // the device is a per-thread setting: the workers inherit the caller's
-        auto work = [&]() {
+        auto work_body = [&]() {
             (void)hipSetDevice(cur_dev);
             AnofoxHipBatch *wb = nullptr;
             static const double dummy = 0.0;
@@ -1511,6 +1516,18 @@ bool anofox_ts_forecast_batch(const double *const *values, const uint64_t *const
                 }
             }
             if (wb) anofox_hip_batch_destroy(wb);
+        };
+        auto work = [&]() {
+            try { work_body(); }
+            catch (const std::exception &e) {           // nothing may leave a worker thread
+                std::lock_guard<std::mutex> lock(err_mu);
+                if (all_ok) set_error(&first_err, INTERNAL_ERROR, std::string("Internal error: ") + e.what());
+                all_ok = false;
+            } catch (...) {
+                std::lock_guard<std::mutex> lock(err_mu);
+                if (all_ok) set_error(&first_err, INTERNAL_ERROR, "Internal error: worker failed");
+                all_ok = false;
+            }
         };
         const unsigned n_thr = (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)std::thread::hardware_concurrency(), 16, parts.size() - first_small}));
         std::vector<std::thread> pool;
