@@ -78,6 +78,8 @@ def parse_frequency(freq) -> ParsedFrequency:
 
 
 _US_PER_DAY = 86400 * 1000000
+_EMPTY_SERIES = np.zeros(1)                       # kept alive: the address handed to C for series of length 0
+_EMPTY_SERIES_ADDR = _EMPTY_SERIES.ctypes.data
 
 
 def _date_kind(dates: np.ndarray) -> str:
@@ -259,7 +261,7 @@ def forecast_batch(series, opts, valids=None, horizons=None):
     n = len(series)
     arrs = [np.ascontiguousarray(s, dtype=np.float64) for s in series]
     masks = [validity_mask(v) if v is not None else None for v in valids] if valids is not None else None
-    vptr = (C.c_void_p * n)(*[a.ctypes.data if len(a) else C.addressof(C.c_double()) for a in arrs])
+    vptr = (C.c_void_p * n)(*[a.ctypes.data if len(a) else _EMPTY_SERIES_ADDR for a in arrs])
     mptr = None
     if masks is not None:
         mptr = (C.c_void_p * n)(*[m.ctypes.data if m is not None and len(m) else None for m in masks])
@@ -439,7 +441,7 @@ def inspect_batch(series, opts, valids=None):
         raise InvalidInputException(err.message.decode(errors="replace"))
     try:
         masks = [validity_mask(v) for v in valids] if valids is not None else None
-        vptr = (C.c_void_p * n)(*[a.ctypes.data if len(a) else C.addressof(C.c_double()) for a in arrs])
+        vptr = (C.c_void_p * n)(*[a.ctypes.data if len(a) else _EMPTY_SERIES_ADDR for a in arrs])
         mptr = (C.c_void_p * n)(*[m.ctypes.data if len(m) else None for m in masks]) if masks is not None else None
         lens = (C.c_size_t * n)(*[len(a) for a in arrs])
         if not L.anofox_hip_batch_pack_host(hb, vptr, mptr, lens, C.byref(err)) or not L.anofox_hip_batch_run(hb, None, C.byref(err)):

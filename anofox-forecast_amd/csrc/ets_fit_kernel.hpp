@@ -232,7 +232,7 @@ void ets_round_launch(const FitArgs &a, hipStream_t stream)
     size_t lds_bytes = sizeof(double) * (size_t)nm_lds_doubles<Cfg::DIM>();
     if (MS == -1) lds_bytes += sizeof(double) * (size_t)a.m * NM_BLOCK;
     if (lds_bytes > 48 * 1024)
-        (void)hipFuncSetAttribute((const void *)ets_round_kernel<Cfg, MS, SPEC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        anofox_check_attr(hipFuncSetAttribute((const void *)ets_round_kernel<Cfg, MS, SPEC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     hipLaunchKernelGGL((ets_round_kernel<Cfg, MS, SPEC>), dim3(grid), dim3(NM_BLOCK), lds_bytes, stream, a);
 }
 

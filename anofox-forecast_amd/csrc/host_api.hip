@@ -41,6 +41,18 @@ void report_hip_failure(AnofoxError *out_error, const HipFail &f)
         if (_e != hipSuccess) throw HipFail{std::string(#expr) + ": " + hipGetErrorString(_e), _e == hipErrorOutOfMemory};    \
     } while (0)
 
+// A launch that the runtime refuses (no code object for this GPU, LDS request over the limit, invalid grid) is only
+// visible through hipGetLastError: without this check the outputs would keep whatever the buffers held.
+#define LAUNCHCHECK(what)                                                                          \
+    do {                                                                                           \
+        hipError_t _e = hipGetLastError();                                                         \
+        if (_e != hipSuccess) throw HipFail{std::string("kernel launch failed (") + (what) + "): " + hipGetErrorString(_e), false};    \
+    } while (0)
+
+// d_status of a usable series before any kernel has written it: a series a kernel never reached is reported as an
+// INTERNAL_ERROR instead of a success with uninitialised forecasts
+constexpr int32_t STATUS_NOT_COMPUTED = -1;
+
 template <class T> T *dalloc(size_t n)
 {
     void *p = nullptr;
@@ -71,6 +83,7 @@ struct AnofoxHipBatch {
     std::vector<int32_t> h_len;        // true lengths
     std::vector<int32_t> h_period;     // per-series period
     std::vector<int32_t> h_base_status;
+    std::vector<int32_t> h_seed_status;  // what d_status is seeded with: base status, usable series = STATUS_NOT_COMPUTED
     std::vector<int32_t> h_slot_spec;
     double *h_stage = nullptr;         // pinned staging copy of the time-major block (packer output, H2D source)
     size_t h_stage_elems = 0;
@@ -131,6 +144,9 @@ struct AnofoxHipBatch {
     int spec_below_md = 8192; // same, for the damped multiplicative-trend specs (their pass is ~10x longer: the stragglers matter more)
     int spec_below = 8192;   // per spec: switch to the speculative driver once this few problems are still running
     bool use_gather = false; // rebuild a dense block of the running problems between rounds (else index y by series)
+    // BASELINE config 2: ETS(spec) with GIVEN smoothing parameters -- no optimiser, one streamed pass per series
+    bool fixed_params = false;
+    double fixed_x[4] = {0.0, 0.0, 0.0, 0.0};   // optimiser coordinates (alpha, beta*, gamma*, phi) of the given parameters
 };
 
 namespace {
@@ -483,6 +499,26 @@ __global__ void holt_winters_plan_kernel(int n, const int32_t *len, int m, uint3
     if (L > 0) detail[s] = FIT_PERIOD;        // overwritten by the stage that fits the series
 }
 
+// Fixed-parameter ETS (BASELINE config 2): what the first fit round would have decided about admissibility, and the given
+// parameters parked where the final pass reads the optimum (vertex 0 of the simplex).  dim = number of coordinates.
+__global__ void ets_fixed_setup_kernel(int n, size_t ld, const int32_t *len, const uint32_t *flags, int seasonal, int m, int n_param,
+                                       int need_positive, int dim, double x0, double x1, double x2, double x3, int32_t *status,
+                                       double *sim, int32_t *evals, int32_t *iters, int32_t *passes, int32_t *done)
+{
+    int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= n) return;
+    const int L = len[s];
+    int st = FIT_OK;
+    if (L <= 0) st = FIT_SKIPPED;
+    else if (seasonal && L < 2 * m) st = FIT_SHORT;
+    else if (L < n_param + 2) st = FIT_SHORT;
+    else if (need_positive && !(flags[s] & SF_POSITIVE)) st = FIT_NONPOSITIVE;
+    status[s] = st;
+    const double x[4] = {x0, x1, x2, x3};
+    for (int i = 0; i < dim; i++) sim[(size_t)i * ld + s] = x[i];
+    evals[s] = 0; iters[s] = 0; passes[s] = 0; done[s] = 1;
+}
+
 void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const int32_t *d_len, int m, bool skip_constant,
                       hipStream_t st)
 {
@@ -567,7 +603,25 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
     // own stream, so that all specs advance together and the hardware queues never hold a long spec behind
     // another one.  Early rounds run the sequential driver (least arithmetic while problems outnumber
     // lanes), late rounds the speculative one (shortest critical path for the stragglers).
-    for (int r = 0; r < n_rounds; r++) {
+    if (b->fixed_params) {
+        // given smoothing parameters: no rounds at all -- admissibility + parameters, then the final pass below
+        for (size_t oi = 0; oi < order.size(); oi++) {
+            const int id = specs[order[oi]];
+            FitArgs &a = args[oi];
+            // coordinates present in this spec, in optimiser order (alpha, [beta*], [gamma*], [phi])
+            double x[4] = {0.0, 0.0, 0.0, 0.0};
+            int d = 0;
+            x[d++] = b->fixed_x[0];
+            if (spec_trend_idx(id) != 0) x[d++] = b->fixed_x[1];
+            if (spec_season(id) != 0) x[d++] = b->fixed_x[2];
+            if (spec_trend_idx(id) == 2 || spec_trend_idx(id) == 4) x[d++] = b->fixed_x[3];
+            hipLaunchKernelGGL(ets_fixed_setup_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, b->aux[stream_of[oi]], (int)n, ld, d_len,
+                               b->d_flags, spec_season(id) != 0 ? 1 : 0, a.m, a.n_param, a.need_positive, d, x[0], x[1], x[2], x[3], a.status,
+                               a.st.sim, a.st.evals, a.st.iters, a.st.passes, a.st.done);
+        }
+        LAUNCHCHECK("ETS fixed-parameter setup");
+    }
+    for (int r = 0; r < (b->fixed_params ? 0 : n_rounds); r++) {
         for (size_t oi = 0; oi < order.size(); oi++) {
             const int q = (int)(oi % (size_t)n_lanes);
             auto &lane = b->lanes[q];
@@ -626,8 +680,10 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
             }
             b->fit_launches++;
         }
+        LAUNCHCHECK("ETS fit round");
     }
     for (size_t oi = 0; oi < order.size(); oi++) fns[oi].final(args[oi], b->aux[stream_of[oi]]);
+    LAUNCHCHECK("ETS final pass");
     for (int i = 0; i < n_lanes; i++) {
         HIPCHECK(hipEventRecord(b->ev_join[i], b->aux[i]));
         HIPCHECK(hipStreamWaitEvent(st, b->ev_join[i], 0));
@@ -797,6 +853,7 @@ void run_group(AnofoxHipBatch *b, int period, const int32_t *d_len, hipStream_t 
     }
     default: throw HipFail{"model not implemented"};
     }
+    LAUNCHCHECK(model_name(p.model));
 }
 
 void run_batch(AnofoxHipBatch *b, hipStream_t st)
@@ -807,7 +864,16 @@ void run_batch(AnofoxHipBatch *b, hipStream_t st)
     b->timed_fit = false;
     b->insp_ok = false;
     HIPCHECK(hipEventRecord(b->ev_start, st));
-    HIPCHECK(hipMemcpyAsync(b->d_status, b->h_base_status.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    // usable series start as "not computed" and only a kernel turns that into success; the forecasts start as NaN
+    b->h_seed_status.resize(n);
+    for (size_t s = 0; s < n; s++) b->h_seed_status[s] = b->h_base_status[s] == 0 ? STATUS_NOT_COMPUTED : b->h_base_status[s];
+    HIPCHECK(hipMemcpyAsync(b->d_status, b->h_seed_status.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    if (b->h > 0) {
+        const size_t bytes = n * (size_t)b->h * sizeof(double);
+        HIPCHECK(hipMemsetAsync(b->d_yhat, 0xff, bytes, st));
+        HIPCHECK(hipMemsetAsync(b->d_lo, 0xff, bytes, st));
+        HIPCHECK(hipMemsetAsync(b->d_hi, 0xff, bytes, st));
+    }
     HIPCHECK(hipMemsetAsync(b->d_passes_total, 0, ld * sizeof(int32_t), st));
     HIPCHECK(hipMemsetAsync(b->d_evals_total, 0, ld * sizeof(int32_t), st));
     HIPCHECK(hipMemsetAsync(b->d_model_code, 0, ld * sizeof(int32_t), st));
@@ -840,6 +906,7 @@ void run_batch(AnofoxHipBatch *b, hipStream_t st)
     ia.n_series = (int)n; ia.h = b->h; ia.yhat = b->d_yhat; ia.sd = b->d_sd; ia.status = b->d_status; ia.z = b->plan.z;
     ia.lower = b->d_lo; ia.upper = b->d_hi;
     launch_intervals(ia, st);
+    LAUNCHCHECK("intervals");
     HIPCHECK(hipEventRecord(b->ev_stop, st));
     b->last_stream = st;
     b->ran = true;
@@ -848,6 +915,7 @@ void run_batch(AnofoxHipBatch *b, hipStream_t st)
 std::string series_error_message(const AnofoxHipBatch *b, size_t s, int code, int detail)
 {
     char buf[512];
+    if (code == INTERNAL_ERROR) return "Internal error: the device never computed this series (kernel did not run)";
     if (code == INSUFFICIENT_DATA) {
         int got = b->h_len[s];
         std::snprintf(buf, sizeof buf, "Insufficient data: need at least %d observations, got %d", got == 0 ? 1 : 3, got);
@@ -888,15 +956,8 @@ void fitted_values_host(const double *y, size_t n, ModelType model, size_t perio
 }
 
 // The candidate specs of a batch run on concurrent streams; ROCm maps streams onto GPU_MAX_HW_QUEUES hardware queues
-// (default 4: the 25-spec grid then runs ~2x slower).  A caller that has not chosen a value gets the measured best one
-// (16; 8 / 24 / 32 are slower) -- set when the library is loaded, which is before the HIP runtime reads it at its first call.
-// An explicit value in the environment is left alone.
-__attribute__((constructor)) void anofox_default_hw_queues()
-{
-    const char *cur = std::getenv("GPU_MAX_HW_QUEUES");
-    if (!cur || !*cur) (void)setenv("GPU_MAX_HW_QUEUES", "16", 1);
-}
-
+// (default 4: the 25-spec grid then runs ~2x slower; 16 is the measured best).  The library does NOT touch the process
+// environment: the host sets the variable before its first HIP call (lib.py and bench.py do).
 bool device_ready(AnofoxError *err)
 {
     int cnt = 0;
@@ -984,6 +1045,37 @@ void anofox_hip_batch_destroy(AnofoxHipBatch *b)
 }
 
 size_t anofox_hip_batch_ld(const AnofoxHipBatch *b) { return b ? b->ld : 0; }
+size_t anofox_hip_batch_n_series(const AnofoxHipBatch *b) { return b ? b->n : 0; }
+
+bool anofox_hip_batch_set_fixed_params(AnofoxHipBatch *b, double alpha, double beta, double gamma, double phi, AnofoxError *out_error)
+{
+    if (out_error) { out_error->code = SUCCESS; std::memset(out_error->message, 0, sizeof out_error->message); }
+    if (!b) { set_error(out_error, NULL_POINTER, "Null pointer argument"); return false; }
+    if (!(b->plan.model == M_ETS && b->plan.ets_spec_id >= 0)) {
+        set_error(out_error, INVALID_INPUT, "Invalid input: fixed smoothing parameters need model 'ETS' with an explicit ets_model");
+        return false;
+    }
+    const int id = b->plan.ets_spec_id;
+    const bool has_trend = spec_trend_idx(id) != 0, has_season = spec_season(id) != 0;
+    const bool damped = spec_trend_idx(id) == 2 || spec_trend_idx(id) == 4;
+    // the model's own parameters: 0 < alpha < 1, 0 <= beta <= alpha, 0 <= gamma <= 1 - alpha, 0 < phi <= 1
+    bool ok = alpha > 0.0 && alpha < 1.0;
+    if (has_trend) ok = ok && beta >= 0.0 && beta <= alpha;
+    if (has_season) ok = ok && gamma >= 0.0 && gamma <= 1.0 - alpha;
+    if (damped) ok = ok && phi > 0.0 && phi <= 1.0;
+    if (!ok) {
+        set_error(out_error, INVALID_INPUT,
+                  "Invalid input: smoothing parameters out of range (0 < alpha < 1, 0 <= beta <= alpha, 0 <= gamma <= 1 - alpha, 0 < phi <= 1)");
+        return false;
+    }
+    // optimiser coordinates of the recursion (ets_device.hpp ets_unpack): beta = alpha beta*, gamma = gamma* (1 - alpha)
+    b->fixed_x[0] = alpha;
+    b->fixed_x[1] = has_trend ? beta / alpha : 0.0;
+    b->fixed_x[2] = has_season ? gamma / (1.0 - alpha) : 0.0;
+    b->fixed_x[3] = damped ? phi : 1.0;
+    b->fixed_params = true;
+    return true;
+}
 
 bool anofox_hip_batch_pack_host(AnofoxHipBatch *b, const double *const *values, const uint64_t *const *validity,
                                 const size_t *lengths, AnofoxError *out_error)
@@ -1184,6 +1276,7 @@ bool anofox_hip_batch_fetch(AnofoxHipBatch *b, ForecastResult *out_results, Anof
         ForecastResult &r = out_results[s];
         std::memset(&r, 0, sizeof r);
         if (out_errors) { out_errors[s].code = SUCCESS; std::memset(out_errors[s].message, 0, sizeof out_errors[s].message); }
+        if (status[s] == STATUS_NOT_COMPUTED) status[s] = INTERNAL_ERROR;
         if (status[s] != 0) {
             if (out_errors) set_error(&out_errors[s], status[s], series_error_message(b, s, status[s], detail[s]));
             continue;

@@ -144,6 +144,13 @@ bool anofox_hip_batch_pack_ingest(AnofoxHipBatch *batch, const AnofoxHipIngest *
 {
     if (!batch || !g) { anofox::set_error(out_error, NULL_POINTER, "Null pointer argument"); return false; }
     if (!g->finished) { anofox::set_error(out_error, INVALID_INPUT, "Invalid input: ingest not finished"); return false; }
+    // the packer indexes values / validity / lengths for every series of the batch: the batch must have been created for
+    // exactly the ingested groups
+    if (anofox_hip_batch_n_series(batch) != g->keys.size()) {
+        anofox::set_error(out_error, INVALID_INPUT, "Invalid input: the batch was created for " + std::to_string(anofox_hip_batch_n_series(batch)) +
+                                                        " series, the ingest holds " + std::to_string(g->keys.size()) + " groups");
+        return false;
+    }
     return anofox_hip_batch_pack_host(batch, g->vptr.data(), g->mptr.data(), g->len.data(), out_error);
 }
 

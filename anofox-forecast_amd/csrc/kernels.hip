@@ -118,14 +118,14 @@ void launch_classic(int kind, const ClassicArgs &a, hipStream_t stream)
     case CK_HW: {
         size_t bytes = sizeof(double) * nm_lds_doubles<3>() + ring;
         if (bytes > 48 * 1024)
-            (void)hipFuncSetAttribute((const void *)classic_kernel<CK_HW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+            anofox_check_attr(hipFuncSetAttribute((const void *)classic_kernel<CK_HW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
         hipLaunchKernelGGL(classic_kernel<CK_HW>, dim3(grid), dim3(NM_BLOCK), bytes, stream, a);
         break;
     }
     default: {
         size_t bytes = sizeof(double) * nm_lds_doubles<1>() + ring;
         if (bytes > 48 * 1024)
-            (void)hipFuncSetAttribute((const void *)classic_kernel<CK_SEASONAL_ES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+            anofox_check_attr(hipFuncSetAttribute((const void *)classic_kernel<CK_SEASONAL_ES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
         hipLaunchKernelGGL(classic_kernel<CK_SEASONAL_ES>, dim3(grid), dim3(NM_BLOCK), bytes, stream, a);
         break;
     }
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(NM_BLOCK) void compact_kernel(const int32_t *series
 void launch_compact(const int32_t *series_prev, const int32_t *n_prev, int n_series, const int32_t *done,
                     int32_t *series_next, int32_t *n_next, hipStream_t stream, int32_t *n_clear)
 {
-    if (!n_clear) (void)hipMemsetAsync(n_next, 0, sizeof(int32_t), stream);   // stand-alone use: clear the output counter here
+    if (!n_clear) anofox_check_attr(hipMemsetAsync(n_next, 0, sizeof(int32_t), stream));   // stand-alone use: clear the output counter here
     const int grid = (n_series + NM_BLOCK - 1) / NM_BLOCK;
     hipLaunchKernelGGL(compact_kernel, dim3(grid), dim3(NM_BLOCK), 0, stream, series_prev, n_prev, n_series, done, series_next, n_next, n_clear);
 }

@@ -6,7 +6,17 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <stdexcept>
+#include <string>
+
 namespace anofox {
+
+// results of the runtime calls made while preparing a launch (raising a kernel's LDS limit, clearing a counter) are
+// never discarded: a refused request would otherwise surface as a silent launch failure
+inline void anofox_check_attr(hipError_t e)
+{
+    if (e != hipSuccess) throw std::runtime_error(std::string("launch preparation failed: ") + hipGetErrorString(e));
+}
 
 // per-series flag bits produced by the prep kernel
 enum : uint32_t { SF_POSITIVE = 1u, SF_CONSTANT = 2u, SF_HAS_NAN = 4u };

@@ -177,7 +177,7 @@ void launch_prep(const PrepArgs &a, hipStream_t stream)
     const int grid = (a.n_series + NM_BLOCK - 1) / NM_BLOCK;
     size_t lds_bytes = 0;
     if (a.l0 != nullptr && a.m >= 2 && a.m <= ETS_MAX_PERIOD) lds_bytes = sizeof(double) * (size_t)((2 * (a.m / 2) + 1) + 3 * a.m) * NM_BLOCK;
-    if (lds_bytes > 48 * 1024) (void)hipFuncSetAttribute((const void *)prep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (lds_bytes > 48 * 1024) anofox_check_attr(hipFuncSetAttribute((const void *)prep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     hipLaunchKernelGGL(prep_kernel, dim3(grid), dim3(NM_BLOCK), lds_bytes, stream, a);
 }
 

@@ -54,6 +54,12 @@ class DeviceBatch:
         if not self.L.anofox_hip_batch_set_device_block(self.handle, y_time_major.data_ptr(), self.ld, lengths.data_ptr(), C.byref(err)):
             raise RuntimeError(f"set_device_block failed: [{err.code}] {err.message.decode()}")
 
+    def set_fixed_params(self, alpha: float, beta: float = 0.0, gamma: float = 0.0, phi: float = 1.0):
+        """ETS(spec) with given smoothing parameters: one streamed pass per series, no optimiser (BASELINE config 2)."""
+        err = _lib.AnofoxError()
+        if not self.L.anofox_hip_batch_set_fixed_params(self.handle, float(alpha), float(beta), float(gamma), float(phi), C.byref(err)):
+            raise RuntimeError(f"set_fixed_params failed: [{err.code}] {err.message.decode()}")
+
     def run(self, stream: torch.cuda.Stream | None = None):
         st = stream if stream is not None else torch.cuda.current_stream(self.device)
         err = _lib.AnofoxError()

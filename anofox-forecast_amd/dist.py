@@ -48,8 +48,9 @@ def gather_forecasts(local: dict, n_total: int, rank: int, world: int, dst: int 
         return local
     per = (n_total + world - 1) // world
     out = {}
+    host_only = dist.get_backend() == "gloo"          # gloo gathers host tensors only (CPU tests, the one-GPU debug mode)
     for key in ("yhat", "lower", "upper", "model_code", "status"):
-        x = local[key]
+        x = local[key].cpu() if host_only else local[key]
         pad_shape = (per,) + tuple(x.shape[1:])
         buf = torch.zeros(pad_shape, dtype=x.dtype, device=x.device)
         buf[: x.shape[0]] = x

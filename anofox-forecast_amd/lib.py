@@ -92,6 +92,7 @@ EXPORTED_SYMBOLS = [
     "anofox_hip_ingest_create", "anofox_hip_ingest_destroy", "anofox_hip_ingest_append", "anofox_hip_ingest_finish",
     "anofox_hip_ingest_group_keys", "anofox_hip_ingest_last_dates", "anofox_hip_ingest_lengths", "anofox_hip_ingest_values",
     "anofox_hip_ingest_validity", "anofox_hip_batch_pack_ingest", "anofox_hip_batch_inspect",
+    "anofox_hip_batch_n_series", "anofox_hip_batch_set_fixed_params",
 ]
 
 _lib = None
@@ -128,6 +129,10 @@ def load():
     L.anofox_hip_batch_destroy.argtypes = [C.c_void_p]
     L.anofox_hip_batch_ld.restype = C.c_size_t
     L.anofox_hip_batch_ld.argtypes = [C.c_void_p]
+    L.anofox_hip_batch_n_series.restype = C.c_size_t
+    L.anofox_hip_batch_n_series.argtypes = [C.c_void_p]
+    L.anofox_hip_batch_set_fixed_params.restype = C.c_bool
+    L.anofox_hip_batch_set_fixed_params.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, P(AnofoxError)]
     L.anofox_hip_batch_pack_host.restype = C.c_bool
     L.anofox_hip_batch_pack_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, P(AnofoxError)]
     L.anofox_hip_batch_set_device_block.restype = C.c_bool

@@ -4,24 +4,35 @@
 A "step" is one full pass of the hot path (prep -> every candidate ETS spec fitted per series by
 per-lane Nelder-Mead -> AICc selection -> fallback chain -> intervals) over one synthetic batch that
 is already resident in HBM when the timed region starts.  One process per GPU; series-id ranges
-shard across ranks with no data-path collective (weak scaling: every rank owns a full batch) and the
-only exchange is the gather of the forecast chunks to rank 0, inside the timed region.
+shard across ranks with no data-path collective and the only exchange is the gather of the forecast
+chunks to rank 0, inside the timed region.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
+--scaling weak   (default) every rank owns a full batch of the workload's size: value = N x series / time
+--scaling strong the workload's series are split over the ranks (BASELINE config 3: "M5 30,490 series,
+                 series-sharded 1->8 GPUs"): rank r owns dist.shard_range(n, r, N)
+
 Workloads (--workload):
     autoets_m5_positive   (default) 30,490 x 1,913, h=28, m=7, strictly positive counts: all 25
                           valid specs of the 30-model grid are fitted for every series
     autoets_m5            same shape, raw intermittent counts (zeros -> only the 6 additive specs admissible)
-    ets_aaa_m5            ETS(A,A,A) single spec on the same batch
+    ets_aaa_fixed_m5      BASELINE config 2: ETS(A,A,A) with GIVEN smoothing parameters (alpha 0.2, beta 0.05,
+                          gamma 0.1): one streamed pass per series, 15,976 algorithmic bytes per series
+    ets_aaa_m5            ETS(A,A,A) fitted (Nelder-Mead over alpha, beta*, gamma*) on the same batch
     autoets_stress        n x 1,024 AutoETS (use --n-series; the 1M config shards over 8 GPUs)
     autoarima_m5          AutoARIMA stepwise search, m = 7, on the M5-shape batch (BASELINE config 4)
+
+The JSON line also carries, on rank 0 at N = 1: `e2e` (the same workload through anofox_ts_forecast_batch: host
+buffers in, results on host -- pack + H2D + fit + D2H, SURVEY.md 8(d) metric (ii); never `value`) and
+`cpu_baseline` (the oracle on a bounded sample of the same batch, on this box's host cores).
 """
 from __future__ import annotations
 
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -34,6 +45,7 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # before HIP initialises: the spec streams need hardware queues
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP64_VALU_PEAK_WAVE_INSTS = 256 * 4 * 2.4e9 / 4.0   # wave-level fp64 VALU issue slots per second: 1,024 SIMDs, one wave64 fp64 op per 4 cycles at 2.4 GHz
 
 
 def parse_args():
@@ -42,24 +54,52 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="autoets_m5_positive")
-    ap.add_argument("--n-series", type=int, default=0, help="series per GPU (0 = workload default)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--n-series", type=int, default=0, help="series per GPU (weak) / in total (strong); 0 = workload default")
     ap.add_argument("--t", type=int, default=0, help="observations per series (0 = workload default)")
     ap.add_argument("--horizon", type=int, default=28)
     ap.add_argument("--cpu-sample", type=int, default=-1, help="series for the CPU baseline (-1 auto, 0 skip)")
+    ap.add_argument("--e2e-steps", type=int, default=-1, help="timed passes of the host-buffer entry (-1 auto, 0 skip)")
     return ap.parse_args()
 
 
+def W(model, ets_model, n, T, m, positive, seed, cpu_sample, fixed=None):
+    return dict(model=model, ets_model=ets_model, n=n, T=T, m=m, positive=positive, seed=seed, cpu_sample=cpu_sample, fixed=fixed)
+
+
 WORKLOADS = {
-    # name: (model, ets_model, n, T, m, positive, seed, cpu_sample)
-    "autoets_m5_positive": ("AutoETS", "", 30490, 1913, 7, True, 20260101, 384),
-    "autoets_m5": ("AutoETS", "", 30490, 1913, 7, False, 20260101, 8192),
-    "ets_aaa_m5": ("ETS", "AAA", 30490, 1913, 7, False, 20260101, 8192),
-    "autoets_stress": ("AutoETS", "", 125000, 1024, 7, False, 20260102, 8192),
-    "autoarima_m5": ("AutoARIMA", "", 30490, 1913, 7, False, 20260101, 512),
+    "autoets_m5_positive": W("AutoETS", "", 30490, 1913, 7, True, 20260101, 384),
+    "autoets_m5": W("AutoETS", "", 30490, 1913, 7, False, 20260101, 8192),
+    "ets_aaa_fixed_m5": W("ETS", "AAA", 30490, 1913, 7, False, 20260101, 30490, fixed=(0.2, 0.05, 0.1, 1.0)),
+    "ets_aaa_m5": W("ETS", "AAA", 30490, 1913, 7, False, 20260101, 8192),
+    "autoets_stress": W("AutoETS", "", 125000, 1024, 7, False, 20260102, 8192),
+    "autoarima_m5": W("AutoARIMA", "", 30490, 1913, 7, False, 20260101, 512),
     # single-spec probes (kernel efficiency without cross-kernel effects)
-    "ets_amdn_stress": ("ETS", "AMdN", 125000, 1024, 7, True, 20260102, 256),
-    "ets_mam_stress": ("ETS", "MAM", 125000, 1024, 7, True, 20260102, 256),
+    "ets_amdn_stress": W("ETS", "AMdN", 125000, 1024, 7, True, 20260102, 256),
+    "ets_mam_stress": W("ETS", "MAM", 125000, 1024, 7, True, 20260102, 256),
 }
+
+
+def e2e_pass(lib, Y, opts, steps):
+    """The same batch through the host-buffer entry (anofox_ts_forecast_batch): pack + H2D + fit + D2H + result arrays."""
+    L = lib.load()
+    n, T = Y.shape
+    vptr = (C.c_void_p * n)(*[Y.ctypes.data + s * T * 8 for s in range(n)])
+    lens = (C.c_size_t * n)(*([T] * n))
+    times = []
+    for _ in range(steps):
+        results = (lib.ForecastResult * n)()
+        errors = (lib.AnofoxError * n)()
+        berr = lib.AnofoxError()
+        t0 = time.perf_counter()
+        ok = L.anofox_ts_forecast_batch(vptr, None, lens, n, C.byref(opts), None, results, errors, C.byref(berr))
+        times.append(time.perf_counter() - t0)
+        if not ok:
+            raise RuntimeError(f"anofox_ts_forecast_batch failed: [{berr.code}] {berr.message.decode()}")
+        n_ok = sum(1 for i in range(n) if errors[i].code == 0)
+        for i in range(n):
+            L.anofox_free_forecast_result(C.byref(results[i]))
+    return times, n_ok
 
 
 def main():
@@ -69,15 +109,15 @@ def main():
 
     from anofox_forecast_amd import lib, synth
     from anofox_forecast_amd.device import DeviceBatch, pack_time_major
-    from anofox_forecast_amd.dist import gather_forecasts
+    from anofox_forecast_amd.dist import gather_forecasts, shard_range
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP backend has no CPU fallback")
-    # ANOFOX_BENCH_ONE_GPU=1 (debug only): every rank uses GPU 0 and the gather runs over gloo -- exercises the N > 1 code
-    # path on a single-GPU box; RCCL refuses two ranks on one device
+    # ANOFOX_BENCH_ONE_GPU=1 (debug / test only): every rank uses GPU 0 and the gather runs over gloo -- exercises the
+    # N > 1 code path on a single-GPU box; RCCL refuses two ranks on one device
     one_gpu = os.environ.get("ANOFOX_BENCH_ONE_GPU") == "1"
     dev_index = 0 if one_gpu else local_rank
     torch.cuda.set_device(dev_index)
@@ -89,16 +129,26 @@ def main():
         else:
             dist.init_process_group(backend="nccl", device_id=dev)     # "nccl" is RCCL on ROCm
 
-    model, ets_model, n_def, T_def, m, positive, seed, cpu_def = WORKLOADS[args.workload]
-    n = args.n_series or n_def
-    T = args.t or T_def
+    wl = WORKLOADS[args.workload]
+    model, ets_model, m, positive, seed = wl["model"], wl["ets_model"], wl["m"], wl["positive"], wl["seed"]
+    n_arg = args.n_series or wl["n"]
+    T = args.t or wl["T"]
     h = args.horizon
+    if args.scaling == "strong":
+        n_total = n_arg
+        lo, hi = shard_range(n_total, rank, world)        # this rank's series-id range of the ONE batch
+    else:
+        n_total = n_arg * world
+        lo, hi = rank * n_arg, (rank + 1) * n_arg          # every rank a full batch of its own
+    n = hi - lo
 
     # ---- synthetic batch, resident in HBM before anything is timed ------------------------------
     t0 = time.time()
-    Y = synth.gen_series(seed, rank * n, n, T, m, positive)                 # this rank's series-id range
+    Y = synth.gen_series(seed, lo, n, T, m, positive)                       # this rank's series-id range
     opts = lib.make_options(model, h, ets_model=ets_model, seasonal_period=m)
     batch = DeviceBatch(n, T, opts, dev)
+    if wl["fixed"]:
+        batch.set_fixed_params(*wl["fixed"])
     y_dev = torch.from_numpy(pack_time_major(Y, batch.ld)).to(dev)
     len_dev = torch.full((batch.ld,), T, dtype=torch.int32, device=dev)
     len_dev[n:] = 0
@@ -115,7 +165,7 @@ def main():
         batch.run()                                   # async on torch's current stream
         local = batch.results()
         if world > 1:
-            gather_forecasts(local, n * world, rank, world)   # the only exchange: forecast chunks -> rank 0
+            gather_forecasts(local, n_total, rank, world)     # the only exchange: forecast chunks -> rank 0
         return local
 
     for _ in range(args.warmup):
@@ -135,7 +185,12 @@ def main():
     elapsed = time.perf_counter() - t_start
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        if one_gpu:
+            tcpu = tmax.cpu()
+            dist.all_reduce(tcpu, op=dist.ReduceOp.MAX)
+            tmax = tcpu
+        else:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
 
     res = batch.results()
@@ -143,48 +198,83 @@ def main():
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        value = n * world * args.steps / elapsed
+        value = n_total * args.steps / elapsed
         fit_ms_avg = float(np.mean(fit_ms))
         achieved = float(np.mean(alg_bytes)) / (fit_ms_avg * 1e-3) / 1e9 if fit_ms_avg > 0 else 0.0
+        if model == "AutoARIMA":
+            kernel = "arima_fit_kernel + arima_fit_spec_kernel (all sweeps of one step)"
+        elif wl["fixed"]:
+            kernel = "ets_final_kernel<spec,period> (one streamed pass per series)"
+        else:
+            kernel = "ets_round_kernel<spec,period,driver> + ets_final_kernel (all spec launches of one step, concurrent streams)"
         out = {
             "metric": f"series/sec fit+forecast, {'AutoETS' if model != 'AutoARIMA' else 'AutoARIMA'} h={h} on M5-shape batches",
             "value": round(value, 1), "unit": "series/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": args.workload, "model": model + (f"({ets_model})" if ets_model else ""),
-                       "series_per_gpu": n, "T": T, "horizon": h, "seasonal_period": m, "positive": positive,
-                       "parallelism": f"series-sharded x{world}, gather of yhat chunks to rank 0",
+                       "fixed_params": list(wl["fixed"]) if wl["fixed"] else None,
+                       "series_total": n_total, "series_per_gpu": n, "T": T, "horizon": h, "seasonal_period": m, "positive": positive,
+                       "parallelism": f"series-sharded x{world} ({args.scaling}), gather of yhat chunks to rank 0",
                        "series_ok": n_ok, "mean_passes_per_series": round(st["total_passes"] / max(n, 1), 1),
                        "max_passes_per_series": st["max_passes"], "mean_evals_per_series": round(st["total_evals"] / max(n, 1), 1),
                        "problems": st["n_problems"], "fit_kernel_launches": st["fit_kernel_launches"],
                        "device_ms_per_step": round(float(np.mean(dev_ms)), 3), "datagen_s": round(gen_s, 1)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": ("arima_fit_kernel + arima_fit_spec_kernel (all sweeps of one step)" if model == "AutoARIMA" else
-                                    "ets_round_kernel<spec,period,driver> + ets_final_kernel (all spec launches of one step, concurrent streams)"),
-                         "kernel_ms": round(fit_ms_avg, 3), "algorithmic_bytes": int(np.mean(alg_bytes))},
+                         "kernel": kernel, "kernel_ms": round(fit_ms_avg, 3), "algorithmic_bytes": int(np.mean(alg_bytes))},
         }
-        # HBM traffic of the fit kernels comes from separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE,
-        # corrected as MI355X_MICROARCH.md prescribes); the committed summary is quoted when it was taken on
-        # this workload and shape, else the field stays null.
-        try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            if tr.get("workload") == args.workload and n == n_def and T == T_def:
-                out["roofline"]["traffic"] = int(tr["ets_round_kernel_traffic_bytes_per_step"])
-                out["roofline"]["traffic_source"] = "profiles/r01_pmc_traffic.json (PMC passes, per step)"
-        except (OSError, ValueError, KeyError):
-            pass
+        # HBM traffic and VALU issue of the fit kernels come from separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE
+        # corrected as MI355X_MICROARCH.md prescribes; SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU); the committed summary of the
+        # newest round is quoted when it was taken on this workload and shape, else the fields stay null.
+        for fn in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            try:
+                tr = json.load(open(os.path.join(ROOT, "profiles", fn)))
+            except (OSError, ValueError):
+                continue
+            if tr.get("workload") == args.workload and n == wl["n"] and T == wl["T"]:
+                try:
+                    out["roofline"]["traffic"] = int(tr["ets_round_kernel_traffic_bytes_per_step"])
+                    out["roofline"]["traffic_source"] = f"profiles/{fn} (PMC passes, per step)"
+                    if "valu_insts_per_step" in tr:
+                        issued = float(tr["valu_insts_per_step"])
+                        rate = issued / (fit_ms_avg * 1e-3)
+                        out["roofline"]["valu"] = {"issued_insts": int(issued), "peak_issue": FP64_VALU_PEAK_WAVE_INSTS,
+                                                   "frac": round(rate / FP64_VALU_PEAK_WAVE_INSTS, 4),
+                                                   "unit": "wave-level VALU instructions per second against one fp64 issue per SIMD per 4 cycles",
+                                                   "source": f"profiles/{fn} (SQ_INSTS_VALU per step) / this run's kernel_ms"}
+                except (KeyError, ValueError):
+                    pass
+                break
+        # ---- end to end: host buffers in, results on host (never `value`) -----------------------------
+        e2e_steps = args.e2e_steps if args.e2e_steps >= 0 else (0 if world > 1 else (1 if ms_per_step > 400 else 2))
+        if wl["fixed"]:
+            out["e2e"] = None        # the fixed-parameter entry exists on the device-resident API only
+        elif e2e_steps > 0 and world == 1:
+            times, e_ok = e2e_pass(lib, Y, opts, e2e_steps + 1)          # first pass untimed (allocations)
+            if True:
+                best = float(np.mean(times[1:]))
+                out["e2e"] = {"value": round(n / best, 1), "unit": "series/s", "ms_per_step": round(best * 1e3, 3), "steps": e2e_steps,
+                              "series_ok": e_ok,
+                              "what": "anofox_ts_forecast_batch: NULL fill + pack to the pinned time-major block (all host threads) + H2D + "
+                                      "fit + D2H + per-series malloc'd result arrays; PCIe-inclusive, never the headline value"}
         # ---- CPU baseline: the oracle ("port") on a bounded sample of the same workload -------------
-        sample = cpu_def if args.cpu_sample < 0 else args.cpu_sample
+        sample = wl["cpu_sample"] if args.cpu_sample < 0 else args.cpu_sample
         if sample > 0:
             from oracle import oracle as O
             sample = min(sample, n)
-            oo = O.make_options(model, h, ets_model=ets_model, seasonal_period=m)
             vals = np.ascontiguousarray(Y[:sample]).reshape(-1)
             offs = np.arange(sample + 1, dtype=np.int64) * T
             c0 = time.perf_counter()
-            cres = O.forecast_batch(vals, offs, oo, 0)
-            cdt = time.perf_counter() - c0
+            if wl["fixed"]:
+                reps = 8                                   # one pass per series is ~0.1 s of CPU work: repeat for a stable figure
+                for _ in range(reps):
+                    cres = O.ets_fixed_batch(vals, offs, ets_model, m, *wl["fixed"], h)
+                cdt = (time.perf_counter() - c0) / reps
+            else:
+                oo = O.make_options(model, h, ets_model=ets_model, seasonal_period=m)
+                cres = O.forecast_batch(vals, offs, oo, 0)
+                cdt = time.perf_counter() - c0
             got = res["yhat"][:sample].cpu().numpy()
             okm = cres["status"] == 0
             rel = np.abs(got[okm] - cres["yhat"][okm]) / np.maximum(1.0, np.abs(cres["yhat"][okm]))

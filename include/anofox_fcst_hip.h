@@ -168,6 +168,18 @@ bool anofox_hip_batch_create(size_t n_series, size_t t_max,
 void anofox_hip_batch_destroy(AnofoxHipBatch *batch);
 
 size_t anofox_hip_batch_ld(const AnofoxHipBatch *batch);
+size_t anofox_hip_batch_n_series(const AnofoxHipBatch *batch);
+
+/*
+ * ETS(spec) with GIVEN smoothing parameters (BASELINE.json configs[1]: "ETS(A,A,A) fixed smoothing params"): the batch
+ * must have been created for model "ETS" with an explicit `ets_model`.  No optimiser runs: every series takes ONE
+ * streamed pass (initial states as in the fitted path, then filter + forecast with these parameters).  Parameters are in
+ * the model's own terms, as anofox_hip_batch_inspect reports them: 0 < alpha < 1, 0 <= beta <= alpha,
+ * 0 <= gamma <= 1 - alpha, 0 < phi <= 1; the ones the spec does not have are ignored.  What the external crate's
+ * `ETS::new(spec, m)` + explicit parameters would be for forecast.rs:1357-1367; additive, no reference entry exists.
+ */
+bool anofox_hip_batch_set_fixed_params(AnofoxHipBatch *batch, double alpha, double beta, double gamma, double phi,
+                                       struct AnofoxError *out_error);
 
 /* Host series -> HBM block (NULL interpolation, imputation.rs:61-114, then pack + H2D). */
 bool anofox_hip_batch_pack_host(AnofoxHipBatch *batch,

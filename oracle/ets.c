@@ -436,6 +436,40 @@ int ets_fit(const EtsSpec *spec, const double *y, int n, EtsFit *fit, double *s_
     return fit->status = ETS_OK;
 }
 
+/* Fixed smoothing parameters (BASELINE config 2): the same preconditions and initial states as ets_fit, no optimiser --
+ * one likelihood pass with par = (alpha, beta / alpha, gamma / (1 - alpha), phi) restricted to the spec's coordinates. */
+int ets_fit_fixed(const EtsSpec *spec, const double *y, int n, double alpha, double beta, double gamma, double phi,
+                  EtsFit *fit, double *s_final)
+{
+    memset(fit, 0, sizeof *fit);
+    const int dim = ets_dim(spec);
+    const int k = ets_n_param(spec);
+    fit->dim = dim;
+    fit->n_param = k;
+    if (spec->season != ETS_NONE && (spec->m < 2 || spec->m > ETS_MAX_PERIOD)) return fit->status = ETS_ERR_PERIOD;
+    if (spec->season != ETS_NONE && n < 2 * spec->m) return fit->status = ETS_ERR_SHORT;
+    if (n < k + 2) return fit->status = ETS_ERR_SHORT;
+    if (spec->error == ETS_MUL || spec->trend == ETS_MUL || spec->season == ETS_MUL) {
+        for (int i = 0; i < n; i++) if (!(y[i] > 0.0)) return fit->status = ETS_ERR_NONPOSITIVE;
+    }
+    double s0[ETS_MAX_PERIOD];
+    int st = ets_init_states(spec, y, n, &fit->l0, &fit->b0, s0);
+    if (st != ETS_OK) return fit->status = st;
+    int d = 0;
+    fit->par[d++] = alpha;
+    if (spec->trend != ETS_NONE) fit->par[d++] = beta / alpha;
+    if (spec->season != ETS_NONE) fit->par[d++] = gamma / (1.0 - alpha);
+    if (spec->damped) fit->par[d++] = phi;
+    ets_unpack(spec, fit->par, &fit->alpha, &fit->beta_star, &fit->gamma_star, &fit->phi);
+    fit->lik = ets_lik(spec, y, n, fit->par, fit->l0, fit->b0, s0, &fit->sse, &fit->l, &fit->b, s_final);
+    if (!(fabs(fit->lik) <= DBL_MAX)) return fit->status = ETS_ERR_NONFINITE;
+    double dk = (double)k, dn = (double)n;
+    fit->aic = fit->lik + 2.0 * dk;
+    fit->aicc = fit->aic + 2.0 * dk * (dk + 1.0) / (dn - dk - 1.0);
+    fit->bic = fit->lik + dk * det_log(dn);
+    return fit->status = ETS_OK;
+}
+
 void ets_forecast(const EtsSpec *spec, int n, const EtsFit *fit, const double *s_final,
                   int h, double *out)
 {

@@ -86,6 +86,10 @@ double ets_lik(const EtsSpec *spec, const double *y, int n, const double *par,
 /* Fit (Nelder-Mead over the smoothing parameters) + final pass. s_final[m]. */
 int ets_fit(const EtsSpec *spec, const double *y, int n, EtsFit *fit, double *s_final);
 
+/* Given smoothing parameters in the model's own terms (no optimiser): one pass + final states. */
+int ets_fit_fixed(const EtsSpec *spec, const double *y, int n, double alpha, double beta, double gamma, double phi,
+                  EtsFit *fit, double *s_final);
+
 /* h-step point forecasts from final states. */
 void ets_forecast(const EtsSpec *spec, int n, const EtsFit *fit, const double *s_final,
                   int h, double *out);

@@ -27,6 +27,7 @@
 #include <ctype.h>
 #include <float.h>
 #include <math.h>
+#include <omp.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -826,6 +827,33 @@ int oracle_ets_inspect(const double *y, int n, int period, int pool, int spec_id
     states[0] = fit.l; states[1] = fit.b;
     if (sp.season != ETS_NONE) for (int j = 0; j < sp.m; j++) states[2 + j] = sfin[j];
     return best;
+}
+
+/* ETS(notation) with given smoothing parameters over many series (BASELINE config 2), OpenMP over series: the checker of
+ * anofox_hip_batch_set_fixed_params and the CPU baseline of bench.py --workload ets_aaa_fixed_m5.
+ * status: 0 ok, else ErrorCode (6 insufficient data, 3 computation error). */
+int oracle_ets_fixed_batch(const double *values, const int64_t *offsets, size_t n_series, const char *notation, int period,
+                           double alpha, double beta, double gamma, double phi, int h, double conf,
+                           double *yhat, double *lo, double *hi, int32_t *status, int n_threads)
+{
+    if (!valid_ets_notation(notation)) return -1;
+    if (n_threads <= 0) n_threads = omp_get_max_threads();
+#pragma omp parallel for schedule(dynamic, 16) num_threads(n_threads)
+    for (long s = 0; s < (long)n_series; s++) {
+        const double *y = values + offsets[s];
+        const size_t n = (size_t)(offsets[s + 1] - offsets[s]);
+        if (n < 3) { status[s] = INSUFFICIENT_DATA; continue; }
+        EtsSpec spec = spec_from_notation(notation);
+        if (spec.season != ETS_NONE && period > 1) spec.m = period;
+        else { spec.season = ETS_NONE; spec.m = 1; }
+        EtsFit fit;
+        double sfin[ETS_MAX_PERIOD];
+        if (ets_fit_fixed(&spec, y, (int)n, alpha, beta, gamma, phi, &fit, sfin) != ETS_OK) { status[s] = COMPUTATION_ERROR; continue; }
+        ets_forecast(&spec, (int)n, &fit, sfin, h, yhat + (size_t)s * h);
+        confidence_intervals(yhat + (size_t)s * h, h, y, n, conf, lo + (size_t)s * h, hi + (size_t)s * h);
+        status[s] = 0;
+    }
+    return n_threads;
 }
 
 /* test hooks */

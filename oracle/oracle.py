@@ -187,3 +187,25 @@ def ets_inspect(values, period, spec_id=-1, pool=0):
     out = dict(zip(keys, par))
     out.update(spec_id=sid, level=states[0], trend=states[1], seasonal_states=states[2:2 + max(period, 1)], fitted_values=fitted)
     return out
+
+
+def ets_fixed_batch(values_concat, offsets, notation, period, alpha, beta, gamma, phi, h, conf=0.90, n_threads=0):
+    """ETS(notation) with GIVEN smoothing parameters over many series (BASELINE config 2): initial states as in the fitted
+    path, one pass, forecasts + intervals.  The checker of anofox_hip_batch_set_fixed_params."""
+    v = np.ascontiguousarray(values_concat, dtype=np.float64)
+    off = np.ascontiguousarray(offsets, dtype=np.int64)
+    n = len(off) - 1
+    L = lib()
+    L.oracle_ets_fixed_batch.restype = C.c_int
+    L.oracle_ets_fixed_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_char_p, C.c_int, C.c_double, C.c_double, C.c_double,
+                                         C.c_double, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    yhat = np.full((n, h), np.nan)
+    lo = np.full((n, h), np.nan)
+    hi = np.full((n, h), np.nan)
+    status = np.zeros(n, dtype=np.int32)
+    used = L.oracle_ets_fixed_batch(v.ctypes.data, off.ctypes.data, n, notation.encode(), int(period), float(alpha), float(beta),
+                                    float(gamma), float(phi), int(h), float(conf), yhat.ctypes.data, lo.ctypes.data, hi.ctypes.data,
+                                    status.ctypes.data, int(n_threads))
+    if used < 0:
+        raise ValueError(f"bad ETS notation {notation!r}")
+    return {"yhat": yhat, "lower": lo, "upper": hi, "status": status, "threads": used}

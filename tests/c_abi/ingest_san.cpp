@@ -24,6 +24,10 @@ extern "C" bool anofox_hip_batch_pack_host(AnofoxHipBatch *, const double *const
     return true;
 }
 
+// ... and the batch it was "created" for: the harness names the series count the ingest is checked against
+static size_t g_batch_n = 0;
+extern "C" size_t anofox_hip_batch_n_series(const AnofoxHipBatch *) { return g_batch_n; }
+
 #define CHECK(c) do { if (!(c)) { std::fprintf(stderr, "FAIL %s:%d %s (seed %u)\n", __FILE__, __LINE__, #c, seed); return 1; } } while (0)
 
 int main(int argc, char **argv)
@@ -85,6 +89,9 @@ int main(int argc, char **argv)
             }
         }
         CHECK(tmax == want_tmax);
+        g_batch_n = G + 1;                                    // a batch created for another number of series is refused
+        CHECK(!anofox_hip_batch_pack_ingest((AnofoxHipBatch *)(uintptr_t)0x10, g, &err) && err.code == INVALID_INPUT);
+        g_batch_n = G;
         CHECK(anofox_hip_batch_pack_ingest((AnofoxHipBatch *)(uintptr_t)0x10, g, &err));
         CHECK(g_seen.values == vals && g_seen.validity == masks && g_seen.lengths == len);
         CHECK(!anofox_hip_batch_pack_ingest(nullptr, g, &err) && err.code == NULL_POINTER);

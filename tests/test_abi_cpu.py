@@ -74,7 +74,14 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")) or f == "Makefile":
                 txt = open(os.path.join(dp, f), errors="replace").read()
                 assert "import oracle" not in txt and "from oracle" not in txt and "liboracle" not in txt, os.path.join(dp, f)
-                assert '#include "../../oracle' not in txt and "oracle/" not in txt.replace("oracle/ets.c", "").replace("oracle/", "oracle/") or True
+                # no source under the package reaches into oracle/: neither an #include nor a path (comments that NAME an
+                # oracle file for provenance, "oracle/ets.c", are the only mentions allowed)
+                assert '#include "../../oracle' not in txt and '#include "oracle' not in txt, os.path.join(dp, f)
+                for line in txt.splitlines():
+                    if "oracle/" not in line:
+                        continue
+                    code = line.split("//")[0].split("#")[0] if f.endswith((".hip", ".hpp", ".cpp", ".h", ".py")) or f == "Makefile" else line
+                    assert "oracle/" not in code, (os.path.join(dp, f), line)
     out = subprocess.check_output(["ldd", os.path.join(pkg, "libanofox_fcst_hip.so")]).decode() if os.path.exists(os.path.join(pkg, "libanofox_fcst_hip.so")) else ""
     assert "liboracle" not in out
 

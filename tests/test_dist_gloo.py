@@ -57,3 +57,46 @@ def test_balanced_shards_cover_and_balance():
         work = np.array([lens[a:b].sum() for a, b in r], dtype=float)
         assert work.max() <= work.mean() * 1.01 + 2000            # within one series of the ideal share
     assert shard_ranges_balanced([5, 5], 4) and sum(b - a for a, b in shard_ranges_balanced([5, 5], 4)) == 2
+
+
+def _pipeline_worker(rank, world, port, n_total, T, h, scaling, ret):
+    """What bench.py does per rank, with the oracle standing in for the device (no GPU here): regenerate this rank's series-id
+    range, forecast it, gather the chunks to rank 0."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from anofox_forecast_amd import synth
+    from anofox_forecast_amd.dist import gather_forecasts, shard_range
+    from oracle import oracle as O
+    if scaling == "strong":
+        total = n_total
+        lo, hi = shard_range(total, rank, world)
+    else:
+        total = n_total * world
+        lo, hi = rank * n_total, (rank + 1) * n_total
+    Y = synth.gen_series(synth.SEED_M5, lo, hi - lo, T, 7, False)
+    r = O.ets_fixed_batch(Y.reshape(-1), np.arange(hi - lo + 1, dtype=np.int64) * T, "AAA", 7, 0.2, 0.05, 0.1, 1.0, h, n_threads=2)
+    local = {"yhat": torch.from_numpy(r["yhat"]), "lower": torch.from_numpy(r["lower"]), "upper": torch.from_numpy(r["upper"]),
+             "model_code": torch.zeros(hi - lo, dtype=torch.int32), "status": torch.from_numpy(r["status"])}
+    out = gather_forecasts(local, total, rank, world)
+    if rank == 0:
+        ret["yhat"] = out["yhat"].numpy()
+        ret["status"] = out["status"].numpy()
+    dist.destroy_process_group()
+
+
+def test_sharded_pipeline_world2_gloo():
+    """Two ranks, both scaling modes of bench.py: the gathered forecasts equal one process over the whole series-id range
+    (series regenerate from their ids, shards are contiguous, chunks arrive in rank order, uneven last shard included)."""
+    from anofox_forecast_amd import synth
+    from oracle import oracle as O
+    T, h, world = 60, 6, 2
+    for scaling, n_arg in (("strong", 1031), ("weak", 300)):
+        mgr = mp.Manager()
+        ret = mgr.dict()
+        mp.spawn(_pipeline_worker, args=(world, 29117 + os.getpid() % 500, n_arg, T, h, scaling, ret), nprocs=world, join=True)
+        total = n_arg if scaling == "strong" else n_arg * world
+        Y = synth.gen_series(synth.SEED_M5, 0, total, T, 7, False)
+        ref = O.ets_fixed_batch(Y.reshape(-1), np.arange(total + 1, dtype=np.int64) * T, "AAA", 7, 0.2, 0.05, 0.1, 1.0, h, n_threads=2)
+        np.testing.assert_array_equal(ret["yhat"], ref["yhat"])
+        np.testing.assert_array_equal(ret["status"], ref["status"])

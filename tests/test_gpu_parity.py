@@ -420,6 +420,132 @@ def test_device_resident_batch_and_stats(env):
     b.close()
 
 
+def _fixed_batch(lib, Y, spec, m, h, params, lens=None):
+    """ETS(spec) with given parameters over a resident block; returns host copies of the device results + stats."""
+    import torch
+    from anofox_forecast_amd.device import DeviceBatch, pack_time_major
+    n, T = Y.shape
+    opts = lib.make_options("ETS", h, ets_model=spec, seasonal_period=m)
+    b = DeviceBatch(n, T, opts, "cuda:0")
+    ln = torch.zeros(b.ld, dtype=torch.int32, device="cuda")
+    ln[:n] = torch.as_tensor(np.full(n, T) if lens is None else lens, dtype=torch.int32)
+    b.set_block(torch.from_numpy(pack_time_major(Y, b.ld)).cuda(), ln)
+    b.set_fixed_params(*params)
+    b.run()
+    torch.cuda.synchronize()
+    out = {k: v.cpu().numpy().copy() for k, v in b.results().items()}
+    st = b.stats()
+    b.close()
+    return out, st
+
+
+@pytest.mark.parametrize("spec,params", [("AAA", (0.2, 0.05, 0.1, 1.0)), ("AAdA", (0.3, 0.1, 0.2, 0.9)), ("ANN", (0.5, 0.0, 0.0, 1.0)),
+                                         ("MAM", (0.15, 0.02, 0.3, 1.0)), ("MMdM", (0.25, 0.2, 0.05, 0.85)), ("AAN", (0.9, 0.9, 0.0, 1.0))])
+def test_fixed_parameter_ets_matches_oracle(env, spec, params):
+    """BASELINE config 2's path at test size: ETS(spec) with GIVEN smoothing parameters -- no optimiser, one streamed pass --
+    equals the oracle's restatement (same initial states, same recursion) bit for bit, ragged lengths and short series
+    included; exactly one pass per fitted series is counted."""
+    api, O, lib, synth = env
+    n, T, h, m = 300, 180, 12, 7
+    Y = synth.gen_series(synth.SEED_M5, 12000, n, T, m, positive=True)
+    lens = np.array([T - (s % 9) * 17 for s in range(n)], dtype=np.int64)
+    lens[:4] = [2, 3, 9, 13]                               # too short for anything / for a seasonal model
+    Yz = Y.copy()
+    for s in range(n):
+        Yz[s, lens[s]:] = 0.0
+    out, st = _fixed_batch(lib, Yz, spec, m, h, params, lens)
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    vals = np.concatenate([Y[s, :lens[s]] for s in range(n)])
+    ref = O.ets_fixed_batch(vals, offs, spec, m, *params, h)
+    assert np.array_equal(out["status"][:n], ref["status"])
+    ok = ref["status"] == 0
+    assert ok.sum() >= n - 4
+    for k in ("yhat", "lower", "upper"):
+        assert _rel(out[k][:n][ok], ref[k][ok]) <= REL_TOL, (spec, k)
+    assert st["total_passes"] == int(ok.sum())              # one pass per fitted series: the 8 T + 24 h bytes of SURVEY 8(d) C2
+    assert st["algorithmic_bytes"] == 8 * int(lens[ok].sum()) + 24 * h * n
+
+
+def test_fixed_parameter_entry_rejects_bad_input(env):
+    api, O, lib, synth = env
+    import ctypes as C
+    L = lib.load()
+    err = lib.AnofoxError()
+    for model, ets, args in (("AutoETS", "", (0.2, 0.05, 0.1, 1.0)), ("ETS", "", (0.2, 0.05, 0.1, 1.0)),
+                             ("ETS", "AAA", (1.2, 0.05, 0.1, 1.0)), ("ETS", "AAA", (0.2, 0.3, 0.1, 1.0)),
+                             ("ETS", "AAA", (0.2, 0.05, 0.9, 1.0)), ("ETS", "AAdA", (0.2, 0.05, 0.1, 1.5)),
+                             ("ETS", "AAA", (float("nan"), 0.05, 0.1, 1.0))):
+        h = C.c_void_p()
+        o = lib.make_options(model, 4, ets_model=ets, seasonal_period=7)
+        assert L.anofox_hip_batch_create(8, 32, C.byref(o), C.byref(h), C.byref(err))
+        assert not L.anofox_hip_batch_set_fixed_params(h, *args, C.byref(err)) and err.code == lib.INVALID_INPUT, (model, ets, args)
+        L.anofox_hip_batch_destroy(h)
+
+
+def test_fixed_parameter_aaa_full_size_m5(env):
+    """BASELINE.json configs[1] at its full size: ETS(A,A,A) with alpha 0.2, beta 0.05, gamma 0.1 on 30,490 x
+    1,913, h = 28 -- against the oracle on EVERY series (one pass each: seconds on the host), plus the properties that hold
+    without it (second run identical, intervals bracket the forecast)."""
+    api, O, lib, synth = env
+    n, T, h, m = 30490, 1913, 28, 7
+    Y = synth.gen_series(synth.SEED_M5, 0, n, T, m, False)
+    params = (0.2, 0.05, 0.1, 1.0)
+    out, st = _fixed_batch(lib, Y, "AAA", m, h, params)
+    again, _ = _fixed_batch(lib, Y, "AAA", m, h, params)
+    for k in ("yhat", "lower", "upper", "status"):
+        assert np.array_equal(out[k], again[k], equal_nan=True)
+    assert np.all(out["status"][:n] == 0) and np.all(out["lower"][:n] <= out["yhat"][:n]) and np.all(out["yhat"][:n] <= out["upper"][:n])
+    ref = O.ets_fixed_batch(Y.reshape(-1), np.arange(n + 1, dtype=np.int64) * T, "AAA", m, *params, h)
+    assert np.all(ref["status"] == 0)
+    for k in ("yhat", "lower", "upper"):
+        assert _rel(out[k][:n], ref[k]) <= REL_TOL, k
+    assert st["total_passes"] == n and st["algorithmic_bytes"] == n * (8 * T + 24 * h)
+
+
+def test_stress_shape_properties(env):
+    """BASELINE.json configs[4], one GPU's share (125,000 series x 1,024 observations, AutoETS, h = 28, m = 7): every series
+    gets a forecast, intervals bracket it, a second run reproduces every bit, an arbitrary shuffled sub-batch reproduces
+    the full batch and equals the oracle."""
+    api, O, lib, synth = env
+    n, T, h, m = 125000, 1024, 28, 7
+    Y = synth.gen_series(synth.SEED_STRESS, 0, n, T, m, False)
+    full, again, names = _run_device_batch(lib, Y, "AutoETS", h, m)
+    for k in ("yhat", "lower", "upper", "model_code", "status"):
+        assert np.array_equal(full[k], again[k], equal_nan=True), f"{k}: second run differs"
+    assert np.all(full["status"][:n] == 0)
+    yh, lo, hi = full["yhat"][:n], full["lower"][:n], full["upper"][:n]
+    assert np.all(np.isfinite(yh)) and np.all(lo <= yh) and np.all(yh <= hi)
+    assert all(nm.startswith("AutoETS") for nm in names)
+    pick = np.random.default_rng(9).choice(n, 128, replace=False)
+    sub, _, sub_names = _run_device_batch(lib, Y[pick], "AutoETS", h, m)
+    for k in ("yhat", "lower", "upper", "model_code"):
+        assert np.array_equal(sub[k][:128], full[k][pick], equal_nan=True), f"{k}: result depends on the batch"
+    oo = O.make_options("AutoETS", h, seasonal_period=m)
+    for j in range(64):
+        ref = O.forecast(Y[pick[j]], oo)
+        assert _rel(sub["yhat"][j], ref["point"]) <= REL_TOL and sub_names[j] == ref["model_name"]
+
+
+@pytest.mark.parametrize("scaling", ["strong", "weak"])
+def test_bench_two_ranks_on_one_gpu(env, scaling):
+    """bench.py's N > 1 path end to end -- two processes, torch.distributed rendezvous, sharded batches on the device, gather
+    of the forecast chunks, max-over-ranks timing, one JSON line -- on this box's single GPU (ANOFOX_BENCH_ONE_GPU: both
+    ranks use GPU 0 and the gather runs over gloo, since RCCL refuses two ranks on one device)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    envv = dict(os.environ, ANOFOX_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29300 + os.getpid() % 400), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--workload", "autoets_m5", "--n-series", "1500", "--t", "200", "--scaling", scaling, "--cpu-sample", "0"]
+    out = subprocess.run(cmd, env=envv, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["scaling"] == scaling and j["value"] > 0
+    assert j["config"]["series_total"] == (1500 if scaling == "strong" else 3000)
+    assert j["config"]["series_per_gpu"] == (750 if scaling == "strong" else 1500)
+
+
 def test_auto_arima_matches_oracle(env):
     """AutoARIMA (stepwise CSS search) on the GPU walks the oracle's search bit for bit: same selected order,
     same forecasts -- seasonal (m = 7: VGPR-free generic lag polynomials), non-seasonal, ragged, short."""
