@@ -120,53 +120,71 @@ __device__ __forceinline__ double dm_exp(double x)
     return dm_scalbn(y, k);
 }
 
-// x^y for the per-step damped multiplicative growth b^phi: x in [2^-1000, 2^1000], 0 < y <= 1 (the caller rejects
-// the trial point otherwise and ignores the value).  Same reductions as dm_log / dm_exp, but written for that domain
-// only -- no special cases, straight-line code -- and with the polynomial and recombination steps fused: this one function
-// is most of the arithmetic of the five damped multiplicative-trend specs, which carry ~70 % of the 30-spec workload's
-// VALU instructions.  oracle/det_math.h (det_pow_step) states the identical sequence of operations.
+// x^y for the per-step damped multiplicative growth b^phi: x in [2^-1000, 2^1000], 0 < y <= 1 (the caller rejects the
+// trial point otherwise and ignores the value).  This one function is most of the arithmetic of the five damped
+// multiplicative-trend specs and sits on the critical path of their slowest fits, so it is table driven: no division,
+// two degree-6 polynomials in Estrin form (5 dependent fused multiply-adds each), the tables (tools/gen_pow_tables.py,
+// 2.5 KB) in LDS.  oracle/det_math.h (det_pow_step) states the identical sequence of operations on the identical
+// tables.   ln x = e ln2 + LOG_C[j] + log1p(m INV_C[j] - 1);   e^t = 2^(n >> 6) EXP2_T[n & 63] (1 + p(t - n ln2/64)).
+#include "pow_tables.inc"
+static __device__ const double dm_pow_inv_c_src[ANOFOX_POW_INV_C_N] = { ANOFOX_POW_INV_C_VALUES };
+static __device__ const double dm_pow_log_c_src[ANOFOX_POW_LOG_C_N] = { ANOFOX_POW_LOG_C_VALUES };
+static __device__ const double dm_pow_exp2_t_src[ANOFOX_POW_EXP2_T_N] = { ANOFOX_POW_EXP2_T_VALUES };
+constexpr int DM_POW_TAB_DOUBLES = 2 * ANOFOX_POW_INV_C_N + ANOFOX_POW_EXP2_T_N;
+
+// the workgroup's copy: {INV_C[j], LOG_C[j]} side by side (one 128-bit LDS read), then EXP2_T
+__device__ __forceinline__ double *dm_pow_tab()
+{
+    __shared__ __attribute__((aligned(16))) double tab[DM_POW_TAB_DOUBLES];
+    return tab;
+}
+
+// once per kernel, by a 64-lane workgroup, before the first dm_pow_step
+__device__ __forceinline__ void dm_pow_tab_init()
+{
+    double *tab = dm_pow_tab();
+    const int l = threadIdx.x & 63;
+    tab[2 * l] = dm_pow_inv_c_src[l];
+    tab[2 * l + 1] = dm_pow_log_c_src[l];
+    tab[2 * (l + 64)] = dm_pow_inv_c_src[l + 64];
+    tab[2 * (l + 64) + 1] = dm_pow_log_c_src[l + 64];
+    tab[2 * ANOFOX_POW_INV_C_N + l] = dm_pow_exp2_t_src[l];
+    __syncthreads();
+}
+
 __device__ __forceinline__ double dm_pow_step(double x, double y)
 {
     const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
-    const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
-                 Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
-                 Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
-                 Lg7 = 1.479819860511658591e-01;
-    const double invln2 = 1.44269504088896338700e+00;
+    const double n_per_ln2 = 0x1.71547652b82fep+6;                           // 64 / ln2
+    const double L_hi = 0x1.62e42fee00000p-7, L_lo = 0x1.a39ef35793c76p-39;  // ln2 / 64 = L_hi + L_lo, L_hi has 32 significant bits
+    const double *tab = dm_pow_tab();
     const uint64_t u = dm_bits(x);
-    uint32_t hx = (uint32_t)(u >> 32);
-    hx += 0x3ff00000u - 0x3fe6a09eu;
-    const int k = (int)(hx >> 20) - 0x3ff;
-    hx = (hx & 0x000fffffu) + 0x3fe6a09eu;
-    const double m = dm_from_bits(((uint64_t)hx << 32) | (u & 0xffffffffull));
-    const double f = m - 1.0;
-    const double hfsq = 0.5 * f * f;
-    const double s = f / (2.0 + f);
-    const double z = s * s;
-    const double w = z * z;
-    const double t1 = w * fma(w, fma(w, Lg6, Lg4), Lg2);
-    const double t2 = z * fma(w, fma(w, fma(w, Lg7, Lg5), Lg3), Lg1);
-    const double R = t2 + t1;
-    const double dk = (double)k;
-    const double lg = fma(dk, ln2_hi, (fma(s, hfsq + R, dk * ln2_lo) - hfsq) + f);
+    const uint32_t hx = (uint32_t)(u >> 32);
+    const int e = (int)(hx >> 20) - 1023;                                    // x is a positive normal number
+    const int j = (int)(hx >> 13) & 127;
+    const double m = dm_from_bits((u & 0x000fffffffffffffull) | 0x3ff0000000000000ull);
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    const d2_t ic = *reinterpret_cast<const d2_t *>(tab + 2 * j);            // {INV_C[j], LOG_C[j]}
+    const double r = fma(m, ic.x, -1.0);
+    const double r2 = r * r;
+    const double pa = fma(r, 1.0 / 3.0, -0.5);
+    const double pb = fma(r, 0.2, -0.25);
+    const double pl = fma(r2, fma(r2, -1.0 / 6.0, pb), pa);
+    const double l1p = fma(r2, pl, r);
+    const double de = (double)e;
+    const double lg = fma(de, ln2_hi, ic.y) + fma(de, ln2_lo, l1p);
     const double t = y * lg;
-    const double dn = __builtin_rint(invln2 * t);       // round to nearest even (v_rndne_f64); |dn| <= 1000
-    const double r = fma(-dn, ln2_lo, fma(-dn, ln2_hi, t));
-    double p = 1.0 / 6227020800.0;
-    p = fma(p, r, 1.0 / 479001600.0);
-    p = fma(p, r, 1.0 / 39916800.0);
-    p = fma(p, r, 1.0 / 3628800.0);
-    p = fma(p, r, 1.0 / 362880.0);
-    p = fma(p, r, 1.0 / 40320.0);
-    p = fma(p, r, 1.0 / 5040.0);
-    p = fma(p, r, 1.0 / 720.0);
-    p = fma(p, r, 1.0 / 120.0);
-    p = fma(p, r, 1.0 / 24.0);
-    p = fma(p, r, 1.0 / 6.0);
-    p = fma(p, r, 0.5);
-    p = fma(p, r, 1.0);
-    const double e = fma(p, r, 1.0);
-    return e * dm_from_bits((uint64_t)(0x3ff + (int)dn) << 52);
+    const double dn = __builtin_rint(n_per_ln2 * t);    // round to nearest even (v_rndne_f64); |dn| <= 64000
+    const double s = fma(-dn, L_lo, fma(-dn, L_hi, t));
+    const double s2 = s * s;
+    const double qa = fma(s, 1.0 / 6.0, 0.5);
+    const double qb = fma(s, 1.0 / 120.0, 1.0 / 24.0);
+    const double q = fma(s2, fma(s2, 1.0 / 720.0, qb), qa);
+    const double p = fma(s2, q, s);
+    const int n = (int)dn;
+    const double tv = tab[2 * ANOFOX_POW_INV_C_N + (n & 63)];
+    const double ev = fma(tv, p, tv);
+    return ev * dm_from_bits((uint64_t)(uint32_t)(0x3ff + (n >> 6)) << 52);
 }
 
 // general x^y, x > 0 (forecast path: the exponent is a partial geometric sum and may exceed 1)

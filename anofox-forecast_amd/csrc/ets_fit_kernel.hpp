@@ -68,6 +68,7 @@ __global__ __launch_bounds__(NM_BLOCK, ANOFOX_ROUND_WAVES) void ets_round_kernel
     v.wave_min_len = wave_min_i32(active ? len : 0x7fffffff);
     v.rows = a.t_rows;
     if (v.wave_len == 0) return;
+    if constexpr (Cfg::T == C_MUL && Cfg::D) dm_pow_tab_init();     // b^phi tables -> LDS (wave-uniform point: no lane has left)
 
     EtsModel<Cfg, MS, 1> mdl;
     mdl.v = v;
@@ -165,6 +166,7 @@ __global__ __launch_bounds__(NM_BLOCK) void ets_final_kernel(const FitArgs a)
         if (!inspect && valid && len > 0) { a.aicc[s] = __builtin_huge_val(); a.evals[s] = 0; a.iters[s] = 0; a.passes[s] = 0; }
         return;
     }
+    if constexpr (Cfg::T == C_MUL && Cfg::D) dm_pow_tab_init();
     EtsInit in;
     in.l0 = active ? a.l0[s] : 0.0;
     in.b0 = (active && Cfg::T != C_NONE) ? a.b0[s] : 0.0;

@@ -859,6 +859,7 @@ void run_group(AnofoxHipBatch *b, int period, const int32_t *d_len, hipStream_t 
 void run_batch(AnofoxHipBatch *b, hipStream_t st)
 {
     const size_t n = b->n, ld = b->ld;
+    (void)hipGetLastError();     // the launch checks below must only see THIS run's errors (an earlier, already reported failure is sticky)
     b->fit_launches = 0;
     b->n_problems = 0;
     b->timed_fit = false;

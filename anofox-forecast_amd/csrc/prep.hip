@@ -13,6 +13,29 @@
 
 namespace anofox {
 
+// Rows of the time-major block, S at a time, for a wave whose lanes own adjacent columns: range-checked buffer loads
+// (descriptor per block from scalars, row stride in the scalar offset, the lane's column in the vector offset; rows past
+// `rows` read as zeros) -- the loader of ets_pass (ets_device.hpp).  The S rows of the NEXT block are requested before the
+// current block is consumed, so a wave keeps S loads in flight instead of waiting for every row.
+template <int S>
+struct RowLoader {
+    const char *base; unsigned col_bytes; size_t row_bytes, total_bytes;
+    __device__ __forceinline__ void load(double (&buf)[S], const int row0) const
+    {
+        typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+        const size_t off = (size_t)row0 * row_bytes;
+        const size_t rem = off < total_bytes ? total_bytes - off : 0;
+        const unsigned nrec = rem > 0xffffffffull ? 0xffffffffu : (unsigned)rem;
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(base + (rem ? off : 0)), 0, nrec, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < S; j++) {
+            const u32x2_t w = __builtin_amdgcn_raw_buffer_load_b64(rsrc, col_bytes, (unsigned)(j * row_bytes), 0);
+            buf[j] = __builtin_bit_cast(double, w);
+        }
+    }
+};
+constexpr int PREP_S = 16;
+
 __global__ __launch_bounds__(NM_BLOCK) void prep_kernel(const PrepArgs a)
 {
     extern __shared__ double lds[];
@@ -22,8 +45,14 @@ __global__ __launch_bounds__(NM_BLOCK) void prep_kernel(const PrepArgs a)
     const int n = valid ? a.len[s] : 0;
     const int wave_n = wave_max_i32(n);
     if (wave_n == 0) return;
-    const double *y = a.y + (valid ? s : 0);
     const size_t ld = a.ld;
+    const int wave_rows = __builtin_amdgcn_readfirstlane(wave_n);
+    RowLoader<PREP_S> rows;
+    rows.base = (const char *)a.y;
+    rows.col_bytes = (unsigned)(valid ? s : 0) * 8u;
+    rows.row_bytes = ld * 8;
+    rows.total_bytes = (size_t)wave_rows * rows.row_bytes;
+    double cur[PREP_S], nxt[PREP_S];
     const bool states = a.l0 != nullptr;
     const int m = a.m;
     const bool want_season = states && m >= 2 && m <= ETS_MAX_PERIOD;
@@ -42,13 +71,18 @@ __global__ __launch_bounds__(NM_BLOCK) void prep_kernel(const PrepArgs a)
     // ---- pass A ----------------------------------------------------------------------------------------
     double sum = 0.0;
     bool positive = true, constant = true, has_nan = false;
-    const double y0 = n > 0 ? y[0] : 0.0;
+    rows.load(cur, 0);
+    const double y0 = n > 0 ? cur[0] : 0.0;
     int slot = 0;                       // t % L
     int ph = 0;                         // (t - half) % m, phase of the window centre
     if (want_season) ph = ((-half) % m + m) % m;
-    for (int t = 0; t < wave_n; t++) {
+    for (int base = 0; base < wave_rows; base += PREP_S) {
+      rows.load(nxt, base + PREP_S);
+#pragma unroll
+      for (int jj = 0; jj < PREP_S; jj++) {
+        const int t = base + jj;
         if (t < n) {
-            const double v = y[(size_t)t * ld];
+            const double v = cur[jj];
             sum += v;
             if (!(v > 0.0)) positive = false;
             if (v != y0) constant = false;
@@ -76,6 +110,9 @@ __global__ __launch_bounds__(NM_BLOCK) void prep_kernel(const PrepArgs a)
         }
         slot = slot + 1 == L ? 0 : slot + 1;
         if (want_season) ph = ph + 1 == m ? 0 : ph + 1;
+      }
+#pragma unroll
+      for (int jj = 0; jj < PREP_S; jj++) cur[jj] = nxt[jj];
     }
     if (n <= 0) return;
     const double mean = sum / (double)n;
@@ -116,8 +153,14 @@ __global__ __launch_bounds__(NM_BLOCK) void prep_kernel(const PrepArgs a)
     int Km = 2 * m > 10 ? 2 * m : 10;
     if (Km > n) Km = n;
     int j = 0;
-    for (int t = 0; t < n; t++) {
-        const double v = y[(size_t)t * ld];
+    rows.load(cur, 0);
+    for (int base = 0; base < wave_rows; base += PREP_S) {
+      rows.load(nxt, base + PREP_S);
+#pragma unroll
+      for (int jj = 0; jj < PREP_S; jj++) {
+        const int t = base + jj;
+        if (t >= n) continue;
+        const double v = cur[jj];
         const double dv = v - mean;
         var += dv * dv;
         if (states) {
@@ -135,6 +178,9 @@ __global__ __launch_bounds__(NM_BLOCK) void prep_kernel(const PrepArgs a)
             }
             if (want_season) j = j + 1 == m ? 0 : j + 1;
         }
+      }
+#pragma unroll
+      for (int jj = 0; jj < PREP_S; jj++) cur[jj] = nxt[jj];
     }
     a.sd[s] = sqrt(var / (double)n);
     if (!states) return;

@@ -141,52 +141,51 @@ static inline double det_pow_pos(double x, double y) { return det_exp(y * det_lo
 
 /*
  * b^phi of the damped multiplicative trend, evaluated once per observation: x in [2^-1000, 2^1000], 0 < y <= 1 (ets.c
- * rejects the trial point otherwise).  Same reductions as det_log / det_exp, but written for that domain only -- no
- * special cases -- and with the polynomial and recombination steps fused (fma), because this one function is most of the
- * arithmetic of the five damped multiplicative-trend specs.  csrc/det_math.hpp states the identical sequence.
+ * rejects the trial point otherwise).  Table driven (tools/gen_pow_tables.py -> pow_tables.inc), because this one function
+ * is most of the arithmetic of the five damped multiplicative-trend specs and sits on the critical path of their slowest
+ * fits: no division, two short polynomials.
+ *   ln x  = e ln2 + LOG_C[j] + log1p(r),  x = 2^e m, m in [1, 2), j = top 7 mantissa bits, r = m INV_C[j] - 1, |r| <= 2^-8,
+ *           log1p(r) = r + r^2 (-1/2 + r/3 + r^2 (-1/4 + r/5 + r^2 (-1/6)))          (remainder r^7/7 < 2e-18)
+ *   e^t   = 2^(n >> 6) EXP2_T[n & 63] (1 + p(s)),  n = rint(t 64/ln2), s = t - n ln2/64 (two-part), |s| <= ln2/128,
+ *           p(s)     = s + s^2 (1/2 + s/6 + s^2 (1/24 + s/120 + s^2/720))             (remainder s^7/5040 < 3e-20)
+ * Every operation is an IEEE-754 binary64 +, *, fma or an exact integer step, in a fixed order: csrc/det_math.hpp
+ * (dm_pow_step) states the identical sequence and reads the identical tables, so kernel and checker agree bit for bit.
+ * Accuracy against the exact power: < 1.5 ulp over the domain (tests/test_host_logic.py).
  */
+#include "pow_tables.inc"
+static const double det_pow_inv_c[ANOFOX_POW_INV_C_N] = { ANOFOX_POW_INV_C_VALUES };
+static const double det_pow_log_c[ANOFOX_POW_LOG_C_N] = { ANOFOX_POW_LOG_C_VALUES };
+static const double det_pow_exp2_t[ANOFOX_POW_EXP2_T_N] = { ANOFOX_POW_EXP2_T_VALUES };
+
 static inline double det_pow_step(double x, double y)
 {
     const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
-    const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
-                 Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
-                 Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
-                 Lg7 = 1.479819860511658591e-01;
-    const double invln2 = 1.44269504088896338700e+00;
+    const double n_per_ln2 = 0x1.71547652b82fep+6;                         /* 64 / ln2 */
+    const double L_hi = 0x1.62e42fee00000p-7, L_lo = 0x1.a39ef35793c76p-39;  /* ln2 / 64 = L_hi + L_lo, L_hi has 32 significant bits */
     const uint64_t u = det_bits(x);
-    uint32_t hx = (uint32_t)(u >> 32);
-    hx += 0x3ff00000u - 0x3fe6a09eu;
-    const int k = (int)(hx >> 20) - 0x3ff;
-    hx = (hx & 0x000fffffu) + 0x3fe6a09eu;
-    const double m = det_from_bits(((uint64_t)hx << 32) | (u & 0xffffffffull));
-    const double f = m - 1.0;
-    const double hfsq = 0.5 * f * f;
-    const double s = f / (2.0 + f);
-    const double z = s * s;
-    const double w = z * z;
-    const double t1 = w * fma(w, fma(w, Lg6, Lg4), Lg2);
-    const double t2 = z * fma(w, fma(w, fma(w, Lg7, Lg5), Lg3), Lg1);
-    const double R = t2 + t1;
-    const double dk = (double)k;
-    const double lg = fma(dk, ln2_hi, (fma(s, hfsq + R, dk * ln2_lo) - hfsq) + f);
+    const int e = (int)(u >> 52) - 1023;                                   /* x is a positive normal number */
+    const int j = (int)(u >> 45) & 127;
+    const double m = det_from_bits((u & 0x000fffffffffffffull) | 0x3ff0000000000000ull);
+    const double r = fma(m, det_pow_inv_c[j], -1.0);
+    const double r2 = r * r;
+    const double pa = fma(r, 1.0 / 3.0, -0.5);
+    const double pb = fma(r, 0.2, -0.25);
+    const double pl = fma(r2, fma(r2, -1.0 / 6.0, pb), pa);
+    const double l1p = fma(r2, pl, r);
+    const double de = (double)e;
+    const double lg = fma(de, ln2_hi, det_pow_log_c[j]) + fma(de, ln2_lo, l1p);
     const double t = y * lg;
-    const double dn = rint(invln2 * t);                 /* round to nearest even; |dn| <= 1000 */
-    const double r = fma(-dn, ln2_lo, fma(-dn, ln2_hi, t));
-    double p = 1.0 / 6227020800.0;
-    p = fma(p, r, 1.0 / 479001600.0);
-    p = fma(p, r, 1.0 / 39916800.0);
-    p = fma(p, r, 1.0 / 3628800.0);
-    p = fma(p, r, 1.0 / 362880.0);
-    p = fma(p, r, 1.0 / 40320.0);
-    p = fma(p, r, 1.0 / 5040.0);
-    p = fma(p, r, 1.0 / 720.0);
-    p = fma(p, r, 1.0 / 120.0);
-    p = fma(p, r, 1.0 / 24.0);
-    p = fma(p, r, 1.0 / 6.0);
-    p = fma(p, r, 0.5);
-    p = fma(p, r, 1.0);
-    const double e = fma(p, r, 1.0);
-    return e * det_from_bits((uint64_t)(0x3ff + (int)dn) << 52);
+    const double dn = rint(n_per_ln2 * t);              /* round to nearest even; |dn| <= 64000 */
+    const double s = fma(-dn, L_lo, fma(-dn, L_hi, t));
+    const double s2 = s * s;
+    const double qa = fma(s, 1.0 / 6.0, 0.5);
+    const double qb = fma(s, 1.0 / 120.0, 1.0 / 24.0);
+    const double q = fma(s2, fma(s2, 1.0 / 720.0, qb), qa);
+    const double p = fma(s2, q, s);
+    const int n = (int)dn;
+    const double tv = det_pow_exp2_t[n & 63];
+    const double ev = fma(tv, p, tv);
+    return ev * det_from_bits((uint64_t)(0x3ff + (n >> 6)) << 52);
 }
 
 #endif /* ORACLE_DET_MATH_H */

@@ -859,3 +859,4 @@ int oracle_ets_fixed_batch(const double *values, const int64_t *offsets, size_t 
 /* test hooks */
 double oracle_det_log(double x) { return det_log(x); }
 double oracle_det_exp(double x) { return det_exp(x); }
+double oracle_det_pow_step(double x, double y) { return det_pow_step(x, y); }

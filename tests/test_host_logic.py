@@ -1,9 +1,13 @@
 """CPU: host logic of the operator mirror (frequency strings, forecast timestamps, bind validation,
 validity masks) against the reference's binding behaviour."""
+import os
+
 import numpy as np
 import pytest
 
 from anofox_forecast_amd import api
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_parse_frequency():
@@ -161,3 +165,30 @@ def test_backtest_fold_bounds_and_metric():
     assert abs(api.backtest_metric("r2", a, f, lo, hi) - (1.0 - 2.25 / tot)) < 1e-15
     assert np.isnan(api.backtest_metric("r2", np.ones(3), np.ones(3), [], []))
     assert np.isnan(api.backtest_metric("mae", [], [], [], []))
+
+
+def test_pow_tables_are_one_file_and_pow_step_is_accurate(oracle):
+    """The b^phi tables exist twice (product / checker), byte for byte the output of tools/gen_pow_tables.py; the table
+    driven power stays within 2 ulp of the exact one where growth rates live ([1/2, 2]) and 1^phi is exactly 1."""
+    import ctypes as C
+    import math
+    import subprocess
+    import sys
+    from decimal import Decimal, getcontext
+    a = open(os.path.join(ROOT, "oracle", "pow_tables.inc")).read()
+    b = open(os.path.join(ROOT, "anofox-forecast_amd", "csrc", "pow_tables.inc")).read()
+    assert a == b
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_pow_tables.py")], stdout=subprocess.DEVNULL)
+    assert open(os.path.join(ROOT, "oracle", "pow_tables.inc")).read() == a            # regenerating changes nothing
+    L = oracle.lib()
+    L.oracle_det_pow_step.restype = C.c_double
+    L.oracle_det_pow_step.argtypes = [C.c_double, C.c_double]
+    getcontext().prec = 50
+    rng = np.random.default_rng(3)
+    worst = 0.0
+    for x, y in zip(np.exp(rng.uniform(-0.69, 0.69, 1500)), rng.uniform(0.8, 0.98, 1500)):
+        got = L.oracle_det_pow_step(float(x), float(y))
+        ref = (Decimal(float(x)).ln() * Decimal(float(y))).exp()
+        worst = max(worst, float(abs(Decimal(got) - ref) / Decimal(math.ulp(float(ref)))))
+    assert worst < 2.0, worst
+    assert L.oracle_det_pow_step(1.0, 0.9) == 1.0 and L.oracle_det_pow_step(4.0, 0.5) == 2.0
