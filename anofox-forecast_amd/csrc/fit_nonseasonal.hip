@@ -1,15 +1,6 @@
-// ETS fit kernels without a seasonal component (10 specs).
+// ETS kernels without a seasonal component (10 specs).
 #include "fit_units.hpp"
-namespace anofox {
-FitLaunchers fit_unit_nonseasonal(int spec_id, int m)
-{
-    (void)m;
-    switch (spec_id) {
-        ANOFOX_NONSEASONAL_CASE(0) ANOFOX_NONSEASONAL_CASE(3) ANOFOX_NONSEASONAL_CASE(6)
-        ANOFOX_NONSEASONAL_CASE(9) ANOFOX_NONSEASONAL_CASE(12) ANOFOX_NONSEASONAL_CASE(15)
-        ANOFOX_NONSEASONAL_CASE(18) ANOFOX_NONSEASONAL_CASE(21) ANOFOX_NONSEASONAL_CASE(24)
-        ANOFOX_NONSEASONAL_CASE(27)
-    default: return FitLaunchers{nullptr, nullptr, nullptr};
-    }
-}
-} // namespace anofox
+#define ANOFOX_UNIT_NAME nonseasonal
+#define ANOFOX_UNIT_VARIANTS 0
+#define ANOFOX_UNIT_SPECS(X) X(0) X(3) X(6) X(9) X(12) X(15) X(18) X(21) X(24) X(27)
+#include "fit_unit_impl.inc"

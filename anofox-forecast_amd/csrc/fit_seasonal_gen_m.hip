@@ -1,12 +1,6 @@
-// ETS fit kernels, multiplicative error with multiplicative seasonality.
+// ETS kernels, multiplicative error with multiplicative seasonality.
 #include "fit_units.hpp"
-namespace anofox {
-FitLaunchers fit_unit_seasonal_gen_m(int spec_id, int m)
-{
-    switch (spec_id) {
-        ANOFOX_SEASONAL_CASE(17) ANOFOX_SEASONAL_CASE(20) ANOFOX_SEASONAL_CASE(23)
-        ANOFOX_SEASONAL_CASE(26) ANOFOX_SEASONAL_CASE(29)
-    default: return FitLaunchers{nullptr, nullptr, nullptr};
-    }
-}
-} // namespace anofox
+#define ANOFOX_UNIT_NAME seasonal_gen_m
+#define ANOFOX_UNIT_VARIANTS 1
+#define ANOFOX_UNIT_SPECS(X) X(17) X(20) X(23) X(26) X(29)
+#include "fit_unit_impl.inc"

@@ -144,6 +144,16 @@ struct AnofoxHipBatch {
     int spec_below_md = 8192; // same, for the damped multiplicative-trend specs (their pass is ~10x longer: the stragglers matter more)
     int spec_below = 8192;   // per spec: switch to the speculative driver once this few problems are still running
     bool use_gather = false; // rebuild a dense block of the running problems between rounds (else index y by series)
+    // work-pool schedule (ets_pool_kernel.hpp): persistent waves, lanes refill from a queue, slow problems take four lanes
+    bool pool_sched = false; // ANOFOX_HIP_SCHED=pool selects the work-pool schedule; the round schedule (resumable rounds + compaction + gather)
+                             // is the default: measured 590 ms against 700-800 ms per 30-spec M5 step
+    int pool_waves = 2048;   // persistent waves over all candidate specs of a group (the chip holds 2 x 1,024 waves of these kernels)
+    int pool_promote = 128;  // iterations after which a problem asks for four lanes
+    double *d_ys = nullptr;  // series-major copy of the block [n x pool_tw] (+ one row of slack)
+    size_t pool_tw = 0;
+    int32_t *d_pool_head = nullptr;   // [N_AUX_STREAMS] queue cursors
+    unsigned long long *d_pool_trace = nullptr;   // ANOFOX_HIP_POOL_TRACE=1: [N_AUX_STREAMS x 8] diagnostics, printed to stderr by the next stats call
+    std::vector<int> pool_trace_spec;
     // BASELINE config 2: ETS(spec) with GIVEN smoothing parameters -- no optimiser, one streamed pass per series
     bool fixed_params = false;
     double fixed_x[4] = {0.0, 0.0, 0.0, 0.0};   // optimiser coordinates (alpha, beta*, gamma*, phi) of the given parameters
@@ -290,6 +300,7 @@ void free_batch_buffers(AnofoxHipBatch *b)
     F(b->d_aicc); F(b->d_yhat_slots); F(b->d_status_slots); F(b->d_evals_slots); F(b->d_iters_slots);
     F(b->d_passes_slots); F(b->d_slot_spec);
     F(b->d_yhat); F(b->d_lo); F(b->d_hi); F(b->d_model_code); F(b->d_status); F(b->d_detail);
+    F(b->d_ys); F(b->d_pool_head); F(b->d_pool_trace);
     F(b->d_passes_total); F(b->d_evals_total); F(b->d_mask); F(b->d_len_group); F(b->d_count); F(b->d_pos_map); F(b->d_pos_cnt); F(b->d_notpos); F(b->d_ypos);
     F(b->ar_w); F(b->ar_wmean); F(b->ar_wsd); F(b->ar_l0); F(b->ar_l1); F(b->ar_x); F(b->ar_aicc); F(b->ar_wlen); F(b->ar_d); F(b->ar_D);
     F(b->ar_order); F(b->ar_status); F(b->ar_evals); F(b->ar_passes); F(b->ar_models);
@@ -469,12 +480,15 @@ __global__ void mark_nonpositive_kernel(int n, const int32_t *len, const uint32_
 
 // per (spec with a multiplicative component): the series the dense first round never visits are retired here
 __global__ void retire_nonpositive_kernel(int n, const int32_t *len, const int32_t *notpos, int32_t *status, int32_t *done, int32_t *passes,
-                                          int32_t *evals, int32_t *iters)
+                                          int32_t *evals, int32_t *iters, double *aicc = nullptr, int32_t *f_passes = nullptr,
+                                          int32_t *f_evals = nullptr, int32_t *f_iters = nullptr)
 {
     int s = blockIdx.x * 256 + threadIdx.x;
     if (s >= n || !notpos[s]) return;
     status[s] = len[s] > 0 ? FIT_NONPOSITIVE : FIT_SKIPPED;
     done[s] = 1; passes[s] = 0; evals[s] = 0; iters[s] = 0;
+    // work-pool schedule: there is no final kernel to leave these behind
+    if (aicc && len[s] > 0) { aicc[s] = __builtin_huge_val(); f_passes[s] = 0; f_evals[s] = 0; f_iters[s] = 0; }
 }
 
 // AutoETS fallback plan (forecast.rs:1327-1336): 1 Holt-Winters, 2 Holt, 3 SES(0.3)
@@ -542,7 +556,33 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
     const int n_lanes = std::min<int>(N_AUX_STREAMS, b->n_slots_cap);
     // fork: aux streams wait for everything queued on `st` so far
     HIPCHECK(hipEventRecord(b->ev_fit0, st));
-    for (int i = 0; i < n_lanes; i++) HIPCHECK(hipStreamWaitEvent(b->aux[i], b->ev_fit0, 0));
+    const bool pool = b->pool_sched && !b->fixed_params;
+    const int n_fork = pool ? POOL_UNITS : n_lanes;      // streams that carry work: one per unit kernel / one per spec
+    if (pool) {
+        // the work-pool kernels stream every lane's own series: series-major copy of the block, once per group
+        const size_t T = std::max<size_t>(b->t_max, 1);
+        const size_t tw = (T + 1) / 2 * 2 + 64;
+        if (!b->d_ys || b->pool_tw != tw) {
+            if (b->d_ys) (void)hipFree(b->d_ys);
+            b->d_ys = nullptr;
+            b->d_ys = dalloc<double>((n + 1) * tw);
+            HIPCHECK(hipMemsetAsync(b->d_ys, 0, (n + 1) * tw * sizeof(double), st));
+            b->pool_tw = tw;
+        }
+        if (!b->d_pool_head) b->d_pool_head = dalloc<int32_t>(N_AUX_STREAMS);
+        if (std::getenv("ANOFOX_HIP_POOL_TRACE") && !b->d_pool_trace) b->d_pool_trace = dalloc<unsigned long long>(N_AUX_STREAMS * 8);
+        if (b->d_pool_trace) {
+            std::vector<unsigned long long> init(N_AUX_STREAMS * 8, 0ull);
+            for (int i = 0; i < N_AUX_STREAMS; i++) init[i * 8 + 3] = ~0ull;
+            HIPCHECK(hipMemcpy(b->d_pool_trace, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
+            b->pool_trace_spec.assign(N_AUX_STREAMS, -1);
+        }
+        launch_transpose_rows(b->d_y, ld, (int)n, (int)T, b->d_ys, tw, st);
+        HIPCHECK(hipMemsetAsync(b->d_pool_head, 0, N_AUX_STREAMS * sizeof(int32_t), st));
+        HIPCHECK(hipEventRecord(b->ev_fork, st));
+        for (int i = 0; i < n_fork; i++) HIPCHECK(hipStreamWaitEvent(b->aux[i], b->ev_fork, 0));
+    } else
+        for (int i = 0; i < n_fork; i++) HIPCHECK(hipStreamWaitEvent(b->aux[i], b->ev_fit0, 0));
     // enqueue order: most expensive specs first, dealt round-robin over the streams, so the long
     // multiplicative / damped / seasonal fits start together instead of queueing behind each other
     std::vector<size_t> order(specs.size());
@@ -553,7 +593,7 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
         if (spec_error(id) == 1) c += 4;
         if (spec_season(id) == 2) c += 6;
         if (ti >= 3) c += 6;
-        if (ti == 4) c += 20;       // b^phi every step
+        if (ti == 4) c += 12;       // b^phi every step
         return c;
     };
     // expected work of a spec on THIS batch: a spec with a multiplicative component only runs on the strictly positive series
@@ -621,7 +661,86 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
         }
         LAUNCHCHECK("ETS fixed-parameter setup");
     }
-    for (int r = 0; r < (b->fixed_params ? 0 : n_rounds); r++) {
+    if (pool) {
+        // One persistent kernel per compile unit; a unit's waves walk its specs in priority order (most expensive first), so
+        // the slow problems of one spec overlap with the bulk of the next and nothing waits for a hardware queue.  The grids
+        // are oversubscribed (every unit may fill the chip): slots freed by a unit that runs dry go to the others.  With few
+        // problems (four lanes each fit the chip) every problem runs speculatively from its first pass.
+        double total_live = 0.0;
+        std::vector<double> live(order.size());
+        for (size_t oi = 0; oi < order.size(); oi++) {
+            const int id = specs[order[oi]];
+            live[oi] = (b->live_all >= 0) ? (spec_has_mult(id) ? (double)b->live_pos : (double)b->live_all) : (double)n;
+            total_live += live[oi];
+        }
+        const bool start_spec = total_live * 4.0 <= (double)b->pool_waves * 64.0;
+        PoolUnitArgs units[POOL_UNITS];
+        size_t unit_lds[POOL_UNITS] = {0, 0, 0, 0};
+        double unit_live[POOL_UNITS] = {0, 0, 0, 0};
+        std::vector<double> unit_work[POOL_UNITS];
+        for (auto &u : units) {
+            u = PoolUnitArgs{};
+            u.ys = b->d_ys; u.tw = b->pool_tw; u.ld = ld; u.fig_ld = ld; u.len = d_len; u.flags = b->d_flags;
+            u.n_series = (int)n; u.h = b->h; u.promote = b->pool_promote; u.start_spec = start_spec ? 1 : 0;
+            u.skip_constant = skip_constant ? 1 : 0; u.n_specs = 0;
+        }
+        for (size_t oi = 0; oi < order.size(); oi++) {
+            const int id = specs[order[oi]];
+            const FitArgs &a = args[oi];
+            const int ui = pool_unit_of(id);
+            if (ui < 0 || units[ui].n_specs >= POOL_MAX_SPECS) throw HipFail{"no work-pool kernel for ETS spec id " + std::to_string(id)};
+            PoolSpec &ps = units[ui].spec[units[ui].n_specs++];
+            ps = PoolSpec{};
+            ps.head = b->d_pool_head + oi;
+            ps.trace = b->d_pool_trace ? b->d_pool_trace + oi * 8 : nullptr;
+            if (b->d_pool_trace) b->pool_trace_spec[oi] = id;
+            ps.status = a.status; ps.st = a.st; ps.aicc = a.aicc; ps.evals = a.evals; ps.iters = a.iters; ps.passes = a.passes;
+            ps.l0 = a.l0; ps.b0 = a.b0; ps.fig = a.fig; ps.yhat = a.yhat;
+            ps.m = a.m; ps.n_param = a.n_param; ps.need_positive = a.need_positive;
+            ps.key = id * 4 + pool_period_variant(id, a.m);
+            if (b->use_pos && a.need_positive) {
+                // mixed batch: a spec with a multiplicative component only queues the strictly positive series; the others
+                // get here what the pool would have written for an inadmissible problem
+                hipLaunchKernelGGL(retire_nonpositive_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, b->aux[ui], (int)n, d_len, b->d_notpos,
+                                   a.status, a.st.done, a.st.passes, a.st.evals, a.st.iters, a.aicc, a.passes, a.evals, a.iters);
+                ps.series_of = b->d_pos_map; ps.n_active = b->d_pos_cnt;
+            }
+            const int D = spec_dim(id);
+            size_t lds_bytes = sizeof(double) * (size_t)((D + 1) * D + (D + 1)) * 64;
+            if (ps.key % 4 == 3) lds_bytes += sizeof(double) * (size_t)a.m * 64;
+            unit_lds[ui] = std::max(unit_lds[ui], lds_bytes);
+            unit_live[ui] += live[oi];
+            unit_work[ui].push_back((double)cost(id) * (live[oi] + 1.0));
+        }
+        // deal the waves of a unit to its specs: 64 slots in proportion to the expected work (at least one each), interleaved
+        for (int ui = 0; ui < POOL_UNITS; ui++) {
+            PoolUnitArgs &u = units[ui];
+            if (u.n_specs == 0) continue;
+            std::vector<double> w(u.n_specs), given(u.n_specs, 0.0);
+            double wsum = 0.0;
+            for (int k = 0; k < u.n_specs; k++) { w[k] = unit_work[ui][k]; wsum += w[k]; }
+            for (int slot = 0; slot < 64; slot++) {
+                // largest deficit first: spec k should hold w[k] / wsum of the slots dealt so far
+                int best = 0;
+                double best_def = -1.0e300;
+                for (int k = 0; k < u.n_specs; k++) {
+                    const double def = (slot + 1) * w[k] / wsum - given[k];
+                    if (def > best_def) { best_def = def; best = k; }
+                }
+                given[best] += 1.0;
+                u.first[slot] = (unsigned char)best;
+            }
+        }
+        for (int ui = 0; ui < POOL_UNITS; ui++) {
+            if (units[ui].n_specs == 0) continue;
+            const double per_wave = start_spec ? 16.0 : 64.0;
+            const int grid = (int)std::max(1.0, std::min((double)b->pool_waves, std::ceil((unit_live[ui] + 1.0) / per_wave)));
+            launch_pool_unit(ui, units[ui], grid, unit_lds[ui], b->aux[ui]);
+            b->fit_launches++;
+        }
+        LAUNCHCHECK("ETS work pool");
+    }
+    for (int r = 0; r < ((b->fixed_params || pool) ? 0 : n_rounds); r++) {
         for (size_t oi = 0; oi < order.size(); oi++) {
             const int q = (int)(oi % (size_t)n_lanes);
             auto &lane = b->lanes[q];
@@ -682,9 +801,11 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
         }
         LAUNCHCHECK("ETS fit round");
     }
-    for (size_t oi = 0; oi < order.size(); oi++) fns[oi].final(args[oi], b->aux[stream_of[oi]]);
-    LAUNCHCHECK("ETS final pass");
-    for (int i = 0; i < n_lanes; i++) {
+    if (!pool) {
+        for (size_t oi = 0; oi < order.size(); oi++) fns[oi].final(args[oi], b->aux[stream_of[oi]]);
+        LAUNCHCHECK("ETS final pass");
+    }
+    for (int i = 0; i < n_fork; i++) {
         HIPCHECK(hipEventRecord(b->ev_join[i], b->aux[i]));
         HIPCHECK(hipStreamWaitEvent(st, b->ev_join[i], 0));
     }
@@ -1018,6 +1139,10 @@ bool anofox_hip_batch_create(size_t n_series, size_t t_max, const ForecastOption
         if (const char *e = std::getenv("ANOFOX_HIP_GATHER_MIN")) b->gather_min = std::atoi(e);
         if (const char *e = std::getenv("ANOFOX_HIP_FUSED")) b->fused = std::atoi(e) != 0;
         if (!b->use_gather) b->fused = false;
+        if (const char *e = std::getenv("ANOFOX_HIP_SCHED")) b->pool_sched = std::string(e) == "pool";
+        if (const char *e = std::getenv("ANOFOX_HIP_POOL_WAVES")) b->pool_waves = std::max(1, std::atoi(e));
+        if (const char *e = std::getenv("ANOFOX_HIP_PROMOTE")) b->pool_promote = std::max(1, std::atoi(e));
+        if (b->pool_sched) b->use_gather = false;          // no gather buffers: the pool streams a series-major copy
         alloc_common(b);
     } catch (const HipFail &f) {
         report_hip_failure(out_error, f);
@@ -1215,6 +1340,22 @@ bool anofox_hip_batch_stats(AnofoxHipBatch *b, AnofoxHipStats *out)
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, b->ev_start, b->ev_stop) == hipSuccess) out->total_device_ms = ms;
     if (b->timed_fit && hipEventElapsedTime(&ms, b->ev_fit0, b->ev_fit1) == hipSuccess) out->fit_kernel_ms = ms;
+    if (b->d_pool_trace) {
+        std::vector<unsigned long long> tr(N_AUX_STREAMS * 8);
+        if (hipMemcpy(tr.data(), b->d_pool_trace, tr.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
+            unsigned long long t0 = ~0ull;
+            for (int i = 0; i < N_AUX_STREAMS; i++) if (tr[i * 8] && tr[i * 8 + 3] < t0) t0 = tr[i * 8 + 3];
+            for (int i = 0; i < N_AUX_STREAMS; i++) {
+                if (!tr[i * 8]) continue;
+                char nm[64];
+                auto_ets_name(b->pool_trace_spec[i], nm);
+                std::fprintf(stderr, "pooltrace %-28s unit %d waves %5llu wave-passes %8llu lane-util %.3f spec-lane-frac %.3f ms/pass %.3f start %7.1f end %7.1f ms\n", nm,
+                             pool_unit_of(b->pool_trace_spec[i]), tr[i * 8 + 6], tr[i * 8], (double)tr[i * 8 + 1] / (64.0 * (double)tr[i * 8]),
+                             (double)tr[i * 8 + 5] / (double)std::max<unsigned long long>(tr[i * 8 + 1], 1), (double)tr[i * 8 + 2] / (double)tr[i * 8] / 1e5,
+                             (double)(tr[i * 8 + 3] - t0) / 1e5, (double)(tr[i * 8 + 4] - t0) / 1e5);
+            }
+        }
+    }
     std::vector<int32_t> passes(b->n), evals(b->n);
     if (hipMemcpy(passes.data(), b->d_passes_total, b->n * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) return false;
     if (hipMemcpy(evals.data(), b->d_evals_total, b->n * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) return false;

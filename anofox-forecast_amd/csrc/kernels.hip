@@ -216,6 +216,33 @@ void launch_intervals(const IntervalArgs &a, hipStream_t stream)
 }
 
 // ------------------------------------------------------------------------------------------
+// series-major copy of the block (work-pool schedule): 64 x 64 tiles through LDS, 512-byte reads along the series axis,
+// 512-byte writes along the time axis.  HBM bound: 16 bytes per element.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_rows_kernel(const double *y, size_t ld, int n_series, int t_rows, double *ys, size_t tw)
+{
+    __shared__ double tile[64][65];
+    const int s0 = blockIdx.x * 64, t0 = blockIdx.y * 64;
+    const int c = threadIdx.x & 63, r4 = threadIdx.x >> 6;
+    for (int r = r4; r < 64; r += 4) {
+        const int t = t0 + r, s = s0 + c;
+        tile[r][c] = (t < t_rows && s < n_series) ? y[(size_t)t * ld + s] : 0.0;
+    }
+    __syncthreads();
+    for (int r = r4; r < 64; r += 4) {
+        const int s = s0 + r, t = t0 + c;
+        if (s < n_series && t < t_rows) ys[(size_t)s * tw + t] = tile[c][r];
+    }
+}
+
+void launch_transpose_rows(const double *y, size_t ld, int n_series, int t_rows, double *ys, size_t tw, hipStream_t stream)
+{
+    if (n_series <= 0 || t_rows <= 0) return;
+    dim3 grid((unsigned)((n_series + 63) / 64), (unsigned)((t_rows + 63) / 64));
+    hipLaunchKernelGGL(transpose_rows_kernel, grid, dim3(256), 0, stream, y, ld, n_series, t_rows, ys, tw);
+}
+
+// ------------------------------------------------------------------------------------------
 FitLaunchers ets_fit_launcher(int spec_id, int m)
 {
     FitLaunchers f = fit_unit_nonseasonal(spec_id, m);
@@ -223,6 +250,26 @@ FitLaunchers ets_fit_launcher(int spec_id, int m)
     if (!f.final) f = fit_unit_seasonal_gen_a(spec_id, m);
     if (!f.final) f = fit_unit_seasonal_gen_m(spec_id, m);
     return f;
+}
+
+int pool_unit_of(int spec_id)
+{
+    if (fit_unit_nonseasonal(spec_id, 7).final) return 0;
+    if (fit_unit_seasonal_add(spec_id, 7).final) return 1;
+    if (fit_unit_seasonal_gen_a(spec_id, 7).final) return 2;
+    if (fit_unit_seasonal_gen_m(spec_id, 7).final) return 3;
+    return -1;
+}
+
+void launch_pool_unit(int unit, const PoolUnitArgs &u, int grid, size_t lds_bytes, hipStream_t stream)
+{
+    switch (unit) {
+    case 0: launch_pool_unit_nonseasonal(u, grid, lds_bytes, stream); break;
+    case 1: launch_pool_unit_seasonal_add(u, grid, lds_bytes, stream); break;
+    case 2: launch_pool_unit_seasonal_gen_a(u, grid, lds_bytes, stream); break;
+    case 3: launch_pool_unit_seasonal_gen_m(u, grid, lds_bytes, stream); break;
+    default: throw std::runtime_error("no work-pool unit " + std::to_string(unit));
+    }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -58,6 +58,13 @@ struct FitArgs {
     int32_t *next_map, *next_cnt, *clear_cnt;
     double *next_y;              // next round's dense block [t_rows x ld] (NULL: the next round reads y in place)
     NmStateBuf st;
+    // work-pool schedule (ets_pool_kernel.hpp): series-major copy of the block (row s at ys + s * tw, 64 doubles of slack
+    // behind every row), the queue cursor (zeroed before the launch), the iteration count after which a problem asks for
+    // four lanes, whether every problem runs speculatively from its first pass, and the number of persistent waves
+    const double *ys; size_t tw;
+    int32_t *head;
+    int promote, start_spec;
+    unsigned long long *trace;   // work pool, diagnostics only: wave passes, active lane passes, pass clocks, first / last wall clock, speculative lane passes
     int m, h;
     const double *l0, *b0;       // [ld] for this spec's (season, trend) class
     const double *fig; size_t fig_ld;
@@ -128,14 +135,45 @@ struct IntervalArgs {
 // ETS fit kernels, one per (spec id, ring variant).  ring: 0 = none / VGPR ring for the
 // compile-time period given, -1 = LDS ring.  Returns NULL when not instantiated.
 typedef void (*FitLaunchFn)(const FitArgs &, hipStream_t);
-struct FitLaunchers { FitLaunchFn round_seq, round_spec, final; };   // sequential / speculative Nelder-Mead rounds
+struct FitLaunchers { FitLaunchFn round_seq, round_spec, final; };   // sequential / speculative Nelder-Mead rounds, final pass
 FitLaunchers ets_fit_launcher(int spec_id, int m);
+
+// Work-pool schedule (ets_pool_kernel.hpp): ONE persistent kernel per compile unit serves the unit's candidate specs in
+// priority order.  The arguments travel by value (kernel argument segment: uniform, read-only), per-spec part + common part.
+constexpr int POOL_MAX_SPECS = 10;
+constexpr int POOL_UNITS = 4;     // nonseasonal, seasonal additive class, additive error general, multiplicative error general
+struct PoolSpec {
+    const int32_t *series_of, *n_active;   // the spec's queue: problem -> series (NULL = identity), device count (NULL = n_series)
+    int32_t *head;                         // queue cursor, zeroed before the launch
+    int32_t *status;
+    NmStateBuf st;                         // only vertex 0 (the optimum) and the counters are written: what the inspection pass reads
+    double *aicc;
+    int32_t *evals, *iters, *passes;
+    const double *l0, *b0, *fig;
+    double *yhat;
+    unsigned long long *trace;             // NULL, or 8 counters (ANOFOX_HIP_POOL_TRACE: tools/pool_trace.py prints them)
+    int key;                               // spec id * 4 + period variant (0 none, 1 m = 7, 2 m = 12, 3 run-time period)
+    int m, n_param, need_positive;
+};
+struct PoolUnitArgs {
+    const double *ys; size_t tw, ld, fig_ld;
+    const int32_t *len; const uint32_t *flags;
+    int n_series, h, promote, start_spec, skip_constant, n_specs;
+    unsigned char first[64];               // spec a wave starts with, by blockIdx % 64: the specs' shares of the waves follow their
+                                           // expected work, so that a spec's queue outlasts its waves' first fill (lanes REFILL)
+    PoolSpec spec[POOL_MAX_SPECS];
+};
+int pool_unit_of(int spec_id);              // which unit holds the spec's kernels
+inline int pool_period_variant(int spec_id, int m) { return (spec_id % 3) == 0 ? 0 : (m == 7 ? 1 : ((m == 12 && spec_id < 15 && (spec_id % 3) == 1 && (spec_id % 15) / 3 <= 2) ? 2 : 3)); }
+void launch_pool_unit(int unit, const PoolUnitArgs &, int grid, size_t lds_bytes, hipStream_t);
 
 // compaction of the unfinished problems: series_next[0..n_next) = the series of the previous map whose done flag
 // is 0 (one ballot + one atomic per wave; the order of the survivors is not preserved, results do not depend on it)
 void launch_compact(const int32_t *series_prev, const int32_t *n_prev, int n_series, const int32_t *done,
                     int32_t *series_next, int32_t *n_next, hipStream_t, int32_t *n_clear = nullptr);
 // out[t * ld_out + p] = y[t * ld + series_of[p]] for p < *n_active, t < t_max
+// series-major copy of the time-major block for the work-pool kernels: ys[s * tw + t] = y[t * ld + s], t < t_rows
+void launch_transpose_rows(const double *y, size_t ld, int n_series, int t_rows, double *ys, size_t tw, hipStream_t);
 void launch_gather_columns(const double *y, size_t ld, const int32_t *series_of, const int32_t *n_active, int n_series,
                            int t_max, double *out, size_t ld_out, hipStream_t, int min_active = 0);
 

@@ -368,6 +368,7 @@ def test_fused_compaction_variant_is_bit_identical(env, monkeypatch):
     """ANOFOX_HIP_FUSED=1 (compaction + gather fused into the end of every round kernel) and the 6-round schedule walk the
     same trajectories as the default schedule."""
     api, O, lib, synth = env
+    monkeypatch.setenv("ANOFOX_HIP_SCHED", "rounds")
     monkeypatch.setenv("ANOFOX_HIP_FUSED", "1")
     monkeypatch.setenv("ANOFOX_HIP_BUDGETS", "32,32,64,128,256,1024")
     Y = synth.gen_series(synth.SEED_M5, 5200, 130, 160, 7, positive=True)
@@ -383,12 +384,35 @@ def test_schedule_variants_are_bit_identical(env, monkeypatch, seq_rounds, gathe
     """The sequential and the speculative Nelder-Mead drivers, with or without the column gather between
     rounds, must walk the same trajectory: every schedule reproduces the oracle bit for bit."""
     api, O, lib, synth = env
+    monkeypatch.setenv("ANOFOX_HIP_SCHED", "rounds")
     monkeypatch.setenv("ANOFOX_HIP_SEQ_ROUNDS", seq_rounds)
     monkeypatch.setenv("ANOFOX_HIP_GATHER", gather)
     Y = synth.gen_series(synth.SEED_M5, 5000, 130, 160, 7, positive=True)
     series = [Y[s, : 160 - (s % 5) * 9] for s in range(130)]          # ragged lengths
     _compare(api, O, lib, series, "AutoETS", 12, seasonal_period=7)
     _compare(api, O, lib, series, "ETS", 12, ets_model="MAdM", seasonal_period=7)
+
+
+@pytest.mark.parametrize("waves", ["3", "40", "2048"])
+@pytest.mark.parametrize("promote", ["1", "9", "100000"])
+def test_work_pool_variants_are_bit_identical(env, monkeypatch, waves, promote):
+    """The work-pool schedule (persistent waves, lanes refilling from a queue, slow problems promoted to four lanes) walks
+    the same trajectories whatever the number of waves (3: every lane refills many times; 2,048: few problems per wave,
+    every problem speculative from its first pass) and whenever a problem is promoted (at once, after 9 iterations,
+    never): every variant reproduces the oracle bit for bit -- ragged lengths, a mixed batch (multiplicative specs queue
+    the strictly positive series only) and a run-time period (seasonal ring in LDS) included."""
+    api, O, lib, synth = env
+    monkeypatch.setenv("ANOFOX_HIP_SCHED", "pool")
+    monkeypatch.setenv("ANOFOX_HIP_POOL_WAVES", waves)
+    monkeypatch.setenv("ANOFOX_HIP_PROMOTE", promote)
+    Y = synth.gen_series(synth.SEED_M5, 5000, 130, 160, 7, positive=True)
+    series = [Y[s, : 160 - (s % 5) * 9] for s in range(130)]          # ragged lengths
+    _compare(api, O, lib, series, "AutoETS", 12, seasonal_period=7)
+    _compare(api, O, lib, series, "ETS", 12, ets_model="MAdM", seasonal_period=7)
+    Yi = synth.gen_series(synth.SEED_M5, 5400, 130, 160, 7)
+    mixed = [Yi[s] if s % 3 else Y[s] for s in range(130)] + [np.full(30, 4.0), np.arange(5.0), np.zeros(40)]
+    _compare(api, O, lib, mixed, "AutoETS", 12, seasonal_period=7)
+    _compare(api, O, lib, series[:40], "AutoETS", 6, seasonal_period=5)
 
 
 def test_device_resident_batch_and_stats(env):
