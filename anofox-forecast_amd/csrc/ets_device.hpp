@@ -27,7 +27,10 @@ constexpr double ETS_TOL = 1.0e-10;
 constexpr double ETS_HUGEN = 1.0e10;
 constexpr double ETS_LN2 = 0.693147180559945309417232121458;
 constexpr double PAR_LO = 1.0e-4, PAR_HI = 0.9999, PHI_LO = 0.8, PHI_HI = 0.98;
-constexpr int ETS_MAX_PERIOD = 64;
+constexpr int ETS_LDS_PERIOD = 64;      // run-time periods up to this keep the seasonal ring in LDS (MS == -1); longer ones
+                                        // (weekly 52 fits, hourly 168, yearly-on-daily 365 do not) keep it in an HBM scratch
+                                        // area of the wave (MS == -2: same code, the ring pointer is a global one)
+constexpr int ETS_MAX_PERIOD = 2048;    // beyond this the series reports COMPUTATION_ERROR naming the cap (the reference takes any period)
 
 struct SeriesView {
     const double *y;   // already offset to this lane's series: element t at y[t * ld]
@@ -184,7 +187,7 @@ struct EtsFinalOut {
 };
 
 // The pass.  MS > 0: compile-time period, ring in VGPRs.  MS == 0: no seasonality.
-// MS == -1: run-time period, ring in LDS (`ring`, K * m * 64 doubles).
+// MS == -1: run-time period, ring in LDS (`ring`, K * m * 64 doubles).  MS == -2: run-time period, `ring` points to HBM scratch.
 // ROWS: every lane streams its OWN series from a series-major copy (v.row) with 128-bit loads instead of the wave's 64
 // adjacent columns of the time-major block -- the lanes of a work-pool wave hold unrelated series (ets_pool_kernel.hpp).
 template <class Cfg, int MS, int K, bool FINAL, bool ROWS = false>

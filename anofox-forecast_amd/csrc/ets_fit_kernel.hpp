@@ -77,7 +77,7 @@ __global__ __launch_bounds__(NM_BLOCK, ANOFOX_ROUND_WAVES) void ets_round_kernel
     mdl.in.fig = a.fig ? a.fig + s : nullptr;
     mdl.in.fig_ld = a.fig_ld;
     mdl.in.m = a.m;
-    mdl.ring = lds + nm_lds_doubles<D>();
+    mdl.ring = (MS == -2) ? a.ring_scratch + (size_t)blockIdx.x * (size_t)a.m * NM_BLOCK : lds + nm_lds_doubles<D>();
 
     NmRun r;
     if (a.first_round) nm_init_simplex(mdl, lds, r, active);
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(NM_BLOCK) void ets_final_kernel(const FitArgs a)
         fin.sse_out = &sse;
         fin.h = 0;                                   // the forecasts of the run stay as they are
     }
-    ets_pass<Cfg, MS, 1, true>(v, in, cand, f, lds, &fin);
+    ets_pass<Cfg, MS, 1, true>(v, in, cand, f, (MS == -2) ? a.ring_scratch + (size_t)blockIdx.x * (size_t)a.m * NM_BLOCK : lds, &fin);
     if (inspect) {
         if (active && fabs(f[0]) <= 1.7976931348623157e308) {
             EtsPar par;

@@ -47,7 +47,7 @@ __device__ __noinline__ void ets_pool_body(const FitArgs &a, double *lds)
         EtsModel<Cfg, MS, 1> b0;
         b0.bounds(lo, hi, x0);
     }
-    double *ring = lds + nm_lds_doubles<D>();
+    double *ring = (MS == -2) ? a.ring_scratch + (size_t)blockIdx.x * (size_t)a.m * NM_BLOCK : lds + nm_lds_doubles<D>();
 
     // ---- lane state (a promoted problem's four lanes carry identical copies) ----
     int mode = POOL_IDLE;

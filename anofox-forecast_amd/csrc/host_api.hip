@@ -149,6 +149,10 @@ struct AnofoxHipBatch {
                              // is the default: measured 590 ms against 700-800 ms per 30-spec M5 step
     int pool_waves = 2048;   // persistent waves over all candidate specs of a group (the chip holds 2 x 1,024 waves of these kernels)
     int pool_promote = 128;  // iterations after which a problem asks for four lanes
+    double *d_ring = nullptr;        // seasonal rings of periods above the LDS limit: one area per (candidate spec, workgroup)
+    size_t ring_elems = 0;
+    double *d_prep_scratch = nullptr;   // prep kernel's window ring + per-phase accumulators for such periods
+    size_t prep_scratch_elems = 0;
     double *d_ys = nullptr;  // series-major copy of the block [n x pool_tw] (+ one row of slack)
     size_t pool_tw = 0;
     int32_t *d_pool_head = nullptr;   // [N_AUX_STREAMS] queue cursors
@@ -300,7 +304,7 @@ void free_batch_buffers(AnofoxHipBatch *b)
     F(b->d_aicc); F(b->d_yhat_slots); F(b->d_status_slots); F(b->d_evals_slots); F(b->d_iters_slots);
     F(b->d_passes_slots); F(b->d_slot_spec);
     F(b->d_yhat); F(b->d_lo); F(b->d_hi); F(b->d_model_code); F(b->d_status); F(b->d_detail);
-    F(b->d_ys); F(b->d_pool_head); F(b->d_pool_trace);
+    F(b->d_ys); F(b->d_pool_head); F(b->d_pool_trace); F(b->d_ring); F(b->d_prep_scratch);
     F(b->d_passes_total); F(b->d_evals_total); F(b->d_mask); F(b->d_len_group); F(b->d_count); F(b->d_pos_map); F(b->d_pos_cnt); F(b->d_notpos); F(b->d_ypos);
     F(b->ar_w); F(b->ar_wmean); F(b->ar_wsd); F(b->ar_l0); F(b->ar_l1); F(b->ar_x); F(b->ar_aicc); F(b->ar_wlen); F(b->ar_d); F(b->ar_D);
     F(b->ar_order); F(b->ar_status); F(b->ar_evals); F(b->ar_passes); F(b->ar_models);
@@ -404,6 +408,28 @@ void ensure_fig(AnofoxHipBatch *b, int m)
     b->fig_m = m;
 }
 
+// HBM scratch for seasonal periods whose rings do not fit LDS (ETS_LDS_PERIOD): grown on demand, kept for the batch
+double *ensure_ring(AnofoxHipBatch *b, size_t elems)
+{
+    if (b->ring_elems < elems) {
+        if (b->d_ring) (void)hipFree(b->d_ring);
+        b->d_ring = nullptr; b->ring_elems = 0;
+        b->d_ring = dalloc<double>(elems);
+        b->ring_elems = elems;
+    }
+    return b->d_ring;
+}
+double *ensure_prep_scratch(AnofoxHipBatch *b, size_t elems)
+{
+    if (b->prep_scratch_elems < elems) {
+        if (b->d_prep_scratch) (void)hipFree(b->d_prep_scratch);
+        b->d_prep_scratch = nullptr; b->prep_scratch_elems = 0;
+        b->d_prep_scratch = dalloc<double>(elems);
+        b->prep_scratch_elems = elems;
+    }
+    return b->d_prep_scratch;
+}
+
 // Series that cannot be forecast at all (forecast.rs:516-525) and per-series periods.
 void finalize_lengths(AnofoxHipBatch *b)
 {
@@ -430,7 +456,16 @@ void run_classic(AnofoxHipBatch *b, int kind, const int32_t *d_len, int m, int o
     a.mask = mask; a.want = want; a.min_len = min_len;
     a.yhat = b->d_yhat; a.status = b->d_detail; a.passes = b->d_passes_total;
     a.model_code = code; a.model_code_out = write_code ? b->d_model_code : nullptr;
+    a.ring_scratch = nullptr;
+    if ((kind == CK_HW || kind == CK_SEASONAL_ES) && m > 48)       // CLASSIC_LDS_PERIOD: four candidate rings per lane
+        a.ring_scratch = ensure_ring(b, (size_t)((b->n + 63) / 64) * 4u * (size_t)m * 64u);
     launch_classic(kind, a, st);
+}
+
+__global__ void fill_i32_kernel(int n, int32_t *dst, int32_t v)
+{
+    int s = blockIdx.x * 256 + threadIdx.x;
+    if (s < n) dst[s] = v;
 }
 
 // d_detail holds the per-series fit status of the last model stage; map it into ErrorCodes.
@@ -556,7 +591,7 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
     const int n_lanes = std::min<int>(N_AUX_STREAMS, b->n_slots_cap);
     // fork: aux streams wait for everything queued on `st` so far
     HIPCHECK(hipEventRecord(b->ev_fit0, st));
-    const bool pool = b->pool_sched && !b->fixed_params;
+    const bool pool = b->pool_sched && !b->fixed_params && m <= ETS_LDS_PERIOD;      // long periods: round schedule only
     const int n_fork = pool ? POOL_UNITS : n_lanes;      // streams that carry work: one per unit kernel / one per spec
     if (pool) {
         // the work-pool kernels stream every lane's own series: series-major copy of the block, once per group
@@ -636,8 +671,23 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
         a.iters = b->d_iters_slots + k * ld;
         a.passes = b->d_passes_slots + k * ld;
         a.st = lane.st;
+        a.ring_scratch = nullptr;
         fns[oi] = ets_fit_launcher(id, a.m);
         if (!fns[oi].round_seq || !fns[oi].round_spec || !fns[oi].final) throw HipFail{"no kernel for ETS spec id " + std::to_string(id)};
+    }
+    // Periods above the LDS limit keep the seasonal ring of every lane in HBM: one area per (spec, workgroup of the widest
+    // launch = the speculative driver's 16 problems per workgroup)
+    {
+        size_t n_long = 0;
+        for (size_t oi = 0; oi < order.size(); oi++) if (args[oi].m > ETS_LDS_PERIOD) n_long++;
+        if (n_long) {
+            const size_t per_spec = (size_t)((n + 15) / 16) * (size_t)m * 64u;
+            if ((double)n_long * (double)per_spec * 8.0 > 64.0 * 1073741824.0)
+                throw HipFail{"seasonal period " + std::to_string(m) + " on " + std::to_string(n) + " series needs more than 64 GiB of ring scratch: shard the batch"};
+            double *base = ensure_ring(b, n_long * per_spec);
+            size_t k = 0;
+            for (size_t oi = 0; oi < order.size(); oi++) if (args[oi].m > ETS_LDS_PERIOD) args[oi].ring_scratch = base + (k++) * per_spec;
+        }
     }
     // Round-major submission: round r of every spec is enqueued before round r+1 of any, each spec on its
     // own stream, so that all specs advance together and the hardware queues never hold a long spec behind
@@ -827,9 +877,11 @@ void run_group(AnofoxHipBatch *b, int period, const int32_t *d_len, hipStream_t 
         PrepArgs a{};
         a.y = b->d_y; a.ld = ld; a.len = d_len; a.n_series = (int)n; a.m = m;
         a.mean = b->d_mean; a.sd = b->d_sd; a.flags = b->d_flags;
+        a.scratch = nullptr;
         if (states) {
             if (m >= 2) ensure_fig(b, m);
             a.fig_add = b->d_fig_add; a.fig_mul = b->d_fig_mul; a.l0 = b->d_l0; a.b0 = b->d_b0;
+            if (m > ETS_LDS_PERIOD) a.scratch = ensure_prep_scratch(b, (size_t)((n + 63) / 64) * (size_t)((2 * (m / 2) + 1) + 3 * m) * 64u);
         }
         launch_prep(a, st);
     };
@@ -841,6 +893,19 @@ void run_group(AnofoxHipBatch *b, int period, const int32_t *d_len, hipStream_t 
         launch_simple(a, st);
     };
     auto finish = [&]() { hipLaunchKernelGGL(finish_status_kernel, dim3(blocks256), dim3(256), 0, st, (int)n, d_len, b->d_detail, b->d_status); };
+
+    // A period the kernels cannot hold fails the group's series loudly (COMPUTATION_ERROR naming the cap) -- never a silent
+    // non-seasonal fit.  The reference takes any period (forecast.rs:528-537); 2,048 covers every calendar period.
+    const bool uses_period = p.model == M_AutoETS || p.model == M_HoltWinters || p.model == M_SeasonalES || p.model == M_SeasonalESOptimized ||
+                             (p.model == M_ETS && (p.ets_spec_id < 0 || spec_season(p.ets_spec_id) != 0));
+    if (uses_period && period > ETS_MAX_PERIOD) {
+        prep(1, false);
+        HIPCHECK(hipMemsetAsync(b->d_detail, 0, ld * sizeof(int32_t), st));
+        hipLaunchKernelGGL(fill_i32_kernel, dim3(blocks256), dim3(256), 0, st, (int)n, b->d_detail, (int32_t)FIT_PERIOD);
+        finish();
+        LAUNCHCHECK("period cap");
+        return;
+    }
 
     switch (p.model) {
     case M_Naive: prep(1, false); simple(SK_NAIVE, 1, 0); break;
@@ -1045,7 +1110,7 @@ std::string series_error_message(const AnofoxHipBatch *b, size_t s, int code, in
     }
     const char *why = detail == FIT_SHORT ? "not enough observations for this model"
                       : detail == FIT_NONPOSITIVE ? "multiplicative components require strictly positive data"
-                      : detail == FIT_NONFINITE ? "likelihood is not finite" : "unsupported seasonal period";
+                      : detail == FIT_NONFINITE ? "likelihood is not finite" : "unsupported seasonal period (periods above 2048 are not supported)";
     switch (b->plan.model) {
     case M_ETS:
         if (b->plan.ets_spec_id >= 0) {

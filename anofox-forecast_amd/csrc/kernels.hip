@@ -51,7 +51,8 @@ void launch_select(const SelectArgs &a, hipStream_t stream)
 // ------------------------------------------------------------------------------------------
 // classic fits
 // ------------------------------------------------------------------------------------------
-template <int KIND>
+// GRING: the seasonal ring (NM_K candidates x m phases x 64 lanes) lives in an HBM scratch area of the workgroup (long periods)
+template <int KIND, bool GRING = false>
 __global__ __launch_bounds__(NM_BLOCK) void classic_kernel(const ClassicArgs a)
 {
     extern __shared__ double lds[];
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(NM_BLOCK) void classic_kernel(const ClassicArgs a)
     ClassicModel<KIND> mdl;
     mdl.v = v;
     mdl.m = a.m;
-    mdl.ring = lds + nm_lds_doubles<DIM>();
+    mdl.ring = GRING ? a.ring_scratch + (size_t)blockIdx.x * (size_t)NM_K * (size_t)(a.m > 0 ? a.m : 1) * NM_BLOCK : lds + nm_lds_doubles<DIM>();
 
     double xbest[DIM], fbest;
     NmStats ns = {0, 0, 0};
@@ -103,6 +104,9 @@ __global__ __launch_bounds__(NM_BLOCK) void classic_kernel(const ClassicArgs a)
     }
 }
 
+// the classic kernels hold NM_K = 4 candidate rings per lane: 2 KB of LDS per phase and wave
+constexpr int CLASSIC_LDS_PERIOD = 48;
+
 void launch_classic(int kind, const ClassicArgs &a, hipStream_t stream)
 {
     const int grid = (a.n_series + NM_BLOCK - 1) / NM_BLOCK;
@@ -116,6 +120,11 @@ void launch_classic(int kind, const ClassicArgs &a, hipStream_t stream)
         hipLaunchKernelGGL(classic_kernel<CK_HOLT>, dim3(grid), dim3(NM_BLOCK), sizeof(double) * nm_lds_doubles<2>(), stream, a);
         break;
     case CK_HW: {
+        if (mm > CLASSIC_LDS_PERIOD) {
+            if (!a.ring_scratch) throw std::runtime_error("Holt-Winters: a period above the LDS limit needs the ring scratch area");
+            hipLaunchKernelGGL((classic_kernel<CK_HW, true>), dim3(grid), dim3(NM_BLOCK), sizeof(double) * nm_lds_doubles<3>(), stream, a);
+            break;
+        }
         size_t bytes = sizeof(double) * nm_lds_doubles<3>() + ring;
         if (bytes > 48 * 1024)
             anofox_check_attr(hipFuncSetAttribute((const void *)classic_kernel<CK_HW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
@@ -123,6 +132,11 @@ void launch_classic(int kind, const ClassicArgs &a, hipStream_t stream)
         break;
     }
     default: {
+        if (mm > CLASSIC_LDS_PERIOD) {
+            if (!a.ring_scratch) throw std::runtime_error("SeasonalES: a period above the LDS limit needs the ring scratch area");
+            hipLaunchKernelGGL((classic_kernel<CK_SEASONAL_ES, true>), dim3(grid), dim3(NM_BLOCK), sizeof(double) * nm_lds_doubles<1>(), stream, a);
+            break;
+        }
         size_t bytes = sizeof(double) * nm_lds_doubles<1>() + ring;
         if (bytes > 48 * 1024)
             anofox_check_attr(hipFuncSetAttribute((const void *)classic_kernel<CK_SEASONAL_ES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));

@@ -31,6 +31,7 @@ struct PrepArgs {
     uint32_t *flags;
     double *fig_add, *fig_mul;   // [m x ld] seasonal figures (additive / multiplicative)
     double *l0, *b0;       // [9 x ld]: index (season_type * 3 + trend_type)
+    double *scratch;       // periods above ETS_LDS_PERIOD: (2 (m / 2) + 1 + 3 m) * 64 doubles per workgroup instead of LDS
 };
 
 // Nelder-Mead state parked in HBM between rounds, indexed by series (stride ld)
@@ -58,6 +59,7 @@ struct FitArgs {
     int32_t *next_map, *next_cnt, *clear_cnt;
     double *next_y;              // next round's dense block [t_rows x ld] (NULL: the next round reads y in place)
     NmStateBuf st;
+    double *ring_scratch;        // periods above ETS_LDS_PERIOD: m * 64 doubles per workgroup of the launch (seasonal ring in HBM)
     // work-pool schedule (ets_pool_kernel.hpp): series-major copy of the block (row s at ys + s * tw, 64 doubles of slack
     // behind every row), the queue cursor (zeroed before the launch), the iteration count after which a problem asks for
     // four lanes, whether every problem runs speculatively from its first pass, and the number of persistent waves
@@ -115,6 +117,7 @@ struct ClassicArgs {
     int32_t *passes;             // [n_series] (accumulated)
     int32_t model_code;          // written to model_code[s] when not NULL
     int32_t *model_code_out;
+    double *ring_scratch;        // periods whose K * m * 64 ring does not fit LDS: that many doubles per workgroup in HBM
 };
 
 enum SimpleKind { SK_NAIVE = 0, SK_SEASONAL_NAIVE = 1, SK_SMA = 2, SK_DRIFT = 3, SK_TOY_ARIMA = 4 };

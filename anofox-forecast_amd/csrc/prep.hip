@@ -36,9 +36,13 @@ struct RowLoader {
 };
 constexpr int PREP_S = 16;
 
+// GSCR: the decomposition's window ring and per-phase accumulators live in an HBM scratch area of the workgroup instead of
+// LDS (periods above ETS_LDS_PERIOD: (2 (m / 2) + 1 + 3 m) * 512 bytes no longer fit)
+template <bool GSCR>
 __global__ __launch_bounds__(NM_BLOCK) void prep_kernel(const PrepArgs a)
 {
-    extern __shared__ double lds[];
+    extern __shared__ double lds_dyn[];
+    double *lds = GSCR ? a.scratch + (size_t)blockIdx.x * (size_t)((2 * (a.m / 2) + 1) + 3 * a.m) * NM_BLOCK : lds_dyn;
     const int lane = threadIdx.x;
     const int s = blockIdx.x * NM_BLOCK + lane;
     const bool valid = s < a.n_series;
@@ -222,9 +226,14 @@ void launch_prep(const PrepArgs &a, hipStream_t stream)
 {
     const int grid = (a.n_series + NM_BLOCK - 1) / NM_BLOCK;
     size_t lds_bytes = 0;
-    if (a.l0 != nullptr && a.m >= 2 && a.m <= ETS_MAX_PERIOD) lds_bytes = sizeof(double) * (size_t)((2 * (a.m / 2) + 1) + 3 * a.m) * NM_BLOCK;
-    if (lds_bytes > 48 * 1024) anofox_check_attr(hipFuncSetAttribute((const void *)prep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    hipLaunchKernelGGL(prep_kernel, dim3(grid), dim3(NM_BLOCK), lds_bytes, stream, a);
+    if (a.l0 != nullptr && a.m > ETS_LDS_PERIOD && a.m <= ETS_MAX_PERIOD) {
+        if (!a.scratch) throw std::runtime_error("prep: a period above the LDS limit needs the scratch area");
+        hipLaunchKernelGGL(prep_kernel<true>, dim3(grid), dim3(NM_BLOCK), 0, stream, a);
+        return;
+    }
+    if (a.l0 != nullptr && a.m >= 2 && a.m <= ETS_LDS_PERIOD) lds_bytes = sizeof(double) * (size_t)((2 * (a.m / 2) + 1) + 3 * a.m) * NM_BLOCK;
+    if (lds_bytes > 48 * 1024) anofox_check_attr(hipFuncSetAttribute((const void *)prep_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    hipLaunchKernelGGL(prep_kernel<false>, dim3(grid), dim3(NM_BLOCK), lds_bytes, stream, a);
 }
 
 } // namespace anofox

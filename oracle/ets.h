@@ -30,7 +30,7 @@ typedef struct EtsSpec {
     int m;       /* seasonal period, 1 when season == ETS_NONE */
 } EtsSpec;
 
-#define ETS_MAX_PERIOD 64
+#define ETS_MAX_PERIOD 2048
 #define ETS_MAX_DIM 4
 
 /* Bounds and starting point of the smoothing parameters (alpha, beta*, gamma*, phi). */

@@ -346,7 +346,7 @@ static int m_holt_winters(const double *y, size_t n, int h, size_t period, doubl
      * seasonal_period 7, rows are returned); the caller still names the result "HoltWinters" */
     if (n < 2 * m) return m_holt(y, n, h, out, err);
     if (m > ETS_MAX_PERIOD)
-        FAIL(err, COMPUTATION_ERROR, "Computation error: HoltWinters fit failed: unsupported seasonal period");
+        FAIL(err, COMPUTATION_ERROR, "Computation error: HoltWinters fit failed: unsupported seasonal period (periods above 2048 are not supported)");
     SeriesCtx c = { y, n, m };
     double x0[3] = { 0.3, 0.1, 0.1 };
     NmResult r;
@@ -416,7 +416,7 @@ static const char *ets_status_text(int st)
     case ETS_ERR_SHORT: return "not enough observations for this model";
     case ETS_ERR_NONPOSITIVE: return "multiplicative components require strictly positive data";
     case ETS_ERR_NONFINITE: return "likelihood is not finite";
-    case ETS_ERR_PERIOD: return "unsupported seasonal period";
+    case ETS_ERR_PERIOD: return "unsupported seasonal period (periods above 2048 are not supported)";
     default: return "unknown";
     }
 }
@@ -609,6 +609,14 @@ static int run_forecast(const double *y, size_t n, const ForecastOptions *o, Mod
              "Invalid input: Model '%s' does not use seasonal_period (got %d). For seasonal forecasting, use: "
              "SeasonalNaive, HoltWinters, SeasonalES, AutoETS, AutoMFLES, AutoMSTL, or AutoTBATS.",
              MODEL_NAMES[model], o->seasonal_period);
+
+    /* periods the kernels cannot hold fail loudly (never a silent non-seasonal fit): the checker states the same rule as
+     * csrc/host_api.hip run_group.  The reference takes any period (forecast.rs:528-537). */
+    if (period > ETS_MAX_PERIOD &&
+        (model == M_AutoETS || model == M_HoltWinters || model == M_SeasonalES || model == M_SeasonalESOptimized ||
+         (model == M_ETS && (!o->ets_model[0] || (valid_ets_notation(o->ets_model) && spec_from_notation(o->ets_model).season != ETS_NONE)))))
+        FAIL(err, COMPUTATION_ERROR, "Computation error: %s fit failed: unsupported seasonal period (periods above %d are not supported)",
+             MODEL_NAMES[model], ETS_MAX_PERIOD);
 
     name[0] = 0;
     switch (model) {

@@ -94,15 +94,44 @@ def test_ets_specs_match_oracle(env, spec, period):
     _compare(api, O, lib, list(Y), "ETS", 10, ets_model=spec, seasonal_period=period)
 
 
-@pytest.mark.parametrize("period", [2, 12, 24, 64])
+@pytest.mark.parametrize("period", [2, 12, 24, 64, 65, 168])
 def test_autoets_other_periods(env, period):
-    """The compile-time m = 12 ring (additive class only), the LDS ring at its smallest, a long and the maximum period, with
-    ragged lengths that end inside a streamed block: AutoETS over the whole grid against the oracle."""
+    """The compile-time m = 12 ring (additive class only), the LDS ring at its smallest and at its largest (64), the first period
+    whose ring lives in HBM scratch (65) and the hourly-data week (168, the example of the reference's own header,
+    anofox_fcst_ffi.h:1075), with ragged lengths that end inside a streamed block: AutoETS over the whole grid against the oracle."""
     api, O, lib, synth = env
     T = 5 * period + 37
     Y = synth.gen_series(synth.SEED_M5, 3000 + period, 40, T, period, positive=True)
     series = [Y[s, : T - (s % 7) * 3] for s in range(40)]
     _compare(api, O, lib, series, "AutoETS", period + 3, seasonal_period=period)
+
+
+@pytest.mark.parametrize("period,T", [(52, 260), (168, 1008), (365, 1100)])
+def test_long_seasonal_periods(env, period, T):
+    """Seasonal periods above what LDS holds (weekly-on-yearly 52 still fits; hourly 168 and yearly-on-daily 365 keep the
+    seasonal ring, the decomposition window and the per-phase accumulators in HBM scratch): every seasonal model on the path
+    against the oracle, bit for bit -- the reference takes any period (forecast.rs:528-537, 1347-1351)."""
+    api, O, lib, synth = env
+    Y = synth.gen_series(synth.SEED_STRESS, 100 + period, 24, T, period, positive=True)
+    series = [Y[s, : T - (s % 5) * 7] for s in range(24)] + [Y[0, : 2 * period - 1], Y[1, : 2 * period]]     # one season short / exactly two
+    for model, kw in (("HoltWinters", {}), ("SeasonalES", {}), ("SeasonalESOptimized", {}), ("ETS", dict(ets_model="AAA")),
+                      ("ETS", dict(ets_model="MAdM")), ("ETS", dict(ets_model="AMdA")), ("ETS", {}), ("AutoETS", dict(model_pool="reduced"))):
+        _compare(api, O, lib, series, model, 9, seasonal_period=period, **kw)
+    _compare(api, O, lib, series[:6], "AutoETS", 5, seasonal_period=period)                 # the whole 30-spec grid
+
+
+def test_period_above_the_cap_fails_loudly(env):
+    """A period the kernels cannot hold (> 2,048) is a COMPUTATION_ERROR naming the cap for every seasonal model -- never a
+    silent non-seasonal fit; models that ignore the period are unaffected."""
+    api, O, lib, synth = env
+    y = 50.0 + np.arange(6000.0) * 0.01 + np.sin(np.arange(6000.0) / 9.0)
+    for model, kw in (("AutoETS", {}), ("HoltWinters", {}), ("SeasonalESOptimized", {}), ("ETS", dict(ets_model="AAA")), ("ETS", {})):
+        r = api.forecast_series(y, lib.make_options(model, 4, seasonal_period=2500, **kw))
+        ref = O.forecast(y, O.make_options(model, 4, seasonal_period=2500, **kw))
+        assert not r["ok"] and r["code"] == lib.COMPUTATION_ERROR and "2048" in r["message"], (model, r)
+        assert not ref["ok"] and ref["code"] == r["code"]
+    _compare(api, O, lib, [y], "ETS", 4, seasonal_period=2500, ets_model="AAN")            # no seasonal component: the period is not used
+    _compare(api, O, lib, [y], "SeasonalNaive", 4, seasonal_period=2500)
 
 
 def test_autoets_full_grid_positive(env):
@@ -1281,8 +1310,9 @@ def test_cv_backtest_sql_replay(env):
 
 def test_default_chain_with_unsupported_detected_period(env):
     """Found by the fuzz: `ETS` without a spec (and the AutoETS fallback) plan Holt-Winters when two seasons fit
-    (forecast.rs:1327-1336); with a detected period above the 64 the kernels support nothing ran and the series reported
-    success with an empty forecast.  It fails like the oracle now, alone and inside a batch whose other periods are fine."""
+    (forecast.rs:1327-1336); with a detected period above the 64 the kernels supported at the time nothing ran and the series
+    reported success with an empty forecast.  Long periods are fitted now (HBM ring): oracle and device agree, alone and
+    inside a batch whose other periods differ."""
     api, O, lib, synth = env
     t = np.arange(150)
     long_period = 50.0 + 10.0 * np.sin(2 * np.pi * t / 70.0) + 0.01 * t            # detected period 70: two seasons fit into 150
