@@ -1016,6 +1016,337 @@ __global__ __launch_bounds__(NM_BLOCK) void arima_forecast_kernel(const ArimaArg
     a.model_code[s] = 1000000 + o.p * 100000 + d * 10000 + o.q * 1000 + o.P * 100 + Dd * 10 + o.Q;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// exact Gaussian likelihood refit of the selected model (oracle/arima.c ml_eval / refit_ml)
+// ------------------------------------------------------------------------------------------------
+// "CSS for the search, exact likelihood for the final estimates."  One lane per series; every objective evaluation is the
+// Kalman filter of the Harvey state space (state dimension r = max(p + m P, q + m Q + 1) <= AR_ML_MAX_R) run through the
+// Chandrasekhar recursions, so the state covariance is never formed: O(r) work per step, and the four r-vectors (expanded AR
+// coefficients, gain K, increment L, state) stay in VGPRs -- the loops over the state are unrolled to the compile-time
+// bound RM of the launch's period (coefficients past a lane's own r are exact zeros), no LDS or HBM traffic in the pass
+// besides the lane's row of W.  The stationary start (F_1 and K_1 from the ARMA autocovariances: inverse Levinson recursion on
+// the AR polynomial, then the MA filter) is O(r^2) per evaluation in a small LDS scratch.  Same sequence of IEEE operations
+// as the oracle, so the estimates are bit-identical.
+constexpr int AR_ML_MAX_R = 32;
+constexpr int AR_ML_NM_CAP = 100;       // the refit starts at the CSS optimum: 100 x dim evaluations / iterations at most (oracle: ARIMA_ML_NM_CAP)
+__host__ __device__ inline int ar_ml_rm(int m) { const int l1 = AR_MAXP + AR_MAXSP * (m > 1 ? m : 0) + 1; return l1 <= 8 ? 8 : (l1 <= 20 ? 20 : AR_ML_MAX_R); }
+static size_t ar_ml_lds_bytes(int m)
+{
+    const size_t l1 = (size_t)(AR_MAXP + AR_MAXSP * m + 1), rm = (size_t)ar_ml_rm(m);
+    return sizeof(double) * ((size_t)(AR_MAXDIM + 1) * AR_MAXDIM + 2 * l1 + 5 * rm + 5) * NM_BLOCK;
+}
+
+// 0.5 (log(ssq / n) + sumlog / n) of the model whose expanded polynomials are in PL; +inf when not computable
+// LDS scratch of the stationary start (lane-minor, (5 RM + 5) x 64 doubles): two phases share it
+struct ArMlInit {
+    double *base; int rm;
+    // phase 1: kap [rm + 1], al [rm + 1], tmp [rm + 1]; both phases: gu [2 rm + 2]; phase 2: psi (on kap), bb (on al), gx (on tmp)
+    __device__ double &kap(int i) const { return base[(size_t)i * NM_BLOCK + threadIdx.x]; }
+    __device__ double &al(int i) const { return base[(size_t)(rm + 1 + i) * NM_BLOCK + threadIdx.x]; }
+    __device__ double &tmp(int i) const { return base[(size_t)(2 * rm + 2 + i) * NM_BLOCK + threadIdx.x]; }
+    __device__ double &gu(int i) const { return base[(size_t)(3 * rm + 3 + i) * NM_BLOCK + threadIdx.x]; }
+    __device__ double &psi(int i) const { return kap(i); }
+    __device__ double &bb(int i) const { return al(i); }
+    __device__ double &gx(int i) const { return tmp(i); }
+};
+
+template <int RM>
+__device__ double ar_ml_eval(const ArPolyLds &PL, int La, int Lb, double mu, const double *w, int n, const ArMlInit &Q)
+{
+    const int r = La > Lb + 1 ? La : Lb + 1;
+    if (r > AR_ML_MAX_R || r > RM || n < 1) return __builtin_huge_val();
+    auto Ac = [&](int i) { return (i + 1 <= La) ? PL.a(i + 1) : 0.0; };
+    auto Cc = [&](int i) { return (i == 0) ? 1.0 : ((i <= Lb) ? PL.b(i) : 0.0); };
+    // ---- stationary start (oracle/arima.c ml_eval): autocovariances by the inverse Levinson recursion, O(r^2) ----
+    for (int i = 0; i < La; i++) Q.al(i) = Ac(i);
+    double E0 = 1.0;
+    for (int j = La; j >= 1; j--) {
+        const double kj = Q.al(j - 1);
+        Q.kap(j) = kj;
+        const double den = 1.0 - kj * kj;
+        if (!(den > 0.0)) return __builtin_huge_val();
+        E0 = E0 / den;
+        for (int i = 1; i <= j - 1; i++) Q.tmp(i - 1) = fma(kj, Q.al(j - i - 1), Q.al(i - 1)) / den;
+        for (int i = 1; i <= j - 1; i++) Q.al(i - 1) = Q.tmp(i - 1);
+    }
+    const int G = 2 * r;
+    Q.gu(0) = E0;
+    {
+        double Ej = E0;
+        for (int j = 1; j <= La; j++) {
+            const double kj = Q.kap(j);
+            double acc = kj * Ej;
+            for (int i = 1; i <= j - 1; i++) acc = fma(Q.al(i - 1), Q.gu(j - i), acc);
+            Q.gu(j) = acc;
+            for (int i = 1; i <= j - 1; i++) Q.tmp(i - 1) = fma(-kj, Q.al(j - i - 1), Q.al(i - 1));
+            for (int i = 1; i <= j - 1; i++) Q.al(i - 1) = Q.tmp(i - 1);
+            Q.al(j - 1) = kj;
+            Ej = Ej * (1.0 - kj * kj);
+        }
+    }
+    for (int k = La + 1; k <= G; k++) {
+        double acc = 0.0;
+        for (int l = 1; l <= La; l++) acc = fma(Ac(l - 1), Q.gu(k - l), acc);
+        Q.gu(k) = acc;
+    }
+    // phase 2: kap / al / tmp are free now
+    for (int k = 0; k <= Lb; k++) {
+        double acc = 0.0;
+        for (int i = 0; i + k <= Lb; i++) acc = fma(Cc(i), Cc(i + k), acc);
+        Q.bb(k) = acc;
+    }
+    for (int k = 0; k < r; k++) {
+        double acc = Q.bb(0) * Q.gu(k);
+        for (int d = 1; d <= Lb; d++) {
+            const int km = k - d < 0 ? d - k : k - d;
+            acc = fma(Q.bb(d), Q.gu(k + d) + Q.gu(km), acc);
+        }
+        Q.gx(k) = acc;
+    }
+    for (int k = 0; k < r; k++) {
+        double acc = Cc(k);
+        for (int l = 1; l <= k; l++) acc = fma(Ac(l - 1), Q.psi(k - l), acc);
+        Q.psi(k) = acc;
+    }
+    double F = Q.gx(0);
+    if (!(F > 0.0) || !(F <= 1.7976931348623157e308)) return __builtin_huge_val();
+    // the four r-vectors of the filter live in VGPRs from here on (entries at and above the lane's own r are exact zeros)
+    double A[RM], K[RM], L[RM + 1], st[RM + 1];
+#pragma unroll
+    for (int i = 0; i < RM; i++) { A[i] = Ac(i); K[i] = 0.0; st[i] = 0.0; }
+    {
+        double gnext = 0.0;
+        for (int i = r - 1; i >= 0; i--) {
+            const double kv = fma(Ac(i), F, gnext);
+#pragma unroll
+            for (int q = 0; q < RM; q++) K[q] = (q == i) ? kv : K[q];
+            double acc = 0.0;
+            for (int l = i + 1; l <= r; l++) acc = fma(Ac(l - 1), Q.gx(l - i), acc);
+            for (int l = i; l <= r - 1; l++) acc = fma(Cc(l), Q.psi(l - i), acc);
+            gnext = acc;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < RM; i++) L[i] = K[i];
+    L[RM] = 0.0; st[RM] = 0.0;
+    // the filter: one reciprocal per step while F still moves, none in the steady state.  The lane's row of W comes in blocks
+    // of 8 values (128-bit loads, the next block requested before the current one is consumed; rows are 16-byte aligned and
+    // padded, so reading past the series' end is harmless).
+    double rF = 1.0 / F;
+    double M = -rF;
+    double ssq = 0.0, mant = 1.0;
+    int eacc = 0, t = 0;
+    bool steady = false;
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    constexpr int WB = 8;
+    double wc[WB], wn[WB];
+    auto load_w = [&](double (&buf)[WB], int t0) __attribute__((always_inline)) {
+        const d2_t *p = reinterpret_cast<const d2_t *>(w + t0);
+#pragma unroll
+        for (int j = 0; j < WB / 2; j++) { const d2_t v2 = p[j]; buf[2 * j] = v2.x; buf[2 * j + 1] = v2.y; }
+    };
+    load_w(wc, 0);
+    for (int base = 0; base < n; base += WB) {
+        load_w(wn, base + WB);
+#pragma unroll
+        for (int j = 0; j < WB; j++) {
+            if (base + j < n) {
+                const double a0 = st[0];
+                const double v = (wc[j] - mu) - a0;
+                const double vf = v * rF;
+                ssq = fma(v, vf, ssq);
+                if (!steady) {
+                    int ex;
+                    mant = frexp(mant * F, &ex);
+                    eacc += ex;
+                }
+#pragma unroll
+                for (int i = 0; i < RM; i++) st[i] = fma(K[i], vf, fma(A[i], a0, st[i + 1]));
+                if (!steady) {
+                    const double c = L[0];
+                    const double cm = c * M;
+                    const double dF = c * cm;
+                    const double Fn = F + dF;
+                    if (!(Fn > 0.0)) return __builtin_huge_val();
+                    const double cf = c * rF;
+                    double lmax = 0.0;
+#pragma unroll
+                    for (int i = 0; i < RM; i++) {
+                        const double tl = fma(A[i], c, L[i + 1]);
+                        const double kold = K[i];
+                        K[i] = fma(tl, cm, kold);
+                        const double ln = fma(-kold, cf, tl);
+                        L[i] = ln;
+                        const double al = fabs(ln);
+                        lmax = al > lmax ? al : lmax;
+                    }
+                    const double rFn = 1.0 / Fn;
+                    M = (M * F) * rFn;
+                    F = Fn;
+                    rF = rFn;
+                    t = base + j + 1;                       // steps filtered in the transient so far
+                    if (!(lmax * lmax * fabs(M) > 1.0e-12 * F)) steady = true;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < WB; j++) wc[j] = wn[j];
+    }
+    if (!(fabs(ssq) <= 1.7976931348623157e308) || !(ssq >= 0.0)) return __builtin_huge_val();
+    double s2 = ssq / (double)n;
+    if (s2 < 1.0e-300) s2 = 1.0e-300;
+    double sumlog = dm_log(mant) + (double)eacc * 0.693147180559945309417232121458;
+    const int n_steady = steady ? n - t : 0;
+    if (n_steady > 0) sumlog = fma((double)n_steady, dm_log(F), sumlog);
+    const double f = 0.5 * (dm_log(s2) + sumlog / (double)n);
+    return (f == f) ? f : __builtin_huge_val();
+}
+
+enum { RP_F0 = 0, RP_INIT, RP_ITER, RP_E, RP_OC, RP_IC, RP_SHRINK, RP_DONE };
+
+// Series whose state dimension r lies in (r_lo, RM] are refitted by the RM instantiation (the unrolled loops cost RM whatever
+// the lane's own r, so the common small models -- r = 9 for (0,1,1)(1,0,1)[7] -- run in a narrower kernel); `cursor` is the
+// queue cursor of this launch in ws.counts.
+template <int RM>
+__device__ __noinline__ void ar_refit_body(const ArimaArgs &a, const ArWs &ws, const int r_lo, const int cursor, double *lds)
+{
+    const int lane = threadIdx.x;
+    const int m = a.m;
+    const size_t ld = a.ld;
+    const int l1 = AR_MAXP + AR_MAXSP * m + 1;
+    ArLds L{lds, 0, lane};
+    ArPolyLds PL{lds + (size_t)(AR_MAXDIM + 1) * AR_MAXDIM * NM_BLOCK, l1};
+    ArMlInit Q{PL.base + (size_t)2 * l1 * NM_BLOCK, RM};
+    ArFs F;
+    for (int k = 0; k <= AR_MAXDIM; k++) F.v[k] = 0.0;
+
+    // persistent lanes: a lane that has finished its series takes the next one from the cursor (evaluation counts differ
+    // several-fold between series, so a wave tied to 64 fixed series would idle most of its lanes)
+    int s = 0, len = 0, D = 0;
+    ArOrd o{0, 0, 0, 0, 0};
+    double x0[AR_MAXDIM] = {0, 0, 0, 0, 0, 0};
+    const double *w = ws.W;
+    double wsd = 0.0;
+    bool fin = false;
+    int ph = RP_DONE, vi = 0, nm_evals = 0, nm_iters = 1, evals = 0;
+    double fxr = 0.0, f0 = 0.0;
+
+    for (;;) {
+        // ---- next series of this lane ----
+        for (int attempt = 0; attempt < 4 && !fin && ph == RP_DONE; attempt++) {
+            if (evals > 0) { a.passes[s] += evals; a.evals[s] += evals; evals = 0; }
+            const int item = atomicAdd(&ws.counts[cursor], 1);
+            if (item >= a.n_series) { fin = true; break; }
+            s = item;
+            len = a.wlen[s];
+            if (!(len >= 3 && a.status[s] == FIT_OK)) continue;
+            o.p = a.order[(size_t)0 * ld + s]; o.q = a.order[(size_t)1 * ld + s]; o.P = a.order[(size_t)2 * ld + s];
+            o.Q = a.order[(size_t)3 * ld + s]; o.c = a.order[(size_t)4 * ld + s];
+            D = o.p + o.q + o.P + o.Q + o.c;
+            if (D == 0) continue;
+            {
+                const int la = o.p + m * o.P, lb1 = o.q + m * o.Q + 1;
+                const int rr = la > lb1 ? la : lb1;
+                if (rr <= r_lo || rr > RM) continue;              // another instantiation's series (or beyond AR_ML_MAX_R: CSS estimates stay)
+            }
+            for (int i = 0; i < AR_MAXDIM; i++) x0[i] = a.xbest[(size_t)i * ld + s];
+            w = ws.W + (size_t)s * ws.tw;
+            wsd = a.wsd[s];
+            ph = RP_F0; vi = 0; nm_evals = 0; nm_iters = 1;
+        }
+        if (__all(fin && ph == RP_DONE)) break;
+        double x[AR_MAXDIM] = {0, 0, 0, 0, 0, 0};
+        if (ph != RP_DONE) {
+            if (ph == RP_ITER) {
+                bool stop = !(nm_evals < AR_ML_NM_CAP * D && nm_iters < AR_ML_NM_CAP * D);
+                if (!stop) {
+                    bool small = true;
+                    for (int k = 1; k <= D; k++) {
+                        for (int i = 0; i < D; i++)
+                            if (!(fabs(L.sim(k, i) - L.sim(0, i)) <= 1.0e-4)) small = false;
+                        if (!(fabs(F.get(0) - F.get(k)) <= 1.0e-8)) small = false;
+                    }
+                    stop = small;
+                }
+                if (stop) {
+                    // the exact-likelihood estimates replace the CSS ones when they are at least as good as the start
+                    const double fb = F.get(0);
+                    if (fabs(fb) <= 1.7976931348623157e308 && fb <= f0)
+                        for (int i = 0; i < D; i++) a.xbest[(size_t)i * ld + s] = L.sim(0, i);
+                    ph = RP_DONE;
+                }
+            }
+            if (ph == RP_F0) { for (int i = 0; i < D; i++) x[i] = x0[i]; }
+            else if (ph == RP_INIT) { for (int i = 0; i < D; i++) x[i] = L.sim(vi, i); }
+            else if (ph == RP_ITER) { for (int i = 0; i < D; i++) x[i] = ar_trial(L, D, 0, i); }
+            else if (ph == RP_E || ph == RP_OC || ph == RP_IC) {
+                const int which = ph == RP_E ? 1 : (ph == RP_OC ? 2 : 3);
+                for (int i = 0; i < D; i++) x[i] = ar_trial(L, D, which, i);
+            } else if (ph == RP_SHRINK) { for (int i = 0; i < D; i++) x[i] = L.sim(1 + vi, i); }
+        }
+        double f = __builtin_huge_val();
+        if (ph != RP_DONE) {
+            int La = 0, Lb = 0;
+            double mu = 0.0;
+            ar_build_poly(o, m, x, PL, La, Lb, mu);
+            f = ar_ml_eval<RM>(PL, La, Lb, mu, w, len, Q);
+            evals++;
+        }
+        if (ph == RP_F0) {
+            f0 = f;
+            if (!(fabs(f0) <= 1.7976931348623157e308)) ph = RP_DONE;      // not computable at the start: the CSS estimates stay
+            else {
+                for (int i = 0; i < D; i++) L.sim(0, i) = x0[i];
+                for (int k = 0; k < D; k++) {
+                    for (int i = 0; i < D; i++) L.sim(k + 1, i) = x0[i];
+                    const double step = (o.c && k == D - 1) ? (wsd > 0.0 ? 0.1 * wsd : 1.0e-4) : 0.1;
+                    L.sim(k + 1, k) = x0[k] + step;
+                }
+                nm_evals = 0; nm_iters = 1; vi = 0;
+                ph = RP_INIT;
+            }
+        } else if (ph == RP_INIT) {
+            F.set(vi, f); vi++; nm_evals++;
+            if (vi == D + 1) { ar_sort(L, F, D); ph = RP_ITER; }
+        } else if (ph == RP_ITER) {
+            fxr = f; nm_evals++;
+            if (fxr < F.get(0)) ph = RP_E;
+            else if (fxr < F.get(D - 1)) { ar_accept(L, F, D, 0, fxr); nm_iters++; }
+            else if (fxr < F.get(D)) ph = RP_OC;
+            else ph = RP_IC;
+        } else if (ph == RP_E) {
+            nm_evals++;
+            if (f < fxr) ar_accept(L, F, D, 1, f); else ar_accept(L, F, D, 0, fxr);
+            nm_iters++; ph = RP_ITER;
+        } else if (ph == RP_OC || ph == RP_IC) {
+            nm_evals++;
+            const bool ok = (ph == RP_OC) ? (f <= fxr) : (f < F.get(D));
+            if (ok) { ar_accept(L, F, D, ph == RP_OC ? 2 : 3, f); nm_iters++; ph = RP_ITER; }
+            else {
+                for (int k = 1; k <= D; k++)
+                    for (int i = 0; i < D; i++) L.sim(k, i) = L.sim(0, i) + 0.5 * (L.sim(k, i) - L.sim(0, i));
+                vi = 0; ph = RP_SHRINK;
+            }
+        } else if (ph == RP_SHRINK) {
+            F.set(1 + vi, f); vi++; nm_evals++;
+            if (vi == D) { nm_iters++; ar_sort(L, F, D); ph = RP_ITER; }
+        }
+    }
+    if (evals > 0) { a.passes[s] += evals; a.evals[s] += evals; }
+}
+
+// One persistent launch for all state-dimension classes: a wave works through the classes from the widest down, so the
+// slowest fits of one class overlap with the bulk of the next (ws.counts[9..12] are the class cursors).
+__global__ __launch_bounds__(NM_BLOCK, 1) void arima_refit_kernel(const ArimaArgs a, const ArWs ws, const int l1)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    if (l1 > 20) ar_refit_body<AR_ML_MAX_R>(a, ws, 20, 12, lds);
+    if (l1 > 12) ar_refit_body<20>(a, ws, 12, 11, lds);
+    if (l1 > 8) ar_refit_body<12>(a, ws, 8, 10, lds);
+    ar_refit_body<8>(a, ws, 0, 9, lds);
+}
+
 #define AR_HIPCHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) throw std::runtime_error(std::string("HIP: ") + hipGetErrorString(e_) + " at " #x); } while (0)
 
 int launch_arima(const ArimaArgs &a, hipStream_t stream)
@@ -1071,6 +1402,18 @@ int launch_arima(const ArimaArgs &a, hipStream_t stream)
             const int fit_grid = (int)(waves < max_waves ? waves : max_waves);
             hipLaunchKernelGGL(arima_fit_kernel, dim3(fit_grid), dim3(NM_BLOCK), fit_lds, stream, a, ws, (int)total);
         }
+        launches++;
+    }
+    // final estimates of the selected models: exact Gaussian likelihood (a.ml_scratch == NULL keeps the CSS estimates)
+    if (a.ml_refit) {
+        const int l1 = AR_MAXP + AR_MAXSP * (a.m > 1 ? a.m : 0) + 1;        // largest state dimension of this period
+        const int rm = l1 <= 8 ? 8 : (l1 <= 12 ? 12 : (l1 <= 20 ? 20 : AR_ML_MAX_R));
+        const size_t lds_b = sizeof(double) * ((size_t)(AR_MAXDIM + 1) * AR_MAXDIM + 2 * (size_t)(AR_MAXP + AR_MAXSP * a.m + 1) + 5 * (size_t)rm + 5) * NM_BLOCK;
+        if (lds_b > 48 * 1024) AR_HIPCHECK(hipFuncSetAttribute((const void *)arima_refit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
+        int per = (int)((160 * 1024) / lds_b);
+        per = per < 1 ? 1 : (per > 4 ? 4 : per);
+        const int g = std::min(grid, cus * per);                            // persistent lanes: no more waves than fit the chip
+        hipLaunchKernelGGL(arima_refit_kernel, dim3(g), dim3(NM_BLOCK), lds_b, stream, a, ws, l1);
         launches++;
     }
     hipLaunchKernelGGL(arima_forecast_kernel, dim3(grid), dim3(NM_BLOCK), fc_lds, stream, a, ws);

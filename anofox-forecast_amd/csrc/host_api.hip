@@ -115,6 +115,7 @@ struct AnofoxHipBatch {
     int insp_m = 1;
     int32_t live_pos = -1, live_all = -1;   // usable strictly positive / usable series of the current group (-1: not counted)
     // AutoARIMA workspace
+    bool arima_ml = true;            // exact-likelihood refit of the selected model (ANOFOX_HIP_ARIMA_ML=0: keep the CSS estimates)
     size_t ar_ws_bytes = 0;
     double *ar_w = nullptr, *ar_wmean = nullptr, *ar_wsd = nullptr, *ar_l0 = nullptr, *ar_l1 = nullptr, *ar_x = nullptr, *ar_aicc = nullptr;
     int32_t *ar_wlen = nullptr, *ar_d = nullptr, *ar_D = nullptr, *ar_order = nullptr, *ar_status = nullptr, *ar_evals = nullptr, *ar_passes = nullptr, *ar_models = nullptr;
@@ -898,7 +899,8 @@ void run_group(AnofoxHipBatch *b, int period, const int32_t *d_len, hipStream_t 
     // non-seasonal fit.  The reference takes any period (forecast.rs:528-537); 2,048 covers every calendar period.
     const bool uses_period = p.model == M_AutoETS || p.model == M_HoltWinters || p.model == M_SeasonalES || p.model == M_SeasonalESOptimized ||
                              (p.model == M_ETS && (p.ets_spec_id < 0 || spec_season(p.ets_spec_id) != 0));
-    if (uses_period && period > ETS_MAX_PERIOD) {
+    const bool arima_period = p.model == M_AutoARIMA && period > 24;      // seasonal ARIMA terms: LDS rings of 2 m + 4 slots, m <= 24
+    if ((uses_period && period > ETS_MAX_PERIOD) || arima_period) {
         prep(1, false);
         HIPCHECK(hipMemsetAsync(b->d_detail, 0, ld * sizeof(int32_t), st));
         hipLaunchKernelGGL(fill_i32_kernel, dim3(blocks256), dim3(256), 0, st, (int)n, b->d_detail, (int32_t)FIT_PERIOD);
@@ -1022,12 +1024,13 @@ void run_group(AnofoxHipBatch *b, int period, const int32_t *d_len, hipStream_t 
         prep(1, false);
         ArimaArgs aa{};
         aa.y = b->d_y; aa.ld = ld; aa.len = d_len; aa.n_series = (int)n;
-        aa.m = (period > 1 && period <= 24) ? period : 1;     // seasonal terms for m <= 24 (oracle ARIMA_MAX_PERIOD)
+        aa.m = period > 1 ? period : 1;                        // <= 24 here: longer periods failed loudly above
         aa.h = b->h;
         aa.ws = b->ar_w; aa.ws_bytes = b->ar_ws_bytes; aa.t_max = (int)std::max<size_t>(b->t_max, 1); aa.wlen = b->ar_wlen; aa.d = b->ar_d; aa.D = b->ar_D; aa.wmean = b->ar_wmean; aa.wsd = b->ar_wsd;
         aa.last_d0 = b->ar_l0; aa.last_d1 = b->ar_l1; aa.order = b->ar_order; aa.xbest = b->ar_x; aa.aicc = b->ar_aicc;
         aa.status = b->d_detail; aa.evals = b->d_evals_total; aa.passes = b->d_passes_total; aa.models = b->ar_models;
         aa.yhat = b->d_yhat; aa.model_code = b->d_model_code;
+        aa.ml_refit = b->arima_ml ? 1 : 0;
         HIPCHECK(hipEventRecord(b->ev_fit0, st));
         try { b->fit_launches += launch_arima(aa, st); }
         catch (const std::exception &e) { throw HipFail{e.what()}; }
@@ -1070,7 +1073,12 @@ void run_batch(AnofoxHipBatch *b, hipStream_t st)
     auto used_period = [&](int period) {
         switch (b->plan.model) {
         case M_Naive: case M_RandomWalkDrift: case M_ARIMA: case M_SES: case M_SESOptimized: case M_Holt: return 1;
-        case M_AutoARIMA: return (period > 1 && period <= 24) ? period : 1;
+        case M_AutoARIMA: {
+            // a DETECTED period above the cap of the seasonal ARIMA terms falls back to the non-seasonal search (the reference's
+            // documentation: AutoARIMA without seasonal_period is non-seasonal); an EXPLICIT one fails loudly in run_group
+            const bool detected = b->opt.auto_detect_seasonality && b->opt.seasonal_period == 0;
+            return period > 24 ? (detected ? 1 : 25) : (period > 1 ? period : 1);
+        }
         default: return period;
         }
     };
@@ -1110,7 +1118,9 @@ std::string series_error_message(const AnofoxHipBatch *b, size_t s, int code, in
     }
     const char *why = detail == FIT_SHORT ? "not enough observations for this model"
                       : detail == FIT_NONPOSITIVE ? "multiplicative components require strictly positive data"
-                      : detail == FIT_NONFINITE ? "likelihood is not finite" : "unsupported seasonal period (periods above 2048 are not supported)";
+                      : detail == FIT_NONFINITE ? "likelihood is not finite"
+                      : (b->plan.model == M_AutoARIMA ? "unsupported seasonal period (seasonal ARIMA terms are supported up to period 24)"
+                                                      : "unsupported seasonal period (periods above 2048 are not supported)");
     switch (b->plan.model) {
     case M_ETS:
         if (b->plan.ets_spec_id >= 0) {
@@ -1204,6 +1214,7 @@ bool anofox_hip_batch_create(size_t n_series, size_t t_max, const ForecastOption
         if (const char *e = std::getenv("ANOFOX_HIP_GATHER_MIN")) b->gather_min = std::atoi(e);
         if (const char *e = std::getenv("ANOFOX_HIP_FUSED")) b->fused = std::atoi(e) != 0;
         if (!b->use_gather) b->fused = false;
+        if (const char *e = std::getenv("ANOFOX_HIP_ARIMA_ML")) b->arima_ml = std::atoi(e) != 0;
         if (const char *e = std::getenv("ANOFOX_HIP_SCHED")) b->pool_sched = std::string(e) == "pool";
         if (const char *e = std::getenv("ANOFOX_HIP_POOL_WAVES")) b->pool_waves = std::max(1, std::atoi(e));
         if (const char *e = std::getenv("ANOFOX_HIP_PROMOTE")) b->pool_promote = std::max(1, std::atoi(e));
@@ -1686,7 +1697,7 @@ bool anofox_ts_forecast_batch(const double *const *values, const uint64_t *const
         auto used_period = [&](int period) {
             switch (plan.model) {
             case M_Naive: case M_RandomWalkDrift: case M_ARIMA: case M_SES: case M_SESOptimized: case M_Holt: return 1;
-            case M_AutoARIMA: return (period > 1 && period <= 24) ? period : 1;
+            case M_AutoARIMA: return period > 24 ? 1 : (period > 1 ? period : 1);      // detection is on in this branch: see run_batch
             default: return period;
             }
         };

@@ -194,6 +194,7 @@ struct ArimaArgs {
     int32_t *status, *evals, *passes, *models;
     double *yhat;                       // [n_series x h]
     int32_t *model_code;                // 1000000 + p*1e5 + d*1e4 + q*1e3 + P*100 + D*10 + Q
+    int ml_refit;                       // exact-likelihood (Kalman / Chandrasekhar) refit of the selected models; 0 keeps the CSS estimates
 };
 size_t arima_workspace_bytes(int n_series, int t_max);
 int launch_arima(const ArimaArgs &, hipStream_t);   // returns the number of kernel launches; synchronises the stream between sweeps

@@ -226,19 +226,21 @@ double oracle_arima_css(const ArimaOrder *ord, const double *x, const double *w,
 /* Nelder-Mead with absolute initial steps, run-time dimension (same accept / shrink rules as ets.c) */
 /* ---------------------------------------------------------------------------------------------- */
 
-typedef struct { const ArimaOrder *ord; const double *w; int n; double *e; } CssCtx;
+typedef struct { const ArimaOrder *ord; const double *w; int n; double *e; double (*fn)(const double *x, void *ctx); int cap; } CssCtx;
 
-static double css_obj(const double *x, CssCtx *c)
+static double css_obj_fn(const double *x, void *vc)
 {
+    CssCtx *c = (CssCtx *)vc;
     ArimaPoly pl;
     build_poly(c->ord, x, &pl);
     return css_eval(&pl, c->w, c->n, c->e, NULL, NULL);
 }
+#define css_obj(x, ctx) ((ctx)->fn((x), (ctx)))
 
 static void nm_steps(CssCtx *ctx, int n, const double *x0, const double *step, double *xbest, double *fbest, int *iters_out, int *evals_out)
 {
     double sim[ARIMA_MAX_DIM + 1][ARIMA_MAX_DIM], fs[ARIMA_MAX_DIM + 1], xb[ARIMA_MAX_DIM], xr[ARIMA_MAX_DIM], xt[ARIMA_MAX_DIM];
-    const int maxiter = 200 * n, maxfun = 200 * n;
+    const int maxiter = ctx->cap * n, maxfun = ctx->cap * n;
     int evals = 0, iters = 1;
     if (n == 0) { *fbest = css_obj(x0, ctx); *iters_out = 0; *evals_out = 1; return; }
     for (int i = 0; i < n; i++) sim[0][i] = x0[i];
@@ -314,6 +316,198 @@ static void nm_steps(CssCtx *ctx, int n, const double *x0, const double *step, d
 /* model fit, stepwise search, forecast                                                            */
 /* ---------------------------------------------------------------------------------------------- */
 
+
+/* ---------------------------------------------------------------------------------------------- */
+/* exact Gaussian likelihood (the "Kalman / innovations" likelihood of the north star)             */
+/* ---------------------------------------------------------------------------------------------- */
+/*
+ * -2 log L of the stationary ARMA model pl on x_t = w_t - mu, concentrated over the innovation variance: the objective is
+ * 0.5 (log(ssq / n) + sumlog / n) with ssq = sum v_t^2 / F_t, sumlog = sum log F_t over the Kalman filter of the Harvey
+ * state space (state dimension r = max(p + m P, q + m Q + 1)), as R's arima(method = "ML") / StatsForecast's arima_like
+ * define it (the lineage THIRD_PARTY_NOTICES.md:28-48 names).  Two things make it a lane-sized, O(n r) computation:
+ *   * the state covariance is never formed: with the stationary start P_1 = Pi the increments P_{t+1} - P_t have rank
+ *     one, so (F_t, K_t) follow the Chandrasekhar recursions (Morf, Sidhu & Kailath 1974; Melard 1984 for ARMA):
+ *         c = L[0];  F' = F + c^2 M;  K' = K + (T L) M c;  L' = T L - K c / F;  M' = M F / F'
+ *     from L_1 = K_1 = T Pi[:, 0], M_1 = -1 / F_1, F_1 = Pi[0][0]; the column Pi[:, 0] = Cov(state, x_t) follows from the ARMA
+ *     autocovariances (inverse Levinson recursion on the AR polynomial, then the MA filter): O(r^2), no linear system;
+ *   * once max_i L_i^2 |M| <= 1e-12 F the filter is in steady state and only the state vector moves.
+ * sum log F_t is accumulated as a frexp-renormalised running product (no logarithm per step).
+ * Returns +inf when r exceeds ARIMA_ML_MAX_R or a variance is not positive.
+ * csrc/arima.hip (ar_ml_eval) states the identical sequence of IEEE operations.
+ */
+static double ml_eval(const ArimaPoly *pl, const double *w, int n)
+{
+    const int La = pl->La, Lb = pl->Lb;
+    const int r = La > Lb + 1 ? La : Lb + 1;
+    if (r > ARIMA_ML_MAX_R || n < 1) return INFINITY;
+    double A[ARIMA_ML_MAX_R + 1], C[ARIMA_ML_MAX_R + 1], K[ARIMA_ML_MAX_R + 1], L[ARIMA_ML_MAX_R + 1], a[ARIMA_ML_MAX_R + 1];
+    for (int i = 0; i <= r; i++) {
+        A[i] = (i + 1 <= La) ? pl->a[i + 1] : 0.0;
+        C[i] = (i == 0) ? 1.0 : ((i <= Lb) ? pl->b[i] : 0.0);      /* R = (1, c_1, .., c_{r-1}) */
+    }
+    /* Stationary start: F_1 = Pi[0][0] = gamma_0 and K_1 = T Pi[:, 0] with Pi[:, 0] = Cov(state, x_t), from the
+     * autocovariances of the ARMA process -- exact, O(r^2), O(r) memory, valid up to the stationarity boundary:
+     *   (1) u = AR^{-1} e: reflection coefficients of the AR polynomial by the step-down recursion, then the autocovariances
+     *       gu_0.. by the step-up (Levinson) recursion, continued by the AR recursion;
+     *   (2) x = MA u:      gx_k = sum_d bb_|d| gu_|k+d|,  bb_k = sum_i c_i c_{i+k};
+     *   (3) psi weights;   g_i = sum_{l>i} a_l gx_{l-i} + sum_{l>=i} c_l psi_{l-i}. */
+    double kap[ARIMA_ML_MAX_R + 1], al[ARIMA_ML_MAX_R + 1], tmp[ARIMA_ML_MAX_R + 1];
+    double gu[2 * ARIMA_ML_MAX_R + 2], gx[ARIMA_ML_MAX_R + 1], bb[ARIMA_ML_MAX_R + 1], psi[ARIMA_ML_MAX_R + 1];
+    for (int i = 0; i < La; i++) al[i] = A[i];                     /* al[i] = alpha_{i+1} of the current order */
+    double E0 = 1.0;
+    for (int j = La; j >= 1; j--) {
+        const double kj = al[j - 1];
+        kap[j] = kj;
+        const double den = 1.0 - kj * kj;
+        if (!(den > 0.0)) return INFINITY;                          /* not stationary (cannot happen with tanh-PACF factors) */
+        E0 = E0 / den;
+        for (int i = 1; i <= j - 1; i++) tmp[i - 1] = fma(kj, al[j - i - 1], al[i - 1]) / den;
+        for (int i = 1; i <= j - 1; i++) al[i - 1] = tmp[i - 1];
+    }
+    const int G = 2 * r;                                            /* lags 0..G of gu are needed (k + d <= (r - 1) + Lb) */
+    gu[0] = E0;
+    {
+        double Ej = E0;                                             /* E_{j-1} while order j is built */
+        for (int j = 1; j <= La; j++) {
+            double acc = kap[j] * Ej;
+            for (int i = 1; i <= j - 1; i++) acc = fma(al[i - 1], gu[j - i], acc);      /* al = alpha^(j-1) */
+            gu[j] = acc;
+            for (int i = 1; i <= j - 1; i++) tmp[i - 1] = fma(-kap[j], al[j - i - 1], al[i - 1]);
+            for (int i = 1; i <= j - 1; i++) al[i - 1] = tmp[i - 1];
+            al[j - 1] = kap[j];
+            Ej = Ej * (1.0 - kap[j] * kap[j]);
+        }
+    }
+    for (int k = La + 1; k <= G; k++) {
+        double acc = 0.0;
+        for (int l = 1; l <= La; l++) acc = fma(A[l - 1], gu[k - l], acc);
+        gu[k] = acc;
+    }
+    for (int k = 0; k <= Lb; k++) {
+        double acc = 0.0;
+        for (int i = 0; i + k <= Lb; i++) acc = fma(C[i], C[i + k], acc);
+        bb[k] = acc;
+    }
+    for (int k = 0; k < r; k++) {
+        double acc = bb[0] * gu[k];
+        for (int d = 1; d <= Lb; d++) {
+            const int km = k - d < 0 ? d - k : k - d;
+            acc = fma(bb[d], gu[k + d] + gu[km], acc);
+        }
+        gx[k] = acc;
+    }
+    for (int k = 0; k < r; k++) {
+        double acc = C[k];
+        for (int l = 1; l <= k; l++) acc = fma(A[l - 1], psi[k - l], acc);
+        psi[k] = acc;
+    }
+    double F = gx[0];
+    if (!(F > 0.0) || !(F <= DBL_MAX)) return INFINITY;
+    {
+        double gnext = 0.0;                                         /* g_{i+1}, built from i = r - 1 down */
+        for (int i = r - 1; i >= 0; i--) {
+            K[i] = fma(A[i], F, gnext);                             /* K_1[i] = a_{i+1} g_0 + g_{i+1} */
+            double acc = 0.0;                                       /* g_i for the next round (i >= 1) */
+            for (int l = i + 1; l <= r; l++) acc = fma(A[l - 1], gx[l - i], acc);
+            for (int l = i; l <= r - 1; l++) acc = fma(C[l], psi[l - i], acc);
+            gnext = acc;
+        }
+    }
+    for (int i = 0; i < r; i++) { L[i] = K[i]; a[i] = 0.0; }
+    K[r] = 0.0; L[r] = 0.0; a[r] = 0.0;
+    /* the filter: one reciprocal per step while F still moves (transient), none afterwards (steady state: F and K fixed,
+     * only the state vector moves; log F is counted once per remaining step at the end) */
+    double rF = 1.0 / F;
+    double M = -rF;
+    double ssq = 0.0, mant = 1.0;
+    int eacc = 0, steady = 0, t = 0;
+    for (; t < n && !steady; t++) {
+        const double a0 = a[0];
+        const double v = (w[t] - pl->mu) - a0;
+        const double vf = v * rF;
+        ssq = fma(v, vf, ssq);
+        int ex;
+        mant = frexp(mant * F, &ex);
+        eacc += ex;
+        for (int i = 0; i < r; i++) a[i] = fma(K[i], vf, fma(A[i], a0, a[i + 1]));
+        const double c = L[0];
+        const double cm = c * M;
+        const double dF = c * cm;
+        const double Fn = F + dF;
+        if (!(Fn > 0.0)) return INFINITY;
+        const double cf = c * rF;
+        double lmax = 0.0;
+        for (int i = 0; i < r; i++) {
+            const double tl = fma(A[i], c, L[i + 1]);
+            const double kold = K[i];
+            K[i] = fma(tl, cm, kold);
+            const double ln = fma(-kold, cf, tl);
+            L[i] = ln;
+            const double al_ = fabs(ln);
+            if (al_ > lmax) lmax = al_;
+        }
+        const double rFn = 1.0 / Fn;
+        M = (M * F) * rFn;
+        F = Fn;
+        rF = rFn;
+        /* steady state: no entry of L can move F any more (L[0] alone may be zero for whole seasons of a sparse model) */
+        if (!(lmax * lmax * fabs(M) > 1.0e-12 * F)) steady = 1;
+    }
+    const int n_steady = n - t;
+    for (; t < n; t++) {
+        const double a0 = a[0];
+        const double v = (w[t] - pl->mu) - a0;
+        const double vf = v * rF;
+        ssq = fma(v, vf, ssq);
+        for (int i = 0; i < r; i++) a[i] = fma(K[i], vf, fma(A[i], a0, a[i + 1]));
+    }
+    if (!(fabs(ssq) <= DBL_MAX) || !(ssq >= 0.0)) return INFINITY;
+    double s2 = ssq / (double)n;
+    if (s2 < 1.0e-300) s2 = 1.0e-300;
+    double sumlog = det_log(mant) + (double)eacc * 0.693147180559945309417232121458;
+    if (n_steady > 0) sumlog = fma((double)n_steady, det_log(F), sumlog);
+    const double f = 0.5 * (det_log(s2) + sumlog / (double)n);
+    return (f == f) ? f : INFINITY;
+}
+
+double oracle_arima_ml(const ArimaOrder *ord, const double *x, const double *w, int n)
+{
+    ArimaPoly pl;
+    build_poly(ord, x, &pl);
+    return ml_eval(&pl, w, n);
+}
+
+static double ml_obj_fn(const double *x, void *vc)
+{
+    CssCtx *c = (CssCtx *)vc;
+    ArimaPoly pl;
+    build_poly(c->ord, x, &pl);
+    return ml_eval(&pl, c->w, c->n);
+}
+
+/* Exact-likelihood refit of the selected model ("CSS for the search, exact likelihood for the final estimates": what
+ * forecast::auto.arima / StatsForecast do with approximation = TRUE, i.e. for n > 150 -- every BASELINE configuration):
+ * Nelder-Mead from the CSS optimum with steps of 0.1 (0.1 sd of w for the constant), at most ARIMA_ML_NM_CAP x dim
+ * evaluations / iterations (the start is already close).  The CSS estimates stay when the model
+ * has nothing to estimate, its state dimension exceeds ARIMA_ML_MAX_R or the likelihood is not finite at the start.
+ * Returns the number of objective evaluations. */
+static int refit_ml(ArimaFit *fit, const double *w, int n, double wsd)
+{
+    const ArimaOrder *o = &fit->ord;
+    const int dim = o->p + o->q + o->P + o->Q + (o->with_constant ? 1 : 0);
+    if (dim == 0) return 0;
+    CssCtx ctx = { o, w, n, NULL, ml_obj_fn, ARIMA_ML_NM_CAP };
+    const double f0 = ml_obj_fn(fit->x, &ctx);
+    if (!(fabs(f0) <= DBL_MAX)) return 1;
+    double step[ARIMA_MAX_DIM], xb[ARIMA_MAX_DIM], fb;
+    for (int i = 0; i < dim; i++) step[i] = 0.1;
+    if (o->with_constant) step[dim - 1] = wsd > 0.0 ? 0.1 * wsd : 1.0e-4;
+    int iters = 0, evals = 0;
+    nm_steps(&ctx, dim, fit->x, step, xb, &fb, &iters, &evals);
+    if (fabs(fb) <= DBL_MAX && fb <= f0) for (int i = 0; i < dim; i++) fit->x[i] = xb[i];
+    return evals + 1;
+}
+
 static int model_dim(const ArimaOrder *o) { return o->p + o->q + o->P + o->Q + (o->with_constant ? 1 : 0); }
 
 static int fit_model(const ArimaOrder *o, const double *w, int n, double wmean, double wsd, double *e, ArimaFit *fit)
@@ -328,7 +522,7 @@ static int fit_model(const ArimaOrder *o, const double *w, int n, double wmean, 
     double x0[ARIMA_MAX_DIM], step[ARIMA_MAX_DIM];
     for (int i = 0; i < dim; i++) { x0[i] = 0.0; step[i] = 0.25; }
     if (o->with_constant) { x0[dim - 1] = wmean; step[dim - 1] = wsd > 0.0 ? 0.1 * wsd : 1.0e-4; }
-    CssCtx ctx = { o, w, n, e };
+    CssCtx ctx = { o, w, n, e, css_obj_fn, 200 };
     double f;
     nm_steps(&ctx, dim, x0, step, fit->x, &f, &fit->iters, &fit->evals);
     ArimaPoly pl;
@@ -344,6 +538,8 @@ static int fit_model(const ArimaOrder *o, const double *w, int n, double wmean, 
     fit->aicc = dn * det_log(v) + 2.0 * dk + 2.0 * dk * (dk + 1.0) / (dn - dk - 1.0);
     return fabs(fit->aicc) <= DBL_MAX;
 }
+
+int oracle_arima_ml_refit = 1;      /* test hook: 0 keeps the CSS estimates (the search criterion) */
 
 static int order_key(const ArimaOrder *o) { return (((o->p * 6 + o->q) * 3 + o->P) * 3 + o->Q) * 2 + (o->with_constant ? 1 : 0); }
 
@@ -417,8 +613,10 @@ int oracle_auto_arima_detail(const double *y, int n, int period, int h, double *
     }
 #undef TRY
     if (models_tried) *models_tried = n_models;
+    if (!have) { if (total_evals) *total_evals = evals; free(buf); return 0; }
+    /* the selected model's final estimates: exact Gaussian likelihood, started from the CSS optimum */
+    if (oracle_arima_ml_refit) evals += refit_ml(&best, w, len, wsd);
     if (total_evals) *total_evals = evals;
-    if (!have) { free(buf); return 0; }
 
     /* forecast the differenced series, then integrate */
     ArimaPoly pl;

