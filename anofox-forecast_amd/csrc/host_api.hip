@@ -107,6 +107,7 @@ struct AnofoxHipBatch {
     int32_t *d_pos_map = nullptr, *d_pos_cnt = nullptr, *d_notpos = nullptr;
     double *d_ypos = nullptr;
     bool use_pos = false;
+    bool none_pos = false;             // the group has no strictly positive series: multiplicative specs are retired without a launch chain
     // what the inspection pass needs from the last fit: the final-kernel arguments of every spec, in launch order
     std::vector<anofox::FitArgs> insp_args;
     std::vector<anofox::FitLaunchers> insp_fns;
@@ -694,6 +695,18 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
     // own stream, so that all specs advance together and the hardware queues never hold a long spec behind
     // another one.  Early rounds run the sequential driver (least arithmetic while problems outnumber
     // lanes), late rounds the speculative one (shortest critical path for the stragglers).
+    // specs that are inadmissible for EVERY series of the group (a multiplicative component, no strictly positive series: the raw
+    // M5 counts) get their per-series outputs from one small kernel and no launch chain at all -- 19 of the 25 chains of the
+    // intermittent batch used to be compaction / gather / round launches over empty lists, queueing in front of the live ones
+    std::vector<char> dead(order.size(), 0);
+    if (b->none_pos && !b->fixed_params)
+        for (size_t oi = 0; oi < order.size(); oi++)
+            if (args[oi].need_positive) {
+                dead[oi] = 1;
+                const FitArgs &a = args[oi];
+                hipLaunchKernelGGL(retire_nonpositive_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, b->aux[pool ? 0 : stream_of[oi]], (int)n, d_len,
+                                   b->d_notpos, a.status, a.st.done, a.st.passes, a.st.evals, a.st.iters, a.aicc, a.passes, a.evals, a.iters);
+            }
     if (b->fixed_params) {
         // given smoothing parameters: no rounds at all -- admissibility + parameters, then the final pass below
         for (size_t oi = 0; oi < order.size(); oi++) {
@@ -736,6 +749,7 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
             u.skip_constant = skip_constant ? 1 : 0; u.n_specs = 0;
         }
         for (size_t oi = 0; oi < order.size(); oi++) {
+            if (dead[oi]) continue;
             const int id = specs[order[oi]];
             const FitArgs &a = args[oi];
             const int ui = pool_unit_of(id);
@@ -793,6 +807,7 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
     }
     for (int r = 0; r < ((b->fixed_params || pool) ? 0 : n_rounds); r++) {
         for (size_t oi = 0; oi < order.size(); oi++) {
+            if (dead[oi]) continue;
             const int q = (int)(oi % (size_t)n_lanes);
             auto &lane = b->lanes[q];
             hipStream_t sq = b->aux[stream_of[oi]];
@@ -853,14 +868,17 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
         LAUNCHCHECK("ETS fit round");
     }
     if (!pool) {
-        for (size_t oi = 0; oi < order.size(); oi++) fns[oi].final(args[oi], b->aux[stream_of[oi]]);
+        // fixed parameters: the one streamed pass IS the workload -- the fit events bracket exactly that launch, on its stream
+        if (b->fixed_params && order.size() == 1) HIPCHECK(hipEventRecord(b->ev_fit0, b->aux[stream_of[0]]));
+        for (size_t oi = 0; oi < order.size(); oi++) if (!dead[oi]) fns[oi].final(args[oi], b->aux[stream_of[oi]]);
+        if (b->fixed_params && order.size() == 1) HIPCHECK(hipEventRecord(b->ev_fit1, b->aux[stream_of[0]]));
         LAUNCHCHECK("ETS final pass");
     }
     for (int i = 0; i < n_fork; i++) {
         HIPCHECK(hipEventRecord(b->ev_join[i], b->aux[i]));
         HIPCHECK(hipStreamWaitEvent(st, b->ev_join[i], 0));
     }
-    HIPCHECK(hipEventRecord(b->ev_fit1, st));
+    if (!(b->fixed_params && order.size() == 1)) HIPCHECK(hipEventRecord(b->ev_fit1, st));
     b->timed_fit = true;
     b->n_problems += (uint64_t)specs.size() * n;
     b->insp_args = args; b->insp_fns = fns; b->insp_stream = stream_of; b->insp_m = m;
@@ -996,8 +1014,10 @@ void run_group(AnofoxHipBatch *b, int period, const int32_t *d_len, hipStream_t 
             b->use_pos = false;
             b->live_pos = b->live_all = -1;
         }
-        if (b->use_pos) {
+        b->none_pos = b->live_all >= 0 && b->live_pos == 0;       // no strictly positive series at all: the 19 specs with a multiplicative component have nothing to fit
+        if (b->use_pos || b->none_pos)
             hipLaunchKernelGGL(mark_nonpositive_kernel, dim3((unsigned)blocks256), dim3(256), 0, st, (int)n, d_len, b->d_flags, b->d_notpos);
+        if (b->use_pos) {
             launch_compact(nullptr, nullptr, (int)n, b->d_notpos, b->d_pos_map, b->d_pos_cnt, st);
             if (b->use_gather) {
                 if (!b->d_ypos) b->d_ypos = dalloc<double>(std::max<size_t>(b->t_max, 1) * ld);
@@ -1853,6 +1873,39 @@ bool anofox_ts_forecast_batch(const double *const *values, const uint64_t *const
     }
 }
 
+// Route A (the shipped macro) calls anofox_ts_forecast once per group from every DuckDB worker thread
+// (ts_forecast_scalar.cpp:298-523).  Creating a device batch costs ~30 ms of allocator / stream calls that serialise across
+// threads -- far more than a single-series fit -- so idle single-series batches are kept in a small process-wide pool, keyed
+// by the option block and the device: a call takes a matching batch (or creates one with room for 2x its length), re-packs
+// it, runs, fetches and gives it back.  Entries are never destroyed at process exit (the HIP runtime may be gone by then).
+struct PooledBatch { ForecastOptions opt; int device; AnofoxHipBatch *b; };
+static std::mutex g_pool_mu;
+static std::vector<PooledBatch> g_pool;
+constexpr size_t POOL_MAX_IDLE = 32;
+
+static AnofoxHipBatch *pool_take(const ForecastOptions &o, size_t length, int device)
+{
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    for (size_t i = 0; i < g_pool.size(); i++)
+        if (g_pool[i].device == device && g_pool[i].b->t_max >= length && std::memcmp(&g_pool[i].opt, &o, sizeof o) == 0) {
+            AnofoxHipBatch *b = g_pool[i].b;
+            g_pool.erase(g_pool.begin() + (long)i);
+            return b;
+        }
+    return nullptr;
+}
+
+static void pool_give(const ForecastOptions &o, int device, AnofoxHipBatch *b)
+{
+    AnofoxHipBatch *evict = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mu);
+        if (g_pool.size() >= POOL_MAX_IDLE) { evict = g_pool.front().b; g_pool.erase(g_pool.begin()); }
+        g_pool.push_back(PooledBatch{o, device, b});
+    }
+    if (evict) anofox_hip_batch_destroy(evict);
+}
+
 bool anofox_ts_forecast(const double *values, const uint64_t *validity, size_t length, const ForecastOptions *options,
                         ForecastResult *out_result, AnofoxError *out_error)
 {
@@ -1875,12 +1928,47 @@ bool anofox_ts_forecast(const double *values, const uint64_t *validity, size_t l
         }
     }
     AnofoxError se;
+    se.code = SUCCESS;
+    std::memset(se.message, 0, sizeof se.message);
     const double *vals[1] = {values};
     const uint64_t *valid[1] = {validity};
     size_t lens[1] = {length};
     ForecastResult r;
-    bool ok = anofox_ts_forecast_batch(vals, validity ? valid : nullptr, lens, 1, options, nullptr, &r, &se, &e);
-    if (!ok) { if (out_error) *out_error = e; return false; }
+    std::memset(&r, 0, sizeof r);
+    // a pooled single-series batch: the option block is the key (every byte of it: callers memset it first,
+    // ts_forecast_scalar.cpp:440), the capacity covers series up to twice this length
+    ForecastOptions key;                       // normalised copy: padding and the bytes behind a string's NUL do not take part
+    std::memset(&key, 0, sizeof key);
+    auto copy_str = [](char *dst, const char *src, size_t cap) { for (size_t i = 0; i + 1 < cap && src[i]; i++) dst[i] = src[i]; };
+    copy_str(key.model, options->model, sizeof key.model);
+    copy_str(key.ets_model, options->ets_model, sizeof key.ets_model);
+    copy_str(key.seasonal_periods_str, options->seasonal_periods_str, sizeof key.seasonal_periods_str);
+    copy_str(key.model_pool, options->model_pool, sizeof key.model_pool);
+    copy_str(key.laplace_variant, options->laplace_variant, sizeof key.laplace_variant);
+    key.horizon = options->horizon; key.confidence_level = options->confidence_level; key.seasonal_period = options->seasonal_period;
+    key.auto_detect_seasonality = options->auto_detect_seasonality; key.include_fitted = options->include_fitted;
+    key.include_residuals = options->include_residuals; key.window = options->window;
+    key.laplace_seasonal_batch_init = options->laplace_seasonal_batch_init;
+    int device = 0;
+    (void)hipGetDevice(&device);
+    AnofoxHipBatch *b = pool_take(key, length, device);
+    if (!b) {
+        size_t cap = 256;
+        while (cap < 2 * length) cap *= 2;
+        if (!anofox_hip_batch_create(1, cap, options, &b, &e)) {
+            if (out_error) *out_error = e;                     // INVALID_INPUT etc.: the series is long enough, so the option error is its error
+            return false;
+        }
+    }
+    const bool ok = anofox_hip_batch_pack_host(b, vals, validity ? valid : nullptr, lens, &e) && anofox_hip_batch_run(b, nullptr, &e) &&
+                    anofox_hip_batch_fetch(b, &r, &se);
+    if (!ok) {
+        if (e.code == SUCCESS) set_error(&e, INTERNAL_ERROR, "Internal error: device batch failed");
+        anofox_hip_batch_destroy(b);                            // a batch that failed is not reused
+        if (out_error) *out_error = e;
+        return false;
+    }
+    pool_give(key, device, b);
     if (se.code != SUCCESS) { if (out_error) *out_error = se; return false; }
     *out_result = r;
     return true;

@@ -34,13 +34,19 @@ struct RowLoader {
         }
     }
 };
-constexpr int PREP_S = 16;
+// block length of the streamed rows: 16, or two revolutions of a compile-time period MR (ring slots and phases of a block are
+// compile-time constants then)
+template <int MR> constexpr int prep_block() { return MR > 0 ? 2 * MR : 16; }
 
 // GSCR: the decomposition's window ring and per-phase accumulators live in an HBM scratch area of the workgroup instead of
 // LDS (periods above ETS_LDS_PERIOD: (2 (m / 2) + 1 + 3 m) * 512 bytes no longer fit)
-template <bool GSCR>
+// MR > 0: compile-time odd period (7): the window ring and the per-phase accumulators are VGPR arrays with compile-time
+// indices (the block is two revolutions long) -- no LDS traffic at all; same operations in the same order as the generic path.
+template <bool GSCR, int MR = 0>
 __global__ __launch_bounds__(NM_BLOCK) void prep_kernel(const PrepArgs a)
 {
+    constexpr int PREP_S = prep_block<MR>();
+    static_assert(MR == 0 || (MR % 2 == 1 && MR >= 3), "register variant: odd periods");
     extern __shared__ double lds_dyn[];
     double *lds = GSCR ? a.scratch + (size_t)blockIdx.x * (size_t)((2 * (a.m / 2) + 1) + 3 * a.m) * NM_BLOCK : lds_dyn;
     const int lane = threadIdx.x;
@@ -66,7 +72,11 @@ __global__ __launch_bounds__(NM_BLOCK) void prep_kernel(const PrepArgs a)
     double *sumA = lds + (size_t)(want_season ? L : 0) * NM_BLOCK;
     double *sumM = sumA + (size_t)(want_season ? m : 0) * NM_BLOCK;
     double *cnt = sumM + (size_t)(want_season ? m : 0) * NM_BLOCK;
-    if (want_season)
+    constexpr int MRA = MR > 0 ? MR : 1;
+    double rR[MRA], sAR[MRA], sMR[MRA], cNR[MRA];
+#pragma unroll
+    for (int j = 0; j < MRA; j++) { rR[j] = 0.0; sAR[j] = 0.0; sMR[j] = 0.0; cNR[j] = 0.0; }
+    if (MR == 0 && want_season)
         for (int j = 0; j < m; j++) { sumA[j * NM_BLOCK + lane] = 0.0; sumM[j * NM_BLOCK + lane] = 0.0; cnt[j * NM_BLOCK + lane] = 0.0; }
     const double w = want_season ? 1.0 / (double)m : 0.0;
     const double wend = (want_season && m % 2 == 0) ? 0.5 / (double)m : w;
@@ -91,6 +101,27 @@ __global__ __launch_bounds__(NM_BLOCK) void prep_kernel(const PrepArgs a)
             if (!(v > 0.0)) positive = false;
             if (v != y0) constant = false;
             if (v != v) has_nan = true;
+            if constexpr (MR > 0) {
+                if (seasonal) {
+                    constexpr int HALF = MR / 2;
+                    const int sl = jj % MR;                                  // compile-time after unrolling: base is a multiple of MR
+#pragma unroll
+                    for (int q = 0; q < MR; q++) rR[q] = (q == sl) ? v : rR[q];
+                    if (t >= MR - 1) {
+                        double acc = 0.0;
+#pragma unroll
+                        for (int k = 0; k < MR; k++) acc = acc + w * rR[(sl + 1 + k) % MR];     // odd period: every weight is 1 / m
+                        const double yc = rR[(sl + 1 + HALF) % MR];
+                        const int phc = ((jj - HALF) % MR + MR) % MR;
+#pragma unroll
+                        for (int q = 0; q < MR; q++) {
+                            sAR[q] = (q == phc) ? sAR[q] + (yc - acc) : sAR[q];
+                            sMR[q] = (q == phc) ? sMR[q] + (yc / acc) : sMR[q];
+                            cNR[q] = (q == phc) ? cNR[q] + 1.0 : cNR[q];
+                        }
+                    }
+                }
+            } else
             if (seasonal) {
                 ring[slot * NM_BLOCK + lane] = v;
                 if (t >= L - 1) {
@@ -124,6 +155,34 @@ __global__ __launch_bounds__(NM_BLOCK) void prep_kernel(const PrepArgs a)
     a.flags[s] = (positive ? SF_POSITIVE : 0u) | (constant ? SF_CONSTANT : 0u) | (has_nan ? SF_HAS_NAN : 0u);
 
     // seasonal figures (normalised), kept in LDS for pass B and written to HBM for the fit kernels
+    if constexpr (MR > 0) {
+        if (seasonal) {
+#pragma unroll
+            for (int type = 1; type <= 2; type++) {
+                if (type == 2 && !positive) break;
+                double tot = 0.0;
+#pragma unroll
+                for (int j = 0; j < MR; j++) {
+                    const double fj = (type == 1 ? sAR[j] : sMR[j]) / cNR[j];
+                    if (type == 1) sAR[j] = fj; else sMR[j] = fj;
+                    tot = tot + fj;
+                }
+                const double fmean = tot / (double)m;
+                double *fig = (type == 1 ? a.fig_add : a.fig_mul) + s;
+#pragma unroll
+                for (int j = 0; j < MR; j++) {
+                    double fj = type == 1 ? sAR[j] : sMR[j];
+                    if (type == 1) fj = fj - fmean;
+                    else {
+                        fj = fj / fmean;
+                        if (!(fj >= 1.0e-2)) fj = 1.0e-2;
+                    }
+                    if (type == 1) sAR[j] = fj; else sMR[j] = fj;
+                    fig[(size_t)j * ld] = fj;
+                }
+            }
+        }
+    } else
     if (seasonal) {
         for (int type = 1; type <= 2; type++) {
             if (type == 2 && !positive) break;
@@ -170,8 +229,13 @@ __global__ __launch_bounds__(NM_BLOCK) void prep_kernel(const PrepArgs a)
         if (states) {
             double vs[3];
             vs[0] = v;
-            vs[1] = useA ? v - sumA[j * NM_BLOCK + lane] : 0.0;
-            vs[2] = useM ? v / sumM[j * NM_BLOCK + lane] : 0.0;
+            if constexpr (MR > 0) {
+                vs[1] = useA ? v - sAR[jj % MR] : 0.0;
+                vs[2] = useM ? v / sMR[jj % MR] : 0.0;
+            } else {
+                vs[1] = useA ? v - sumA[j * NM_BLOCK + lane] : 0.0;
+                vs[2] = useM ? v / sumM[j * NM_BLOCK + lane] : 0.0;
+            }
 #pragma unroll
             for (int st = 0; st < 3; st++) {
                 sy[st] = sy[st] + vs[st];
@@ -228,12 +292,16 @@ void launch_prep(const PrepArgs &a, hipStream_t stream)
     size_t lds_bytes = 0;
     if (a.l0 != nullptr && a.m > ETS_LDS_PERIOD && a.m <= ETS_MAX_PERIOD) {
         if (!a.scratch) throw std::runtime_error("prep: a period above the LDS limit needs the scratch area");
-        hipLaunchKernelGGL(prep_kernel<true>, dim3(grid), dim3(NM_BLOCK), 0, stream, a);
+        hipLaunchKernelGGL((prep_kernel<true, 0>), dim3(grid), dim3(NM_BLOCK), 0, stream, a);
+        return;
+    }
+    if (a.l0 != nullptr && a.m == 7) {                    // the M5 / weekly period: ring and accumulators in registers
+        hipLaunchKernelGGL((prep_kernel<false, 7>), dim3(grid), dim3(NM_BLOCK), 0, stream, a);
         return;
     }
     if (a.l0 != nullptr && a.m >= 2 && a.m <= ETS_LDS_PERIOD) lds_bytes = sizeof(double) * (size_t)((2 * (a.m / 2) + 1) + 3 * a.m) * NM_BLOCK;
-    if (lds_bytes > 48 * 1024) anofox_check_attr(hipFuncSetAttribute((const void *)prep_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    hipLaunchKernelGGL(prep_kernel<false>, dim3(grid), dim3(NM_BLOCK), lds_bytes, stream, a);
+    if (lds_bytes > 48 * 1024) anofox_check_attr(hipFuncSetAttribute((const void *)prep_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    hipLaunchKernelGGL((prep_kernel<false, 0>), dim3(grid), dim3(NM_BLOCK), lds_bytes, stream, a);
 }
 
 } // namespace anofox

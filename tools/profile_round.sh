@@ -1,20 +1,32 @@
 #!/bin/bash
-# Collect the round's rocprofv3 evidence on the GPU box.  Output: gpurun_out/prof_round/ (copy the summaries to profiles/).
-#   1. kernel trace of the default bench line (AutoETS, 30-spec positive batch), of the intermittent batch and of AutoARIMA
-#   2. PMC passes (FETCH_SIZE, WRITE_SIZE -- separate runs, kernel trace only) for the default line
+# Collect the round's rocprofv3 evidence on the GPU box.  Output: gpurun_out/prof_round/ (copy the summaries to profiles/ with
+# the round prefix: tools/summarize_profiles.py prints what to keep).
+#   1. kernel traces (--kernel-trace --stats) of the default bench line (AutoETS, 30-spec positive batch), the intermittent batch,
+#      the fixed-parameter config (BASELINE config 2) and AutoARIMA
+#   2. PMC passes for the default line, one counter group per run, kernel trace only (gpurun refuses --pmc with other traces):
+#      FETCH_SIZE, WRITE_SIZE (HBM traffic, corrected as MI355X_MICROARCH.md prescribes) and the SQ issue counters
 # Usage (from the repo root):  bash tools/profile_round.sh
 OUT=/root/repo/gpurun_out/prof_round
-mkdir -p $OUT
+rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 run() { # name, bench args...
   local name=$1; shift
-  rocprofv3 --kernel-trace -d $OUT/$name -o t -- python3 /root/repo/bench.py "$@" > $OUT/$name.log 2>&1
+  rocprofv3 --kernel-trace --stats -d $OUT/$name -o t -- python3 /root/repo/bench.py "$@" > $OUT/$name.log 2>&1
 }
-run trace_autoets_positive --steps 2 --warmup 1 --cpu-sample 0
-run trace_autoets_m5 --workload autoets_m5 --steps 3 --warmup 1 --cpu-sample 0
-run trace_autoarima_m5 --workload autoarima_m5 --steps 1 --warmup 0 --cpu-sample 0
+run trace_autoets_positive --steps 2 --warmup 1 --cpu-sample 0 --e2e-steps 0
+run trace_autoets_m5 --workload autoets_m5 --steps 3 --warmup 1 --cpu-sample 0 --e2e-steps 0
+run trace_ets_aaa_fixed --workload ets_aaa_fixed_m5 --steps 20 --warmup 2 --cpu-sample 0
+run trace_autoarima_m5 --workload autoarima_m5 --steps 1 --warmup 0 --cpu-sample 0 --e2e-steps 0
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace -d $OUT/pmc_$c -o p -- python3 /root/repo/bench.py --steps 1 --warmup 0 --cpu-sample 0 > $OUT/pmc_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace -d $OUT/pmc_$c -o p -- python3 /root/repo/bench.py --steps 1 --warmup 0 --cpu-sample 0 --e2e-steps 0 > $OUT/pmc_$c.log 2>&1
+  rocprofv3 --pmc $c --kernel-trace -d $OUT/pmcfixed_$c -o p -- python3 /root/repo/bench.py --workload ets_aaa_fixed_m5 --steps 4 --warmup 0 --cpu-sample 0 > $OUT/pmcfixed_$c.log 2>&1
 done
+rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_INSTS_SALU SQ_INSTS_LDS --kernel-trace -d $OUT/pmc_SQ_INSTS -o p -- python3 /root/repo/bench.py --steps 1 --warmup 0 --cpu-sample 0 --e2e-steps 0 > $OUT/pmc_SQ_INSTS.log 2>&1
+rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY --kernel-trace -d $OUT/pmc_SQ_CYCLES -o p -- python3 /root/repo/bench.py --steps 1 --warmup 0 --cpu-sample 0 --e2e-steps 0 > $OUT/pmc_SQ_CYCLES.log 2>&1
 python3 /root/repo/tools/summarize_profiles.py $OUT
+# only the summaries travel back (gpurun merges at most 64 MiB): drop the rocpd databases and per-process trace directories
+find $OUT -name "*.db" -delete
+find $OUT -mindepth 1 -type d -empty -delete
+rm -rf $OUT/../r2_*_trace $OUT/../*_trace 2>/dev/null
+du -sh $OUT
 ls $OUT

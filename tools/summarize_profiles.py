@@ -101,7 +101,46 @@ if traffic:
         "hbm_bytes_corrected": {k: int(v) for k, v in corrected.items()},
         "ets_round_kernel_traffic_bytes_per_step": int(corrected.get("ets_round_kernel", 0)),
     }
+    # ---- SQ issue counters (separate passes): wave-level VALU instructions per step and how busy the SIMDs were ----
+    sq = {}
+    for grp in ("pmc_SQ_INSTS", "pmc_SQ_CYCLES"):
+        db = glob.glob(os.path.join(out, grp, "*.db"))
+        if not db:
+            continue
+        c = sqlite3.connect(db[0])
+        for cname, name, val in c.execute("select counter_name, kernel_name, sum(value) from counters_collection group by 1, 2"):
+            sq.setdefault(cname, {})
+            f = family(name)
+            sq[cname][f] = sq[cname].get(f, 0) + val
+    if sq:
+        fit = ("ets_round_kernel", "ets_final_kernel")
+        js["sq_counters_by_kernel"] = {k: {f: int(v) for f, v in sorted(d.items(), key=lambda kv: -kv[1])[:6]} for k, d in sq.items()}
+        if "SQ_INSTS_VALU" in sq:
+            js["valu_insts_per_step"] = int(sum(sq["SQ_INSTS_VALU"].get(f, 0) for f in fit))
+            js["valu_note"] = ("SQ_INSTS_VALU of the fit kernels (wave-level instructions, one bench step); divided by the step's kernel time and by the "
+                               "chip's fp64 issue rate (1,024 SIMDs x 2.4 GHz / 4 cycles per wave64 fp64 instruction) it is roofline.valu.frac")
     json.dump(js, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
+    # the fixed-parameter config (one streamed pass per series): traffic of ets_final_kernel and prep_kernel per step
+    fx = {}
+    for cname in ("FETCH_SIZE", "WRITE_SIZE"):
+        db = glob.glob(os.path.join(out, "pmcfixed_" + cname, "*.db"))
+        if not db:
+            continue
+        c = sqlite3.connect(db[0])
+        for name, val, cnt in c.execute("select kernel_name, sum(value), count(*) from counters_collection where counter_name = ? group by 1", (cname,)):
+            f = family(name)
+            fx.setdefault(f, {})[cname] = val * 1024.0
+            fx[f]["launches"] = cnt
+    if fx:
+        rep = {}
+        for f in ("ets_final_kernel", "prep_kernel"):
+            if f in fx:
+                n = max(fx[f].get("launches", 1), 1)
+                rep[f] = {"launches": n, "hbm_bytes_per_launch_corrected": int((2.0 * fx[f].get("FETCH_SIZE", 0.0) + fx[f].get("WRITE_SIZE", 0.0)) / n),
+                          "FETCH_SIZE_raw_per_launch": int(fx[f].get("FETCH_SIZE", 0.0) / n), "WRITE_SIZE_raw_per_launch": int(fx[f].get("WRITE_SIZE", 0.0) / n)}
+        json.dump({"workload": "ets_aaa_fixed_m5", "algorithmic_bytes_per_launch_ets_final_kernel": 30490 * (8 * 1913 + 8 * 28),
+                   "correction": "fetch x 2 (gfx950 half-reporting, calibrated as in pmc_traffic.json)", "kernels": rep},
+                  open(os.path.join(out, "pmc_traffic_fixed.json"), "w"), indent=1)
     for cname, agg in traffic.items():
         with open(os.path.join(out, f"pmc_{cname}_by_kernel.csv"), "w") as fh:
             fh.write("kernel_family,raw_bytes\n")
