@@ -332,6 +332,8 @@ __device__ __forceinline__ double ar_css_pass(const double *wrow, int len, int w
 // ------------------------------------------------------------------------------------------------
 // workspace (one allocation per batch, carved by ArWs::carve; see arima_workspace_bytes)
 // ------------------------------------------------------------------------------------------------
+// waves the refit kernel is launched with at most (its simplex scratch is sized for them)
+__host__ __device__ inline int ar_ml_sim_waves(int n) { const int g = (2 * n + NM_BLOCK - 1) / NM_BLOCK + 8; return g < 2048 ? g : 2048; }
 struct ArWs {
     double *W;            // [n x tw] differenced series, series-major, 2 S spare elements per row
     double *cache_aicc;   // [n x AR_KEYS] AICc of every fitted candidate (+inf: fit failed)
@@ -342,7 +344,8 @@ struct ArWs {
     double *best_aicc;    // [n]
     int32_t *state;       // [n x 8] stage, idx, base key, best key, have, improved, n_models, fin
     int32_t *q_series, *q_key;   // [7 x cap] problem queues by dimension
-    int32_t *counts;      // [16] 0..6 queue lengths, 8 fetch cursor
+    int32_t *counts;      // [32] 0..6 queue lengths, 8 fetch cursor, 9..13 refit class cursors, 16..20 refit class sizes
+    double *ml_sim;       // [waves x 42 x 64] simplex scratch of the exact-likelihood refit
     size_t tw, cap;
     static size_t align(size_t x) { return (x + 255) & ~(size_t)255; }
     size_t carve(char *p, int n, int t_max)
@@ -361,7 +364,8 @@ struct ArWs {
         state = (int32_t *)take(sizeof(int32_t) * (size_t)n * 8);
         q_series = (int32_t *)take(sizeof(int32_t) * 7 * cap);
         q_key = (int32_t *)take(sizeof(int32_t) * 7 * cap);
-        counts = (int32_t *)take(sizeof(int32_t) * 16);
+        counts = (int32_t *)take(sizeof(int32_t) * 32);
+        ml_sim = (double *)take(sizeof(double) * (size_t)ar_ml_sim_waves(n) * 64 * NM_BLOCK);   // AR_ML_CTX <= 64 slots per lane
         return off;
     }
 };
@@ -647,7 +651,8 @@ __global__ __launch_bounds__(256) void arima_skip_kernel(const ArimaArgs a)
 // ------------------------------------------------------------------------------------------------
 enum { PH_NEXT = 0, PH_INIT, PH_ITER, PH_E, PH_OC, PH_IC, PH_SHRINK, PH_FINAL };
 
-__device__ __forceinline__ double ar_trial(const ArLds &L, int D, int which, int i)
+template <class LT>
+__device__ __forceinline__ double ar_trial(const LT &L, int D, int which, int i)
 {
     double s = L.sim(0, i);
     for (int k = 1; k < D; k++) s = s + L.sim(k, i);
@@ -658,7 +663,8 @@ __device__ __forceinline__ double ar_trial(const ArLds &L, int D, int which, int
     return which == 3 ? a * xb + b * xw : a * xb - b * xw;
 }
 
-__device__ __forceinline__ void ar_accept(const ArLds &L, ArFs &F, int D, int which, double fnew)
+template <class LT, class FT>
+__device__ __forceinline__ void ar_accept(const LT &L, FT &F, int D, int which, double fnew)
 {
     double xn[AR_MAXDIM];
     for (int i = 0; i < D; i++) xn[i] = ar_trial(L, D, which, i);
@@ -672,7 +678,8 @@ __device__ __forceinline__ void ar_accept(const ArLds &L, ArFs &F, int D, int wh
     for (int i = 0; i < D; i++) L.sim(j, i) = xn[i];
 }
 
-__device__ __forceinline__ void ar_sort(const ArLds &L, ArFs &F, int D)
+template <class LT, class FT>
+__device__ __forceinline__ void ar_sort(const LT &L, FT &F, int D)
 {
     for (int k = 1; k <= D; k++) {
         const double fk = F.get(k);
@@ -1030,170 +1037,275 @@ __global__ __launch_bounds__(NM_BLOCK) void arima_forecast_kernel(const ArimaArg
 // as the oracle, so the estimates are bit-identical.
 constexpr int AR_ML_MAX_R = 32;
 constexpr int AR_ML_NM_CAP = 100;       // the refit starts at the CSS optimum: 100 x dim evaluations / iterations at most (oracle: ARIMA_ML_NM_CAP)
-__host__ __device__ inline int ar_ml_rm(int m) { const int l1 = AR_MAXP + AR_MAXSP * (m > 1 ? m : 0) + 1; return l1 <= 8 ? 8 : (l1 <= 20 ? 20 : AR_ML_MAX_R); }
-static size_t ar_ml_lds_bytes(int m)
-{
-    const size_t l1 = (size_t)(AR_MAXP + AR_MAXSP * m + 1), rm = (size_t)ar_ml_rm(m);
-    return sizeof(double) * ((size_t)(AR_MAXDIM + 1) * AR_MAXDIM + 2 * l1 + 5 * rm + 5) * NM_BLOCK;
-}
+// LDS of the refit kernel per wave (lane-minor), in doubles per lane: rm + (l1 - 1) + (2 rm - 1), rm = the state-dimension class
+// of the launch's period, l1 = AR_MAXP + AR_MAXSP m + 1 -- 78 at m = 7 (39 KB per wave: FOUR waves per CU, one per SIMD; the
+// first version kept the simplex, both polynomials with their unused slot 0 and five scratch vectors there: 187, ONE wave
+// per CU).  The Nelder-Mead simplex lives in a global scratch (a few dozen L2 hits per evaluation against a 1,900-step pass).
+__host__ __device__ inline int ar_ml_l1(int m) { return AR_MAXP + AR_MAXSP * m + 1; }
+__host__ __device__ inline int ar_ml_rm(int m) { const int l1 = ar_ml_l1(m); return l1 <= 8 ? 8 : (l1 <= 12 ? 12 : (l1 <= 16 ? 16 : (l1 <= 20 ? 20 : AR_ML_MAX_R))); }
+__host__ __device__ inline size_t ar_ml_lds_doubles(int m) { return (size_t)(3 * ar_ml_rm(m) + ar_ml_l1(m) - 2); }
 
-// 0.5 (log(ssq / n) + sumlog / n) of the model whose expanded polynomials are in PL; +inf when not computable
-// LDS scratch of the stationary start (lane-minor, (5 RM + 5) x 64 doubles): two phases share it
-struct ArMlInit {
-    double *base; int rm;
-    // phase 1: kap [rm + 1], al [rm + 1], tmp [rm + 1]; both phases: gu [2 rm + 2]; phase 2: psi (on kap), bb (on al), gx (on tmp)
-    __device__ double &kap(int i) const { return base[(size_t)i * NM_BLOCK + threadIdx.x]; }
-    __device__ double &al(int i) const { return base[(size_t)(rm + 1 + i) * NM_BLOCK + threadIdx.x]; }
-    __device__ double &tmp(int i) const { return base[(size_t)(2 * rm + 2 + i) * NM_BLOCK + threadIdx.x]; }
-    __device__ double &gu(int i) const { return base[(size_t)(3 * rm + 3 + i) * NM_BLOCK + threadIdx.x]; }
-    __device__ double &psi(int i) const { return kap(i); }
-    __device__ double &bb(int i) const { return al(i); }
-    __device__ double &gx(int i) const { return tmp(i); }
+// s1 [rm]: the AR coefficients a_1.. (slot i = a_{i+1}), then the working polynomial of the Levinson recursions in place (its
+//          slot j - 1 keeps the reflection coefficient of order j), then gx;  cb [l1 - 1]: the MA coefficients b_1..;
+// gu [2 rm - 1]: autocovariances of the AR part, then psi.
+struct ArMlLds {
+    double *base; int rm, l1;
+    __device__ double &s1(int i) const { return base[(size_t)i * NM_BLOCK + threadIdx.x]; }
+    __device__ double &cb(int i) const { return base[(size_t)(rm + i - 1) * NM_BLOCK + threadIdx.x]; }      // i >= 1
+    __device__ double &gu(int i) const { return base[(size_t)(rm + l1 - 1 + i) * NM_BLOCK + threadIdx.x]; }
+    __device__ double &al(int i) const { return s1(i); }
+    __device__ double &gx(int i) const { return s1(i); }
+    __device__ double &psi(int i) const { return gu(i); }
 };
 
-template <int RM>
-__device__ double ar_ml_eval(const ArPolyLds &PL, int La, int Lb, double mu, const double *w, int n, const ArMlInit &Q)
+// the expanded lag polynomials of ar_build_poly (same operations), without the unused slots 0
+__device__ __forceinline__ void ar_build_poly_ml(const ArOrd &o, int m, const double *x, const ArMlLds &Q, int &La, int &Lb, double &mu)
 {
-    const int r = La > Lb + 1 ? La : Lb + 1;
-    if (r > AR_ML_MAX_R || r > RM || n < 1) return __builtin_huge_val();
-    auto Ac = [&](int i) { return (i + 1 <= La) ? PL.a(i + 1) : 0.0; };
-    auto Cc = [&](int i) { return (i == 0) ? 1.0 : ((i <= Lb) ? PL.b(i) : 0.0); };
+    double phi[AR_MAXP], th[AR_MAXP], Phi[AR_MAXSP], Th[AR_MAXSP];
+    int k = 0;
+    ar_pacf(x + k, o.p, phi); k += o.p;
+    ar_pacf(x + k, o.q, th); k += o.q;
+    ar_pacf(x + k, o.P, Phi); k += o.P;
+    ar_pacf(x + k, o.Q, Th); k += o.Q;
+    mu = o.c ? x[k] : 0.0;
+    La = o.p + m * o.P;
+    Lb = o.q + m * o.Q;
+    for (int i = 1; i <= La; i++) Q.s1(i - 1) = 0.0;
+    for (int i = 1; i <= o.p; i++) Q.s1(i - 1) = phi[i - 1];
+    for (int I = 1; I <= o.P; I++) {
+        Q.s1(m * I - 1) = Q.s1(m * I - 1) + Phi[I - 1];
+        for (int i = 1; i <= o.p; i++) Q.s1(m * I + i - 1) = Q.s1(m * I + i - 1) - phi[i - 1] * Phi[I - 1];
+    }
+    for (int i = 1; i <= Lb; i++) Q.cb(i) = 0.0;
+    for (int i = 1; i <= o.q; i++) Q.cb(i) = th[i - 1];
+    for (int I = 1; I <= o.Q; I++) {
+        Q.cb(m * I) = Q.cb(m * I) + Th[I - 1];
+        for (int i = 1; i <= o.q; i++) Q.cb(m * I + i) = Q.cb(m * I + i) - th[i - 1] * Th[I - 1];
+    }
+    for (int i = 1; i <= Lb; i++) Q.cb(i) = -Q.cb(i);
+}
+
+// Two adjacent lanes (2k, 2k + 1) work on ONE series in the refit: the even lane holds entries [0, RM/2) of the filter's
+// r-vectors, the odd lane entries [RM/2, RM).  Values cross the pair through DPP quad permutes (full-rate VALU, no LDS).
+__device__ __forceinline__ int ar_pair_lo(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xA0, 0xF, 0xF, false); }   // quad_perm [0,0,2,2]
+__device__ __forceinline__ int ar_pair_hi(int v) { return __builtin_amdgcn_update_dpp(0, v, 0xF5, 0xF, 0xF, false); }   // quad_perm [1,1,3,3]
+__device__ __forceinline__ double ar_pair_lo(double v) { return __hiloint2double(ar_pair_lo(__double2hiint(v)), ar_pair_lo(__double2loint(v))); }
+__device__ __forceinline__ double ar_pair_hi(double v) { return __hiloint2double(ar_pair_hi(__double2hiint(v)), ar_pair_hi(__double2loint(v))); }
+
+// 0.5 (log(ssq / n) + sumlog / n) of the model whose expanded polynomials ar_build_poly_ml left in Q; +inf when not computable.
+// Called by the WHOLE wave (lanes without a problem pass act = false): the filter loop runs to the longest row of the wave
+// with wave-uniform control flow only -- a lane that has reached its steady state, the end of its row or a non-computable
+// point keeps stepping with its updates switched off by selects (exact no-ops), so a step is straight-line code without
+// per-lane branches (the first version branched per lane and step: 390 instructions per step, 88 of them register copies
+// at the joins, 2,100 cycles; this one ~170).
+template <int RM>
+__device__ double ar_ml_eval(bool act, int La, int Lb, double mu, const double *w, int n, const ArMlLds &Q)
+{
+    int r = La > Lb + 1 ? La : Lb + 1;
+    bool bad = false;
+    if (!act || r > AR_ML_MAX_R || r > RM || n < 1) { bad = true; La = 0; Lb = 0; r = 1; n = 0; mu = 0.0; }
+    auto Cc = [&](int i) { return (i == 0) ? 1.0 : ((i <= Lb) ? Q.cb(i) : 0.0); };
+    // the AR coefficients go to VGPRs first (entries at and above the lane's own La are exact zeros): their LDS slots become
+    // the working polynomial
+    double A[RM];
+#pragma unroll
+    for (int i = 0; i < RM; i++) A[i] = (i < La) ? Q.s1(i) : 0.0;
+    auto Ad = [&](int i) {                                   // run-time index: select chain
+        double v = 0.0;
+#pragma unroll
+        for (int q = 0; q < RM; q++) v = (q == i) ? A[q] : v;
+        return v;
+    };
     // ---- stationary start (oracle/arima.c ml_eval): autocovariances by the inverse Levinson recursion, O(r^2) ----
-    for (int i = 0; i < La; i++) Q.al(i) = Ac(i);
+    // step-down, in place: new al(p) and al(j - 2 - p) need each other's old values only
     double E0 = 1.0;
     for (int j = La; j >= 1; j--) {
-        const double kj = Q.al(j - 1);
-        Q.kap(j) = kj;
+        const double kj = Q.al(j - 1);                       // stays in slot j - 1: the reflection coefficient of order j
         const double den = 1.0 - kj * kj;
-        if (!(den > 0.0)) return __builtin_huge_val();
+        if (!(den > 0.0)) { bad = true; break; }             // not stationary: the point is rejected (the rest runs on garbage)
         E0 = E0 / den;
-        for (int i = 1; i <= j - 1; i++) Q.tmp(i - 1) = fma(kj, Q.al(j - i - 1), Q.al(i - 1)) / den;
-        for (int i = 1; i <= j - 1; i++) Q.al(i - 1) = Q.tmp(i - 1);
+        for (int p = 0; 2 * p <= j - 2; p++) {
+            const int q = j - 2 - p;
+            const double op = Q.al(p), oq = Q.al(q);
+            Q.al(p) = fma(kj, oq, op) / den;
+            if (q != p) Q.al(q) = fma(kj, op, oq) / den;
+        }
     }
-    const int G = 2 * r;
     Q.gu(0) = E0;
     {
         double Ej = E0;
         for (int j = 1; j <= La; j++) {
-            const double kj = Q.kap(j);
+            const double kj = Q.al(j - 1);
             double acc = kj * Ej;
             for (int i = 1; i <= j - 1; i++) acc = fma(Q.al(i - 1), Q.gu(j - i), acc);
             Q.gu(j) = acc;
-            for (int i = 1; i <= j - 1; i++) Q.tmp(i - 1) = fma(-kj, Q.al(j - i - 1), Q.al(i - 1));
-            for (int i = 1; i <= j - 1; i++) Q.al(i - 1) = Q.tmp(i - 1);
-            Q.al(j - 1) = kj;
+            for (int p = 0; 2 * p <= j - 2; p++) {
+                const int q = j - 2 - p;
+                const double op = Q.al(p), oq = Q.al(q);
+                Q.al(p) = fma(-kj, oq, op);
+                if (q != p) Q.al(q) = fma(-kj, op, oq);
+            }
             Ej = Ej * (1.0 - kj * kj);
         }
     }
+    const int G = r - 1 + Lb;                                // the largest lag gx needs
     for (int k = La + 1; k <= G; k++) {
         double acc = 0.0;
-        for (int l = 1; l <= La; l++) acc = fma(Ac(l - 1), Q.gu(k - l), acc);
+#pragma unroll
+        for (int l = 1; l <= RM; l++)
+            if (l <= La) acc = fma(A[l - 1], Q.gu(k - l), acc);
         Q.gu(k) = acc;
     }
-    // phase 2: kap / al / tmp are free now
-    for (int k = 0; k <= Lb; k++) {
+    // MA autocovariances in VGPRs (compile-time lag, run-time sum), then gx over the working polynomial's slots
+    double BB[RM];
+#pragma unroll
+    for (int k = 0; k < RM; k++) {
         double acc = 0.0;
         for (int i = 0; i + k <= Lb; i++) acc = fma(Cc(i), Cc(i + k), acc);
-        Q.bb(k) = acc;
+        BB[k] = acc;
     }
     for (int k = 0; k < r; k++) {
-        double acc = Q.bb(0) * Q.gu(k);
-        for (int d = 1; d <= Lb; d++) {
-            const int km = k - d < 0 ? d - k : k - d;
-            acc = fma(Q.bb(d), Q.gu(k + d) + Q.gu(km), acc);
-        }
+        double acc = BB[0] * Q.gu(k);
+#pragma unroll
+        for (int d = 1; d < RM; d++)
+            if (d <= Lb) {
+                const int km = k - d < 0 ? d - k : k - d;
+                acc = fma(BB[d], Q.gu(k + d) + Q.gu(km), acc);
+            }
         Q.gx(k) = acc;
     }
-    for (int k = 0; k < r; k++) {
+    double F = Q.gx(0);
+    for (int k = 0; k < r; k++) {                            // gu is free now: psi takes its slots
         double acc = Cc(k);
-        for (int l = 1; l <= k; l++) acc = fma(Ac(l - 1), Q.psi(k - l), acc);
+#pragma unroll
+        for (int l = 1; l < RM; l++)
+            if (l <= k) acc = fma(A[l - 1], Q.psi(k - l), acc);
         Q.psi(k) = acc;
     }
-    double F = Q.gx(0);
-    if (!(F > 0.0) || !(F <= 1.7976931348623157e308)) return __builtin_huge_val();
-    // the four r-vectors of the filter live in VGPRs from here on (entries at and above the lane's own r are exact zeros)
-    double A[RM], K[RM], L[RM + 1], st[RM + 1];
-#pragma unroll
-    for (int i = 0; i < RM; i++) { A[i] = Ac(i); K[i] = 0.0; st[i] = 0.0; }
+    if (!(F > 0.0) || !(F <= 1.7976931348623157e308)) { bad = true; F = 1.0; }
+    // K_1 of the whole state, then this lane's half of the four r-vectors (the pair's other lane runs the same code on the
+    // same values up to here; entries at and above the lane's own r are exact zeros)
+    constexpr int H = RM / 2;
+    const bool hi = (threadIdx.x & 1) != 0;
+    double Ah[H], Kh[H], Lh[H + 1], sth[H + 1];
     {
+        double K[RM];
+#pragma unroll
+        for (int i = 0; i < RM; i++) K[i] = 0.0;
         double gnext = 0.0;
         for (int i = r - 1; i >= 0; i--) {
-            const double kv = fma(Ac(i), F, gnext);
+            const double kv = fma(Ad(i), F, gnext);
 #pragma unroll
             for (int q = 0; q < RM; q++) K[q] = (q == i) ? kv : K[q];
+            if (i == 0) break;                               // nothing follows row 0
             double acc = 0.0;
-            for (int l = i + 1; l <= r; l++) acc = fma(Ac(l - 1), Q.gx(l - i), acc);
+#pragma unroll
+            for (int l = 1; l <= RM; l++)
+                if (l >= i + 1 && l <= r) acc = fma(A[l - 1], Q.gx(l - i), acc);
             for (int l = i; l <= r - 1; l++) acc = fma(Cc(l), Q.psi(l - i), acc);
             gnext = acc;
         }
-    }
 #pragma unroll
-    for (int i = 0; i < RM; i++) L[i] = K[i];
-    L[RM] = 0.0; st[RM] = 0.0;
-    // the filter: one reciprocal per step while F still moves, none in the steady state.  The lane's row of W comes in blocks
-    // of 8 values (128-bit loads, the next block requested before the current one is consumed; rows are 16-byte aligned and
-    // padded, so reading past the series' end is harmless).
+        for (int i = 0; i < H; i++) {
+            Ah[i] = hi ? A[H + i] : A[i];
+            Kh[i] = hi ? K[H + i] : K[i];
+            Lh[i] = Kh[i];
+            sth[i] = 0.0;
+        }
+        Lh[H] = 0.0; sth[H] = 0.0;
+    }
+    if (bad) n = 0;
+    // the filter: one division per step while F still moves anywhere in the wave, none once every lane is in its steady state.
+    // The pair's row of W comes in blocks of 4 values (128-bit loads, the next block requested before the current one is
+    // consumed; a row has tw >= t_max + spare elements, so reading on to the longest row of the wave stays inside the lane's own).
     double rF = 1.0 / F;
     double M = -rF;
     double ssq = 0.0, mant = 1.0;
     int eacc = 0, t = 0;
     bool steady = false;
     typedef double d2_t __attribute__((ext_vector_type(2)));
-    constexpr int WB = 8;
+    constexpr int WB = 4;
     double wc[WB], wn[WB];
     auto load_w = [&](double (&buf)[WB], int t0) __attribute__((always_inline)) {
         const d2_t *p = reinterpret_cast<const d2_t *>(w + t0);
 #pragma unroll
         for (int j = 0; j < WB / 2; j++) { const d2_t v2 = p[j]; buf[2 * j] = v2.x; buf[2 * j + 1] = v2.y; }
     };
-    load_w(wc, 0);
-    for (int base = 0; base < n; base += WB) {
-        load_w(wn, base + WB);
+    int n_max = n;
 #pragma unroll
-        for (int j = 0; j < WB; j++) {
-            if (base + j < n) {
-                const double a0 = st[0];
-                const double v = (wc[j] - mu) - a0;
+    for (int o = 32; o >= 1; o >>= 1) { const int other = __shfl_xor(n_max, o); n_max = other > n_max ? other : n_max; }
+    load_w(wc, 0);
+    for (int base = 0; base < n_max; base += WB) {
+        load_w(wn, base + WB);
+        if (__any(!steady && base < n)) {
+#pragma unroll
+            for (int j = 0; j < WB; j++) {
+                const bool inr = base + j < n;
+                const bool live = inr && !steady;            // this series' F, K, L still move
+                // entry 0 of the state and of L (even lane) for both; entry H (the odd lane's first) closes the even lane's shift
+                const double s0 = sth[0], l0 = Lh[0];
+                const double a0 = ar_pair_lo(s0), c = ar_pair_lo(l0);
+                const double sH = ar_pair_hi(s0), lH = ar_pair_hi(l0);
+                sth[H] = hi ? 0.0 : sH;
+                Lh[H] = hi ? 0.0 : lH;
+                const double v = inr ? (wc[j] - mu) - a0 : 0.0;
                 const double vf = v * rF;
                 ssq = fma(v, vf, ssq);
-                if (!steady) {
-                    int ex;
-                    mant = frexp(mant * F, &ex);
-                    eacc += ex;
-                }
+                int ex;
+                const double mm = frexp(mant * F, &ex);
+                mant = live ? mm : mant;
+                eacc += live ? ex : 0;
 #pragma unroll
-                for (int i = 0; i < RM; i++) st[i] = fma(K[i], vf, fma(A[i], a0, st[i + 1]));
-                if (!steady) {
-                    const double c = L[0];
-                    const double cm = c * M;
-                    const double dF = c * cm;
-                    const double Fn = F + dF;
-                    if (!(Fn > 0.0)) return __builtin_huge_val();
-                    const double cf = c * rF;
-                    double lmax = 0.0;
+                for (int i = 0; i < H; i++) sth[i] = fma(Kh[i], vf, fma(Ah[i], a0, sth[i + 1]));
+                const double cm = live ? c * M : 0.0;        // 0: K and F stay as they are, bit for bit
+                const double dF = c * cm;
+                const double Fn = live ? F + dF : F;
+                bad = bad | (live & !(Fn > 0.0));
+                const double cf = c * rF;
 #pragma unroll
-                    for (int i = 0; i < RM; i++) {
-                        const double tl = fma(A[i], c, L[i + 1]);
-                        const double kold = K[i];
-                        K[i] = fma(tl, cm, kold);
-                        const double ln = fma(-kold, cf, tl);
-                        L[i] = ln;
-                        const double al = fabs(ln);
-                        lmax = al > lmax ? al : lmax;
-                    }
-                    const double rFn = 1.0 / Fn;
-                    M = (M * F) * rFn;
-                    F = Fn;
-                    rF = rFn;
-                    t = base + j + 1;                       // steps filtered in the transient so far
-                    if (!(lmax * lmax * fabs(M) > 1.0e-12 * F)) steady = true;
+                for (int i = 0; i < H; i++) {
+                    const double tl = fma(Ah[i], c, Lh[i + 1]);
+                    const double kold = Kh[i];
+                    Kh[i] = fma(tl, cm, kold);                // cm = 0 off the transient: K stays (tl is finite there: L decays)
+                    Lh[i] = fma(-kold, cf, tl);
                 }
+                const double rFn = 1.0 / Fn;
+                const double Mn = (M * F) * rFn;
+                M = live ? Mn : M;
+                rF = live ? rFn : rF;
+                F = Fn;
+                t = live ? base + j + 1 : t;                 // steps filtered in the transient so far
+                if (j == WB - 1) {                           // every fourth step: can any entry of L still move F?
+                    // sum of squares in the oracle's order: entries [0, H) in the even lane, the odd lane carries on from there
+                    double lsq = 0.0;
+#pragma unroll
+                    for (int i = 0; i < H; i++) lsq = fma(Lh[i], Lh[i], lsq);
+                    double lsq2 = ar_pair_lo(lsq);
+#pragma unroll
+                    for (int i = 0; i < H; i++) lsq2 = fma(Lh[i], Lh[i], lsq2);
+                    lsq = ar_pair_hi(lsq2);
+                    steady = steady | (live & !(lsq * fabs(M) > 1.0e-12 * F));
+                }
+                __builtin_amdgcn_sched_barrier(0);           // one step at a time: interleaving steps only adds live registers
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < WB; j++) {
+                const double s0 = sth[0];
+                const double a0 = ar_pair_lo(s0), sH = ar_pair_hi(s0);
+                sth[H] = hi ? 0.0 : sH;
+                const double v = (base + j < n) ? (wc[j] - mu) - a0 : 0.0;
+                const double vf = v * rF;
+                ssq = fma(v, vf, ssq);
+#pragma unroll
+                for (int i = 0; i < H; i++) sth[i] = fma(Kh[i], vf, fma(Ah[i], a0, sth[i + 1]));
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
 #pragma unroll
         for (int j = 0; j < WB; j++) wc[j] = wn[j];
     }
-    if (!(fabs(ssq) <= 1.7976931348623157e308) || !(ssq >= 0.0)) return __builtin_huge_val();
+    if (bad || !(fabs(ssq) <= 1.7976931348623157e308) || !(ssq >= 0.0)) return __builtin_huge_val();
     double s2 = ssq / (double)n;
     if (s2 < 1.0e-300) s2 = 1.0e-300;
     double sumlog = dm_log(mant) + (double)eacc * 0.693147180559945309417232121458;
@@ -1205,38 +1317,52 @@ __device__ double ar_ml_eval(const ArPolyLds &PL, int La, int Lb, double mu, con
 
 enum { RP_F0 = 0, RP_INIT, RP_ITER, RP_E, RP_OC, RP_IC, RP_SHRINK, RP_DONE };
 
+// the refit's Nelder-Mead state per lane in a global scratch (lane-minor per wave, like the LDS layout of the fit kernels):
+// 42 simplex coordinates, 7 function values, the reflection value, the value at the start, the step of the constant --
+// everything the filter loop does not need stays out of its register budget (the r-vectors alone take 164 VGPRs at r = 20)
+constexpr int AR_ML_CTX = (AR_MAXDIM + 1) * AR_MAXDIM + (AR_MAXDIM + 1) + 3;
+struct ArSimG {
+    double *base; int col;
+    __device__ double &sim(int k, int i) const { return base[(size_t)(k * AR_MAXDIM + i) * NM_BLOCK + col]; }
+    __device__ double &fv(int k) const { return base[(size_t)((AR_MAXDIM + 1) * AR_MAXDIM + k) * NM_BLOCK + col]; }
+    __device__ double &fxr() const { return fv(AR_MAXDIM + 1); }
+    __device__ double &f0() const { return fv(AR_MAXDIM + 2); }
+    __device__ double &wsd() const { return fv(AR_MAXDIM + 3); }
+    __device__ double get(int k) const { return fv(k); }
+    __device__ void set(int k, double x) const { fv(k) = x; }
+};
+
 // Series whose state dimension r lies in (r_lo, RM] are refitted by the RM instantiation (the unrolled loops cost RM whatever
 // the lane's own r, so the common small models -- r = 9 for (0,1,1)(1,0,1)[7] -- run in a narrower kernel); `cursor` is the
 // queue cursor of this launch in ws.counts.
 template <int RM>
-__device__ __noinline__ void ar_refit_body(const ArimaArgs &a, const ArWs &ws, const int r_lo, const int cursor, double *lds)
+__device__ __noinline__ int ar_refit_body(const ArimaArgs &a, const ArWs &ws, const int r_lo, const int cursor, double *lds)
 {
     const int lane = threadIdx.x;
+    const bool even = (lane & 1) == 0;                     // the pair's lanes run the same Nelder-Mead on the same values; the even one talks to memory
     const int m = a.m;
     const size_t ld = a.ld;
-    const int l1 = AR_MAXP + AR_MAXSP * m + 1;
-    ArLds L{lds, 0, lane};
-    ArPolyLds PL{lds + (size_t)(AR_MAXDIM + 1) * AR_MAXDIM * NM_BLOCK, l1};
-    ArMlInit Q{PL.base + (size_t)2 * l1 * NM_BLOCK, RM};
-    ArFs F;
-    for (int k = 0; k <= AR_MAXDIM; k++) F.v[k] = 0.0;
+    static_assert(AR_ML_CTX <= 64, "refit context slots");
+    const ArSimG L{ws.ml_sim + (size_t)blockIdx.x * (size_t)64 * NM_BLOCK, lane};
+    const ArSimG &F = L;                                   // the function values live next to the simplex
+    ArMlLds Q{lds, RM, ar_ml_l1(m)};
 
-    // persistent lanes: a lane that has finished its series takes the next one from the cursor (evaluation counts differ
-    // several-fold between series, so a wave tied to 64 fixed series would idle most of its lanes)
+    // persistent lane pairs: a pair that has finished its series takes the next one from the cursor (evaluation counts differ
+    // several-fold between series, so a wave tied to 32 fixed series would idle most of its lanes)
     int s = 0, len = 0, D = 0;
     ArOrd o{0, 0, 0, 0, 0};
-    double x0[AR_MAXDIM] = {0, 0, 0, 0, 0, 0};
     const double *w = ws.W;
-    double wsd = 0.0;
     bool fin = false;
     int ph = RP_DONE, vi = 0, nm_evals = 0, nm_iters = 1, evals = 0;
-    double fxr = 0.0, f0 = 0.0;
 
-    for (;;) {
+    int loops = 0;
+    for (;; loops++) {
         // ---- next series of this lane ----
         for (int attempt = 0; attempt < 4 && !fin && ph == RP_DONE; attempt++) {
-            if (evals > 0) { a.passes[s] += evals; a.evals[s] += evals; evals = 0; }
-            const int item = atomicAdd(&ws.counts[cursor], 1);
+            if (evals > 0) { if (even) { a.passes[s] += evals; a.evals[s] += evals; } evals = 0; }
+            int item = 0;
+            if (even) item = atomicAdd(&ws.counts[cursor], 1);
+            item = ar_pair_lo(item);
             if (item >= a.n_series) { fin = true; break; }
             s = item;
             len = a.wlen[s];
@@ -1250,9 +1376,8 @@ __device__ __noinline__ void ar_refit_body(const ArimaArgs &a, const ArWs &ws, c
                 const int rr = la > lb1 ? la : lb1;
                 if (rr <= r_lo || rr > RM) continue;              // another instantiation's series (or beyond AR_ML_MAX_R: CSS estimates stay)
             }
-            for (int i = 0; i < AR_MAXDIM; i++) x0[i] = a.xbest[(size_t)i * ld + s];
             w = ws.W + (size_t)s * ws.tw;
-            wsd = a.wsd[s];
+            L.wsd() = a.wsd[s];
             ph = RP_F0; vi = 0; nm_evals = 0; nm_iters = 1;
         }
         if (__all(fin && ph == RP_DONE)) break;
@@ -1272,12 +1397,12 @@ __device__ __noinline__ void ar_refit_body(const ArimaArgs &a, const ArWs &ws, c
                 if (stop) {
                     // the exact-likelihood estimates replace the CSS ones when they are at least as good as the start
                     const double fb = F.get(0);
-                    if (fabs(fb) <= 1.7976931348623157e308 && fb <= f0)
+                    if (even && fabs(fb) <= 1.7976931348623157e308 && fb <= L.f0())
                         for (int i = 0; i < D; i++) a.xbest[(size_t)i * ld + s] = L.sim(0, i);
                     ph = RP_DONE;
                 }
             }
-            if (ph == RP_F0) { for (int i = 0; i < D; i++) x[i] = x0[i]; }
+            if (ph == RP_F0) { for (int i = 0; i < D; i++) x[i] = a.xbest[(size_t)i * ld + s]; }      // the CSS optimum
             else if (ph == RP_INIT) { for (int i = 0; i < D; i++) x[i] = L.sim(vi, i); }
             else if (ph == RP_ITER) { for (int i = 0; i < D; i++) x[i] = ar_trial(L, D, 0, i); }
             else if (ph == RP_E || ph == RP_OC || ph == RP_IC) {
@@ -1285,23 +1410,20 @@ __device__ __noinline__ void ar_refit_body(const ArimaArgs &a, const ArWs &ws, c
                 for (int i = 0; i < D; i++) x[i] = ar_trial(L, D, which, i);
             } else if (ph == RP_SHRINK) { for (int i = 0; i < D; i++) x[i] = L.sim(1 + vi, i); }
         }
-        double f = __builtin_huge_val();
-        if (ph != RP_DONE) {
-            int La = 0, Lb = 0;
-            double mu = 0.0;
-            ar_build_poly(o, m, x, PL, La, Lb, mu);
-            f = ar_ml_eval<RM>(PL, La, Lb, mu, w, len, Q);
-            evals++;
-        }
+        int La = 0, Lb = 0;
+        double mu = 0.0;
+        if (ph != RP_DONE) { ar_build_poly_ml(o, m, x, Q, La, Lb, mu); evals++; }
+        const double f = ar_ml_eval<RM>(ph != RP_DONE, La, Lb, mu, w, len, Q);     // the whole wave: wave-uniform filter loop
         if (ph == RP_F0) {
-            f0 = f;
-            if (!(fabs(f0) <= 1.7976931348623157e308)) ph = RP_DONE;      // not computable at the start: the CSS estimates stay
+            L.f0() = f;
+            if (!(fabs(f) <= 1.7976931348623157e308)) ph = RP_DONE;       // not computable at the start: the CSS estimates stay
             else {
-                for (int i = 0; i < D; i++) L.sim(0, i) = x0[i];
+                const double wsd = L.wsd();
+                for (int i = 0; i < D; i++) L.sim(0, i) = a.xbest[(size_t)i * ld + s];
                 for (int k = 0; k < D; k++) {
-                    for (int i = 0; i < D; i++) L.sim(k + 1, i) = x0[i];
+                    for (int i = 0; i < D; i++) L.sim(k + 1, i) = L.sim(0, i);
                     const double step = (o.c && k == D - 1) ? (wsd > 0.0 ? 0.1 * wsd : 1.0e-4) : 0.1;
-                    L.sim(k + 1, k) = x0[k] + step;
+                    L.sim(k + 1, k) = L.sim(0, k) + step;
                 }
                 nm_evals = 0; nm_iters = 1; vi = 0;
                 ph = RP_INIT;
@@ -1310,18 +1432,20 @@ __device__ __noinline__ void ar_refit_body(const ArimaArgs &a, const ArWs &ws, c
             F.set(vi, f); vi++; nm_evals++;
             if (vi == D + 1) { ar_sort(L, F, D); ph = RP_ITER; }
         } else if (ph == RP_ITER) {
-            fxr = f; nm_evals++;
+            const double fxr = f;
+            L.fxr() = fxr; nm_evals++;
             if (fxr < F.get(0)) ph = RP_E;
             else if (fxr < F.get(D - 1)) { ar_accept(L, F, D, 0, fxr); nm_iters++; }
             else if (fxr < F.get(D)) ph = RP_OC;
             else ph = RP_IC;
         } else if (ph == RP_E) {
             nm_evals++;
+            const double fxr = L.fxr();
             if (f < fxr) ar_accept(L, F, D, 1, f); else ar_accept(L, F, D, 0, fxr);
             nm_iters++; ph = RP_ITER;
         } else if (ph == RP_OC || ph == RP_IC) {
             nm_evals++;
-            const bool ok = (ph == RP_OC) ? (f <= fxr) : (f < F.get(D));
+            const bool ok = (ph == RP_OC) ? (f <= L.fxr()) : (f < F.get(D));
             if (ok) { ar_accept(L, F, D, ph == RP_OC ? 2 : 3, f); nm_iters++; ph = RP_ITER; }
             else {
                 for (int k = 1; k <= D; k++)
@@ -1333,18 +1457,63 @@ __device__ __noinline__ void ar_refit_body(const ArimaArgs &a, const ArWs &ws, c
             if (vi == D) { nm_iters++; ar_sort(L, F, D); ph = RP_ITER; }
         }
     }
-    if (evals > 0) { a.passes[s] += evals; a.evals[s] += evals; }
+    if (evals > 0 && even) { a.passes[s] += evals; a.evals[s] += evals; }
+    return loops;
 }
 
-// One persistent launch for all state-dimension classes: a wave works through the classes from the widest down, so the
-// slowest fits of one class overlap with the bulk of the next (ws.counts[9..12] are the class cursors).
-__global__ __launch_bounds__(NM_BLOCK, 1) void arima_refit_kernel(const ArimaArgs a, const ArWs ws, const int l1)
+// class of a series' state dimension: 0..4 = r <= 8 / 12 / 16 / 20 / 32, -1 = nothing to refit
+__device__ __forceinline__ int ar_ml_class(const ArimaArgs &a, int s)
+{
+    if (!(a.wlen[s] >= 3 && a.status[s] == FIT_OK)) return -1;
+    const size_t ld = a.ld;
+    const int p = a.order[(size_t)0 * ld + s], q = a.order[(size_t)1 * ld + s], P = a.order[(size_t)2 * ld + s], Qs = a.order[(size_t)3 * ld + s];
+    if (p + q + P + Qs + a.order[(size_t)4 * ld + s] == 0) return -1;
+    const int la = p + a.m * P, lb1 = q + a.m * Qs + 1;
+    const int rr = la > lb1 ? la : lb1;
+    return rr <= 8 ? 0 : (rr <= 12 ? 1 : (rr <= 16 ? 2 : (rr <= 20 ? 3 : (rr <= AR_ML_MAX_R ? 4 : -1))));
+}
+// series per class -> ws.counts[16..20] (the refit deals its waves to the classes in that proportion)
+__global__ void arima_refit_count_kernel(const ArimaArgs a, const ArWs ws)
+{
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= a.n_series) return;
+    const int c = ar_ml_class(a, s);
+    if (c >= 0) atomicAdd(&ws.counts[16 + c], 1);
+}
+
+// One persistent launch for all state-dimension classes (cursors ws.counts[9..13]).  A wave starts on the class its block
+// index falls into when the grid is dealt to the classes by their series counts, then walks round the other classes (whose
+// cursors it mostly finds exhausted): the classes run side by side and the kernel ends with the slowest class, not with the
+// sum of their critical paths.  256 registers (two waves per SIMD): with 512 allowed the scheduler spread the r-vectors over
+// VGPRs, AGPRs and scratch -- 15 scratch reloads per filter step at r = 20, 2,500 cycles per step, measured.
+__global__ __launch_bounds__(NM_BLOCK, 2) void arima_refit_kernel(const ArimaArgs a, const ArWs ws)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    if (l1 > 20) ar_refit_body<AR_ML_MAX_R>(a, ws, 20, 12, lds);
-    if (l1 > 12) ar_refit_body<20>(a, ws, 12, 11, lds);
-    if (l1 > 8) ar_refit_body<12>(a, ws, 8, 10, lds);
-    ar_refit_body<8>(a, ws, 0, 9, lds);
+    int first = 0;
+    {
+        long tot = 0;
+        for (int c = 0; c < 5; c++) tot += ws.counts[16 + c];
+        if (tot == 0) return;
+        const long pos = ((long)blockIdx.x * tot) / (long)gridDim.x;
+        long cum = 0;
+        for (int c = 0; c < 5; c++) { cum += ws.counts[16 + c]; if (pos < cum) { first = c; break; } }
+    }
+    long long tc[6];
+    int it[5] = {0, 0, 0, 0, 0};
+    tc[0] = wall_clock64();
+    for (int k = 0; k < 5; k++) {
+        const int c = (first + k) % 5;
+        if (ws.counts[16 + c] == 0) { tc[k + 1] = tc[k]; continue; }
+        if (c == 0) it[0] += ar_refit_body<8>(a, ws, 0, 9, lds);
+        else if (c == 1) it[1] += ar_refit_body<12>(a, ws, 8, 10, lds);
+        else if (c == 2) it[2] += ar_refit_body<16>(a, ws, 12, 11, lds);
+        else if (c == 3) it[3] += ar_refit_body<20>(a, ws, 16, 12, lds);
+        else it[4] += ar_refit_body<AR_ML_MAX_R>(a, ws, 20, 13, lds);
+        tc[k + 1] = wall_clock64();
+    }
+    if (a.trace && threadIdx.x == 0 && (blockIdx.x % 32) == 0)      // 100 MHz wall clock: 1e5 ticks per ms
+        printf("refit wave %d: loops class8 %d class12 %d class16 %d class20 %d class32 %d, ticks of its 1st..5th class %lld %lld %lld %lld %lld\n", (int)blockIdx.x,
+               it[0], it[1], it[2], it[3], it[4], tc[1] - tc[0], tc[2] - tc[1], tc[3] - tc[2], tc[4] - tc[3], tc[5] - tc[4]);
 }
 
 #define AR_HIPCHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) throw std::runtime_error(std::string("HIP: ") + hipGetErrorString(e_) + " at " #x); } while (0)
@@ -1406,15 +1575,18 @@ int launch_arima(const ArimaArgs &a, hipStream_t stream)
     }
     // final estimates of the selected models: exact Gaussian likelihood (a.ml_scratch == NULL keeps the CSS estimates)
     if (a.ml_refit) {
-        const int l1 = AR_MAXP + AR_MAXSP * (a.m > 1 ? a.m : 0) + 1;        // largest state dimension of this period
-        const int rm = l1 <= 8 ? 8 : (l1 <= 12 ? 12 : (l1 <= 20 ? 20 : AR_ML_MAX_R));
-        const size_t lds_b = sizeof(double) * ((size_t)(AR_MAXDIM + 1) * AR_MAXDIM + 2 * (size_t)(AR_MAXP + AR_MAXSP * a.m + 1) + 5 * (size_t)rm + 5) * NM_BLOCK;
+        const size_t lds_b = sizeof(double) * ar_ml_lds_doubles(a.m) * NM_BLOCK;
         if (lds_b > 48 * 1024) AR_HIPCHECK(hipFuncSetAttribute((const void *)arima_refit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
         int per = (int)((160 * 1024) / lds_b);
-        per = per < 1 ? 1 : (per > 4 ? 4 : per);
-        const int g = std::min(grid, cus * per);                            // persistent lanes: no more waves than fit the chip
-        hipLaunchKernelGGL(arima_refit_kernel, dim3(g), dim3(NM_BLOCK), lds_b, stream, a, ws, l1);
-        launches++;
+        per = per < 1 ? 1 : (per > 8 ? 8 : per);                            // 256 registers: two waves per SIMD at most
+        // persistent lane pairs, no more waves than fit the chip; two lanes per series and some slack, so that (nearly) every
+        // series finds a pair among the waves that start with its class
+        const int want = (2 * a.n_series + NM_BLOCK - 1) / NM_BLOCK + 8;
+        const int g = std::min(std::min(cus * per, ar_ml_sim_waves(a.n_series)), want);
+        AR_HIPCHECK(hipMemsetAsync(ws.counts + 9, 0, 12 * sizeof(int32_t), stream));
+        hipLaunchKernelGGL(arima_refit_count_kernel, dim3(grid256), dim3(256), 0, stream, a, ws);
+        hipLaunchKernelGGL(arima_refit_kernel, dim3(g), dim3(NM_BLOCK), lds_b, stream, a, ws);
+        launches += 2;
     }
     hipLaunchKernelGGL(arima_forecast_kernel, dim3(grid), dim3(NM_BLOCK), fc_lds, stream, a, ws);
     return launches + 1;

@@ -144,6 +144,9 @@ struct AnofoxHipBatch {
     int gather_min = 0;      // per spec: stop gathering columns once this few problems are still running (measured: the gather pays at every count, 0 = always gather)
     int tail_below = 0;      // per spec: run the remaining problems to completion once this few are left (measured: rounds + compaction win at every threshold, 0 = off)
     int spec_below_md = 8192; // same, for the damped multiplicative-trend specs (their pass is ~10x longer: the stragglers matter more)
+    int spec2_below_md = 2048; // per spec: the last problems run one per wave, two iterations per pass (0 = never); damped multiplicative
+                               // trend.  Measured on the 30-spec M5 batch (tools/spec2_sweep.sh): 0 / 256 / 1024 / 2048 / 4096 / 8192 -> 579 / 575 / 565 / 562 / 594 / 736 ms
+    int spec2_below = 1024;    // same, other specs (single-spec ETS(A,A,A) fit: 22.5 -> 18.2 ms; all specs at 2048 / 4096: 588 / 673 ms)
     int spec_below = 8192;   // per spec: switch to the speculative driver once this few problems are still running
     bool use_gather = false; // rebuild a dense block of the running problems between rounds (else index y by series)
     // work-pool schedule (ets_pool_kernel.hpp): persistent waves, lanes refill from a queue, slow problems take four lanes
@@ -683,7 +686,8 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
         size_t n_long = 0;
         for (size_t oi = 0; oi < order.size(); oi++) if (args[oi].m > ETS_LDS_PERIOD) n_long++;
         if (n_long) {
-            const size_t per_spec = (size_t)((n + 15) / 16) * (size_t)m * 64u;
+            const size_t wg = std::max<size_t>((n + 15) / 16, std::min<size_t>(n, (size_t)std::max(b->spec2_below, b->spec2_below_md)));
+            const size_t per_spec = wg * (size_t)m * 64u;
             if ((double)n_long * (double)per_spec * 8.0 > 64.0 * 1073741824.0)
                 throw HipFail{"seasonal period " + std::to_string(m) + " on " + std::to_string(n) + " series needs more than 64 GiB of ring scratch: shard the batch"};
             double *base = ensure_ring(b, n_long * per_spec);
@@ -814,7 +818,7 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
             FitArgs &a = args[oi];
             const bool spec_mode = r >= b->seq_rounds;
             a.first_round = (r == 0);
-            a.spec_below = -1;
+            a.spec_below = -1; a.spec2_below = -1;
             a.tail_below = (r == 0) ? 0 : b->tail_below;
             a.gathered = 0;
             if (r == 0 && b->use_pos && a.need_positive) {
@@ -850,18 +854,28 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
                 a.next_map = lane.map[(r + 1) & 1]; a.next_cnt = lane.cnt + ((r + 1) % 3); a.clear_cnt = lane.cnt + ((r + 2) % 3);
                 a.next_y = ((r + 1) & 1) ? lane.ybuf2 : lane.ybuf;
             }
+            const int s2 = (spec_trend_idx(specs[order[oi]]) == 4) ? b->spec2_below_md : b->spec2_below;
             if (r == 0 || b->seq_rounds_env >= 0 || b->seq_rounds == 0) {
                 // first round (no device count yet) or a forced schedule: the host picks the driver
                 a.budget = spec_mode ? BUDGET[r] : (BUDGET[r] * 7) / 4;     // ~1.7 passes per iteration when sequential
-                (spec_mode ? fns[oi].round_spec : fns[oi].round_seq)(a, sq);
+                if (spec_mode && r > 0 && s2 > 0) {
+                    // ... but the last s2 problems still go one per wave (device-side count)
+                    a.spec_below = 0x7fffffff; a.spec2_below = s2;
+                    fns[oi].round_spec(a, sq);
+                    fns[oi].round_spec2(a, sq);
+                } else
+                    (spec_mode ? fns[oi].round_spec : fns[oi].round_seq)(a, sq);
             } else {
-                // later rounds: enqueue both drivers, the device-side count of running problems picks one --
-                // sequential (least arithmetic) while this spec still fills >= 1/8 of the chip, else speculative
+                // later rounds: enqueue all drivers, the device-side count of running problems picks one --
+                // sequential (least arithmetic) while this spec still fills >= 1/8 of the chip, then speculative (one pass
+                // per iteration), then two-level speculative (one problem per wave, two iterations per pass)
                 a.spec_below = (spec_trend_idx(specs[order[oi]]) == 4) ? b->spec_below_md : b->spec_below;
+                a.spec2_below = s2 > 0 ? s2 : -1;
                 a.budget = (BUDGET[r] * 7) / 4;
                 fns[oi].round_seq(a, sq);
                 a.budget = BUDGET[r];
                 fns[oi].round_spec(a, sq);
+                if (s2 > 0) fns[oi].round_spec2(a, sq);
             }
             b->fit_launches++;
         }
@@ -1051,6 +1065,7 @@ void run_group(AnofoxHipBatch *b, int period, const int32_t *d_len, hipStream_t 
         aa.status = b->d_detail; aa.evals = b->d_evals_total; aa.passes = b->d_passes_total; aa.models = b->ar_models;
         aa.yhat = b->d_yhat; aa.model_code = b->d_model_code;
         aa.ml_refit = b->arima_ml ? 1 : 0;
+        aa.trace = std::getenv("ANOFOX_HIP_ARIMA_TRACE") ? 1 : 0;
         HIPCHECK(hipEventRecord(b->ev_fit0, st));
         try { b->fit_launches += launch_arima(aa, st); }
         catch (const std::exception &e) { throw HipFail{e.what()}; }
@@ -1230,6 +1245,8 @@ bool anofox_hip_batch_create(size_t n_series, size_t t_max, const ForecastOption
         if (const char *e = std::getenv("ANOFOX_HIP_GATHER")) b->use_gather = std::atoi(e) != 0;
         if (const char *e = std::getenv("ANOFOX_HIP_SPEC_BELOW")) b->spec_below = b->spec_below_md = std::atoi(e);
         if (const char *e = std::getenv("ANOFOX_HIP_SPEC_BELOW_MD")) b->spec_below_md = std::atoi(e);
+        if (const char *e = std::getenv("ANOFOX_HIP_SPEC2_BELOW")) b->spec2_below = b->spec2_below_md = std::atoi(e);
+        if (const char *e = std::getenv("ANOFOX_HIP_SPEC2_BELOW_MD")) b->spec2_below_md = std::atoi(e);
         if (const char *e = std::getenv("ANOFOX_HIP_TAIL_BELOW")) b->tail_below = std::atoi(e);
         if (const char *e = std::getenv("ANOFOX_HIP_GATHER_MIN")) b->gather_min = std::atoi(e);
         if (const char *e = std::getenv("ANOFOX_HIP_FUSED")) b->fused = std::atoi(e) != 0;

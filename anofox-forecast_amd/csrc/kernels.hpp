@@ -52,6 +52,7 @@ struct FitArgs {
     int budget, first_round;
     int spec_below;              // device-side driver choice: the speculative kernel runs iff n_active <= spec_below,
                                  // the sequential one iff n_active > spec_below (both are enqueued; -1 = unconditional)
+    int spec2_below;             // ... and the one-problem-per-wave driver (two iterations per pass) iff n_active <= spec2_below
     int tail_below;              // run to completion once this few problems are still running (0 = never)
     int gather_min;              // the gather (and the gathered view) only applies while more than this many problems run
     int gathered;                // y_round holds the running problems' columns densely (column p), else index by series
@@ -138,7 +139,7 @@ struct IntervalArgs {
 // ETS fit kernels, one per (spec id, ring variant).  ring: 0 = none / VGPR ring for the
 // compile-time period given, -1 = LDS ring.  Returns NULL when not instantiated.
 typedef void (*FitLaunchFn)(const FitArgs &, hipStream_t);
-struct FitLaunchers { FitLaunchFn round_seq, round_spec, final; };   // sequential / speculative Nelder-Mead rounds, final pass
+struct FitLaunchers { FitLaunchFn round_seq, round_spec, round_spec2, final; };   // sequential / speculative / two-level speculative rounds, final pass
 FitLaunchers ets_fit_launcher(int spec_id, int m);
 
 // Work-pool schedule (ets_pool_kernel.hpp): ONE persistent kernel per compile unit serves the unit's candidate specs in
@@ -194,6 +195,7 @@ struct ArimaArgs {
     int32_t *status, *evals, *passes, *models;
     double *yhat;                       // [n_series x h]
     int32_t *model_code;                // 1000000 + p*1e5 + d*1e4 + q*1e3 + P*100 + D*10 + Q
+    int trace;                          // debugging: the refit kernel prints per-wave timings (ANOFOX_HIP_ARIMA_TRACE)
     int ml_refit;                       // exact-likelihood (Kalman / Chandrasekhar) refit of the selected models; 0 keeps the CSS estimates
 };
 size_t arima_workspace_bytes(int n_series, int t_max);

@@ -255,6 +255,179 @@ __device__ void nm_advance_spec(Model &mdl, double *lds, NmRun &r, int budget)
     r.phase = phase; r.evals = evals; r.iters = iters; r.passes = passes; r.done = done;
 }
 
+// ---- two-level speculative driver: TWO iterations per pass, one problem per wave -------------------
+// When only a few problems are left, their dependent chains of passes ARE the run time of the batch while most of the chip
+// idles.  Lanes 0..3 evaluate the four trial points of the current iteration; lanes 4.. evaluate the four trial points of
+// the NEXT iteration under every outcome the current one can have: the accepted point P (reflection, expansion, outside or
+// inside contraction) and its rank j in the re-sorted simplex (the rank decides the order of the centroid sum, so it is
+// part of the hypothesis): (E, 0), (R, 0..D-1), (OC, 0..D), (IC, 0..D) = 3 D + 3 hypotheses x 4 points = 60 lanes for D = 4.
+// After the pass the first iteration is decided exactly as the sequential method decides it, the hypothesis that came true
+// selects four of the speculative values, and the second iteration is decided from them -- same iterates, same evaluation
+// counts, same stopping point (a shrink, or a stop after the first iteration, simply discards the second level).
+// Every lane keeps an identical copy of the simplex in its own LDS slot, so all control flow is wave-uniform.
+template <int D> __device__ __forceinline__ void nm_hypothesis(int hh, int &P, int &j)
+{
+    if (hh == 0) { P = 1; j = 0; }
+    else if (hh <= D) { P = 0; j = hh - 1; }
+    else if (hh <= 2 * D + 1) { P = 2; j = hh - D - 1; }
+    else { P = 3; j = hh - 2 * D - 2; }
+}
+
+// coordinate i of trial point `which` of the simplex that results from accepting trial point P at rank j
+template <int D> __device__ __forceinline__ double nm_trial2(const double *lds, int lane, int P, int j, int which, int i, double lo, double hi)
+{
+    const double xp = nm_trial<D>(lds, lane, P, i, lo, hi);
+    double s = 0.0;
+#pragma unroll
+    for (int pos = 0; pos < D; pos++) {
+        // vertex at position pos of the hypothetical sorted simplex (the D best): the old ones with P inserted at rank j
+        double v;
+        if (j == D) v = ANOFOX_SIM(pos, i);
+        else {
+            const double before = ANOFOX_SIM(pos, i);
+            const double after = pos >= 1 ? ANOFOX_SIM(pos - 1, i) : before;
+            v = pos < j ? before : (pos == j ? xp : after);
+        }
+        s = pos == 0 ? v : s + v;
+    }
+    const double xb = s / (double)D;
+    const double xw = j == D ? xp : ANOFOX_SIM(D - 1, i);
+    const double a = which == 0 ? 2.0 : (which == 1 ? 3.0 : (which == 2 ? 1.5 : 0.5));
+    const double b = which == 0 ? 1.0 : (which == 1 ? 2.0 : 0.5);
+    const double t = which == 3 ? a * xb + b * xw : a * xb - b * xw;
+    return nm_clip(t, lo, hi);
+}
+
+// decide one iteration from the values of its four trial points (the rules of nm_advance_spec); returns false for a shrink
+template <int D> __device__ __forceinline__ bool nm_decide(const double *lds, int lane, const double (&fc)[NM_K], int &evals, int &which, double &fnew)
+{
+    const double fxr = fc[0];
+    evals += 1;
+    which = 0;
+    fnew = fxr;
+    if (fxr < ANOFOX_FS(0)) {
+        evals += 1;
+        if (fc[1] < fxr) { which = 1; fnew = fc[1]; }
+        return true;
+    }
+    if (fxr < ANOFOX_FS(D - 1)) return true;
+    if (fxr < ANOFOX_FS(D)) {
+        evals += 1;
+        if (fc[2] <= fxr) { which = 2; fnew = fc[2]; return true; }
+        return false;
+    }
+    evals += 1;
+    if (fc[3] < ANOFOX_FS(D)) { which = 3; fnew = fc[3]; return true; }
+    return false;
+}
+
+template <class Model>
+__device__ void nm_advance_spec2(Model &mdl, double *lds, NmRun &r, int budget)
+{
+    constexpr int D = Model::DIM;
+    constexpr int NH = 3 * D + 3;                 // hypotheses about the first iteration
+    const int lane = threadIdx.x;
+    double lo[D], hi[D], x0[D];
+    mdl.bounds(lo, hi, x0);
+    const int maxiter = 200 * D, maxfun = 200 * D;
+    int phase = r.phase, evals = r.evals, iters = r.iters, passes = r.passes;
+    bool done = r.done, parked = false;
+    const int hh = lane >= NM_K ? (lane - NM_K) >> 2 : 0, w2 = (lane - NM_K) & 3;
+    int hp = 0, hj = 0;
+    nm_hypothesis<D>(hh < NH ? hh : 0, hp, hj);
+    double x[D];
+
+    for (int pass = 0;; pass++) {
+        if (!done && !parked) {
+            // level-1 roles are those of the 4-lane driver (lanes >= 4 repeat lane 3's point outside NM_ITER)
+            const int sub = lane < NM_K ? lane : NM_K - 1;
+            if (phase == NM_INIT0) {
+#pragma unroll
+                for (int i = 0; i < D; i++) x[i] = ANOFOX_SIM(sub <= D ? sub : D, i);
+            } else if (phase == NM_INIT1) {
+#pragma unroll
+                for (int i = 0; i < D; i++) x[i] = ANOFOX_SIM(D, i);
+            } else if (phase == NM_ITER) {
+                if (!(evals < maxfun && iters < maxiter)) done = true;
+                else if (nm_converged<D>(lds, lane)) done = true;
+                if (!done) {
+                    if (lane < NM_K) {
+#pragma unroll
+                        for (int i = 0; i < D; i++) x[i] = nm_trial<D>(lds, lane, lane, i, lo[i], hi[i]);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < D; i++) x[i] = nm_trial2<D>(lds, lane, hp, hj, w2, i, lo[i], hi[i]);
+                    }
+                }
+            } else { // NM_SHRINK
+#pragma unroll
+                for (int i = 0; i < D; i++) x[i] = ANOFOX_SIM(sub + 1 <= D ? sub + 1 : D, i);
+            }
+        }
+        if (!done && pass >= budget && (phase == NM_ITER || phase == NM_INIT0)) parked = true;
+        if (done || parked) break;                          // one problem per wave: the decision is wave-uniform
+
+        const double f = mdl.eval1(x);
+        passes += 1;
+        double fc[NM_K];
+#pragma unroll
+        for (int k = 0; k < NM_K; k++) fc[k] = __shfl(f, k);
+
+        if (phase == NM_INIT0) {
+#pragma unroll
+            for (int k = 0; k < NM_K; k++)
+                if (k <= D) ANOFOX_FS(k) = fc[k];
+            evals += (D + 1 < NM_K ? D + 1 : NM_K);
+            phase = (D + 1 > NM_K) ? NM_INIT1 : NM_ITER;
+            if (phase == NM_ITER) nm_sort_all<D>(lds, lane);
+        } else if (phase == NM_INIT1) {
+            ANOFOX_FS(D) = fc[0];
+            evals += 1;
+            phase = NM_ITER;
+            nm_sort_all<D>(lds, lane);
+        } else if (phase == NM_ITER) {
+            int which = 0;
+            double fnew = 0.0;
+            if (!nm_decide<D>(lds, lane, fc, evals, which, fnew)) {
+                nm_shrink_vertices<D>(lds, lane, lo, hi);
+                phase = NM_SHRINK;
+            } else {
+                // the rank the accepted point takes (stable insertion, nm_accept) names the hypothesis that came true
+                int j = D;
+#pragma unroll
+                for (int k = D; k >= 1; k--)
+                    if (j == k && fnew < ANOFOX_FS(k - 1)) j = k - 1;
+                const int hstar = which == 1 ? 0 : (which == 0 ? 1 + j : (which == 2 ? D + 1 + j : 2 * D + 2 + j));
+                double fc2[NM_K];
+#pragma unroll
+                for (int k = 0; k < NM_K; k++) fc2[k] = __shfl(f, NM_K + 4 * hstar + k);
+                nm_accept<D>(lds, lane, which, fnew, lo, hi);
+                iters += 1;
+                // second iteration: the checks the sequential loop makes before it, then the same decision
+                if (!(evals < maxfun && iters < maxiter) || nm_converged<D>(lds, lane)) done = true;
+                else if (NM_K + 4 * NH <= NM_BLOCK) {
+                    if (!nm_decide<D>(lds, lane, fc2, evals, which, fnew)) {
+                        nm_shrink_vertices<D>(lds, lane, lo, hi);
+                        phase = NM_SHRINK;
+                    } else {
+                        nm_accept<D>(lds, lane, which, fnew, lo, hi);
+                        iters += 1;
+                    }
+                }
+            }
+        } else { // NM_SHRINK results
+#pragma unroll
+            for (int k = 0; k < NM_K; k++)
+                if (k + 1 <= D) ANOFOX_FS(k + 1) = fc[k];
+            evals += D;
+            iters += 1;
+            phase = NM_ITER;
+            nm_sort_all<D>(lds, lane);
+        }
+    }
+    r.phase = phase; r.evals = evals; r.iters = iters; r.passes = passes; r.done = done;
+}
+
 // ---- sequential driver: one trial point per pass ---------------------------------------------------
 template <class Model>
 __device__ void nm_advance_seq(Model &mdl, double *lds, NmRun &r, int budget)

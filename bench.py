@@ -63,6 +63,9 @@ def parse_args():
     return ap.parse_args()
 
 
+CPU_TARGET_S = 12.0      # CPU work of the baseline leg (the contract asks for 10-30 s)
+
+
 def W(model, ets_model, n, T, m, positive, seed, cpu_sample, fixed=None):
     return dict(model=model, ets_model=ets_model, n=n, T=T, m=m, positive=positive, seed=seed, cpu_sample=cpu_sample, fixed=fixed)
 
@@ -262,24 +265,38 @@ def main():
         sample = wl["cpu_sample"] if args.cpu_sample < 0 else args.cpu_sample
         if sample > 0:
             from oracle import oracle as O
+
+            def cpu_run(k):
+                vals = np.ascontiguousarray(Y[:k]).reshape(-1)
+                offs = np.arange(k + 1, dtype=np.int64) * T
+                t0 = time.perf_counter()
+                if wl["fixed"]:
+                    r = O.ets_fixed_batch(vals, offs, ets_model, m, *wl["fixed"], h)
+                else:
+                    r = O.forecast_batch(vals, offs, O.make_options(model, h, ets_model=ets_model, seasonal_period=m), 0)
+                return r, time.perf_counter() - t0
+
+            # bounded sample: a pilot (the table's figure, ~1 s on 128 cores) sizes the timed run to ~CPU_TARGET_S of work on
+            # THIS host -- more series first, whole repetitions of the batch once it is exhausted
             sample = min(sample, n)
-            vals = np.ascontiguousarray(Y[:sample]).reshape(-1)
-            offs = np.arange(sample + 1, dtype=np.int64) * T
-            c0 = time.perf_counter()
-            if wl["fixed"]:
-                reps = 8                                   # one pass per series is ~0.1 s of CPU work: repeat for a stable figure
-                for _ in range(reps):
-                    cres = O.ets_fixed_batch(vals, offs, ets_model, m, *wl["fixed"], h)
-                cdt = (time.perf_counter() - c0) / reps
-            else:
-                oo = O.make_options(model, h, ets_model=ets_model, seasonal_period=m)
-                cres = O.forecast_batch(vals, offs, oo, 0)
-                cdt = time.perf_counter() - c0
+            reps = 1
+            if args.cpu_sample < 0:
+                _, pdt = cpu_run(sample)
+                want = CPU_TARGET_S / max(pdt, 1e-3) * sample
+                if want > n:
+                    sample, reps = n, int(min(64, max(1, round(want / n))))
+                else:
+                    sample = int(max(sample, want))
+            cdt = 0.0
+            for _ in range(reps):
+                cres, dt1 = cpu_run(sample)
+                cdt += dt1
+            cdt /= reps
             got = res["yhat"][:sample].cpu().numpy()
             okm = cres["status"] == 0
             rel = np.abs(got[okm] - cres["yhat"][okm]) / np.maximum(1.0, np.abs(cres["yhat"][okm]))
             out["cpu_baseline"] = {"value": round(sample / cdt, 2), "unit": "series/s", "cores": int(cres["threads"]),
-                                   "kind": "port", "sample": f"first {sample} series of the same batch, oracle (C, OpenMP), {cdt:.1f} s",
+                                   "kind": "port", "sample": f"first {sample} series of the same batch, oracle (C, OpenMP), {reps} x {cdt:.1f} s",
                                    "max_rel_diff_vs_gpu": float(np.max(rel)) if rel.size else 0.0}
         print(json.dumps(out))
     if world > 1:

@@ -436,22 +436,24 @@ static double ml_eval(const ArimaPoly *pl, const double *w, int n)
         const double Fn = F + dF;
         if (!(Fn > 0.0)) return INFINITY;
         const double cf = c * rF;
-        double lmax = 0.0;
         for (int i = 0; i < r; i++) {
             const double tl = fma(A[i], c, L[i + 1]);
             const double kold = K[i];
             K[i] = fma(tl, cm, kold);
-            const double ln = fma(-kold, cf, tl);
-            L[i] = ln;
-            const double al_ = fabs(ln);
-            if (al_ > lmax) lmax = al_;
+            L[i] = fma(-kold, cf, tl);
         }
         const double rFn = 1.0 / Fn;
         M = (M * F) * rFn;
         F = Fn;
         rF = rFn;
-        /* steady state: no entry of L can move F any more (L[0] alone may be zero for whole seasons of a sparse model) */
-        if (!(lmax * lmax * fabs(M) > 1.0e-12 * F)) steady = 1;
+        /* steady state: no entry of L can move F any more (L[0] alone may be zero for whole seasons of a sparse model);
+         * the sum of squares bounds the largest entry and is one fused multiply-add per entry on the device; looked at after
+         * every fourth step (the device filters in blocks of four) */
+        if (((t + 1) & 3) == 0) {
+            double lsq = 0.0;
+            for (int i = 0; i < r; i++) lsq = fma(L[i], L[i], lsq);
+            if (!(lsq * fabs(M) > 1.0e-12 * F)) steady = 1;
+        }
     }
     const int n_steady = n - t;
     for (; t < n; t++) {

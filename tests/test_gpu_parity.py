@@ -444,6 +444,57 @@ def test_work_pool_variants_are_bit_identical(env, monkeypatch, waves, promote):
     _compare(api, O, lib, series[:40], "AutoETS", 6, seasonal_period=5)
 
 
+@pytest.mark.parametrize("below", ["20", "100000"])
+def test_two_level_speculation_is_bit_identical(env, monkeypatch, below):
+    """ANOFOX_HIP_SPEC2_BELOW: the last problems of a spec run one per wave, lanes 4..63 evaluating the next iteration's
+    trial points under all 3 D + 3 outcomes of the current one (two Nelder-Mead iterations per pass).  Same iterates, same
+    evaluation counts, same forecasts as the oracle -- for every parameter dimension (1..4: the AutoETS grid), ragged
+    lengths, a mixed batch, a run-time period (ring in LDS) and a long one (ring in HBM scratch)."""
+    api, O, lib, synth = env
+    monkeypatch.setenv("ANOFOX_HIP_SCHED", "rounds")
+    monkeypatch.setenv("ANOFOX_HIP_SPEC2_BELOW", below)
+    Y = synth.gen_series(synth.SEED_M5, 5000, 130, 160, 7, positive=True)
+    series = [Y[s, : 160 - (s % 5) * 9] for s in range(130)]          # ragged lengths
+    _compare(api, O, lib, series, "AutoETS", 12, seasonal_period=7)
+    _compare(api, O, lib, series, "ETS", 12, ets_model="MAdM", seasonal_period=7)
+    Yi = synth.gen_series(synth.SEED_M5, 5400, 130, 160, 7)
+    mixed = [Yi[s] if s % 3 else Y[s] for s in range(130)] + [np.full(30, 4.0), np.arange(5.0), np.zeros(40)]
+    _compare(api, O, lib, mixed, "AutoETS", 12, seasonal_period=7)
+    _compare(api, O, lib, series[:40], "AutoETS", 6, seasonal_period=5)
+    Yl = synth.gen_series(synth.SEED_M5, 5600, 24, 300, 70, positive=True)
+    _compare(api, O, lib, list(Yl), "ETS", 5, ets_model="AAA", seasonal_period=70)
+
+
+def test_two_level_speculation_counts(env, monkeypatch):
+    """Same evaluation and iteration totals as the default schedule (the speculative lanes are not evaluations of the
+    method), fewer passes, bit-identical forecasts."""
+    import torch
+    api, O, lib, synth = env
+    from anofox_forecast_amd.device import DeviceBatch, pack_time_major
+    n, T, h = 300, 140, 7
+    Y = synth.gen_series(synth.SEED_M5, 7300, n, T, 7, positive=True)
+    opts = lib.make_options("AutoETS", h, seasonal_period=7)
+    runs = []
+    for below in (None, "100000"):
+        if below is None: monkeypatch.delenv("ANOFOX_HIP_SPEC2_BELOW", raising=False)
+        else: monkeypatch.setenv("ANOFOX_HIP_SPEC2_BELOW", below)
+        b = DeviceBatch(n, T, opts, "cuda:0")
+        y = torch.from_numpy(pack_time_major(Y, b.ld)).cuda()
+        ln = torch.full((b.ld,), T, dtype=torch.int32, device="cuda")
+        ln[n:] = 0
+        b.set_block(y, ln)
+        b.run()
+        torch.cuda.synchronize()
+        out = b.results()
+        runs.append((b.stats(), {k: out[k].cpu().numpy().copy() for k in ("yhat", "lower", "upper", "model_code")}))
+        b.close()
+    (s0, r0), (s1, r1) = runs
+    assert s0["total_evals"] == s1["total_evals"]
+    assert s1["total_passes"] < s0["total_passes"]
+    for k in r0:
+        np.testing.assert_array_equal(r0[k], r1[k])
+
+
 def test_device_resident_batch_and_stats(env):
     """Block already in HBM (torch tensor) -> anofox_hip_batch_* -> device results; counters are consistent."""
     import torch
