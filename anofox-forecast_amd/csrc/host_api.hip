@@ -9,6 +9,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <memory>
+#include <unordered_map>
+#include <chrono>
 #include <cmath>
 #include <mutex>
 #include <cstdlib>
@@ -53,11 +56,177 @@ void report_hip_failure(AnofoxError *out_error, const HipFail &f)
 // INTERNAL_ERROR instead of a success with uninitialised forecasts
 constexpr int32_t STATUS_NOT_COMPUTED = -1;
 
-template <class T> T *dalloc(size_t n)
+// Device memory comes from a small caching allocator: a batch of the M5 shape is ~300 hipMalloc calls (25 spec chains x state,
+// maps and two gather blocks) = 380-400 ms to create and 50-65 ms to destroy, as long as its fit on the intermittent batch four
+// times over; a statement that forecasts chunk after chunk of the same shape pays that once.  Blocks are keyed by (device, size
+// rounded to 512 B / 2 MiB) and handed back as they are -- nothing in the library relies on fresh memory being zero.  At most
+// ANOFOX_HIP_CACHE_GB (default: a quarter of the device) stays cached; an out-of-memory hipMalloc empties the cache and retries.
+struct DevCache {
+    std::mutex mu;
+    std::multimap<std::pair<int, size_t>, void *> idle;
+    std::unordered_map<void *, std::pair<int, size_t>> live;
+    size_t idle_bytes = 0, cap = 0;
+    bool cap_known = false;
+};
+DevCache &dev_cache() { static DevCache *c = new DevCache; return *c; }     // never destroyed: no HIP calls at process exit
+
+size_t dev_round(size_t bytes)
 {
+    const size_t g = bytes < (1u << 20) ? 512 : (2u << 20);
+    return (std::max<size_t>(bytes, 1) + g - 1) / g * g;
+}
+
+void *dev_alloc_bytes(size_t bytes)
+{
+    DevCache &c = dev_cache();
+    int dev = 0;
+    HIPCHECK(hipGetDevice(&dev));
+    const size_t sz = dev_round(bytes);
+    {
+        std::lock_guard<std::mutex> lock(c.mu);
+        if (!c.cap_known) {
+            c.cap_known = true;
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) c.cap = total_b / 4;
+            if (const char *e = std::getenv("ANOFOX_HIP_CACHE_GB")) c.cap = (size_t)(std::atof(e) * 1073741824.0);
+        }
+        auto it = c.idle.find({dev, sz});
+        if (it != c.idle.end()) {
+            void *p = it->second;
+            c.idle.erase(it);
+            c.idle_bytes -= sz;
+            c.live[p] = {dev, sz};
+            return p;
+        }
+    }
     void *p = nullptr;
-    HIPCHECK(hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)));
-    return (T *)p;
+    hipError_t err = hipMalloc(&p, sz);
+    if (err == hipErrorOutOfMemory) {
+        (void)hipGetLastError();
+        std::vector<void *> drop;
+        {
+            std::lock_guard<std::mutex> lock(c.mu);
+            for (auto &kv : c.idle) drop.push_back(kv.second);
+            c.idle.clear();
+            c.idle_bytes = 0;
+        }
+        for (void *q : drop) (void)hipFree(q);
+        err = hipMalloc(&p, sz);
+    }
+    HIPCHECK(err);
+    std::lock_guard<std::mutex> lock(c.mu);
+    c.live[p] = {dev, sz};
+    return p;
+}
+
+// `quiesced`: the caller has already waited for every stream that may touch the block (batch destruction); otherwise the device
+// is synchronised first, which is what hipFree does implicitly
+void dev_free(void *p, bool quiesced = false)
+{
+    if (!p) return;
+    if (!quiesced) (void)hipDeviceSynchronize();
+    DevCache &c = dev_cache();
+    {
+        std::lock_guard<std::mutex> lock(c.mu);
+        auto it = c.live.find(p);
+        if (it != c.live.end()) {
+            const std::pair<int, size_t> key = it->second;
+            c.live.erase(it);
+            if (c.idle_bytes + key.second <= c.cap) {
+                c.idle.insert({key, p});
+                c.idle_bytes += key.second;
+                return;
+            }
+        }
+    }
+    (void)hipFree(p);
+}
+
+template <class T> T *dalloc(size_t n) { return (T *)dev_alloc_bytes(std::max<size_t>(n, 1) * sizeof(T)); }
+
+// ... and the pinned staging blocks of the host packer (page-locking 467 MB is ~20 ms, unlocking it ~40 ms): the same scheme,
+// sizes rounded to 2 MiB, at most ANOFOX_HIP_PINNED_CACHE_GB (default 4) kept
+struct PinCache { std::mutex mu; std::multimap<size_t, void *> idle; std::unordered_map<void *, size_t> live; size_t idle_bytes = 0; };
+PinCache &pin_cache() { static PinCache *c = new PinCache; return *c; }
+void *pin_alloc_bytes(size_t bytes)
+{
+    const size_t sz = (std::max<size_t>(bytes, 1) + (2u << 20) - 1) / (2u << 20) * (2u << 20);
+    PinCache &c = pin_cache();
+    {
+        std::lock_guard<std::mutex> lock(c.mu);
+        auto it = c.idle.find(sz);
+        if (it != c.idle.end()) {
+            void *p = it->second;
+            c.idle.erase(it);
+            c.idle_bytes -= sz;
+            c.live[p] = sz;
+            return p;
+        }
+    }
+    void *p = nullptr;
+    HIPCHECK(hipHostMalloc(&p, sz, hipHostMallocDefault));
+    std::lock_guard<std::mutex> lock(c.mu);
+    c.live[p] = sz;
+    return p;
+}
+void pin_free(void *p)
+{
+    if (!p) return;
+    static const size_t cap = [] { const char *e = std::getenv("ANOFOX_HIP_PINNED_CACHE_GB"); return (size_t)((e ? std::atof(e) : 4.0) * 1073741824.0); }();
+    PinCache &c = pin_cache();
+    {
+        std::lock_guard<std::mutex> lock(c.mu);
+        auto it = c.live.find(p);
+        if (it != c.live.end()) {
+            const size_t sz = it->second;
+            c.live.erase(it);
+            if (c.idle_bytes + sz <= cap) { c.idle.insert({sz, p}); c.idle_bytes += sz; return; }
+        }
+    }
+    (void)hipHostFree(p);
+}
+
+// ... and the streams and events of a batch: 33 streams + 37 events are ~10 ms to create, and -- measured -- the streams a
+// process creates FIRST get the better mapping onto the 16 hardware queues: the same 30-spec batch runs in 580 ms on the first
+// batch of a process and in 690-700 ms on every batch created after that one was destroyed (tools/time_run_variants.py).  A
+// batch borrows a set and hands it back (synchronised) when it is destroyed; sets are never destroyed.
+struct StreamSet {
+    int dev = 0;
+    unsigned long id = 0;              // creation order
+    hipStream_t own = nullptr, aux[N_AUX_STREAMS] = {};
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_fit0 = nullptr, ev_fit1 = nullptr, ev_fork = nullptr, ev_join[N_AUX_STREAMS] = {};
+};
+struct StreamPool { std::mutex mu; std::vector<StreamSet *> idle; unsigned long created = 0; };
+StreamPool &stream_pool() { static StreamPool *p = new StreamPool; return *p; }
+StreamSet *stream_set_take()
+{
+    int dev = 0;
+    HIPCHECK(hipGetDevice(&dev));
+    StreamPool &p = stream_pool();
+    {
+        std::lock_guard<std::mutex> lock(p.mu);
+        // the OLDEST idle set of this device first: that is the one with the favourable queue mapping
+        long best = -1;
+        for (size_t i = 0; i < p.idle.size(); i++)
+            if (p.idle[i]->dev == dev && (best < 0 || p.idle[i]->id < p.idle[(size_t)best]->id)) best = (long)i;
+        if (best >= 0) { StreamSet *s = p.idle[(size_t)best]; p.idle.erase(p.idle.begin() + best); return s; }
+    }
+    std::unique_ptr<StreamSet> s(new StreamSet);
+    s->dev = dev;
+    HIPCHECK(hipStreamCreateWithFlags(&s->own, hipStreamNonBlocking));
+    for (auto &q : s->aux) HIPCHECK(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
+    for (hipEvent_t *e : {&s->ev_start, &s->ev_stop, &s->ev_fit0, &s->ev_fit1}) HIPCHECK(hipEventCreate(e));
+    HIPCHECK(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
+    for (auto &e : s->ev_join) HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    { std::lock_guard<std::mutex> lock(p.mu); s->id = p.created++; }
+    return s.release();        // (a set whose creation failed half way leaks its few handles: the process is out of resources anyway)
+}
+void stream_set_give(StreamSet *s)
+{
+    if (!s) return;
+    StreamPool &p = stream_pool();
+    std::lock_guard<std::mutex> lock(p.mu);
+    p.idle.push_back(s);
 }
 
 struct Plan {
@@ -120,7 +289,8 @@ struct AnofoxHipBatch {
     size_t ar_ws_bytes = 0;
     double *ar_w = nullptr, *ar_wmean = nullptr, *ar_wsd = nullptr, *ar_l0 = nullptr, *ar_l1 = nullptr, *ar_x = nullptr, *ar_aicc = nullptr;
     int32_t *ar_wlen = nullptr, *ar_d = nullptr, *ar_D = nullptr, *ar_order = nullptr, *ar_status = nullptr, *ar_evals = nullptr, *ar_passes = nullptr, *ar_models = nullptr;
-    // streams / events
+    // streams / events (borrowed from the process-wide pool: `sset`)
+    StreamSet *sset = nullptr;
     hipStream_t own_stream = nullptr;
     hipStream_t aux[N_AUX_STREAMS] = {};
     hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_fit0 = nullptr, ev_fit1 = nullptr, ev_fork = nullptr;
@@ -301,9 +471,9 @@ int detect_seasonality_first(const double *v, size_t n)
 
 void free_batch_buffers(AnofoxHipBatch *b)
 {
-    auto F = [](void *p) { if (p) (void)hipFree(p); };
+    auto F = [](void *p) { dev_free(p, true); };             // the caller has synchronised the batch's streams
     if (b->owns_y) F(b->d_y);
-    if (b->h_stage) (void)hipHostFree(b->h_stage);
+    pin_free(b->h_stage);
     if (b->owns_len) F(b->d_len);
     F(b->d_mean); F(b->d_sd); F(b->d_fig_add); F(b->d_fig_mul); F(b->d_l0); F(b->d_b0); F(b->d_flags);
     F(b->d_aicc); F(b->d_yhat_slots); F(b->d_status_slots); F(b->d_evals_slots); F(b->d_iters_slots);
@@ -313,10 +483,12 @@ void free_batch_buffers(AnofoxHipBatch *b)
     F(b->d_passes_total); F(b->d_evals_total); F(b->d_mask); F(b->d_len_group); F(b->d_count); F(b->d_pos_map); F(b->d_pos_cnt); F(b->d_notpos); F(b->d_ypos);
     F(b->ar_w); F(b->ar_wmean); F(b->ar_wsd); F(b->ar_l0); F(b->ar_l1); F(b->ar_x); F(b->ar_aicc); F(b->ar_wlen); F(b->ar_d); F(b->ar_D);
     F(b->ar_order); F(b->ar_status); F(b->ar_evals); F(b->ar_passes); F(b->ar_models);
-    if (b->own_stream) (void)hipStreamDestroy(b->own_stream);
-    for (auto &s : b->aux) if (s) (void)hipStreamDestroy(s);
-    for (hipEvent_t e : {b->ev_start, b->ev_stop, b->ev_fit0, b->ev_fit1, b->ev_fork}) if (e) (void)hipEventDestroy(e);
-    for (auto &e : b->ev_join) if (e) (void)hipEventDestroy(e);
+    if (b->sset) {
+        // the caller has synchronised the set's streams (or nothing was ever launched on them)
+        stream_set_give(b->sset);
+        b->sset = nullptr; b->own_stream = nullptr;
+        for (auto &s : b->aux) s = nullptr;
+    }
     for (auto &l : b->lanes) {
         F(l.ybuf); F(l.ybuf2); F(l.map[0]); F(l.map[1]); F(l.cnt);
         F(l.st.sim); F(l.st.fs); F(l.st.phase); F(l.st.evals); F(l.st.iters); F(l.st.passes); F(l.st.done);
@@ -396,18 +568,18 @@ void alloc_common(AnofoxHipBatch *b)
             l.st.done = dalloc<int32_t>(ld);
         }
     }
-    HIPCHECK(hipStreamCreateWithFlags(&b->own_stream, hipStreamNonBlocking));
-    for (auto &s : b->aux) HIPCHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-    for (hipEvent_t *e : {&b->ev_start, &b->ev_stop, &b->ev_fit0, &b->ev_fit1}) HIPCHECK(hipEventCreate(e));
-    HIPCHECK(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
-    for (auto &e : b->ev_join) HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    b->sset = stream_set_take();
+    b->own_stream = b->sset->own;
+    for (int i = 0; i < N_AUX_STREAMS; i++) { b->aux[i] = b->sset->aux[i]; b->ev_join[i] = b->sset->ev_join[i]; }
+    b->ev_start = b->sset->ev_start; b->ev_stop = b->sset->ev_stop; b->ev_fit0 = b->sset->ev_fit0; b->ev_fit1 = b->sset->ev_fit1;
+    b->ev_fork = b->sset->ev_fork;
 }
 
 void ensure_fig(AnofoxHipBatch *b, int m)
 {
     if (m <= b->fig_m) return;
-    if (b->d_fig_add) (void)hipFree(b->d_fig_add);
-    if (b->d_fig_mul) (void)hipFree(b->d_fig_mul);
+    dev_free(b->d_fig_add);
+    dev_free(b->d_fig_mul);
     b->d_fig_add = dalloc<double>((size_t)m * b->ld);
     b->d_fig_mul = dalloc<double>((size_t)m * b->ld);
     b->fig_m = m;
@@ -417,7 +589,7 @@ void ensure_fig(AnofoxHipBatch *b, int m)
 double *ensure_ring(AnofoxHipBatch *b, size_t elems)
 {
     if (b->ring_elems < elems) {
-        if (b->d_ring) (void)hipFree(b->d_ring);
+        dev_free(b->d_ring);
         b->d_ring = nullptr; b->ring_elems = 0;
         b->d_ring = dalloc<double>(elems);
         b->ring_elems = elems;
@@ -427,7 +599,7 @@ double *ensure_ring(AnofoxHipBatch *b, size_t elems)
 double *ensure_prep_scratch(AnofoxHipBatch *b, size_t elems)
 {
     if (b->prep_scratch_elems < elems) {
-        if (b->d_prep_scratch) (void)hipFree(b->d_prep_scratch);
+        dev_free(b->d_prep_scratch);
         b->d_prep_scratch = nullptr; b->prep_scratch_elems = 0;
         b->d_prep_scratch = dalloc<double>(elems);
         b->prep_scratch_elems = elems;
@@ -603,7 +775,7 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
         const size_t T = std::max<size_t>(b->t_max, 1);
         const size_t tw = (T + 1) / 2 * 2 + 64;
         if (!b->d_ys || b->pool_tw != tw) {
-            if (b->d_ys) (void)hipFree(b->d_ys);
+            dev_free(b->d_ys);
             b->d_ys = nullptr;
             b->d_ys = dalloc<double>((n + 1) * tw);
             HIPCHECK(hipMemsetAsync(b->d_ys, 0, (n + 1) * tw * sizeof(double), st));
@@ -1328,9 +1500,9 @@ bool anofox_hip_batch_pack_host(AnofoxHipBatch *b, const double *const *values, 
         // 64 series (one 512-byte row segment of the time-major block) per tile, straight into a pinned staging block that
         // is allocated once per batch, so the H2D copy that follows is a single DMA at link speed.
         if (b->h_stage_elems < T * ld) {
-            if (b->h_stage) (void)hipHostFree(b->h_stage);
+            pin_free(b->h_stage);
             b->h_stage = nullptr; b->h_stage_elems = 0;
-            HIPCHECK(hipHostMalloc((void **)&b->h_stage, T * ld * sizeof(double), hipHostMallocDefault));
+            b->h_stage = (double *)pin_alloc_bytes(T * ld * sizeof(double));
             b->h_stage_elems = T * ld;
         }
         double *block = b->h_stage;
@@ -1411,7 +1583,7 @@ bool anofox_hip_batch_set_device_block(AnofoxHipBatch *b, const void *d_y, size_
         return false;
     }
     try {
-        if (b->owns_y && b->d_y) { (void)hipFree(b->d_y); }
+        if (b->owns_y && b->d_y) { dev_free(b->d_y); }
         b->d_y = (double *)d_y;
         b->owns_y = false;
         b->h_len.assign(b->n, 0);
@@ -1625,7 +1797,7 @@ bool anofox_hip_batch_inspect(AnofoxHipBatch *b, AnofoxHipInspection *out, doubl
             HIPCHECK(hipMemcpy(info.data(), d_info, 8 * ld * sizeof(double), hipMemcpyDeviceToHost));
             HIPCHECK(hipMemcpy(states.data(), d_states, rows * ld * sizeof(double), hipMemcpyDeviceToHost));
             if (fitted) { fit.resize(T * ld); HIPCHECK(hipMemcpy(fit.data(), d_fit, T * ld * sizeof(double), hipMemcpyDeviceToHost)); }
-            (void)hipFree(d_fit); (void)hipFree(d_states); (void)hipFree(d_info);
+            dev_free(d_fit, true); dev_free(d_states, true); dev_free(d_info, true);       // the stream was synchronised above
             for (size_t s = 0; s < n; s++) {
                 AnofoxHipInspection &o = out[s];
                 o.alpha = info[0 * ld + s]; o.beta = info[1 * ld + s]; o.gamma = info[2 * ld + s]; o.phi = info[3 * ld + s];
@@ -1673,6 +1845,7 @@ static bool forecast_batch_uniform(const double *const *values, const uint64_t *
     for (size_t s = 0; s < n_series; s++) t_max = std::max(t_max, lengths[s]);
     AnofoxHipBatch *b = nullptr;
     AnofoxError e;
+    const auto t0 = std::chrono::steady_clock::now();
     if (!anofox_hip_batch_create(n_series, t_max, &opt, &b, &e)) {
         if (e.code == INVALID_INPUT) {
             // an option block the core rejects (seasonal_period on a non-seasonal model, bad ETS notation or pool) is a
@@ -1691,8 +1864,15 @@ static bool forecast_batch_uniform(const double *const *values, const uint64_t *
         if (out_errors) for (size_t s = 0; s < n_series; s++) out_errors[s] = e;
         return false;
     }
-    bool ok = anofox_hip_batch_pack_host(b, values, validity, lengths, &e) && anofox_hip_batch_run(b, nullptr, &e) &&
-              anofox_hip_batch_fetch(b, out_results, out_errors);
+    static const bool timing = std::getenv("ANOFOX_HIP_TIMING") != nullptr;     // phase times of the batch entry on stderr
+    const auto t1 = std::chrono::steady_clock::now();
+    bool ok = anofox_hip_batch_pack_host(b, values, validity, lengths, &e);
+    const auto t2 = std::chrono::steady_clock::now();
+    ok = ok && anofox_hip_batch_run(b, nullptr, &e);
+    if (ok && timing) (void)hipStreamSynchronize(b->last_stream);
+    const auto t3 = std::chrono::steady_clock::now();
+    ok = ok && anofox_hip_batch_fetch(b, out_results, out_errors);
+    const auto t4 = std::chrono::steady_clock::now();
     if (!ok) {
         if (e.code == SUCCESS) set_error(&e, INTERNAL_ERROR, "Internal error: device batch failed");
         if (out_batch_error) *out_batch_error = e;
@@ -1708,6 +1888,11 @@ static bool forecast_batch_uniform(const double *const *values, const uint64_t *
             }
     }
     anofox_hip_batch_destroy(b);
+    if (timing) {
+        auto ms = [](auto a, auto z) { return std::chrono::duration<double, std::milli>(z - a).count(); };
+        std::fprintf(stderr, "[anofox-hip] batch of %zu: create %.1f ms, pack + H2D %.1f ms, run %.1f ms, fetch %.1f ms, destroy %.1f ms\n", n_series,
+                     ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), ms(t4, std::chrono::steady_clock::now()));
+    }
     return ok;
 }
 
