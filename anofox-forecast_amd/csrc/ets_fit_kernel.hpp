@@ -62,7 +62,7 @@ __global__ __launch_bounds__(NM_BLOCK, ANOFOX_ROUND_WAVES) void ets_round_kernel
     }
 
     SeriesView v;
-    const bool gathered = a.gathered && n_act > a.gather_min;      // below the threshold the gather kernel did nothing
+    const bool gathered = a.gathered && n_act > a.gather_min && n_act <= a.gather_max;      // outside, the gather kernel did nothing
     v.col = valid ? (gathered ? p : s) : 0;
     v.yb = gathered ? a.y_round : a.y;
     v.y = v.yb + v.col;

@@ -311,6 +311,9 @@ struct AnofoxHipBatch {
     int seq_rounds_env = -1; // ANOFOX_HIP_SEQ_ROUNDS override (-1 = decide from the number of live problems)
     bool fused = false;      // ANOFOX_HIP_FUSED=1: compaction + gather fused into the end of every round kernel (measured 3-8 % slower
                              // than the separate kernels: the gaps between a spec's rounds are queueing, not those kernels)
+    double gather_max_frac = 1.0;    // per spec: no gather while more than this share of the series is still running (1.0 = always gather:
+                                     // tools/gather_sweep.sh, 1.0 / 0.9 / 0.75 / 0.5 / 0.25 -> 85.6 / 85.9 / 86.5 / 88.5 / 94.7 ms on the intermittent
+                                     // M5 batch, 150 / 152 / 159 / 184 / 233 ms on the stress batch: the gather pays at every count)
     int gather_min = 0;      // per spec: stop gathering columns once this few problems are still running (measured: the gather pays at every count, 0 = always gather)
     int tail_below = 0;      // per spec: run the remaining problems to completion once this few are left (measured: rounds + compaction win at every threshold, 0 = off)
     int spec_below_md = 8192; // same, for the damped multiplicative-trend specs (their pass is ~10x longer: the stragglers matter more)
@@ -992,7 +995,8 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
             a.first_round = (r == 0);
             a.spec_below = -1; a.spec2_below = -1;
             a.tail_below = (r == 0) ? 0 : b->tail_below;
-            a.gathered = 0;
+            a.gathered = 0; a.gather_min = 0; a.gather_max = 0x7fffffff;
+            const int gather_max = b->gather_max_frac >= 1.0 ? 0x7fffffff : (int)(b->gather_max_frac * (double)n);
             if (r == 0 && b->use_pos && a.need_positive) {
                 // mixed batch: this spec is admissible for the strictly positive series only -- its first round runs on
                 // their dense list (built once per group) instead of sweeping every wave for a few live lanes
@@ -1006,7 +1010,7 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
             } else if (b->fused) {
                 // the previous round left its unfinished problems, densely, in map / ybuf [r & 1] with their count in cnt[r % 3]
                 a.series_of = lane.map[r & 1]; a.n_active = lane.cnt + (r % 3);
-                a.y_round = (r & 1) ? lane.ybuf2 : lane.ybuf; a.ld_round = ld; a.gathered = 1; a.gather_min = 0;
+                a.y_round = (r & 1) ? lane.ybuf2 : lane.ybuf; a.ld_round = ld; a.gathered = 1; a.gather_min = 0; a.gather_max = 0x7fffffff;
             } else {
                 const int32_t *prev_map = (r == 1) ? nullptr : lane.map[(r - 1) & 1];
                 const int32_t *prev_cnt = (r == 1) ? nullptr : lane.cnt + ((r - 1) % 3);
@@ -1014,8 +1018,8 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
                 launch_compact(prev_map, prev_cnt, (int)n, lane.st.done, lane.map[r & 1], lane.cnt + (r % 3), sq, lane.cnt + ((r + 1) % 3));
                 a.series_of = lane.map[r & 1]; a.n_active = lane.cnt + (r % 3);
                 if (b->use_gather && lane.ybuf) {
-                    launch_gather_columns(b->d_y, ld, lane.map[r & 1], lane.cnt + (r % 3), (int)n, (int)b->t_max, lane.ybuf, ld, sq, b->gather_min);
-                    a.y_round = lane.ybuf; a.ld_round = ld; a.gathered = 1; a.gather_min = b->gather_min;
+                    launch_gather_columns(b->d_y, ld, lane.map[r & 1], lane.cnt + (r % 3), (int)n, (int)b->t_max, lane.ybuf, ld, sq, b->gather_min, gather_max);
+                    a.y_round = lane.ybuf; a.ld_round = ld; a.gathered = 1; a.gather_min = b->gather_min; a.gather_max = gather_max;
                 } else {
                     a.y_round = b->d_y; a.ld_round = ld;
                 }
@@ -1193,7 +1197,8 @@ void run_group(AnofoxHipBatch *b, int period, const int32_t *d_len, hipStream_t 
             size_t n_add = 0;
             for (int id : specs) if (!spec_has_mult(id)) n_add++;
             const double live = (double)cnt[0] * (double)specs.size() + (double)(cnt[1] - cnt[0]) * (double)n_add;
-            b->seq_rounds = live >= 8.0 * 65536.0 ? 4 : 0;    // >= 8 problems per SIMD lane-slot: VALU-bound, go sequential
+            static const double seq_live = [] { const char *e = std::getenv("ANOFOX_HIP_SEQ_LIVE"); return e ? std::atof(e) : 8.0 * 65536.0; }();
+            b->seq_rounds = live >= seq_live ? 4 : 0;         // >= 8 problems per SIMD lane-slot: VALU-bound, go sequential
             b->use_pos = cnt[0] > 0 && (double)cnt[0] < 0.7 * (double)cnt[1];
             b->live_pos = cnt[0]; b->live_all = cnt[1];
         } else {
@@ -1421,6 +1426,7 @@ bool anofox_hip_batch_create(size_t n_series, size_t t_max, const ForecastOption
         if (const char *e = std::getenv("ANOFOX_HIP_SPEC2_BELOW_MD")) b->spec2_below_md = std::atoi(e);
         if (const char *e = std::getenv("ANOFOX_HIP_TAIL_BELOW")) b->tail_below = std::atoi(e);
         if (const char *e = std::getenv("ANOFOX_HIP_GATHER_MIN")) b->gather_min = std::atoi(e);
+        if (const char *e = std::getenv("ANOFOX_HIP_GATHER_MAX_FRAC")) b->gather_max_frac = std::atof(e);
         if (const char *e = std::getenv("ANOFOX_HIP_FUSED")) b->fused = std::atoi(e) != 0;
         if (!b->use_gather) b->fused = false;
         if (const char *e = std::getenv("ANOFOX_HIP_ARIMA_ML")) b->arima_ml = std::atoi(e) != 0;

@@ -331,10 +331,11 @@ void launch_compact(const int32_t *series_prev, const int32_t *n_prev, int n_ser
 // ------------------------------------------------------------------------------------------
 constexpr int GATHER_TB = 32;
 __global__ __launch_bounds__(NM_BLOCK) void gather_columns_kernel(const double *y, size_t ld, const int32_t *series_of,
-                                                                  const int32_t *n_active, int t_max, double *out, size_t ld_out, int min_active)
+                                                                  const int32_t *n_active, int t_max, double *out, size_t ld_out, int min_active, int max_active)
 {
     const int n_act = *n_active;
-    if ((int)blockIdx.x * NM_BLOCK >= n_act || n_act <= min_active) return;     // few problems left: the round reads y in place
+    // few problems left, or nearly all of them (the block is still dense): the round reads y in place
+    if ((int)blockIdx.x * NM_BLOCK >= n_act || n_act <= min_active || n_act > max_active) return;
     const int p = blockIdx.x * NM_BLOCK + threadIdx.x;
     const int s = series_of[p < n_act ? p : n_act - 1];
     const int t0 = blockIdx.y * GATHER_TB;
@@ -343,10 +344,10 @@ __global__ __launch_bounds__(NM_BLOCK) void gather_columns_kernel(const double *
 }
 
 void launch_gather_columns(const double *y, size_t ld, const int32_t *series_of, const int32_t *n_active, int n_series,
-                           int t_max, double *out, size_t ld_out, hipStream_t stream, int min_active)
+                           int t_max, double *out, size_t ld_out, hipStream_t stream, int min_active, int max_active)
 {
     dim3 grid((n_series + NM_BLOCK - 1) / NM_BLOCK, (t_max + GATHER_TB - 1) / GATHER_TB);
-    hipLaunchKernelGGL(gather_columns_kernel, grid, dim3(NM_BLOCK), 0, stream, y, ld, series_of, n_active, t_max, out, ld_out, min_active);
+    hipLaunchKernelGGL(gather_columns_kernel, grid, dim3(NM_BLOCK), 0, stream, y, ld, series_of, n_active, t_max, out, ld_out, min_active, max_active);
 }
 
 } // namespace anofox

@@ -55,6 +55,7 @@ struct FitArgs {
     int spec2_below;             // ... and the one-problem-per-wave driver (two iterations per pass) iff n_active <= spec2_below
     int tail_below;              // run to completion once this few problems are still running (0 = never)
     int gather_min;              // the gather (and the gathered view) only applies while more than this many problems run
+    int gather_max;              // ... and no more than this many (nearly all still running: the block is dense as it is)
     int gathered;                // y_round holds the running problems' columns densely (column p), else index by series
     // fused compaction + gather at the end of a round (NULL: the host runs compact / gather kernels instead)
     int32_t *next_map, *next_cnt, *clear_cnt;
@@ -179,7 +180,7 @@ void launch_compact(const int32_t *series_prev, const int32_t *n_prev, int n_ser
 // series-major copy of the time-major block for the work-pool kernels: ys[s * tw + t] = y[t * ld + s], t < t_rows
 void launch_transpose_rows(const double *y, size_t ld, int n_series, int t_rows, double *ys, size_t tw, hipStream_t);
 void launch_gather_columns(const double *y, size_t ld, const int32_t *series_of, const int32_t *n_active, int n_series,
-                           int t_max, double *out, size_t ld_out, hipStream_t, int min_active = 0);
+                           int t_max, double *out, size_t ld_out, hipStream_t, int min_active = 0, int max_active = 0x7fffffff);
 
 // AutoARIMA (arima.hip): prep (D, d, differenced block), stepwise CSS search (advance / fit sweeps), forecast + integration
 struct ArimaArgs {
