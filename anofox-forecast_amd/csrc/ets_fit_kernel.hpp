@@ -22,19 +22,24 @@ namespace anofox {
 // SPEC = 0: sequential Nelder-Mead, one lane per problem (64 problems per wave)
 // SPEC = 1: speculative, the four trial points of a problem in four adjacent lanes (16 problems per wave)
 // SPEC = 2: two-level speculative, two iterations per pass, one problem per wave (the last problems of a spec)
+// SPEC = 3: all three in one kernel, picked from the device-side count of running problems -- ONE launch per round and spec:
+//           a launch whose workgroups only find out that another driver owns the round still has to be dispatched, and on a
+//           saturated chip that stalls the spec's chain for milliseconds (6 ms measured for 1,024 empty workgroups)
 template <class Cfg, int MS, int SPEC>
 __global__ __launch_bounds__(NM_BLOCK, ANOFOX_ROUND_WAVES) void ets_round_kernel(const FitArgs a)
 {
     extern __shared__ double lds[];
     constexpr int D = Cfg::DIM;
-    constexpr int LPP = SPEC == 0 ? 1 : (SPEC == 1 ? NM_K : NM_BLOCK);   // lanes per problem
-    constexpr int PPB = NM_BLOCK / LPP;          // problems per workgroup
     const int lane = threadIdx.x;
     const int n_act = a.n_active ? *a.n_active : a.n_series;
-    if (a.spec_below >= 0) {                                                // another driver may own this round
+    int mode = SPEC;
+    if constexpr (SPEC == 3) mode = n_act > a.spec_below ? 0 : ((a.spec2_below > 0 && n_act <= a.spec2_below && n_act <= (int)gridDim.x) ? 2 : 1);
+    else if (a.spec_below >= 0) {                                           // another driver may own this round
         const int owner = n_act > a.spec_below ? 0 : (n_act > a.spec2_below ? 1 : 2);
         if (owner != SPEC) return;
     }
+    const int LPP = mode == 0 ? 1 : (mode == 1 ? NM_K : NM_BLOCK);         // lanes per problem (a constant unless SPEC == 3)
+    const int PPB = NM_BLOCK / LPP;                                         // problems per workgroup
     // fused compaction: this round appends its unfinished problems to the next round's list; the counter of the round
     // after that is cleared here (three counters rotate), by the round's owner even when nothing is left to run
     if (a.clear_cnt && blockIdx.x == 0 && lane == 0) *a.clear_cnt = 0;
@@ -102,8 +107,12 @@ __global__ __launch_bounds__(NM_BLOCK, ANOFOX_ROUND_WAVES) void ets_round_kernel
 
     // few problems left (they no longer fill the chip): run them to completion now instead of paying a compaction +
     // gather + launch gap per remaining round -- the later rounds then find nothing to do
-    const int budget = (n_act <= a.tail_below || SPEC == 2) ? (1 << 30) : a.budget;
-    if constexpr (SPEC == 2) nm_advance_spec2(mdl, lds, r, budget);
+    const int budget = (n_act <= a.tail_below || mode == 2) ? (1 << 30) : ((SPEC == 3 && mode == 0) ? a.budget_seq : a.budget);
+    if constexpr (SPEC == 3) {
+        if (mode == 2) nm_advance_spec2(mdl, lds, r, budget);
+        else if (mode == 1) nm_advance_spec(mdl, lds, r, budget);
+        else nm_advance_seq(mdl, lds, r, budget);
+    } else if constexpr (SPEC == 2) nm_advance_spec2(mdl, lds, r, budget);
     else if constexpr (SPEC == 1) nm_advance_spec(mdl, lds, r, budget);
     else nm_advance_seq(mdl, lds, r, budget);
 
@@ -134,7 +143,7 @@ __global__ __launch_bounds__(NM_BLOCK, ANOFOX_ROUND_WAVES) void ets_round_kernel
             if (lane == 0) base = atomicAdd(a.next_cnt, cnt);
             base = __shfl(base, 0);
             int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
-            if constexpr (SPEC != 0) pos = __shfl(pos, lane & ~(LPP - 1));
+            if (LPP != 1) pos = __shfl(pos, lane & ~(LPP - 1));
             if (lead) a.next_map[pos] = s;
             if (push && a.next_y) {
                 const double *src = v.y;
@@ -235,9 +244,20 @@ template <class Cfg, int MS, int SPEC>
 void ets_round_launch(const FitArgs &a, hipStream_t stream)
 {
     constexpr int PPB = SPEC == 0 ? NM_BLOCK : (SPEC == 1 ? NM_BLOCK / NM_K : 1);
-    // the one-problem-per-wave driver only ever owns a round with <= spec2_below running problems
-    const int n_max = (SPEC == 2 && a.spec_below >= 0 && a.spec2_below < a.n_series) ? a.spec2_below : a.n_series;
-    const int grid = (n_max + PPB - 1) / PPB;
+    int grid;
+    if (SPEC == 3) {
+        // enough workgroups for whichever driver the count picks: sequential for any count, four lanes per problem up to
+        // spec_below problems, one wave per problem up to spec2_below
+        const int n = a.n_series;
+        const int g_seq = (n + NM_BLOCK - 1) / NM_BLOCK;
+        const int g_spec = (std::min(n, std::max(a.spec_below, 0)) + NM_BLOCK / NM_K - 1) / (NM_BLOCK / NM_K);
+        const int g_spec2 = std::min(n, std::max(a.spec2_below, 0));
+        grid = std::max(g_seq, std::max(g_spec, g_spec2));
+    } else {
+        // the one-problem-per-wave driver only ever owns a round with <= spec2_below running problems
+        const int n_max = (SPEC == 2 && a.spec_below >= 0 && a.spec2_below < a.n_series) ? a.spec2_below : a.n_series;
+        grid = (n_max + PPB - 1) / PPB;
+    }
     if (grid <= 0) return;
     size_t lds_bytes = sizeof(double) * (size_t)nm_lds_doubles<Cfg::DIM>();
     if (MS == -1) lds_bytes += sizeof(double) * (size_t)a.m * NM_BLOCK;

@@ -19,7 +19,8 @@ template <int ID> struct SpecOf {
 template <int ID, int MS> FitLaunchers launchers_of()
 {
     return FitLaunchers{&ets_round_launch<typename SpecOf<ID>::Cfg, MS, 0>, &ets_round_launch<typename SpecOf<ID>::Cfg, MS, 1>,
-                        &ets_round_launch<typename SpecOf<ID>::Cfg, MS, 2>, &ets_final_launch<typename SpecOf<ID>::Cfg, MS>};
+                        &ets_round_launch<typename SpecOf<ID>::Cfg, MS, 2>, &ets_round_launch<typename SpecOf<ID>::Cfg, MS, 3>,
+                        &ets_final_launch<typename SpecOf<ID>::Cfg, MS>};
 }
 
 // one spec of the unit's work-pool kernel: the FitArgs view of the by-value arguments, then the spec's pool loop

@@ -317,6 +317,7 @@ struct AnofoxHipBatch {
     int gather_min = 0;      // per spec: stop gathering columns once this few problems are still running (measured: the gather pays at every count, 0 = always gather)
     int tail_below = 0;      // per spec: run the remaining problems to completion once this few are left (measured: rounds + compaction win at every threshold, 0 = off)
     int spec_below_md = 8192; // same, for the damped multiplicative-trend specs (their pass is ~10x longer: the stragglers matter more)
+    bool one_launch = true;    // the three Nelder-Mead drivers of a later round in ONE kernel (ANOFOX_HIP_ONE_LAUNCH=0: one launch each, two of them empty)
     int spec2_below_md = 2048; // per spec: the last problems run one per wave, two iterations per pass (0 = never); damped multiplicative
                                // trend.  Measured on the 30-spec M5 batch (tools/spec2_sweep.sh): 0 / 256 / 1024 / 2048 / 4096 / 8192 -> 579 / 575 / 565 / 562 / 594 / 736 ms
     int spec2_below = 1024;    // same, other specs (single-spec ETS(A,A,A) fit: 22.5 -> 18.2 ms; all specs at 2048 / 4096: 588 / 673 ms)
@@ -853,7 +854,7 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
         a.st = lane.st;
         a.ring_scratch = nullptr;
         fns[oi] = ets_fit_launcher(id, a.m);
-        if (!fns[oi].round_seq || !fns[oi].round_spec || !fns[oi].final) throw HipFail{"no kernel for ETS spec id " + std::to_string(id)};
+        if (!fns[oi].round_seq || !fns[oi].round_spec || !fns[oi].round_auto || !fns[oi].final) throw HipFail{"no kernel for ETS spec id " + std::to_string(id)};
     }
     // Periods above the LDS limit keep the seasonal ring of every lane in HBM: one area per (spec, workgroup of the widest
     // launch = the speculative driver's 16 problems per workgroup)
@@ -1035,23 +1036,29 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
                 // first round (no device count yet) or a forced schedule: the host picks the driver
                 a.budget = spec_mode ? BUDGET[r] : (BUDGET[r] * 7) / 4;     // ~1.7 passes per iteration when sequential
                 if (spec_mode && r > 0 && s2 > 0) {
-                    // ... but the last s2 problems still go one per wave (device-side count)
-                    a.spec_below = 0x7fffffff; a.spec2_below = s2;
-                    fns[oi].round_spec(a, sq);
-                    fns[oi].round_spec2(a, sq);
+                    // ... but the last s2 problems still go one per wave (device-side count), in the same launch
+                    a.spec_below = 0x7fffffff; a.spec2_below = s2; a.budget_seq = a.budget;
+                    if (b->one_launch) fns[oi].round_auto(a, sq);
+                    else { fns[oi].round_spec(a, sq); fns[oi].round_spec2(a, sq); }
                 } else
                     (spec_mode ? fns[oi].round_spec : fns[oi].round_seq)(a, sq);
             } else {
-                // later rounds: enqueue all drivers, the device-side count of running problems picks one --
-                // sequential (least arithmetic) while this spec still fills >= 1/8 of the chip, then speculative (one pass
-                // per iteration), then two-level speculative (one problem per wave, two iterations per pass)
+                // later rounds: the device-side count of running problems picks the driver -- sequential (least arithmetic)
+                // while this spec still fills >= 1/8 of the chip, then speculative (one pass per iteration), then two-level
+                // speculative (one problem per wave, two iterations per pass)
                 a.spec_below = (spec_trend_idx(specs[order[oi]]) == 4) ? b->spec_below_md : b->spec_below;
                 a.spec2_below = s2 > 0 ? s2 : -1;
-                a.budget = (BUDGET[r] * 7) / 4;
-                fns[oi].round_seq(a, sq);
-                a.budget = BUDGET[r];
-                fns[oi].round_spec(a, sq);
-                if (s2 > 0) fns[oi].round_spec2(a, sq);
+                a.budget_seq = (BUDGET[r] * 7) / 4;
+                if (b->one_launch) {
+                    a.budget = BUDGET[r];
+                    fns[oi].round_auto(a, sq);
+                } else {
+                    a.budget = a.budget_seq;
+                    fns[oi].round_seq(a, sq);
+                    a.budget = BUDGET[r];
+                    fns[oi].round_spec(a, sq);
+                    if (s2 > 0) fns[oi].round_spec2(a, sq);
+                }
             }
             b->fit_launches++;
         }
@@ -1424,6 +1431,7 @@ bool anofox_hip_batch_create(size_t n_series, size_t t_max, const ForecastOption
         if (const char *e = std::getenv("ANOFOX_HIP_SPEC_BELOW_MD")) b->spec_below_md = std::atoi(e);
         if (const char *e = std::getenv("ANOFOX_HIP_SPEC2_BELOW")) b->spec2_below = b->spec2_below_md = std::atoi(e);
         if (const char *e = std::getenv("ANOFOX_HIP_SPEC2_BELOW_MD")) b->spec2_below_md = std::atoi(e);
+        if (const char *e = std::getenv("ANOFOX_HIP_ONE_LAUNCH")) b->one_launch = std::atoi(e) != 0;
         if (const char *e = std::getenv("ANOFOX_HIP_TAIL_BELOW")) b->tail_below = std::atoi(e);
         if (const char *e = std::getenv("ANOFOX_HIP_GATHER_MIN")) b->gather_min = std::atoi(e);
         if (const char *e = std::getenv("ANOFOX_HIP_GATHER_MAX_FRAC")) b->gather_max_frac = std::atof(e);

@@ -52,6 +52,7 @@ struct FitArgs {
     int budget, first_round;
     int spec_below;              // device-side driver choice: the speculative kernel runs iff n_active <= spec_below,
                                  // the sequential one iff n_active > spec_below (both are enqueued; -1 = unconditional)
+    int budget_seq;              // passes per round when the device-side choice (round_auto) lands on the sequential driver
     int spec2_below;             // ... and the one-problem-per-wave driver (two iterations per pass) iff n_active <= spec2_below
     int tail_below;              // run to completion once this few problems are still running (0 = never)
     int gather_min;              // the gather (and the gathered view) only applies while more than this many problems run
@@ -140,7 +141,7 @@ struct IntervalArgs {
 // ETS fit kernels, one per (spec id, ring variant).  ring: 0 = none / VGPR ring for the
 // compile-time period given, -1 = LDS ring.  Returns NULL when not instantiated.
 typedef void (*FitLaunchFn)(const FitArgs &, hipStream_t);
-struct FitLaunchers { FitLaunchFn round_seq, round_spec, round_spec2, final; };   // sequential / speculative / two-level speculative rounds, final pass
+struct FitLaunchers { FitLaunchFn round_seq, round_spec, round_spec2, round_auto, final; };   // sequential / speculative / two-level speculative rounds, all three behind a device-side choice, final pass
 FitLaunchers ets_fit_launcher(int spec_id, int m);
 
 // Work-pool schedule (ets_pool_kernel.hpp): ONE persistent kernel per compile unit serves the unit's candidate specs in
