@@ -205,7 +205,7 @@ def main():
         fit_ms_avg = float(np.mean(fit_ms))
         achieved = float(np.mean(alg_bytes)) / (fit_ms_avg * 1e-3) / 1e9 if fit_ms_avg > 0 else 0.0
         if model == "AutoARIMA":
-            kernel = "arima_fit_kernel + arima_fit_spec_kernel (all sweeps of one step)"
+            kernel = "arima_fit_kernel + arima_fit_spec_kernel + arima_refit_kernel (all sweeps of one step and the exact-likelihood refit)"
         elif wl["fixed"]:
             kernel = "ets_final_kernel<spec,period> (one streamed pass per series)"
         else:
@@ -215,6 +215,10 @@ def main():
             "value": round(value, 1), "unit": "series/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
+            # what the results are checked against: the oracle restates the published algorithms and reproduces every known answer the
+            # reference's SQL tests hold EXCEPT AutoARIMA's (18.000000 against 18.014537)
+            "parity": ("bit-identical to oracle/ (restatement; AutoARIMA known answer of the reference NOT reproduced: unpinned)" if model == "AutoARIMA"
+                       else "bit-identical to oracle/ (restatement pinned on the reference's known answers; crate-internal arithmetic unpinned)"),
             "config": {"workload": args.workload, "model": model + (f"({ets_model})" if ets_model else ""),
                        "fixed_params": list(wl["fixed"]) if wl["fixed"] else None,
                        "series_total": n_total, "series_per_gpu": n, "T": T, "horizon": h, "seasonal_period": m, "positive": positive,
