@@ -283,7 +283,7 @@ def forecast_batch(series, opts, valids=None, horizons=None):
              "message": (errors[i].message if ok else berr.message).decode(errors="replace")}
         if d["ok"]:
             d.update(_result_dict(results[i], len(arrs[i])))
-            L.anofox_free_forecast_result(C.byref(results[i]))
+        L.anofox_free_forecast_result(C.byref(results[i]))      # every result, also on failure paths (NULL arrays are fine)
         out.append(d)
     return out, {"ok": bool(ok), "code": int(berr.code), "message": berr.message.decode(errors="replace")}
 

@@ -2043,6 +2043,7 @@ bool anofox_ts_forecast_batch(const double *const *values, const uint64_t *const
                                 anofox_hip_batch_run(wb, nullptr, &be) && anofox_hip_batch_fetch(wb, res.data(), errs.data());
                 if (!ok) {
                     if (be.code == SUCCESS) set_error(&be, INTERNAL_ERROR, "Internal error: device batch failed");
+                    for (size_t j = 0; j < cap; j++) anofox_free_forecast_result(&res[j]);      // whatever the fetch had allocated
                     std::lock_guard<std::mutex> lock(err_mu);
                     if (all_ok) first_err = be;
                     all_ok = false;

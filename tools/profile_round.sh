@@ -24,6 +24,12 @@ done
 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_INSTS_SALU SQ_INSTS_LDS --kernel-trace -d $OUT/pmc_SQ_INSTS -o p -- python3 /root/repo/bench.py --steps 1 --warmup 0 --cpu-sample 0 --e2e-steps 0 > $OUT/pmc_SQ_INSTS.log 2>&1
 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY --kernel-trace -d $OUT/pmc_SQ_CYCLES -o p -- python3 /root/repo/bench.py --steps 1 --warmup 0 --cpu-sample 0 --e2e-steps 0 > $OUT/pmc_SQ_CYCLES.log 2>&1
 python3 /root/repo/tools/summarize_profiles.py $OUT
+# occupancy picture of the default line and the intermittent batch: per-spec start / end / busy time and the number of round
+# kernels in flight per 25 ms window
+for t in trace_autoets_positive trace_autoets_m5; do
+  db=$(find $OUT/$t -name "*.db" | head -1)
+  [ -n "$db" ] && python3 /root/repo/tools/timeline.py $db > $OUT/timeline_${t#trace_}.txt 2>&1
+done
 # only the summaries travel back (gpurun merges at most 64 MiB): drop the rocpd databases and per-process trace directories
 find $OUT -name "*.db" -delete
 find $OUT -mindepth 1 -type d -empty -delete
