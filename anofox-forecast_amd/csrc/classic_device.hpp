@@ -22,6 +22,33 @@ template <int KIND> struct ClassicDim { static constexpr int value = KIND == CK_
 
 struct ClassicFinalOut { double *yhat; int h; bool write; };
 
+// The lane's column in blocks of S rows, the next block requested before the current one is consumed (the first version loaded one
+// row per step behind a per-lane condition: every step waited for its own HBM round trip, ~1,000 cycles).  Row indices are
+// wave-uniform, so the clamp to the wave's last row is scalar arithmetic; a lane past its own length ignores what it read.
+template <int S, class Step>
+__device__ __forceinline__ void classic_stream(const double *yp, size_t ld, int t_begin, int wave_len, int len, Step step)
+{
+    double cur[S], nxt[S];
+    auto load = [&](double (&dst)[S], int t0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < S; j++) {
+            int t = t0 + j;
+            t = t < wave_len ? t : wave_len - 1;
+            dst[j] = yp[(size_t)t * ld];
+        }
+    };
+    load(cur, t_begin);
+    for (int base = t_begin; base < wave_len; base += S) {
+        load(nxt, base + S);
+#pragma unroll
+        for (int j = 0; j < S; j++)
+            if (base + j < len) step(cur[j]);
+#pragma unroll
+        for (int j = 0; j < S; j++) cur[j] = nxt[j];
+    }
+}
+constexpr int CLASSIC_S = 16;
+
 template <int KIND, int K, bool FINAL>
 __device__ __forceinline__ void classic_pass(const SeriesView &v, int m,
                                              const double (&cand)[K][ClassicDim<KIND>::value],
@@ -39,17 +66,14 @@ __device__ __forceinline__ void classic_pass(const SeriesView &v, int m,
         const double y0 = yp[0];
 #pragma unroll
         for (int k = 0; k < K; k++) l[k] = y0;
-        for (int t = 1; t < v.wave_len; t++) {
-            if (t < v.len) {
-                const double yv = yp[(size_t)t * ld];
+        classic_stream<CLASSIC_S>(yp, ld, 1, v.wave_len, v.len, [&](const double yv) __attribute__((always_inline)) {
 #pragma unroll
-                for (int k = 0; k < K; k++) {
-                    double e = yv - l[k];
-                    sse[k] = fma(e, e, sse[k]);
-                    l[k] = fma(cand[k][0], e, l[k]);
-                }
+            for (int k = 0; k < K; k++) {
+                double e = yv - l[k];
+                sse[k] = fma(e, e, sse[k]);
+                l[k] = fma(cand[k][0], e, l[k]);
             }
-        }
+        });
         if constexpr (FINAL) {
             if (fin->write) for (int i = 0; i < fin->h; i++) fin->yhat[i] = l[0];
         }
@@ -58,20 +82,17 @@ __device__ __forceinline__ void classic_pass(const SeriesView &v, int m,
         const double y0 = yp[0], y1 = yp[ld];
 #pragma unroll
         for (int k = 0; k < K; k++) { l[k] = y0; b[k] = y1 - y0; }
-        for (int t = 1; t < v.wave_len; t++) {
-            if (t < v.len) {
-                const double yv = yp[(size_t)t * ld];
+        classic_stream<CLASSIC_S>(yp, ld, 1, v.wave_len, v.len, [&](const double yv) __attribute__((always_inline)) {
 #pragma unroll
-                for (int k = 0; k < K; k++) {
-                    double f = l[k] + b[k];
-                    double e = yv - f;
-                    sse[k] = fma(e, e, sse[k]);
-                    double ln = fma(cand[k][0], e, f);
-                    b[k] = fma(cand[k][1], (ln - l[k]) - b[k], b[k]);
-                    l[k] = ln;
-                }
+            for (int k = 0; k < K; k++) {
+                double f = l[k] + b[k];
+                double e = yv - f;
+                sse[k] = fma(e, e, sse[k]);
+                double ln = fma(cand[k][0], e, f);
+                b[k] = fma(cand[k][1], (ln - l[k]) - b[k], b[k]);
+                l[k] = ln;
             }
-        }
+        });
         if constexpr (FINAL) {
             if (fin->write) for (int i = 1; i <= fin->h; i++) fin->yhat[i - 1] = l[0] + (double)i * b[0];
         }
@@ -89,24 +110,21 @@ __device__ __forceinline__ void classic_pass(const SeriesView &v, int m,
 #pragma unroll
             for (int k = 0; k < K; k++) ring[(k * m + i) * NM_BLOCK + lane] = s0;
         }
-        int j = 0;
-        for (int t = m; t < v.wave_len; t++) {
-            if (t < v.len) {
-                const double yv = yp[(size_t)t * ld];
+        int j = 0;              // phase of the step: every step up to the lane's length runs, so it advances with the steps
+        classic_stream<CLASSIC_S>(yp, ld, m, v.wave_len, v.len, [&](const double yv) __attribute__((always_inline)) {
 #pragma unroll
-                for (int k = 0; k < K; k++) {
-                    double s = ring[(k * m + j) * NM_BLOCK + lane];
-                    double q = l[k] + b[k];
-                    double e = yv - (q + s);
-                    sse[k] = fma(e, e, sse[k]);
-                    double ln = fma(cand[k][0], (yv - s) - q, q);
-                    b[k] = fma(cand[k][1], (ln - l[k]) - b[k], b[k]);
-                    ring[(k * m + j) * NM_BLOCK + lane] = fma(cand[k][2], (yv - ln) - s, s);
-                    l[k] = ln;
-                }
+            for (int k = 0; k < K; k++) {
+                double s = ring[(k * m + j) * NM_BLOCK + lane];
+                double q = l[k] + b[k];
+                double e = yv - (q + s);
+                sse[k] = fma(e, e, sse[k]);
+                double ln = fma(cand[k][0], (yv - s) - q, q);
+                b[k] = fma(cand[k][1], (ln - l[k]) - b[k], b[k]);
+                ring[(k * m + j) * NM_BLOCK + lane] = fma(cand[k][2], (yv - ln) - s, s);
+                l[k] = ln;
             }
             j = (j + 1 == m) ? 0 : j + 1;
-        }
+        });
         if constexpr (FINAL) {
             if (fin->write)
                 for (int i = 1; i <= fin->h; i++) {
@@ -121,19 +139,16 @@ __device__ __forceinline__ void classic_pass(const SeriesView &v, int m,
             for (int k = 0; k < K; k++) ring[(k * m + i) * NM_BLOCK + lane] = s0;
         }
         int j = 0;
-        for (int t = m; t < v.wave_len; t++) {
-            if (t < v.len) {
-                const double yv = yp[(size_t)t * ld];
+        classic_stream<CLASSIC_S>(yp, ld, m, v.wave_len, v.len, [&](const double yv) __attribute__((always_inline)) {
 #pragma unroll
-                for (int k = 0; k < K; k++) {
-                    double s = ring[(k * m + j) * NM_BLOCK + lane];
-                    double e = yv - s;
-                    sse[k] = fma(e, e, sse[k]);
-                    ring[(k * m + j) * NM_BLOCK + lane] = fma(cand[k][0], e, s);
-                }
+            for (int k = 0; k < K; k++) {
+                double s = ring[(k * m + j) * NM_BLOCK + lane];
+                double e = yv - s;
+                sse[k] = fma(e, e, sse[k]);
+                ring[(k * m + j) * NM_BLOCK + lane] = fma(cand[k][0], e, s);
             }
             j = (j + 1 == m) ? 0 : j + 1;
-        }
+        });
         if constexpr (FINAL) {
             if (fin->write)
                 for (int i = 0; i < fin->h; i++) fin->yhat[i] = ring[(0 * m + (v.len + i) % m) * NM_BLOCK + lane];
