@@ -49,14 +49,19 @@ __global__ __launch_bounds__(NM_BLOCK, ANOFOX_ROUND_WAVES) void ets_round_kernel
     const int s = valid ? (a.series_of ? a.series_of[p] : p) : 0;
     const int len = valid ? a.len[s] : 0;
 
+    // merged batch of several periods: the workgroup's problems share one (lane 0 always holds a problem)
+    const int m = a.m_col ? __builtin_amdgcn_readfirstlane(a.m_col[s]) : a.m;
+    const int n_param = a.n_param - ((Cfg::S != C_NONE && a.m_col) ? a.m - m : 0);      // a.n_param counts the m - 1 seasonal states of a.m
     bool active = valid;
+    // ... and it runs without compaction: every round sweeps all columns and skips the finished ones
+    if (!a.first_round && a.series_of == nullptr && valid && a.st.done[s]) active = false;
     if (a.first_round) {
         // admissibility of this (series, spec) -- mirrors the preconditions of oracle ets_fit
         int st = FIT_OK;
         const uint32_t fl = valid ? a.flags[s] : 0u;
         if (len <= 0) st = FIT_SKIPPED;
-        else if (Cfg::S != C_NONE && len < 2 * a.m) st = FIT_SHORT;
-        else if (len < a.n_param + 2) st = FIT_SHORT;
+        else if (Cfg::S != C_NONE && len < 2 * m) st = FIT_SHORT;
+        else if (len < n_param + 2) st = FIT_SHORT;
         else if (a.need_positive && !(fl & SF_POSITIVE)) st = FIT_NONPOSITIVE;
         else if (a.skip_constant && (fl & SF_CONSTANT)) st = FIT_SKIPPED;
         active = valid && st == FIT_OK;
@@ -85,7 +90,7 @@ __global__ __launch_bounds__(NM_BLOCK, ANOFOX_ROUND_WAVES) void ets_round_kernel
     mdl.in.b0 = (active && Cfg::T != C_NONE) ? a.b0[s] : 0.0;
     mdl.in.fig = a.fig ? a.fig + s : nullptr;
     mdl.in.fig_ld = a.fig_ld;
-    mdl.in.m = a.m;
+    mdl.in.m = m;
     mdl.ring = (MS == -2) ? a.ring_scratch + (size_t)blockIdx.x * (size_t)a.m * NM_BLOCK : lds + nm_lds_doubles<D>();
 
     NmRun r;
@@ -186,7 +191,8 @@ __global__ __launch_bounds__(NM_BLOCK) void ets_final_kernel(const FitArgs a)
     in.b0 = (active && Cfg::T != C_NONE) ? a.b0[s] : 0.0;
     in.fig = a.fig ? a.fig + (valid ? s : 0) : nullptr;
     in.fig_ld = a.fig_ld;
-    in.m = a.m;
+    in.m = a.m_col ? a.m_col[(size_t)blockIdx.x * NM_BLOCK] : a.m;
+    const int n_param = a.n_param - ((Cfg::S != C_NONE && a.m_col) ? a.m - in.m : 0);
 
     double cand[1][D], f[1];
 #pragma unroll
@@ -208,7 +214,7 @@ __global__ __launch_bounds__(NM_BLOCK) void ets_final_kernel(const FitArgs a)
         if (active && fabs(f[0]) <= 1.7976931348623157e308) {
             EtsPar par;
             ets_unpack<Cfg>(cand[0], par);
-            const double dk = (double)a.n_param, dn = (double)len, aic = f[0] + 2.0 * dk;
+            const double dk = (double)n_param, dn = (double)len, aic = f[0] + 2.0 * dk;
             double *o = a.insp_info + s;
             o[0 * a.ld] = par.alpha;
             o[1 * a.ld] = Cfg::T != C_NONE ? par.beta : __builtin_nan("");
@@ -228,7 +234,7 @@ __global__ __launch_bounds__(NM_BLOCK) void ets_final_kernel(const FitArgs a)
             const double lik = f[0];
             if (!(fabs(lik) <= 1.7976931348623157e308)) { st = FIT_NONFINITE; a.status[s] = st; }
             else {
-                const double dk = (double)a.n_param, dn = (double)len;
+                const double dk = (double)n_param, dn = (double)len;
                 const double aic = lik + 2.0 * dk;
                 aicc = aic + 2.0 * dk * (dk + 1.0) / (dn - dk - 1.0);
             }

@@ -338,6 +338,8 @@ struct AnofoxHipBatch {
     int gather_min = 0;      // per spec: stop gathering columns once this few problems are still running (measured: the gather pays at every count, 0 = always gather)
     int tail_below = 0;      // per spec: run the remaining problems to completion once this few are left (measured: rounds + compaction win at every threshold, 0 = off)
     int spec_below_md = 8192; // same, for the damped multiplicative-trend specs (their pass is ~10x longer: the stragglers matter more)
+    int merged_m_max = 0;         // ... and its largest period (sizes)
+    int32_t *d_m_col = nullptr;   // merged batch of several seasonal periods (auto-detected): period of every column, constant within 64 columns
     bool one_launch = true;    // the three Nelder-Mead drivers of a later round in ONE kernel (ANOFOX_HIP_ONE_LAUNCH=0: one launch each, two of them empty)
     int spec2_below_md = 2048; // per spec: the last problems run one per wave, two iterations per pass (0 = never); damped multiplicative
                                // trend.  Measured on the 30-spec M5 batch (tools/spec2_sweep.sh): 0 / 256 / 1024 / 2048 / 4096 / 8192 -> 579 / 575 / 565 / 562 / 594 / 736 ms
@@ -504,7 +506,7 @@ void free_batch_buffers(AnofoxHipBatch *b)
     F(b->d_aicc); F(b->d_yhat_slots); F(b->d_status_slots); F(b->d_evals_slots); F(b->d_iters_slots);
     F(b->d_passes_slots); F(b->d_slot_spec);
     F(b->d_yhat); F(b->d_lo); F(b->d_hi); F(b->d_model_code); F(b->d_status); F(b->d_detail);
-    F(b->d_ys); F(b->d_pool_head); F(b->d_pool_trace); F(b->d_ring); F(b->d_prep_scratch);
+    F(b->d_m_col); F(b->d_ys); F(b->d_pool_head); F(b->d_pool_trace); F(b->d_ring); F(b->d_prep_scratch);
     F(b->d_passes_total); F(b->d_evals_total); F(b->d_mask); F(b->d_len_group); F(b->d_count); F(b->d_pos_map); F(b->d_pos_cnt); F(b->d_notpos); F(b->d_ypos);
     F(b->ar_w); F(b->ar_wmean); F(b->ar_wsd); F(b->ar_l0); F(b->ar_l1); F(b->ar_x); F(b->ar_aicc); F(b->ar_wlen); F(b->ar_d); F(b->ar_D);
     F(b->ar_order); F(b->ar_status); F(b->ar_evals); F(b->ar_passes); F(b->ar_models);
@@ -659,6 +661,7 @@ void run_classic(AnofoxHipBatch *b, int kind, const int32_t *d_len, int m, int o
     a.yhat = b->d_yhat; a.status = b->d_detail; a.passes = b->d_passes_total;
     a.model_code = code; a.model_code_out = write_code ? b->d_model_code : nullptr;
     a.ring_scratch = nullptr;
+    a.m_col = (kind == CK_HW || kind == CK_SEASONAL_ES) ? b->d_m_col : nullptr;
     if ((kind == CK_HW || kind == CK_SEASONAL_ES) && m > 48)       // CLASSIC_LDS_PERIOD: four candidate rings per lane
         a.ring_scratch = ensure_ring(b, (size_t)((b->n + 63) / 64) * 4u * (size_t)m * 64u);
     launch_classic(kind, a, st);
@@ -729,10 +732,11 @@ __global__ void retire_nonpositive_kernel(int n, const int32_t *len, const int32
 }
 
 // AutoETS fallback plan (forecast.rs:1327-1336): 1 Holt-Winters, 2 Holt, 3 SES(0.3)
-__global__ void fallback_plan_kernel(int n, const int32_t *len, int period, uint32_t *mask, int32_t *detail)
+__global__ void fallback_plan_kernel(int n, const int32_t *len, int period, uint32_t *mask, int32_t *detail, const int32_t *m_col)
 {
     int s = blockIdx.x * 256 + threadIdx.x;
     if (s >= n) return;
+    if (m_col) period = m_col[s];                  // merged batch: the column's own period
     const int L = len[s];
     if (L <= 0) { mask[s] = 0; return; }
     if (mask[s] == 0) { detail[s] = FIT_OK; return; }
@@ -741,10 +745,11 @@ __global__ void fallback_plan_kernel(int n, const int32_t *len, int period, uint
 }
 
 // HoltWinters: 1 = two full seasons or more (seasonal fit), 2 = shorter (Holt); an unsupported period fails the long series
-__global__ void holt_winters_plan_kernel(int n, const int32_t *len, int m, uint32_t *mask, int32_t *detail)
+__global__ void holt_winters_plan_kernel(int n, const int32_t *len, int m, uint32_t *mask, int32_t *detail, const int32_t *m_col)
 {
     int s = blockIdx.x * 256 + threadIdx.x;
     if (s >= n) return;
+    if (m_col) m = m_col[s] > 2 ? m_col[s] : 2;    // merged batch: the column's own period
     const int L = len[s];
     mask[s] = L <= 0 ? 0u : (L >= 2 * m ? 1u : 2u);
     if (L > 0) detail[s] = FIT_PERIOD;        // overwritten by the stage that fits the series
@@ -793,7 +798,8 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
     const int n_lanes = std::min<int>(N_AUX_STREAMS, b->n_slots_cap);
     // fork: aux streams wait for everything queued on `st` so far
     HIPCHECK(hipEventRecord(b->ev_fit0, st));
-    const bool pool = b->pool_sched && !b->fixed_params && m <= ETS_LDS_PERIOD;      // long periods: round schedule only
+    const bool merged = b->d_m_col != nullptr;           // several periods in one block: no compaction (a wave's columns share a period)
+    const bool pool = b->pool_sched && !b->fixed_params && m <= ETS_LDS_PERIOD && !merged;      // long periods: round schedule only
     const int n_fork = pool ? POOL_UNITS : n_lanes;      // streams that carry work: one per unit kernel / one per spec
     if (pool) {
         // the work-pool kernels stream every lane's own series: series-major copy of the block, once per group
@@ -874,7 +880,9 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
         a.passes = b->d_passes_slots + k * ld;
         a.st = lane.st;
         a.ring_scratch = nullptr;
-        fns[oi] = ets_fit_launcher(id, a.m);
+        a.m_col = b->d_m_col;
+        // a merged batch runs the run-time-period kernels whatever its largest period is (7 and 12 have compile-time variants)
+        fns[oi] = ets_fit_launcher(id, (merged && (a.m == 7 || a.m == 12)) ? 13 : a.m);
         if (!fns[oi].round_seq || !fns[oi].round_spec || !fns[oi].round_auto || !fns[oi].final) throw HipFail{"no kernel for ETS spec id " + std::to_string(id)};
     }
     // Periods above the LDS limit keep the seasonal ring of every lane in HBM: one area per (spec, workgroup of the widest
@@ -883,7 +891,7 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
         size_t n_long = 0;
         for (size_t oi = 0; oi < order.size(); oi++) if (args[oi].m > ETS_LDS_PERIOD) n_long++;
         if (n_long) {
-            const size_t wg = std::max<size_t>((n + 15) / 16, std::min<size_t>(n, (size_t)std::max(b->spec2_below, b->spec2_below_md)));
+            const size_t wg = merged ? n : std::max<size_t>((n + 15) / 16, std::min<size_t>(n, (size_t)std::max(b->spec2_below, b->spec2_below_md)));
             const size_t per_spec = wg * (size_t)m * 64u;
             if ((double)n_long * (double)per_spec * 8.0 > 64.0 * 1073741824.0)
                 throw HipFail{"seasonal period " + std::to_string(m) + " on " + std::to_string(n) + " series needs more than 64 GiB of ring scratch: shard the batch"};
@@ -1006,7 +1014,29 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
         }
         LAUNCHCHECK("ETS work pool");
     }
-    for (int r = 0; r < ((b->fixed_params || pool) ? 0 : n_rounds); r++) {
+    if (merged && !b->fixed_params) {
+        // Three launches per spec, every one over all columns in place (finished problems are skipped in the kernel): 64 and 128
+        // iterations with four lanes per problem, then everything that is left one problem per wave to completion.  A merged batch
+        // is small (the series of the rare periods of an auto-detected batch), so lane efficiency is not what bounds it: the
+        // chains of 138 separate tiny batches on 16 hardware queues were (5.3 s for 1,024 series).
+        for (int r = 0; r < 3; r++) {
+            for (size_t oi = 0; oi < order.size(); oi++) {
+                if (dead[oi]) continue;
+                hipStream_t sq = b->aux[stream_of[oi]];
+                FitArgs &a = args[oi];
+                a.first_round = (r == 0);
+                a.spec_below = -1; a.spec2_below = -1; a.tail_below = 0;
+                a.gathered = 0; a.gather_min = 0; a.gather_max = 0x7fffffff;
+                a.y_round = b->d_y; a.ld_round = ld; a.series_of = nullptr; a.n_active = nullptr;
+                a.next_map = nullptr; a.next_cnt = nullptr; a.clear_cnt = nullptr; a.next_y = nullptr;
+                a.budget = r == 0 ? 64 : 128; a.budget_seq = a.budget;
+                (r < 2 ? fns[oi].round_spec : fns[oi].round_spec2)(a, sq);
+                b->fit_launches++;
+            }
+            LAUNCHCHECK("ETS fit round (merged periods)");
+        }
+    }
+    for (int r = 0; r < ((b->fixed_params || pool || merged) ? 0 : n_rounds); r++) {
         for (size_t oi = 0; oi < order.size(); oi++) {
             if (dead[oi]) continue;
             const int q = (int)(oi % (size_t)n_lanes);
@@ -1113,6 +1143,7 @@ void run_group(AnofoxHipBatch *b, int period, const int32_t *d_len, hipStream_t 
     auto prep = [&](int m, bool states) {
         PrepArgs a{};
         a.y = b->d_y; a.ld = ld; a.len = d_len; a.n_series = (int)n; a.m = m;
+        a.m_col = (states && m >= 2) ? b->d_m_col : nullptr;
         a.mean = b->d_mean; a.sd = b->d_sd; a.flags = b->d_flags;
         a.scratch = nullptr;
         if (states) {
@@ -1159,7 +1190,7 @@ void run_group(AnofoxHipBatch *b, int period, const int32_t *d_len, hipStream_t 
         prep(1, false);
         // fewer than two seasons -> Holt's linear trend under the same name (the crate's fallback, pinned by
         // test/sql/ts_forecast_exp_smoothing.test:498-503 and ts_forecast_params.test:203-207)
-        hipLaunchKernelGGL(holt_winters_plan_kernel, dim3(blocks256), dim3(256), 0, st, (int)n, d_len, m, b->d_mask, b->d_detail);
+        hipLaunchKernelGGL(holt_winters_plan_kernel, dim3(blocks256), dim3(256), 0, st, (int)n, d_len, m, b->d_mask, b->d_detail, (const int32_t *)b->d_m_col);
         if (m <= ETS_MAX_PERIOD) run_classic(b, CK_HW, d_len, m, 1, 0.0, 2 * m, b->d_mask, 1u, 0, false, st);
         run_classic(b, CK_HOLT, d_len, 1, 1, 0.0, 0, b->d_mask, 2u, 0, false, st);
         finish();
@@ -1195,7 +1226,7 @@ void run_group(AnofoxHipBatch *b, int period, const int32_t *d_len, hipStream_t 
             prep(1, false);
             // default chain decided by length only: mark every usable series for fallback
             HIPCHECK(hipMemsetAsync(b->d_mask, 0x01, ld * sizeof(uint32_t), st));
-            hipLaunchKernelGGL(fallback_plan_kernel, dim3(blocks256), dim3(256), 0, st, (int)n, d_len, period, b->d_mask, b->d_detail);
+            hipLaunchKernelGGL(fallback_plan_kernel, dim3(blocks256), dim3(256), 0, st, (int)n, d_len, period, b->d_mask, b->d_detail, (const int32_t *)nullptr);
             if (period > 1 && period <= ETS_MAX_PERIOD)
                 run_classic(b, CK_HW, d_len, period, 1, 0.0, 2 * period, b->d_mask, 1u, 0, false, st);
             run_classic(b, CK_HOLT, d_len, 1, 1, 0.0, 0, b->d_mask, 2u, 0, false, st);
@@ -1227,7 +1258,7 @@ void run_group(AnofoxHipBatch *b, int period, const int32_t *d_len, hipStream_t 
             const double live = (double)cnt[0] * (double)specs.size() + (double)(cnt[1] - cnt[0]) * (double)n_add;
             static const double seq_live = [] { const char *e = std::getenv("ANOFOX_HIP_SEQ_LIVE"); return e ? std::atof(e) : 8.0 * 65536.0; }();
             b->seq_rounds = live >= seq_live ? 4 : 0;         // >= 8 problems per SIMD lane-slot: VALU-bound, go sequential
-            b->use_pos = cnt[0] > 0 && (double)cnt[0] < 0.7 * (double)cnt[1];
+            b->use_pos = cnt[0] > 0 && (double)cnt[0] < 0.7 * (double)cnt[1] && !b->d_m_col;     // (a dense list of the positive series would mix periods)
             b->live_pos = cnt[0]; b->live_all = cnt[1];
         } else {
             b->use_pos = false;
@@ -1251,7 +1282,7 @@ void run_group(AnofoxHipBatch *b, int period, const int32_t *d_len, hipStream_t 
         sa.yhat = b->d_yhat; sa.model_code = b->d_model_code; sa.status = b->d_detail; sa.fallback_mask = b->d_mask;
         sa.passes_total = b->d_passes_total; sa.evals_total = b->d_evals_total;
         launch_select(sa, st);
-        hipLaunchKernelGGL(fallback_plan_kernel, dim3(blocks256), dim3(256), 0, st, (int)n, d_len, period, b->d_mask, b->d_detail);
+        hipLaunchKernelGGL(fallback_plan_kernel, dim3(blocks256), dim3(256), 0, st, (int)n, d_len, period, b->d_mask, b->d_detail, (const int32_t *)b->d_m_col);
         if (period > 1 && period <= ETS_MAX_PERIOD)
             run_classic(b, CK_HW, d_len, period, 1, 0.0, 2 * period, b->d_mask, 1u, 0, true, st);
         run_classic(b, CK_HOLT, d_len, 1, 1, 0.0, 0, b->d_mask, 2u, 0, true, st);
@@ -1325,7 +1356,8 @@ void run_batch(AnofoxHipBatch *b, hipStream_t st)
     std::map<int, std::vector<size_t>> groups;
     bool uniform = true;
     for (size_t s = 1; s < n; s++) if (used_period(b->h_period[s]) != used_period(b->h_period[0])) { uniform = false; break; }
-    if (uniform) run_group(b, n ? used_period(b->h_period[0]) : 1, b->d_len, st);
+    if (b->d_m_col) run_group(b, b->merged_m_max, b->d_len, st);        // several periods, one run: the kernels read the period per column
+    else if (uniform) run_group(b, n ? used_period(b->h_period[0]) : 1, b->d_len, st);
     else {
         for (size_t s = 0; s < n; s++) groups[used_period(b->h_period[s])].push_back(s);
         std::vector<int32_t> eff(ld);
@@ -2019,6 +2051,126 @@ bool anofox_ts_forecast_batch(const double *const *values, const uint64_t *const
                 all_ok = false;
             }
         };
+        // AutoETS: the small parts with periods 2..48 run as ONE batch whose columns are grouped by period in blocks of 64 (the
+        // kernels read the period per block): 138 tiny batches x 25 spec chains on 16 hardware queues were latency bound end to end
+        static const bool merge_periods = [] { const char *e = std::getenv("ANOFOX_HIP_MERGE_PERIODS"); return e ? std::atoi(e) != 0 : true; }();
+        if (merge_periods && (plan.model == M_AutoETS || plan.model == M_HoltWinters || plan.model == M_SeasonalES || plan.model == M_SeasonalESOptimized)) {
+            // one merged batch per ring class (seasonal ring in LDS up to 64, in an HBM scratch above; the scratch is sized by the
+            // class's largest period, hence a few classes)
+            using Part = std::pair<int, std::vector<size_t>>;
+            std::mutex merged_mu;
+            auto run_merged = [&](std::vector<Part> &take) -> bool {
+                std::sort(take.begin(), take.end(), [](const Part &x, const Part &y) { return x.first < y.first; });
+                static const double dummy_v = 0.0;
+                std::vector<const double *> v;
+                std::vector<const uint64_t *> mk;
+                std::vector<size_t> len, src;                       // src: index of the caller's series, or SIZE_MAX for padding
+                std::vector<int32_t> mcol;
+                size_t t_cap = 0;
+                int h_cap = options->horizon, m_max = 0;
+                for (const auto &part : take) {
+                    for (size_t idx : part.second) {
+                        v.push_back(values[idx]); mk.push_back(validity ? validity[idx] : nullptr); len.push_back(lengths[idx]); src.push_back(idx);
+                        mcol.push_back(part.first);
+                        t_cap = std::max(t_cap, lengths[idx]);
+                        if (horizons) h_cap = std::max(h_cap, horizons[idx]);
+                    }
+                    while (v.size() % 64) { v.push_back(&dummy_v); mk.push_back(nullptr); len.push_back(0); src.push_back(SIZE_MAX); mcol.push_back(part.first); }
+                    m_max = std::max(m_max, part.first);
+                }
+                const size_t nc = v.size();
+                ForecastOptions o = *options;
+                o.auto_detect_seasonality = false;
+                o.seasonal_period = m_max;
+                o.horizon = h_cap;
+                AnofoxHipBatch *mb = nullptr;
+                AnofoxError be;
+                be.code = SUCCESS; be.message[0] = 0;
+                std::vector<ForecastResult> res(nc);
+                std::vector<AnofoxError> errs(nc);
+                for (size_t j = 0; j < nc; j++) { std::memset(&res[j], 0, sizeof(ForecastResult)); errs[j].code = SUCCESS; errs[j].message[0] = 0; }
+                const auto tm0 = std::chrono::steady_clock::now();
+                bool ok = anofox_hip_batch_create(nc, t_cap, &o, &mb, &be);
+                if (ok) {
+                    ok = anofox_hip_batch_pack_host(mb, v.data(), validity ? mk.data() : nullptr, len.data(), &be);
+                    if (ok) {
+                        try {
+                            mcol.resize(mb->ld, mcol.empty() ? 1 : mcol.back());
+                            mb->d_m_col = dalloc<int32_t>(mb->ld);
+                            HIPCHECK(hipMemcpy(mb->d_m_col, mcol.data(), mb->ld * sizeof(int32_t), hipMemcpyHostToDevice));
+                            mb->merged_m_max = m_max;
+                            for (size_t j = 0; j < nc; j++) mb->h_period[j] = mcol[j];     // what the host-side fitted values use
+                        } catch (const HipFail &f) { report_hip_failure(&be, f); ok = false; }
+                    }
+                    ok = ok && anofox_hip_batch_run(mb, nullptr, &be) && anofox_hip_batch_fetch(mb, res.data(), errs.data());
+                    anofox_hip_batch_destroy(mb);
+                }
+                if (std::getenv("ANOFOX_HIP_TIMING"))
+                    std::fprintf(stderr, "[anofox-hip] merged batch: %zu parts with periods %d..%d in %zu columns: %.1f ms\n", take.size(), take.front().first, m_max, nc,
+                                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tm0).count());
+                if (!ok) {
+                    if (be.code == SUCCESS) set_error(&be, INTERNAL_ERROR, "Internal error: device batch failed");
+                    for (size_t j = 0; j < nc; j++) anofox_free_forecast_result(&res[j]);
+                    std::lock_guard<std::mutex> lock(merged_mu);
+                    if (out_batch_error && out_batch_error->code == SUCCESS) *out_batch_error = be;
+                    return false;
+                }
+                for (size_t j = 0; j < nc; j++) {
+                    if (src[j] == SIZE_MAX) { anofox_free_forecast_result(&res[j]); continue; }
+                    ForecastResult &r = res[j];
+                    const int hs = horizons ? horizons[src[j]] : options->horizon;      // forecasts are prefix-consistent: truncate
+                    if (r.point_forecasts && hs >= 0 && (size_t)hs < r.n_forecasts) {
+                        r.n_forecasts = (size_t)hs;
+                        if (hs == 0) {
+                            std::free(r.point_forecasts); std::free(r.lower_bounds); std::free(r.upper_bounds);
+                            r.point_forecasts = r.lower_bounds = r.upper_bounds = nullptr;
+                        }
+                    }
+                    out_results[src[j]] = r;
+                    if (out_errors) out_errors[src[j]] = errs[j];
+                }
+                return true;
+            };
+            static const int CLASS_HI[] = {ETS_LDS_PERIOD, 128, 256, 512, ETS_MAX_PERIOD};
+            std::vector<Part> keep;
+            std::vector<std::vector<Part>> take(sizeof CLASS_HI / sizeof CLASS_HI[0]);
+            for (auto &part : parts) {
+                int c = -1;
+                if (part.first >= 2 && part.second.size() < 2048)
+                    for (size_t k = 0; k < take.size(); k++) if (part.first <= CLASS_HI[k]) { c = (int)k; break; }
+                (c >= 0 ? take[(size_t)c] : keep).push_back(std::move(part));
+            }
+            // the classes side by side (each is latency bound by its slowest fit and far from filling the chip)
+            std::vector<std::vector<Part> *> todo;
+            for (auto &cls : take) {
+                if (cls.size() >= 2) todo.push_back(&cls);
+                else for (auto &part : cls) keep.push_back(std::move(part));
+            }
+            std::atomic<bool> merged_ok{true};
+            int cur_dev_m = 0;
+            (void)hipGetDevice(&cur_dev_m);
+            auto run_cls = [&](std::vector<Part> *cls) {
+                try {
+                    (void)hipSetDevice(cur_dev_m);
+                    if (!run_merged(*cls)) merged_ok = false;
+                } catch (...) { merged_ok = false; }                // nothing may leave a worker thread
+            };
+            std::vector<std::thread> cls_threads;
+            for (size_t k = 1; k < todo.size(); k++) cls_threads.emplace_back(run_cls, todo[k]);
+            if (!todo.empty()) run_cls(todo[0]);
+            for (auto &t : cls_threads) t.join();
+            if (!merged_ok) {
+                if (out_batch_error && out_batch_error->code == SUCCESS) set_error(out_batch_error, INTERNAL_ERROR, "Internal error: device batch failed");
+                return false;
+            }
+            parts = std::move(keep);
+            std::sort(parts.begin(), parts.end(), [](const Part &x, const Part &y) { return x.second.size() > y.second.size(); });
+        }
+        if (std::getenv("ANOFOX_HIP_TIMING")) {
+            std::string desc;
+            for (auto &part : parts) desc += " " + std::to_string(part.first) + "x" + std::to_string(part.second.size());
+            std::fprintf(stderr, "[anofox-hip] remaining parts (period x series):%s\n", desc.c_str());
+        }
         // the big parts fill the chip on their own and hold the most memory: one at a time; the small ones side by side
         size_t first_small = 0;
         while (first_small < parts.size() && parts[first_small].second.size() >= 2048) run_part(parts[first_small++]);

@@ -60,8 +60,10 @@ __global__ __launch_bounds__(NM_BLOCK) void classic_kernel(const ClassicArgs a)
     const int s = blockIdx.x * NM_BLOCK + threadIdx.x;
     const int len = (s < a.n_series) ? a.len[s] : 0;
     bool selected = (s < a.n_series) && len > 0 && (a.mask == nullptr || a.mask[s] == a.want);
+    const int m = a.m_col ? a.m_col[(size_t)blockIdx.x * NM_BLOCK] : a.m;      // merged batch: the workgroup's own period
+    const int min_len = !a.m_col ? a.min_len : (KIND == CK_HW ? 2 * m : (KIND == CK_SEASONAL_ES ? m : a.min_len));
     int st = FIT_OK;
-    if (selected && len < a.min_len) st = FIT_SHORT;
+    if (selected && len < min_len) st = FIT_SHORT;
     const bool active = selected && st == FIT_OK;
 
     SeriesView v;
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(NM_BLOCK) void classic_kernel(const ClassicArgs a)
     }
     ClassicModel<KIND> mdl;
     mdl.v = v;
-    mdl.m = a.m;
+    mdl.m = m;
     mdl.ring = GRING ? a.ring_scratch + (size_t)blockIdx.x * (size_t)NM_K * (size_t)(a.m > 0 ? a.m : 1) * NM_BLOCK : lds + nm_lds_doubles<DIM>();
 
     double xbest[DIM], fbest;
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(NM_BLOCK) void classic_kernel(const ClassicArgs a)
     fin.h = a.h;
     fin.write = active;
     fin.yhat = a.yhat + (size_t)(s < a.n_series ? s : 0) * a.h;
-    classic_pass<KIND, NM_K, true>(v, a.m, cand, f, mdl.ring, &fin);
+    classic_pass<KIND, NM_K, true>(v, m, cand, f, mdl.ring, &fin);
     if (selected) {
         a.status[s] = st;
         if (active) {

@@ -26,7 +26,8 @@ enum : int32_t { FIT_OK = 0, FIT_SHORT = 1, FIT_NONPOSITIVE = 2, FIT_NONFINITE =
 
 struct PrepArgs {
     const double *y; size_t ld; const int32_t *len; int n_series;
-    int m;                 // seasonal period to prepare figures for (<= 1: none)
+    int m;                 // seasonal period to prepare figures for (<= 1: none); with m_col: the LARGEST period of the block (sizes)
+    const int32_t *m_col;  // [ld] period of every column, constant within each group of 64 columns (a merged batch of several periods); NULL = m
     double *mean, *sd;     // population mean / sd of the series (forecast.rs:2558-2591)
     uint32_t *flags;
     double *fig_add, *fig_mul;   // [m x ld] seasonal figures (additive / multiplicative)
@@ -50,6 +51,7 @@ struct FitArgs {
     const int32_t *series_of;
     const int32_t *n_active;
     int budget, first_round;
+    const int32_t *m_col;        // [ld] per-column seasonal period (constant within 64 columns) of a merged batch of several periods; NULL = m (then m is the size bound)
     int spec_below;              // device-side driver choice: the speculative kernel runs iff n_active <= spec_below,
                                  // the sequential one iff n_active > spec_below (both are enqueued; -1 = unconditional)
     int budget_seq;              // passes per round when the device-side choice (round_auto) lands on the sequential driver
@@ -121,6 +123,7 @@ struct ClassicArgs {
     int32_t model_code;          // written to model_code[s] when not NULL
     int32_t *model_code_out;
     double *ring_scratch;        // periods whose K * m * 64 ring does not fit LDS: that many doubles per workgroup in HBM
+    const int32_t *m_col;        // [ld] per-column period (constant within 64 columns) of a merged batch; NULL = m.  min_len is then 2 m (Holt-Winters) of the column's own period
 };
 
 enum SimpleKind { SK_NAIVE = 0, SK_SEASONAL_NAIVE = 1, SK_SMA = 2, SK_DRIFT = 3, SK_TOY_ARIMA = 4 };

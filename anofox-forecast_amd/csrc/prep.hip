@@ -64,7 +64,7 @@ __global__ __launch_bounds__(NM_BLOCK) void prep_kernel(const PrepArgs a)
     rows.total_bytes = (size_t)wave_rows * rows.row_bytes;
     double cur[PREP_S], nxt[PREP_S];
     const bool states = a.l0 != nullptr;
-    const int m = a.m;
+    const int m = a.m_col ? a.m_col[(size_t)blockIdx.x * NM_BLOCK] : a.m;      // merged batch: this workgroup's own period (a.m bounds the sizes)
     const bool want_season = states && m >= 2 && m <= ETS_MAX_PERIOD;
     const int half = m / 2, L = 2 * half + 1;
     // LDS (lane-minor): window ring [L], sumA [m], sumM [m], cnt [m]
@@ -295,7 +295,7 @@ void launch_prep(const PrepArgs &a, hipStream_t stream)
         hipLaunchKernelGGL((prep_kernel<true, 0>), dim3(grid), dim3(NM_BLOCK), 0, stream, a);
         return;
     }
-    if (a.l0 != nullptr && a.m == 7) {                    // the M5 / weekly period: ring and accumulators in registers
+    if (a.l0 != nullptr && a.m == 7 && !a.m_col) {        // the M5 / weekly period: ring and accumulators in registers
         hipLaunchKernelGGL((prep_kernel<false, 7>), dim3(grid), dim3(NM_BLOCK), 0, stream, a);
         return;
     }

@@ -494,6 +494,27 @@ def test_two_level_speculation_counts(env, monkeypatch):
         np.testing.assert_array_equal(r0[k], r1[k])
 
 
+@pytest.mark.parametrize("model", ["AutoETS", "HoltWinters", "SeasonalESOptimized"])
+def test_auto_detected_periods_merge_into_one_batch(env, monkeypatch, model):
+    """params := MAP{} (no seasonal_period): every series gets its own detected period.  The batch entry runs the series of all
+    periods of a ring class as ONE batch whose 64-column blocks each have their own period (prep, fit, final pass and the
+    fallback chain read the period per block) instead of one tiny batch per period -- same forecasts as the oracle, which
+    detects and fits series by series; the split path (ANOFOX_HIP_MERGE_PERIODS=0) gives the same results."""
+    api, O, lib, synth = env
+    rng = np.random.default_rng(17)
+    series = []
+    for p, reps in ((5, 3), (7, 5), (12, 2), (24, 2), (30, 1), (52, 2), (70, 2), (130, 1), (300, 1)):
+        for r in range(reps):
+            T = int(max(6 * p, 90) + rng.integers(0, 40))
+            t = np.arange(T)
+            y = 50.0 + 0.02 * t + (8.0 + r) * np.sin(2 * np.pi * t / p) + 3.0 * np.cos(4 * np.pi * t / p) + rng.normal(0, 0.6, T)
+            series.append(y)
+    series += [np.full(40, 3.0), np.arange(30.0), rng.normal(10, 1, 50), np.array([1.0, 2.0]), np.array([])]
+    _compare(api, O, lib, series, model, 9)
+    monkeypatch.setenv("ANOFOX_HIP_MERGE_PERIODS", "0")
+    _compare(api, O, lib, series, model, 9)
+
+
 def test_device_resident_batch_and_stats(env):
     """Block already in HBM (torch tensor) -> anofox_hip_batch_* -> device results; counters are consistent."""
     import torch

@@ -12,7 +12,7 @@ rng = np.random.default_rng(3)
 Y = synth.gen_series(synth.SEED_M5 + 3, 1234, n, 2000, 7, True)
 lens = rng.integers(300, 2001, size=n)
 series = [Y[i, 2000 - lens[i]:].copy() for i in range(n)]
-for model in ("Naive", "AutoARIMA", "AutoETS", "HoltWinters"):
+for model in ("Naive", "AutoARIMA", "AutoETS", "HoltWinters", "SeasonalES", "SeasonalESOptimized"):
     opts = lib.make_options(model, 14)                       # seasonal_period 0 -> auto_detect on
     for _ in range(2):
         t0 = time.time()
