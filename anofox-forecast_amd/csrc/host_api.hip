@@ -2054,7 +2054,7 @@ bool anofox_ts_forecast_batch(const double *const *values, const uint64_t *const
         // AutoETS: the small parts with periods 2..48 run as ONE batch whose columns are grouped by period in blocks of 64 (the
         // kernels read the period per block): 138 tiny batches x 25 spec chains on 16 hardware queues were latency bound end to end
         static const bool merge_periods = [] { const char *e = std::getenv("ANOFOX_HIP_MERGE_PERIODS"); return e ? std::atoi(e) != 0 : true; }();
-        if (merge_periods && (plan.model == M_AutoETS || plan.model == M_HoltWinters || plan.model == M_SeasonalES || plan.model == M_SeasonalESOptimized)) {
+        const bool do_merge = merge_periods && (plan.model == M_AutoETS || plan.model == M_HoltWinters || plan.model == M_SeasonalES || plan.model == M_SeasonalESOptimized);
             // one merged batch per ring class (seasonal ring in LDS up to 64, in an HBM scratch above; the scratch is sized by the
             // class's largest period, hence a few classes)
             using Part = std::pair<int, std::vector<size_t>>;
@@ -2131,12 +2131,12 @@ bool anofox_ts_forecast_batch(const double *const *values, const uint64_t *const
                 }
                 return true;
             };
-            static const int CLASS_HI[] = {ETS_LDS_PERIOD, 128, 256, 512, ETS_MAX_PERIOD};
+            static const int CLASS_HI[] = {ETS_LDS_PERIOD, ETS_MAX_PERIOD};
             std::vector<Part> keep;
             std::vector<std::vector<Part>> take(sizeof CLASS_HI / sizeof CLASS_HI[0]);
             for (auto &part : parts) {
                 int c = -1;
-                if (part.first >= 2 && part.second.size() < 2048)
+                if (do_merge && part.first >= 2 && part.second.size() < 2048)
                     for (size_t k = 0; k < take.size(); k++) if (part.first <= CLASS_HI[k]) { c = (int)k; break; }
                 (c >= 0 ? take[(size_t)c] : keep).push_back(std::move(part));
             }
@@ -2155,17 +2155,12 @@ bool anofox_ts_forecast_batch(const double *const *values, const uint64_t *const
                     if (!run_merged(*cls)) merged_ok = false;
                 } catch (...) { merged_ok = false; }                // nothing may leave a worker thread
             };
+            // ... and beside the parts that stay separate (below); joined before this function returns, whatever the way out
             std::vector<std::thread> cls_threads;
-            for (size_t k = 1; k < todo.size(); k++) cls_threads.emplace_back(run_cls, todo[k]);
-            if (!todo.empty()) run_cls(todo[0]);
-            for (auto &t : cls_threads) t.join();
-            if (!merged_ok) {
-                if (out_batch_error && out_batch_error->code == SUCCESS) set_error(out_batch_error, INTERNAL_ERROR, "Internal error: device batch failed");
-                return false;
-            }
+            struct Joiner { std::vector<std::thread> &t; ~Joiner() { for (auto &x : t) if (x.joinable()) x.join(); } } cls_joiner{cls_threads};
+            for (size_t k = 0; k < todo.size(); k++) cls_threads.emplace_back(run_cls, todo[k]);
             parts = std::move(keep);
             std::sort(parts.begin(), parts.end(), [](const Part &x, const Part &y) { return x.second.size() > y.second.size(); });
-        }
         if (std::getenv("ANOFOX_HIP_TIMING")) {
             std::string desc;
             for (auto &part : parts) desc += " " + std::to_string(part.first) + "x" + std::to_string(part.second.size());
@@ -2255,6 +2250,11 @@ bool anofox_ts_forecast_batch(const double *const *values, const uint64_t *const
         for (unsigned i = 1; i < n_thr; i++) pool.emplace_back(work);
         work();
         for (auto &t : pool) t.join();
+        for (auto &t : cls_threads) t.join();
+        if (!merged_ok) {
+            if (out_batch_error && out_batch_error->code == SUCCESS) set_error(out_batch_error, INTERNAL_ERROR, "Internal error: device batch failed");
+            return false;
+        }
         if (!all_ok && out_batch_error) *out_batch_error = first_err;
         return all_ok;
     } catch (const std::exception &e) {
