@@ -515,6 +515,36 @@ def test_auto_detected_periods_merge_into_one_batch(env, monkeypatch, model):
     _compare(api, O, lib, series, model, 9)
 
 
+@pytest.mark.parametrize("envset", [{"ANOFOX_HIP_CACHE_GB": "0", "ANOFOX_HIP_PINNED_CACHE_GB": "0"}, {"ANOFOX_HIP_PRIO_STREAMS": "0", "ANOFOX_HIP_ONE_LAUNCH": "0"},
+                                    {"ANOFOX_HIP_PRIO_STREAMS": "3", "GPU_MAX_HW_QUEUES": "8"}])
+def test_process_wide_switches(envset):
+    """The allocation caches, the stream priorities and the one-launch rounds are decided once per process: a fresh process
+    with each of them switched off (or sized differently) reproduces the oracle like the defaults do -- three batches in a
+    row, so that blocks and stream sets are handed back and taken again."""
+    import os, subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys
+        sys.path.insert(0, %r)
+        import numpy as np
+        from anofox_forecast_amd import api, lib, synth
+        from oracle import oracle as O
+        Y = synth.gen_series(synth.SEED_M5, 8100, 40, 120, 7, positive=True)
+        for rep, (model, kw) in enumerate((("AutoETS", {"seasonal_period": 7}), ("HoltWinters", {"seasonal_period": 7}), ("AutoETS", {"seasonal_period": 7}))):
+            series = [Y[s, : 120 - (s %% 4) * 7] for s in range(40 - rep)]
+            got, berr = api.forecast_batch(series, lib.make_options(model, 6, **kw))
+            assert berr["ok"], berr
+            oo = O.make_options(model, 6, **kw)
+            for s, y in enumerate(series):
+                ref = O.forecast(y, oo)
+                assert got[s]["ok"] and ref["ok"] and got[s]["model_name"] == ref["model_name"], (model, s)
+                assert np.array_equal(np.asarray(got[s]["point"]), np.asarray(ref["point"])), (model, s)
+        print("OK")
+    """) % root
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **envset), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stderr[-2000:]
+
+
 def test_device_resident_batch_and_stats(env):
     """Block already in HBM (torch tensor) -> anofox_hip_batch_* -> device results; counters are consistent."""
     import torch
