@@ -12,6 +12,8 @@
 //   SeasonalES     s_j = y_j ; s_j += alpha (y - s_j), t >= m
 // Seasonal rings live in LDS (run-time period).  Same K = 4 candidate sharing as the ETS pass.
 #pragma once
+#include <utility>
+#include <type_traits>
 #include "ets_device.hpp"
 
 namespace anofox {
@@ -49,7 +51,35 @@ __device__ __forceinline__ void classic_stream(const double *yp, size_t ld, int 
 }
 constexpr int CLASSIC_S = 16;
 
-template <int KIND, int K, bool FINAL>
+// The same stream with the position inside the block as a compile-time constant (blocks of S = 2 x 7 rows starting at t = 7: the
+// phase of a step is its position mod 7, so a weekly seasonal ring can live in registers with static indices).
+template <int S, class Step, int... J>
+__device__ __forceinline__ void classic_block_steps(const double (&cur)[S], int base, int len, Step &step, std::integer_sequence<int, J...>)
+{
+    ((base + J < len ? step(std::integral_constant<int, J>{}, cur[J]) : void()), ...);
+}
+template <int S, class Step>
+__device__ __forceinline__ void classic_stream_static(const double *yp, size_t ld, int t_begin, int wave_len, int len, Step step)
+{
+    double cur[S], nxt[S];
+    auto load = [&](double (&dst)[S], int t0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < S; j++) {
+            int t = t0 + j;
+            t = t < wave_len ? t : wave_len - 1;
+            dst[j] = yp[(size_t)t * ld];
+        }
+    };
+    load(cur, t_begin);
+    for (int base = t_begin; base < wave_len; base += S) {
+        load(nxt, base + S);
+        classic_block_steps<S>(cur, base, len, step, std::make_integer_sequence<int, S>{});
+#pragma unroll
+        for (int j = 0; j < S; j++) cur[j] = nxt[j];
+    }
+}
+
+template <int KIND, int K, bool FINAL, bool M7 = false>
 __device__ __forceinline__ void classic_pass(const SeriesView &v, int m,
                                              const double (&cand)[K][ClassicDim<KIND>::value],
                                              double (&fout)[K], double *ring, const ClassicFinalOut *fin)
@@ -95,6 +125,74 @@ __device__ __forceinline__ void classic_pass(const SeriesView &v, int m,
         });
         if constexpr (FINAL) {
             if (fin->write) for (int i = 1; i <= fin->h; i++) fin->yhat[i - 1] = l[0] + (double)i * b[0];
+        }
+    } else if constexpr (KIND == CK_HW && M7) {
+        // m = 7: the seasonal ring in registers (same operations as the run-time-period branch below)
+        double l[K], b[K], sr[K][7];
+        double m1 = 0.0, m2 = 0.0;
+        for (int i = 0; i < 7; i++) m1 += yp[(size_t)i * ld];
+        for (int i = 7; i < 14; i++) m2 += yp[(size_t)i * ld];
+        m1 /= 7.0;
+        m2 /= 7.0;
+#pragma unroll
+        for (int k = 0; k < K; k++) { l[k] = m1; b[k] = (m2 - m1) / 7.0; }
+#pragma unroll
+        for (int i = 0; i < 7; i++) {
+            const double s0 = yp[(size_t)i * ld] - m1;
+#pragma unroll
+            for (int k = 0; k < K; k++) sr[k][i] = s0;
+        }
+        classic_stream_static<14>(yp, ld, 7, v.wave_len, v.len, [&](auto jc, const double yv) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value % 7;
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                double s = sr[k][j];
+                double q = l[k] + b[k];
+                double e = yv - (q + s);
+                sse[k] = fma(e, e, sse[k]);
+                double ln = fma(cand[k][0], (yv - s) - q, q);
+                b[k] = fma(cand[k][1], (ln - l[k]) - b[k], b[k]);
+                sr[k][j] = fma(cand[k][2], (yv - ln) - s, s);
+                l[k] = ln;
+            }
+        });
+        if constexpr (FINAL) {
+            if (fin->write)
+                for (int i = 1; i <= fin->h; i++) {
+                    const int jj = (v.len + i - 1) % 7;
+                    double sv = sr[0][0];
+#pragma unroll
+                    for (int q = 1; q < 7; q++) sv = (jj == q) ? sr[0][q] : sv;
+                    fin->yhat[i - 1] = (l[0] + (double)i * b[0]) + sv;
+                }
+        }
+    } else if constexpr (KIND == CK_SEASONAL_ES && M7) {
+        double sr[K][7];
+#pragma unroll
+        for (int i = 0; i < 7; i++) {
+            const double s0 = yp[(size_t)i * ld];
+#pragma unroll
+            for (int k = 0; k < K; k++) sr[k][i] = s0;
+        }
+        classic_stream_static<14>(yp, ld, 7, v.wave_len, v.len, [&](auto jc, const double yv) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value % 7;
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                double s = sr[k][j];
+                double e = yv - s;
+                sse[k] = fma(e, e, sse[k]);
+                sr[k][j] = fma(cand[k][0], e, s);
+            }
+        });
+        if constexpr (FINAL) {
+            if (fin->write)
+                for (int i = 0; i < fin->h; i++) {
+                    const int jj = (v.len + i) % 7;
+                    double sv = sr[0][0];
+#pragma unroll
+                    for (int q = 1; q < 7; q++) sv = (jj == q) ? sr[0][q] : sv;
+                    fin->yhat[i] = sv;
+                }
         }
     } else if constexpr (KIND == CK_HW) {
         double l[K], b[K];
@@ -157,6 +255,56 @@ __device__ __forceinline__ void classic_pass(const SeriesView &v, int m,
 #pragma unroll
     for (int k = 0; k < K; k++) fout[k] = sse[k];
 }
+
+// The family on the ETS round kernels (sub-cases of the same machinery with their own start values and the
+// SSE as objective): ClassicCfg<KIND> stands where an EtsCfg stands, ClassicRoundModel where EtsModel<Cfg, MS, 1> stands.
+template <int KIND_>
+struct ClassicCfg {
+    static constexpr int KIND = KIND_;
+    static constexpr int DIM = ClassicDim<KIND_>::value;
+    static constexpr int E = C_ADD;
+    static constexpr int T = (KIND_ == CK_HOLT || KIND_ == CK_HW) ? C_ADD : C_NONE;
+    static constexpr int S = (KIND_ == CK_HW || KIND_ == CK_SEASONAL_ES) ? C_ADD : C_NONE;
+    static constexpr bool D = false;
+    static constexpr bool ADDITIVE = true;
+    static constexpr bool CLASSIC = true;
+};
+
+template <int KIND, int MS = -1>
+struct ClassicRoundModel {
+    static constexpr int DIM = ClassicDim<KIND>::value;
+    SeriesView v;
+    EtsInit in;             // only in.m is used (the start values come from the series itself)
+    double *ring;
+    __device__ void bounds(double (&lo)[DIM], double (&hi)[DIM], double (&x0)[DIM]) const
+    {
+#pragma unroll
+        for (int i = 0; i < DIM; i++) { lo[i] = PAR_LO; hi[i] = PAR_HI; }
+        if constexpr (KIND == CK_SES || KIND == CK_SEASONAL_ES) x0[0] = 0.5;
+        else if constexpr (KIND == CK_HOLT) { x0[0] = 0.3; x0[1] = 0.1; }
+        else { x0[0] = 0.3; x0[1] = 0.1; x0[2] = 0.1; }
+    }
+    __device__ double eval1(const double (&x)[DIM]) const
+    {
+        double c1[1][DIM], f1[1];
+#pragma unroll
+        for (int i = 0; i < DIM; i++) c1[0][i] = x[i];
+        classic_pass<KIND, 1, false, MS == 7>(v, in.m, c1, f1, ring, nullptr);
+        return f1[0];
+    }
+    // the four trial points of an iteration in four adjacent lanes (same exchange as EtsModel::eval)
+    __device__ void eval(const double (&cand)[NM_K][DIM], double (&f)[NM_K]) const
+    {
+        const int sub = threadIdx.x & 3;
+        double mine[DIM];
+#pragma unroll
+        for (int i = 0; i < DIM; i++) mine[i] = sub == 0 ? cand[0][i] : (sub == 1 ? cand[1][i] : (sub == 2 ? cand[2][i] : cand[3][i]));
+        const double f1 = eval1(mine);
+        const int base = threadIdx.x & ~3;
+#pragma unroll
+        for (int k = 0; k < NM_K; k++) f[k] = __shfl(f1, base + k);
+    }
+};
 
 template <int KIND>
 struct ClassicModel {

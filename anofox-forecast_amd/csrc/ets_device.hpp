@@ -64,6 +64,7 @@ struct EtsCfg {
     static constexpr bool D = DAMPED;
     static constexpr int DIM = 1 + (TREND != C_NONE) + (SEAS != C_NONE) + (DAMPED ? 1 : 0);
     static constexpr bool ADDITIVE = (ERR == C_ADD) && (TREND != C_MUL) && (SEAS != C_MUL);
+    static constexpr bool CLASSIC = false;      // (classic_device.hpp: the SES / Holt / Holt-Winters / SeasonalES family on the same round kernels)
 };
 
 struct EtsPar { double alpha, bstar, phi, beta, gamma; };

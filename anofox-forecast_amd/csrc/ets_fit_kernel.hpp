@@ -12,12 +12,17 @@
 // (a scan, not a contraction).
 #pragma once
 #include "ets_device.hpp"
+#include "classic_device.hpp"
 #include "kernels.hpp"
 
 #ifndef ANOFOX_ROUND_WAVES
 #define ANOFOX_ROUND_WAVES 2   // min waves per SIMD of the round kernels (caps VGPRs at 256); measured best of 1/2/4
 #endif
 namespace anofox {
+
+// the model behind a Cfg: an ETS spec, or one of the SES / Holt / Holt-Winters / SeasonalES family (SSE objective, own start values)
+template <class Cfg, int MS, bool CLASSIC = Cfg::CLASSIC> struct RoundModelOf { using type = EtsModel<Cfg, MS, 1>; };
+template <class Cfg, int MS> struct RoundModelOf<Cfg, MS, true> { using type = ClassicRoundModel<Cfg::KIND, MS>; };
 
 // SPEC = 0: sequential Nelder-Mead, one lane per problem (64 problems per wave)
 // SPEC = 1: speculative, the four trial points of a problem in four adjacent lanes (16 problems per wave)
@@ -58,12 +63,20 @@ __global__ __launch_bounds__(NM_BLOCK, ANOFOX_ROUND_WAVES) void ets_round_kernel
     if (a.first_round) {
         // admissibility of this (series, spec) -- mirrors the preconditions of oracle ets_fit
         int st = FIT_OK;
-        const uint32_t fl = valid ? a.flags[s] : 0u;
-        if (len <= 0) st = FIT_SKIPPED;
-        else if (Cfg::S != C_NONE && len < 2 * m) st = FIT_SHORT;
-        else if (len < n_param + 2) st = FIT_SHORT;
-        else if (a.need_positive && !(fl & SF_POSITIVE)) st = FIT_NONPOSITIVE;
-        else if (a.skip_constant && (fl & SF_CONSTANT)) st = FIT_SKIPPED;
+        if constexpr (Cfg::CLASSIC) {
+            // the family's own preconditions (oracle/forecast.c m_holt_winters / m_seasonal_es): a series the caller's mask does
+            // not select is left alone, Holt-Winters needs two seasons, SeasonalES one
+            const int min_len = Cfg::KIND == CK_HW ? 2 * m : (Cfg::KIND == CK_SEASONAL_ES ? m : a.min_len);
+            if (len <= 0 || (a.mask != nullptr && valid && a.mask[s] != a.want)) st = FIT_SKIPPED;
+            else if (len < min_len) st = FIT_SHORT;
+        } else {
+            const uint32_t fl = valid ? a.flags[s] : 0u;
+            if (len <= 0) st = FIT_SKIPPED;
+            else if (Cfg::S != C_NONE && len < 2 * m) st = FIT_SHORT;
+            else if (len < n_param + 2) st = FIT_SHORT;
+            else if (a.need_positive && !(fl & SF_POSITIVE)) st = FIT_NONPOSITIVE;
+            else if (a.skip_constant && (fl & SF_CONSTANT)) st = FIT_SKIPPED;
+        }
         active = valid && st == FIT_OK;
         if (valid) {
             a.status[s] = st;
@@ -84,10 +97,10 @@ __global__ __launch_bounds__(NM_BLOCK, ANOFOX_ROUND_WAVES) void ets_round_kernel
     if (v.wave_len == 0) return;
     if constexpr (Cfg::T == C_MUL && Cfg::D) dm_pow_tab_init();     // b^phi tables -> LDS (wave-uniform point: no lane has left)
 
-    EtsModel<Cfg, MS, 1> mdl;
+    typename RoundModelOf<Cfg, MS>::type mdl;
     mdl.v = v;
-    mdl.in.l0 = active ? a.l0[s] : 0.0;
-    mdl.in.b0 = (active && Cfg::T != C_NONE) ? a.b0[s] : 0.0;
+    mdl.in.l0 = (active && !Cfg::CLASSIC) ? a.l0[s] : 0.0;
+    mdl.in.b0 = (active && !Cfg::CLASSIC && Cfg::T != C_NONE) ? a.b0[s] : 0.0;
     mdl.in.fig = a.fig ? a.fig + s : nullptr;
     mdl.in.fig_ld = a.fig_ld;
     mdl.in.m = m;

@@ -338,6 +338,11 @@ struct AnofoxHipBatch {
     int gather_min = 0;      // per spec: stop gathering columns once this few problems are still running (measured: the gather pays at every count, 0 = always gather)
     int tail_below = 0;      // per spec: run the remaining problems to completion once this few are left (measured: rounds + compaction win at every threshold, 0 = off)
     int spec_below_md = 8192; // same, for the damped multiplicative-trend specs (their pass is ~10x longer: the stragglers matter more)
+    // the SES / Holt / Holt-Winters / SeasonalES family on the round kernels: its own Nelder-Mead state, status and compaction lists
+    // (the spec lanes keep the optima an inspection call re-reads)
+    anofox::NmStateBuf classic_st{};
+    int32_t *d_classic_status = nullptr, *classic_map[2] = {nullptr, nullptr}, *classic_cnt = nullptr;
+    double *d_classic_ybuf = nullptr;
     int merged_m_max = 0;         // ... and its largest period (sizes)
     int32_t *d_m_col = nullptr;   // merged batch of several seasonal periods (auto-detected): period of every column, constant within 64 columns
     bool one_launch = true;    // the three Nelder-Mead drivers of a later round in ONE kernel (ANOFOX_HIP_ONE_LAUNCH=0: one launch each, two of them empty)
@@ -506,6 +511,8 @@ void free_batch_buffers(AnofoxHipBatch *b)
     F(b->d_aicc); F(b->d_yhat_slots); F(b->d_status_slots); F(b->d_evals_slots); F(b->d_iters_slots);
     F(b->d_passes_slots); F(b->d_slot_spec);
     F(b->d_yhat); F(b->d_lo); F(b->d_hi); F(b->d_model_code); F(b->d_status); F(b->d_detail);
+    F(b->classic_st.sim); F(b->classic_st.fs); F(b->classic_st.phase); F(b->classic_st.evals); F(b->classic_st.iters); F(b->classic_st.passes); F(b->classic_st.done);
+    F(b->d_classic_ybuf); F(b->d_classic_status); F(b->classic_map[0]); F(b->classic_map[1]); F(b->classic_cnt);
     F(b->d_m_col); F(b->d_ys); F(b->d_pool_head); F(b->d_pool_trace); F(b->d_ring); F(b->d_prep_scratch);
     F(b->d_passes_total); F(b->d_evals_total); F(b->d_mask); F(b->d_len_group); F(b->d_count); F(b->d_pos_map); F(b->d_pos_cnt); F(b->d_notpos); F(b->d_ypos);
     F(b->ar_w); F(b->ar_wmean); F(b->ar_wsd); F(b->ar_l0); F(b->ar_l1); F(b->ar_x); F(b->ar_aicc); F(b->ar_wlen); F(b->ar_d); F(b->ar_D);
@@ -662,6 +669,76 @@ void run_classic(AnofoxHipBatch *b, int kind, const int32_t *d_len, int m, int o
     a.model_code = code; a.model_code_out = write_code ? b->d_model_code : nullptr;
     a.ring_scratch = nullptr;
     a.m_col = (kind == CK_HW || kind == CK_SEASONAL_ES) ? b->d_m_col : nullptr;
+    const bool optimise = kind == CK_HOLT || kind == CK_HW || optimized != 0;
+    static const bool on_rounds = [] { const char *e = std::getenv("ANOFOX_HIP_CLASSIC_ROUNDS"); return e ? std::atoi(e) != 0 : true; }();
+    if (optimise && on_rounds) {
+        // The optimised members of the family run on the ETS round kernels (ClassicCfg<KIND>, fit_classic.hip): resumable rounds
+        // with compaction, the drivers picked from the device-side count, then one final pass.  One chain on `st`.
+        const size_t n = b->n, ld = b->ld;
+        if (!b->classic_st.sim) {
+            b->classic_st.sim = dalloc<double>(12 * ld); b->classic_st.fs = dalloc<double>(4 * ld);
+            b->classic_st.phase = dalloc<int32_t>(ld); b->classic_st.evals = dalloc<int32_t>(ld); b->classic_st.iters = dalloc<int32_t>(ld);
+            b->classic_st.passes = dalloc<int32_t>(ld); b->classic_st.done = dalloc<int32_t>(ld);
+            b->d_classic_status = dalloc<int32_t>(ld);
+            b->classic_map[0] = dalloc<int32_t>(ld); b->classic_map[1] = dalloc<int32_t>(ld); b->classic_cnt = dalloc<int32_t>(3);
+        }
+        // dense re-gather between rounds: the spec lanes' block when there is one (free by now), else the family's own
+        double *ybuf = (b->n_slots_cap > 0 && b->use_gather) ? b->lanes[0].ybuf : nullptr;
+        if (!ybuf && (double)std::max<size_t>(b->t_max, 1) * (double)ld * 8.0 <= 8.0 * 1073741824.0) {
+            if (!b->d_classic_ybuf) b->d_classic_ybuf = dalloc<double>(std::max<size_t>(b->t_max, 1) * ld);
+            ybuf = b->d_classic_ybuf;
+        }
+        const bool seasonal = kind == CK_HW || kind == CK_SEASONAL_ES;
+        FitArgs f{};
+        f.y = b->d_y; f.ld = ld; f.len = d_len; f.n_series = (int)n; f.t_rows = (int)std::max<size_t>(b->t_max, 1);
+        f.m = seasonal ? std::max(m, 1) : 1; f.h = b->h;
+        f.flags = b->d_flags; f.fig = nullptr; f.fig_ld = ld;
+        f.status = b->d_classic_status; f.st = b->classic_st;
+        f.mask = mask; f.want = want; f.min_len = min_len;
+        f.m_col = a.m_col;
+        const bool merged = f.m_col != nullptr;
+        FitLaunchers fns = classic_fit_launcher(kind, (merged && f.m == 7) ? 8 : f.m);          // (7 has a register-ring variant: one period only)
+        if (!fns.round_seq || !fns.round_spec || !fns.round_spec2 || !fns.round_auto) throw HipFail{"no round kernel for this model"};
+        if (f.m > ETS_LDS_PERIOD) {
+            const size_t wg = merged ? n : std::max<size_t>((n + 15) / 16, std::min<size_t>(n, 1024));
+            f.ring_scratch = ensure_ring(b, wg * (size_t)f.m * 64u);
+        }
+        static const int BUDGET[] = {24, 24, 24, 24, 48, 48, 96, 192, 1024};
+        const int n_rounds = merged ? 3 : (int)(sizeof BUDGET / sizeof BUDGET[0]);
+        for (int r = 0; r < n_rounds; r++) {
+            f.first_round = (r == 0);
+            f.spec_below = -1; f.spec2_below = -1; f.tail_below = 0;
+            f.gathered = 0; f.gather_min = 0; f.gather_max = 0x7fffffff;
+            f.y_round = b->d_y; f.ld_round = ld; f.series_of = nullptr; f.n_active = nullptr;
+            f.next_map = nullptr; f.next_cnt = nullptr; f.clear_cnt = nullptr; f.next_y = nullptr;
+            if (merged) {
+                // several periods in one block: every launch sweeps all columns in place (see launch_fit_slots)
+                f.budget = r == 0 ? 64 : 128; f.budget_seq = f.budget;
+                (r < 2 ? fns.round_spec : fns.round_spec2)(f, st);
+            } else if (r == 0) {
+                const bool seq0 = n >= 4u * 65536u;           // the chip is full with one lane per problem
+                f.budget = seq0 ? (BUDGET[0] * 7) / 4 : BUDGET[0];
+                (seq0 ? fns.round_seq : fns.round_spec)(f, st);
+            } else {
+                int32_t **map = b->classic_map, *cnt = b->classic_cnt;
+                const int32_t *prev_map = (r == 1) ? nullptr : map[(r - 1) & 1];
+                const int32_t *prev_cnt = (r == 1) ? nullptr : cnt + ((r - 1) % 3);
+                if (r == 1) HIPCHECK(hipMemsetAsync(cnt, 0, 3 * sizeof(int32_t), st));
+                launch_compact(prev_map, prev_cnt, (int)n, b->classic_st.done, map[r & 1], cnt + (r % 3), st, cnt + ((r + 1) % 3));
+                f.series_of = map[r & 1]; f.n_active = cnt + (r % 3);
+                if (ybuf) {
+                    launch_gather_columns(b->d_y, ld, map[r & 1], cnt + (r % 3), (int)n, (int)b->t_max, ybuf, ld, st, 0, 0x7fffffff);
+                    f.y_round = ybuf; f.gathered = 1;
+                }
+                f.spec_below = 8192; f.spec2_below = 1024;
+                f.budget = BUDGET[r]; f.budget_seq = (BUDGET[r] * 7) / 4;
+                fns.round_auto(f, st);
+            }
+            b->fit_launches++;
+        }
+        launch_classic_final(kind, f, a, st);
+        return;
+    }
     if ((kind == CK_HW || kind == CK_SEASONAL_ES) && m > 48)       // CLASSIC_LDS_PERIOD: four candidate rings per lane
         a.ring_scratch = ensure_ring(b, (size_t)((b->n + 63) / 64) * 4u * (size_t)m * 64u);
     launch_classic(kind, a, st);

@@ -54,6 +54,9 @@ struct FitArgs {
     const int32_t *m_col;        // [ld] per-column seasonal period (constant within 64 columns) of a merged batch of several periods; NULL = m (then m is the size bound)
     int spec_below;              // device-side driver choice: the speculative kernel runs iff n_active <= spec_below,
                                  // the sequential one iff n_active > spec_below (both are enqueued; -1 = unconditional)
+    const uint32_t *mask;        // SES / Holt / Holt-Winters / SeasonalES on the round kernels: run only where mask[s] == want (NULL = all series)
+    uint32_t want;
+    int min_len;                 // ... and fail shorter series (Holt-Winters and SeasonalES derive theirs from the period)
     int budget_seq;              // passes per round when the device-side choice (round_auto) lands on the sequential driver
     int spec2_below;             // ... and the one-problem-per-wave driver (two iterations per pass) iff n_active <= spec2_below
     int tail_below;              // run to completion once this few problems are still running (0 = never)
@@ -146,6 +149,9 @@ struct IntervalArgs {
 typedef void (*FitLaunchFn)(const FitArgs &, hipStream_t);
 struct FitLaunchers { FitLaunchFn round_seq, round_spec, round_spec2, round_auto, final; };   // sequential / speculative / two-level speculative rounds, all three behind a device-side choice, final pass
 FitLaunchers ets_fit_launcher(int spec_id, int m);
+FitLaunchers classic_fit_launcher(int kind, int m);          // fit_classic.hip: the SES / Holt / Holt-Winters / SeasonalES family on the round kernels (final = NULL)
+struct ClassicArgs;
+void launch_classic_final(int kind, const FitArgs &a, const ClassicArgs &c, hipStream_t stream);
 
 // Work-pool schedule (ets_pool_kernel.hpp): ONE persistent kernel per compile unit serves the unit's candidate specs in
 // priority order.  The arguments travel by value (kernel argument segment: uniform, read-only), per-spec part + common part.
