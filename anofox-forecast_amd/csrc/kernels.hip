@@ -348,6 +348,7 @@ __global__ __launch_bounds__(NM_BLOCK) void gather_columns_kernel(const double *
 void launch_gather_columns(const double *y, size_t ld, const int32_t *series_of, const int32_t *n_active, int n_series,
                            int t_max, double *out, size_t ld_out, hipStream_t stream, int min_active, int max_active)
 {
+    if (n_series <= 0 || t_max <= 0) return;          // a batch of empty series: nothing to copy (and no zero-sized grid)
     dim3 grid((n_series + NM_BLOCK - 1) / NM_BLOCK, (t_max + GATHER_TB - 1) / GATHER_TB);
     hipLaunchKernelGGL(gather_columns_kernel, grid, dim3(NM_BLOCK), 0, stream, y, ld, series_of, n_active, t_max, out, ld_out, min_active, max_active);
 }

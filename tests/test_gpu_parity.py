@@ -545,6 +545,16 @@ def test_process_wide_switches(envset):
     assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stderr[-2000:]
 
 
+def test_batches_of_empty_series(env):
+    """A batch whose every series is empty (t_max = 0) reports InsufficientData per series for every model -- no kernel is
+    launched with an empty grid (found by tools/fuzz_parity.py after the SES / Holt family moved to the round kernels)."""
+    api, O, lib, synth = env
+    for model, kw in (("AutoETS", {"seasonal_period": 3}), ("HoltWinters", {"seasonal_period": 7}), ("Holt", {}), ("SESOptimized", {}),
+                      ("SeasonalESOptimized", {"seasonal_period": 4}), ("ETS", {"ets_model": "AAA", "seasonal_period": 7}), ("AutoARIMA", {}), ("Naive", {})):
+        for k in (1, 3):
+            _compare(api, O, lib, [np.array([])] * k, model, 5, **kw)
+
+
 def test_device_resident_batch_and_stats(env):
     """Block already in HBM (torch tensor) -> anofox_hip_batch_* -> device results; counters are consistent."""
     import torch
