@@ -555,6 +555,32 @@ def test_batches_of_empty_series(env):
             _compare(api, O, lib, [np.array([])] * k, model, 5, **kw)
 
 
+def test_merged_periods_with_nulls_horizons_and_fitted(env):
+    """The merged batch keeps the per-series extras: NULLs are interpolated before detection, per-series horizons truncate
+    (the cross-validation caller), fitted values and residuals use the series' own period."""
+    api, O, lib, synth = env
+    rng = np.random.default_rng(23)
+    series, valids, hz = [], [], []
+    for p, reps in ((4, 2), (7, 3), (9, 2), (26, 2), (66, 2), (90, 1)):
+        for r in range(reps):
+            T = int(max(7 * p, 100) + rng.integers(0, 30))
+            t = np.arange(T)
+            y = 40.0 + (6.0 + r) * np.sin(2 * np.pi * t / p) + rng.normal(0, 0.5, T)
+            v = rng.random(T) > 0.04
+            v[0] = v[-1] = True
+            series.append(np.where(v, y, 0.0)); valids.append(v); hz.append(int(rng.integers(0, 11)))
+    opts = lib.make_options("AutoETS", 10, include_fitted=True, include_residuals=True)
+    oo = O.make_options("AutoETS", 10, include_fitted=True, include_residuals=True)
+    got, berr = api.forecast_batch(series, opts, valids, hz)
+    assert berr["ok"], berr
+    for s, (y, v) in enumerate(zip(series, valids)):
+        ref = O.forecast(y, oo, v)
+        assert got[s]["ok"] and ref["ok"] and got[s]["model_name"] == ref["model_name"], s
+        assert len(got[s]["point"]) == hz[s]
+        assert np.array_equal(np.asarray(got[s]["point"]), np.asarray(ref["point"])[: hz[s]]), s
+        assert _rel(np.asarray(got[s]["fitted"]), np.asarray(ref["fitted"])) <= REL_TOL and _rel(np.asarray(got[s]["residuals"]), np.asarray(ref["residuals"])) <= REL_TOL, s
+
+
 def test_device_resident_batch_and_stats(env):
     """Block already in HBM (torch tensor) -> anofox_hip_batch_* -> device results; counters are consistent."""
     import torch
