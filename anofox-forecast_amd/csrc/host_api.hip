@@ -2131,7 +2131,8 @@ bool anofox_ts_forecast_batch(const double *const *values, const uint64_t *const
         // AutoETS: the small parts with periods 2..48 run as ONE batch whose columns are grouped by period in blocks of 64 (the
         // kernels read the period per block): 138 tiny batches x 25 spec chains on 16 hardware queues were latency bound end to end
         static const bool merge_periods = [] { const char *e = std::getenv("ANOFOX_HIP_MERGE_PERIODS"); return e ? std::atoi(e) != 0 : true; }();
-        const bool do_merge = merge_periods && (plan.model == M_AutoETS || plan.model == M_HoltWinters || plan.model == M_SeasonalES || plan.model == M_SeasonalESOptimized);
+        const bool do_merge = merge_periods && (plan.model == M_AutoETS || plan.model == M_HoltWinters || plan.model == M_SeasonalES || plan.model == M_SeasonalESOptimized ||
+                                                (plan.model == M_ETS && plan.ets_spec_id >= 0 && spec_season(plan.ets_spec_id) != 0));
             // one merged batch per ring class (seasonal ring in LDS up to 64, in an HBM scratch above; the scratch is sized by the
             // class's largest period, hence a few classes)
             using Part = std::pair<int, std::vector<size_t>>;

@@ -494,7 +494,7 @@ def test_two_level_speculation_counts(env, monkeypatch):
         np.testing.assert_array_equal(r0[k], r1[k])
 
 
-@pytest.mark.parametrize("model", ["AutoETS", "HoltWinters", "SeasonalESOptimized"])
+@pytest.mark.parametrize("model", ["AutoETS", "HoltWinters", "SeasonalESOptimized", "ETS:AAA", "ETS:MAdM"])
 def test_auto_detected_periods_merge_into_one_batch(env, monkeypatch, model):
     """params := MAP{} (no seasonal_period): every series gets its own detected period.  The batch entry runs the series of all
     periods of a ring class as ONE batch whose 64-column blocks each have their own period (prep, fit, final pass and the
@@ -510,9 +510,11 @@ def test_auto_detected_periods_merge_into_one_batch(env, monkeypatch, model):
             y = 50.0 + 0.02 * t + (8.0 + r) * np.sin(2 * np.pi * t / p) + 3.0 * np.cos(4 * np.pi * t / p) + rng.normal(0, 0.6, T)
             series.append(y)
     series += [np.full(40, 3.0), np.arange(30.0), rng.normal(10, 1, 50), np.array([1.0, 2.0]), np.array([])]
-    _compare(api, O, lib, series, model, 9)
+    kw = {}
+    if ":" in model: model, kw = model.split(":")[0], {"ets_model": model.split(":")[1]}
+    _compare(api, O, lib, series, model, 9, **kw)
     monkeypatch.setenv("ANOFOX_HIP_MERGE_PERIODS", "0")
-    _compare(api, O, lib, series, model, 9)
+    _compare(api, O, lib, series, model, 9, **kw)
 
 
 @pytest.mark.parametrize("envset", [{"ANOFOX_HIP_CACHE_GB": "0", "ANOFOX_HIP_PINNED_CACHE_GB": "0"}, {"ANOFOX_HIP_PRIO_STREAMS": "0", "ANOFOX_HIP_ONE_LAUNCH": "0"},
