@@ -92,6 +92,9 @@ __global__ __launch_bounds__(NM_BLOCK) void prep_kernel(const PrepArgs a)
     if (want_season) ph = ((-half) % m + m) % m;
     for (int base = 0; base < wave_rows; base += PREP_S) {
       rows.load(nxt, base + PREP_S);
+      // the multiplicative figure (one IEEE division per step) only matters for strictly positive series: once every series of
+      // the wave has shown a value <= 0 (intermittent demand: within the first blocks) the wave stops computing it
+      const bool wave_pos = __any(positive && base < n);
 #pragma unroll
       for (int jj = 0; jj < PREP_S; jj++) {
         const int t = base + jj;
@@ -116,8 +119,12 @@ __global__ __launch_bounds__(NM_BLOCK) void prep_kernel(const PrepArgs a)
 #pragma unroll
                         for (int q = 0; q < MR; q++) {
                             sAR[q] = (q == phc) ? sAR[q] + (yc - acc) : sAR[q];
-                            sMR[q] = (q == phc) ? sMR[q] + (yc / acc) : sMR[q];
                             cNR[q] = (q == phc) ? cNR[q] + 1.0 : cNR[q];
+                        }
+                        if (wave_pos) {
+                            const double ratio = yc / acc;
+#pragma unroll
+                            for (int q = 0; q < MR; q++) sMR[q] = (q == phc) ? sMR[q] + ratio : sMR[q];
                         }
                     }
                 }
@@ -138,7 +145,7 @@ __global__ __launch_bounds__(NM_BLOCK) void prep_kernel(const PrepArgs a)
                         k0 = k0 + 1 == L ? 0 : k0 + 1;
                     }
                     sumA[ph * NM_BLOCK + lane] = sumA[ph * NM_BLOCK + lane] + (yc - acc);
-                    sumM[ph * NM_BLOCK + lane] = sumM[ph * NM_BLOCK + lane] + (yc / acc);
+                    if (wave_pos) sumM[ph * NM_BLOCK + lane] = sumM[ph * NM_BLOCK + lane] + (yc / acc);
                     cnt[ph * NM_BLOCK + lane] += 1.0;
                 }
             }
@@ -212,6 +219,7 @@ __global__ __launch_bounds__(NM_BLOCK) void prep_kernel(const PrepArgs a)
     double var = 0.0;
     double sy[3] = {0, 0, 0}, sxy[3] = {0, 0, 0}, sk[3] = {0, 0, 0}, ysa0[3] = {0, 0, 0}, ysa1[3] = {0, 0, 0};
     const bool useA = seasonal, useM = seasonal && positive;
+    const bool wave_useM = __any(useM);            // no strictly positive series in the wave: no multiplicative states, no division per step
     int K0 = 10 > n ? n : 10;
     int Km = 2 * m > 10 ? 2 * m : 10;
     if (Km > n) Km = n;
@@ -231,10 +239,12 @@ __global__ __launch_bounds__(NM_BLOCK) void prep_kernel(const PrepArgs a)
             vs[0] = v;
             if constexpr (MR > 0) {
                 vs[1] = useA ? v - sAR[jj % MR] : 0.0;
-                vs[2] = useM ? v / sMR[jj % MR] : 0.0;
+                vs[2] = 0.0;
+                if (wave_useM) vs[2] = useM ? v / sMR[jj % MR] : 0.0;
             } else {
                 vs[1] = useA ? v - sumA[j * NM_BLOCK + lane] : 0.0;
-                vs[2] = useM ? v / sumM[j * NM_BLOCK + lane] : 0.0;
+                vs[2] = 0.0;
+                if (wave_useM) vs[2] = useM ? v / sumM[j * NM_BLOCK + lane] : 0.0;
             }
 #pragma unroll
             for (int st = 0; st < 3; st++) {
