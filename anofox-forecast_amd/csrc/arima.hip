@@ -605,7 +605,17 @@ __global__ __launch_bounds__(256) void arima_advance_kernel(const ArimaArgs a, c
                     }
                     for (int jj = 0; jj < AR_SWEEP; jj++) {
                         ArOrd c;
-                        if (ar_candidate(1, jj, nb, allow_c, maxP, c)) emit(c);
+                        if (!ar_candidate(1, jj, nb, allow_c, maxP, c)) continue;
+                        emit(c);
+                        if (lookahead >= 2) {
+                            // a handful of series left: one sweep deeper still (the neighbours of that neighbour)
+                            const int ck = ar_key(c);
+                            if (tried[ck >> 5] & (1u << (ck & 31))) continue;
+                            for (int kk = 0; kk < AR_SWEEP; kk++) {
+                                ArOrd c2;
+                                if (ar_candidate(1, kk, c, allow_c, maxP, c2)) emit(c2);
+                            }
+                        }
                     }
                 }
             }
@@ -1549,7 +1559,11 @@ int launch_arima(const ArimaArgs &a, hipStream_t stream)
         // look one sweep ahead once the previous sweep's queue times the fan-out (~18 candidates per series) fits the
         // resident lanes `la_factor` times over: the extra fits cost idle lanes, the saved sweeps cost ~0.1-0.2 s each
         static const double la_factor = [] { const char *e = std::getenv("ANOFOX_HIP_ARIMA_LOOKAHEAD"); return e ? std::atof(e) : 4.0; }();   // measured 0 / 0.25 / 1 / 4 / 16: 2.16 / 2.03 / 1.93 / 1.92 / 1.90 s on the M5 batch
-        const int lookahead = (prev_total >= 0 && (double)prev_total * (AR_SWEEP + 1) <= la_factor * (double)max_waves * NM_BLOCK) ? 1 : 0;
+        int lookahead = (prev_total >= 0 && (double)prev_total * (AR_SWEEP + 1) <= la_factor * (double)max_waves * NM_BLOCK) ? 1 : 0;
+        // ... and two sweeps ahead once even that fan-out squared fits the resident lanes (the late sweeps of a few hundred series are
+        // each bound by their slowest fit, ~0.1 s: 5 of them on the M5 batch)
+        static const int la_depth = [] { const char *e = std::getenv("ANOFOX_HIP_ARIMA_LOOKAHEAD_DEPTH"); return e ? std::atoi(e) : 2; }();
+        if (lookahead && la_depth >= 2 && (double)prev_total * (AR_SWEEP + 1) * (AR_SWEEP + 1) <= la_factor * (double)max_waves * NM_BLOCK) lookahead = 2;
         hipLaunchKernelGGL(arima_advance_kernel, dim3(grid256), dim3(256), 0, stream, a, ws, lookahead);
         int32_t counts[8];
         AR_HIPCHECK(hipMemcpyAsync(counts, ws.counts, sizeof counts, hipMemcpyDeviceToHost, stream));
@@ -1558,6 +1572,7 @@ int launch_arima(const ArimaArgs &a, hipStream_t stream)
         long total = 0;
         for (int i = 0; i <= AR_MAXDIM; i++) total += counts[i];
         if (total == 0) break;
+        if (a.trace) std::fprintf(stderr, "[anofox-hip] AutoARIMA sweep %d: %ld problems queued (lookahead %d)\n", sweep, total, lookahead);
         prev_total = total;
         static const double spec_factor = [] { const char *e = std::getenv("ANOFOX_HIP_ARIMA_SPEC_FACTOR"); return e ? std::atof(e) : 3.0; }();   // measured 1 / 2 / 2.5 / 3 / 4: 1.83 / 1.83 / 1.74 / 1.74 / 1.73 s
         if ((double)total <= spec_factor * (double)max_waves * (NM_BLOCK / 4)) {
