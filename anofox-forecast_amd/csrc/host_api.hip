@@ -2218,6 +2218,29 @@ bool anofox_ts_forecast_batch(const double *const *values, const uint64_t *const
                     for (size_t k = 0; k < take.size(); k++) if (part.first <= CLASS_HI[k]) { c = (int)k; break; }
                 (c >= 0 ? take[(size_t)c] : keep).push_back(std::move(part));
             }
+            // The HBM-ring class is cut where its ring scratch (columns x largest period x 512 B per seasonal spec, one workgroup per
+            // column in the last launch) would pass 1 GiB per spec: many rare long periods (252 parts up to 744 in 8,192 M5-like
+            // series: 16,640 columns) otherwise ask for 100 GB.
+            {
+                std::vector<std::vector<Part>> cut;
+                for (auto &cls : take) {
+                    std::sort(cls.begin(), cls.end(), [](const Part &x, const Part &y) { return x.first < y.first; });
+                    std::vector<Part> cur;
+                    size_t cols = 0;
+                    for (auto &part : cls) {
+                        const size_t pc = (part.second.size() + 63) / 64 * 64;
+                        if (!cur.empty() && part.first > ETS_LDS_PERIOD && (double)(cols + pc) * (double)part.first * 512.0 > 1073741824.0) {
+                            cut.push_back(std::move(cur));
+                            cur.clear();
+                            cols = 0;
+                        }
+                        cols += pc;
+                        cur.push_back(std::move(part));
+                    }
+                    if (!cur.empty()) cut.push_back(std::move(cur));
+                }
+                take = std::move(cut);
+            }
             // the classes side by side (each is latency bound by its slowest fit and far from filling the chip)
             std::vector<std::vector<Part> *> todo;
             for (auto &cls : take) {

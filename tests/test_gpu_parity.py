@@ -583,6 +583,21 @@ def test_merged_periods_with_nulls_horizons_and_fitted(env):
         assert _rel(np.asarray(got[s]["fitted"]), np.asarray(ref["fitted"])) <= REL_TOL and _rel(np.asarray(got[s]["residuals"]), np.asarray(ref["residuals"])) <= REL_TOL, s
 
 
+def test_merged_periods_many_long_periods(env):
+    """Seventy-two series with as many different long periods (an auto-detected batch of M5-like series has hundreds of rare ones): the
+    HBM-ring class is cut into several merged batches so that its ring scratch stays bounded (one 64-column block per period
+    x the largest period x 512 B per seasonal spec had asked for 100 GB on 8,192 series and failed the whole call)."""
+    api, O, lib, synth = env
+    rng = np.random.default_rng(29)
+    series = []
+    for k in range(72):
+        p = 556 + 2 * k
+        T = 2 * p + 220 + int(rng.integers(0, 30))
+        t = np.arange(T)
+        series.append(30.0 + 9.0 * np.sin(2 * np.pi * t / p) + rng.normal(0, 0.4, T))
+    _compare(api, O, lib, series, "ETS", 6, ets_model="AAA")
+
+
 def test_device_resident_batch_and_stats(env):
     """Block already in HBM (torch tensor) -> anofox_hip_batch_* -> device results; counters are consistent."""
     import torch
