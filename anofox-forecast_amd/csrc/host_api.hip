@@ -343,6 +343,8 @@ struct AnofoxHipBatch {
     anofox::NmStateBuf classic_st{};
     int32_t *d_classic_status = nullptr, *classic_map[2] = {nullptr, nullptr}, *classic_cnt = nullptr;
     double *d_classic_ybuf = nullptr;
+    std::vector<void *> retired;  // blocks a run outgrew while kernels may still read them: handed back when the batch is destroyed
+                                  // (freeing them on the spot needs a device-wide synchronisation, which couples every host thread's batch)
     int merged_m_max = 0;         // ... and its largest period (sizes)
     int32_t *d_m_col = nullptr;   // merged batch of several seasonal periods (auto-detected): period of every column, constant within 64 columns
     bool one_launch = true;    // the three Nelder-Mead drivers of a later round in ONE kernel (ANOFOX_HIP_ONE_LAUNCH=0: one launch each, two of them empty)
@@ -513,6 +515,8 @@ void free_batch_buffers(AnofoxHipBatch *b)
     F(b->d_yhat); F(b->d_lo); F(b->d_hi); F(b->d_model_code); F(b->d_status); F(b->d_detail);
     F(b->classic_st.sim); F(b->classic_st.fs); F(b->classic_st.phase); F(b->classic_st.evals); F(b->classic_st.iters); F(b->classic_st.passes); F(b->classic_st.done);
     F(b->d_classic_ybuf); F(b->d_classic_status); F(b->classic_map[0]); F(b->classic_map[1]); F(b->classic_cnt);
+    for (void *p : b->retired) F(p);
+    b->retired.clear();
     F(b->d_m_col); F(b->d_ys); F(b->d_pool_head); F(b->d_pool_trace); F(b->d_ring); F(b->d_prep_scratch);
     F(b->d_passes_total); F(b->d_evals_total); F(b->d_mask); F(b->d_len_group); F(b->d_count); F(b->d_pos_map); F(b->d_pos_cnt); F(b->d_notpos); F(b->d_ypos);
     F(b->ar_w); F(b->ar_wmean); F(b->ar_wsd); F(b->ar_l0); F(b->ar_l1); F(b->ar_x); F(b->ar_aicc); F(b->ar_wlen); F(b->ar_d); F(b->ar_D);
@@ -612,8 +616,8 @@ void alloc_common(AnofoxHipBatch *b)
 void ensure_fig(AnofoxHipBatch *b, int m)
 {
     if (m <= b->fig_m) return;
-    dev_free(b->d_fig_add);
-    dev_free(b->d_fig_mul);
+    if (b->d_fig_add) b->retired.push_back(b->d_fig_add);
+    if (b->d_fig_mul) b->retired.push_back(b->d_fig_mul);
     b->d_fig_add = dalloc<double>((size_t)m * b->ld);
     b->d_fig_mul = dalloc<double>((size_t)m * b->ld);
     b->fig_m = m;
@@ -623,7 +627,7 @@ void ensure_fig(AnofoxHipBatch *b, int m)
 double *ensure_ring(AnofoxHipBatch *b, size_t elems)
 {
     if (b->ring_elems < elems) {
-        dev_free(b->d_ring);
+        if (b->d_ring) b->retired.push_back(b->d_ring);
         b->d_ring = nullptr; b->ring_elems = 0;
         b->d_ring = dalloc<double>(elems);
         b->ring_elems = elems;
@@ -633,7 +637,7 @@ double *ensure_ring(AnofoxHipBatch *b, size_t elems)
 double *ensure_prep_scratch(AnofoxHipBatch *b, size_t elems)
 {
     if (b->prep_scratch_elems < elems) {
-        dev_free(b->d_prep_scratch);
+        if (b->d_prep_scratch) b->retired.push_back(b->d_prep_scratch);
         b->d_prep_scratch = nullptr; b->prep_scratch_elems = 0;
         b->d_prep_scratch = dalloc<double>(elems);
         b->prep_scratch_elems = elems;
@@ -704,7 +708,7 @@ void run_classic(AnofoxHipBatch *b, int kind, const int32_t *d_len, int m, int o
             f.ring_scratch = ensure_ring(b, wg * (size_t)f.m * 64u);
         }
         static const int BUDGET[] = {24, 24, 24, 24, 48, 48, 96, 192, 1024};
-        const int n_rounds = merged ? 3 : (int)(sizeof BUDGET / sizeof BUDGET[0]);
+        const int n_rounds = merged ? (n > 4096 ? 4 : 3) : (int)(sizeof BUDGET / sizeof BUDGET[0]);
         for (int r = 0; r < n_rounds; r++) {
             f.first_round = (r == 0);
             f.spec_below = -1; f.spec2_below = -1; f.tail_below = 0;
@@ -713,8 +717,8 @@ void run_classic(AnofoxHipBatch *b, int kind, const int32_t *d_len, int m, int o
             f.next_map = nullptr; f.next_cnt = nullptr; f.clear_cnt = nullptr; f.next_y = nullptr;
             if (merged) {
                 // several periods in one block: every launch sweeps all columns in place (see launch_fit_slots)
-                f.budget = r == 0 ? 64 : 128; f.budget_seq = f.budget;
-                (r < 2 ? fns.round_spec : fns.round_spec2)(f, st);
+                f.budget = r == 0 ? 64 : (r == 1 ? 128 : 256); f.budget_seq = f.budget;
+                (r < n_rounds - 1 ? fns.round_spec : fns.round_spec2)(f, st);
             } else if (r == 0) {
                 const bool seq0 = n >= 4u * 65536u;           // the chip is full with one lane per problem
                 f.budget = seq0 ? (BUDGET[0] * 7) / 4 : BUDGET[0];
@@ -883,7 +887,7 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
         const size_t T = std::max<size_t>(b->t_max, 1);
         const size_t tw = (T + 1) / 2 * 2 + 64;
         if (!b->d_ys || b->pool_tw != tw) {
-            dev_free(b->d_ys);
+            if (b->d_ys) b->retired.push_back(b->d_ys);
             b->d_ys = nullptr;
             b->d_ys = dalloc<double>((n + 1) * tw);
             HIPCHECK(hipMemsetAsync(b->d_ys, 0, (n + 1) * tw * sizeof(double), st));
@@ -1096,7 +1100,19 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
         // iterations with four lanes per problem, then everything that is left one problem per wave to completion.  A merged batch
         // is small (the series of the rare periods of an auto-detected batch), so lane efficiency is not what bounds it: the
         // chains of 138 separate tiny batches on 16 hardware queues were (5.3 s for 1,024 series).
-        for (int r = 0; r < 3; r++) {
+        // (a large merged batch gets a third four-lane launch of 256 iterations first: one WAVE per problem is 16 times the
+        //  arithmetic, so the last launch should find a few thousand problems, not a third of them -- 30,490 auto-detected series
+        //  spent 2.5-3.5 s per merged batch in it)
+        // a large one starts with the sequential driver (one lane per problem: a workgroup's 64 columns share a period too)
+        struct MergedRound { int driver, budget; };              // driver 0 sequential, 1 four lanes per problem, 2 one wave per problem
+        static const MergedRound SMALL[] = {{1, 64}, {1, 128}, {2, 0}};
+        static const MergedRound LARGE[] = {{0, 42}, {0, 84}, {0, 168}, {1, 128}, {1, 256}, {2, 0}};
+        size_t n_real = 0;                                        // the padding columns of the period blocks do not count
+        for (size_t s2 = 0; s2 < n && s2 < b->h_len.size(); s2++) if (b->h_len[s2] > 0) n_real++;
+        const bool large = n_real > 4096;
+        const MergedRound *plan_r = large ? LARGE : SMALL;
+        const int n_merged_rounds = large ? 6 : 3;
+        for (int r = 0; r < n_merged_rounds; r++) {
             for (size_t oi = 0; oi < order.size(); oi++) {
                 if (dead[oi]) continue;
                 hipStream_t sq = b->aux[stream_of[oi]];
@@ -1106,8 +1122,8 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
                 a.gathered = 0; a.gather_min = 0; a.gather_max = 0x7fffffff;
                 a.y_round = b->d_y; a.ld_round = ld; a.series_of = nullptr; a.n_active = nullptr;
                 a.next_map = nullptr; a.next_cnt = nullptr; a.clear_cnt = nullptr; a.next_y = nullptr;
-                a.budget = r == 0 ? 64 : 128; a.budget_seq = a.budget;
-                (r < 2 ? fns[oi].round_spec : fns[oi].round_spec2)(a, sq);
+                a.budget = plan_r[r].budget; a.budget_seq = a.budget;
+                (plan_r[r].driver == 0 ? fns[oi].round_seq : (plan_r[r].driver == 1 ? fns[oi].round_spec : fns[oi].round_spec2))(a, sq);
                 b->fit_launches++;
             }
             LAUNCHCHECK("ETS fit round (merged periods)");
@@ -2225,11 +2241,17 @@ bool anofox_ts_forecast_batch(const double *const *values, const uint64_t *const
                 std::vector<std::vector<Part>> cut;
                 for (auto &cls : take) {
                     std::sort(cls.begin(), cls.end(), [](const Part &x, const Part &y) { return x.first < y.first; });
+                    // a class that fits 2 GiB per spec as a whole stays whole (a thousand series: one latency-bound batch instead of
+                    // two); a larger one is cut at 1 GiB and its pieces run one after the other (below), re-using the same blocks
+                    size_t all_cols = 0;
+                    for (const auto &part : cls) all_cols += (part.second.size() + 63) / 64 * 64;
+                    const double whole = cls.empty() ? 0.0 : (double)all_cols * (double)cls.back().first * 512.0;
+                    const double bound = whole <= 2.0 * 1073741824.0 ? 2.0 * 1073741824.0 : 1073741824.0;
                     std::vector<Part> cur;
                     size_t cols = 0;
                     for (auto &part : cls) {
                         const size_t pc = (part.second.size() + 63) / 64 * 64;
-                        if (!cur.empty() && part.first > ETS_LDS_PERIOD && (double)(cols + pc) * (double)part.first * 512.0 > 1073741824.0) {
+                        if (!cur.empty() && part.first > ETS_LDS_PERIOD && (double)(cols + pc) * (double)part.first * 512.0 > bound) {
                             cut.push_back(std::move(cur));
                             cur.clear();
                             cols = 0;
@@ -2250,16 +2272,21 @@ bool anofox_ts_forecast_batch(const double *const *values, const uint64_t *const
             std::atomic<bool> merged_ok{true};
             int cur_dev_m = 0;
             (void)hipGetDevice(&cur_dev_m);
-            auto run_cls = [&](std::vector<Part> *cls) {
+            // one host thread for the LDS-ring batch, one for the HBM-ring batches (one after the other: each is latency bound by its
+            // slowest fit, side by side they take as long and hold several times the scratch)
+            auto run_cls = [&](std::vector<std::vector<Part> *> group) {
                 try {
                     (void)hipSetDevice(cur_dev_m);
-                    if (!run_merged(*cls)) merged_ok = false;
+                    for (auto *cls : group) if (!run_merged(*cls)) merged_ok = false;
                 } catch (...) { merged_ok = false; }                // nothing may leave a worker thread
             };
             // ... and beside the parts that stay separate (below); joined before this function returns, whatever the way out
             std::vector<std::thread> cls_threads;
             struct Joiner { std::vector<std::thread> &t; ~Joiner() { for (auto &x : t) if (x.joinable()) x.join(); } } cls_joiner{cls_threads};
-            for (size_t k = 0; k < todo.size(); k++) cls_threads.emplace_back(run_cls, todo[k]);
+            std::vector<std::vector<Part> *> grp_lds, grp_hbm;
+            for (auto *cls : todo) (cls->back().first <= ETS_LDS_PERIOD ? grp_lds : grp_hbm).push_back(cls);
+            if (!grp_lds.empty()) cls_threads.emplace_back(run_cls, grp_lds);
+            if (!grp_hbm.empty()) cls_threads.emplace_back(run_cls, grp_hbm);
             parts = std::move(keep);
             std::sort(parts.begin(), parts.end(), [](const Part &x, const Part &y) { return x.second.size() > y.second.size(); });
         if (std::getenv("ANOFOX_HIP_TIMING")) {
@@ -2351,7 +2378,7 @@ bool anofox_ts_forecast_batch(const double *const *values, const uint64_t *const
         for (unsigned i = 1; i < n_thr; i++) pool.emplace_back(work);
         work();
         for (auto &t : pool) t.join();
-        for (auto &t : cls_threads) t.join();
+        for (auto &t : cls_threads) if (t.joinable()) t.join();
         if (!merged_ok) {
             if (out_batch_error && out_batch_error->code == SUCCESS) set_error(out_batch_error, INTERNAL_ERROR, "Internal error: device batch failed");
             return false;

@@ -13,13 +13,16 @@ Y = synth.gen_series(synth.SEED_M5 + 5, 4321, n, 1913, 7, True)
 lens = rng.integers(400, 1914, size=n)
 series = [Y[i, 1913 - lens[i]:].copy() for i in range(n)]
 opts = lib.make_options(model, 28)
-t0 = time.time()
-got, berr = api.forecast_batch(series, opts)
-dt = time.time() - t0
-assert berr["ok"], berr
+times = []
+for _ in range(2):
+    t0 = time.time()
+    got, berr = api.forecast_batch(series, opts)
+    times.append(time.time() - t0)
+    assert berr["ok"], berr
+dt = times[-1]
 bad = 0
 for i in range(0, n, max(1, n // 24)):
     ref = O.forecast(series[i], O.make_options(model, 28))
     if ref["ok"] != got[i]["ok"] or (ref["ok"] and (ref["model_name"] != got[i]["model_name"] or not np.array_equal(ref["point"], got[i]["point"]))):
         bad += 1
-print(f"{model}: {dt:.2f} s for {n} series with auto-detected periods = {n / dt:.0f} series/s (first call, Python marshalling included), {bad} mismatches in the sample")
+print(f"{model}: {dt:.2f} s for {n} series with auto-detected periods = {n / dt:.0f} series/s (second call; first {times[0]:.2f} s; Python marshalling included), {bad} mismatches in the sample")
