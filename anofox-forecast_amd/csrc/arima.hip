@@ -1574,7 +1574,7 @@ int launch_arima(const ArimaArgs &a, hipStream_t stream)
         if (total == 0) break;
         if (a.trace) std::fprintf(stderr, "[anofox-hip] AutoARIMA sweep %d: %ld problems queued (lookahead %d)\n", sweep, total, lookahead);
         prev_total = total;
-        static const double spec_factor = [] { const char *e = std::getenv("ANOFOX_HIP_ARIMA_SPEC_FACTOR"); return e ? std::atof(e) : 3.0; }();   // measured 1 / 2 / 2.5 / 3 / 4: 1.83 / 1.83 / 1.74 / 1.74 / 1.73 s
+        static const double spec_factor = [] { const char *e = std::getenv("ANOFOX_HIP_ARIMA_SPEC_FACTOR"); return e ? std::atof(e) : 8.0; }();   // measured 1 / 2 / 2.5 / 3 / 4: 1.83 / 1.83 / 1.74 / 1.74 / 1.73 s (round 1); with the refit and the longer lookahead 2 / 4 / 6 / 8 / 10 / 12 / 16: 2.31 / 2.14 / 2.12 / 2.10 / 2.10 / 2.19 / 2.35 s
         if ((double)total <= spec_factor * (double)max_waves * (NM_BLOCK / 4)) {
             // short queue (up to three problems per resident 4-lane group): four lanes per problem, one pass per Nelder-Mead
             // iteration -- such a sweep is bound by its slowest fit, not by throughput
