@@ -30,6 +30,7 @@ from dataclasses import dataclass
 import numpy as np
 
 from . import lib as _lib
+from .backtest_metrics import backtest_metric
 
 VALID_PARAM_KEYS = ("model", "seasonal_period", "seasonal_periods", "confidence_level", "window", "model_pool",
                     "laplace_variant", "laplace_seasonal_batch_init")
@@ -802,39 +803,6 @@ def backtest_fold_bounds(n_dates, horizon, folds, window_type="expanding", min_t
             train_start = max(train_start, out[-1][4] + 1 + int(embargo))
         out.append((fold + 1, train_start, train_end, test_start, test_end))
     return out
-
-
-def backtest_metric(metric, actual, forecast, lower, upper):
-    """ComputeMetric (ts_backtest_native.cpp:280-373): sums run in row order like the reference's loops."""
-    a, f = np.asarray(actual, dtype=np.float64), np.asarray(forecast, dtype=np.float64)
-    n = len(a)
-    if n == 0 or len(f) == 0:
-        return float("nan")
-    seq = lambda x: float(np.cumsum(x)[-1]) if len(x) else 0.0      # sequential accumulation, not pairwise
-    with np.errstate(all="ignore"):
-        if metric == "mae":
-            return seq(np.abs(a - f)) / n
-        if metric == "mse":
-            return seq((a - f) * (a - f)) / n
-        if metric == "mape":
-            k = a != 0
-            return seq(np.abs((a[k] - f[k]) / a[k])) / int(k.sum()) * 100.0 if k.any() else float("nan")
-        if metric == "smape":
-            d = np.abs(a) + np.abs(f)
-            k = d > 0
-            return seq(np.abs(a[k] - f[k]) / d[k]) / int(k.sum()) * 200.0 if k.any() else float("nan")
-        if metric == "bias":
-            return seq(f - a) / n
-        if metric == "r2":
-            mean = seq(a) / n
-            res, tot = seq((a - f) * (a - f)), seq((a - mean) * (a - mean))
-            return 1.0 - res / tot if tot > 0 else float("nan")
-        if metric == "coverage":
-            lo, hi = np.asarray(lower), np.asarray(upper)
-            if len(lo) != n or len(hi) != n:
-                return float("nan")
-            return int(((a >= lo) & (a <= hi)).sum()) / n
-        return float(np.sqrt(seq((a - f) * (a - f)) / n))           # "rmse" and every unknown name
 
 
 def ts_backtest_native(group, date, value, horizon=7, folds=5, params=None, metric="rmse", group_name="id", date_name="date"):

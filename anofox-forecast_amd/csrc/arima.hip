@@ -31,6 +31,11 @@
 namespace anofox {
 
 constexpr int AR_MAXP = 5, AR_MAXSP = 2, AR_MAXORDER = 5, AR_MAXDIM = 6, AR_MAXMODELS = 94;
+// Nelder-Mead budgets (evaluations / iterations), oracle/arima.h: every candidate of the stepwise search gets a bounded run
+// (ARIMA_SEARCH_EVALS: an approximate criterion, which keeps the whole search inside the reference's measured cost), the
+// selected model's CSS estimates then run to convergence (ARIMA_POLISH_NM_CAP x dim)
+__host__ __device__ inline int ar_search_cap(int dim) { return 20 + 10 * dim; }
+__host__ __device__ inline int ar_polish_cap(int dim) { return 200 * dim; }
 constexpr int AR_KEYS = 6 * 6 * 3 * 3 * 2;            // order keys (p, q, P, Q, constant)
 constexpr int AR_KEYWORDS = (AR_KEYS + 31) / 32;      // bitmap words
 constexpr int AR_SWEEP = 17;                          // candidates of one sweep (8 seasonal, 8 non-seasonal, constant)
@@ -656,6 +661,19 @@ __global__ __launch_bounds__(256) void arima_skip_kernel(const ArimaArgs a)
     if (a.wlen[s] < 3) { a.status[s] = FIT_SHORT; a.models[s] = 0; }
 }
 
+// the selected model of every series whose search found one, queued by dimension for the polish run of the fit kernels
+__global__ __launch_bounds__(256) void arima_polish_queue_kernel(const ArimaArgs a, const ArWs ws)
+{
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= a.n_series || a.wlen[s] < 3 || a.status[s] != FIT_OK) return;
+    const int key = ws.state[(size_t)s * 8 + AS_BEST];
+    const int dim = ar_dim(ar_unkey(key));
+    if (dim == 0) return;                                    // nothing to estimate
+    const int pos = atomicAdd(&ws.counts[dim], 1);
+    ws.q_series[(size_t)dim * ws.cap + pos] = s;
+    ws.q_key[(size_t)dim * ws.cap + pos] = key;
+}
+
 // ------------------------------------------------------------------------------------------------
 // fit: persistent lanes, one (series, order) problem at a time from the queue
 // ------------------------------------------------------------------------------------------------
@@ -706,7 +724,9 @@ __device__ __forceinline__ void ar_sort(const LT &L, FT &F, int D)
     }
 }
 
-__global__ __launch_bounds__(NM_BLOCK) void arima_fit_kernel(const ArimaArgs a, const ArWs ws, const int total)
+// `polish`: the problems are the SELECTED models (one per series, queued by arima_polish_queue_kernel): start at the search's
+// estimates (a.xbest) with steps of 0.1, run to convergence, write the estimates and their criterion back (oracle polish_css)
+__global__ __launch_bounds__(NM_BLOCK) void arima_fit_kernel(const ArimaArgs a, const ArWs ws, const int total, const int polish)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int m = a.m;
@@ -743,11 +763,11 @@ __global__ __launch_bounds__(NM_BLOCK) void arima_fit_kernel(const ArimaArgs a, 
                 len = a.wlen[s];
                 wrow = ws.W + (size_t)s * ws.tw;
                 const double wmean = a.wmean[s], wsd = a.wsd[s];
-                for (int i = 0; i < D; i++) L.sim(0, i) = 0.0;
-                if (cur.c) L.sim(0, D - 1) = wmean;
+                for (int i = 0; i < D; i++) L.sim(0, i) = polish ? a.xbest[(size_t)i * a.ld + s] : 0.0;
+                if (cur.c && !polish) L.sim(0, D - 1) = wmean;
                 for (int k = 0; k < D; k++) {
                     for (int i = 0; i < D; i++) L.sim(k + 1, i) = L.sim(0, i);
-                    const double step = (cur.c && k == D - 1) ? (wsd > 0.0 ? 0.1 * wsd : 1.0e-4) : 0.25;
+                    const double step = (cur.c && k == D - 1) ? (wsd > 0.0 ? 0.1 * wsd : 1.0e-4) : (polish ? 0.1 : 0.25);
                     L.sim(k + 1, k) = L.sim(0, k) + step;
                 }
                 nm_evals = 0; nm_iters = 1; vi = 0; passes = 0;
@@ -759,7 +779,8 @@ __global__ __launch_bounds__(NM_BLOCK) void arima_fit_kernel(const ArimaArgs a, 
         double x[AR_MAXDIM] = {0, 0, 0, 0, 0, 0};
         if (!fin) {
             if (ph == PH_ITER) {
-                bool stop = !(nm_evals < 200 * D && nm_iters < 200 * D);
+                const int cap = polish ? ar_polish_cap(D) : ar_search_cap(D);
+                bool stop = !(nm_evals < cap && nm_iters < cap);
                 if (!stop) {
                     bool small = true;
                     for (int k = 1; k <= D; k++) {
@@ -829,10 +850,16 @@ __global__ __launch_bounds__(NM_BLOCK) void arima_fit_kernel(const ArimaArgs a, 
                 aicc = dn * dm_log(v) + 2.0 * dk + 2.0 * dk * (dk + 1.0) / (dn - dk - 1.0);
                 if (!(fabs(aicc) <= 1.7976931348623157e308)) aicc = __builtin_huge_val();
             }
-            const size_t ci = (size_t)s * AR_KEYS + key;
-            ws.cache_aicc[ci] = aicc;
-            ws.cache_evals[ci] = nm_evals;
-            for (int i = 0; i < AR_MAXDIM; i++) ws.cache_x[ci * AR_MAXDIM + i] = i < D ? L.sim(0, i) : 0.0;
+            if (polish) {
+                a.aicc[s] = aicc;
+                a.evals[s] += nm_evals;
+                for (int i = 0; i < D; i++) a.xbest[(size_t)i * a.ld + s] = L.sim(0, i);
+            } else {
+                const size_t ci = (size_t)s * AR_KEYS + key;
+                ws.cache_aicc[ci] = aicc;
+                ws.cache_evals[ci] = nm_evals;
+                for (int i = 0; i < AR_MAXDIM; i++) ws.cache_x[ci * AR_MAXDIM + i] = i < D ? L.sim(0, i) : 0.0;
+            }
             atomicAdd(&a.passes[s], passes);
             ph = PH_NEXT;
         }
@@ -845,7 +872,7 @@ __global__ __launch_bounds__(NM_BLOCK) void arima_fit_kernel(const ArimaArgs a, 
 // sequential method would have made, so iterates, evaluation counts and the stopping point are those of the sequential
 // fit.  An iteration costs one pass instead of ~1.7: the critical path of a sweep's slowest fit shortens accordingly.
 // The simplex lives in the group leader's LDS column; all four lanes run the same bookkeeping on it (identical values).
-__global__ __launch_bounds__(NM_BLOCK) void arima_fit_spec_kernel(const ArimaArgs a, const ArWs ws, const int total)
+__global__ __launch_bounds__(NM_BLOCK) void arima_fit_spec_kernel(const ArimaArgs a, const ArWs ws, const int total, const int polish)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int m = a.m;
@@ -881,11 +908,11 @@ __global__ __launch_bounds__(NM_BLOCK) void arima_fit_spec_kernel(const ArimaArg
                 len = a.wlen[s];
                 wrow = ws.W + (size_t)s * ws.tw;
                 const double wmean = a.wmean[s], wsd = a.wsd[s];
-                for (int i = 0; i < D; i++) L.sim(0, i) = 0.0;
-                if (cur.c) L.sim(0, D - 1) = wmean;
+                for (int i = 0; i < D; i++) L.sim(0, i) = polish ? a.xbest[(size_t)i * a.ld + s] : 0.0;
+                if (cur.c && !polish) L.sim(0, D - 1) = wmean;
                 for (int k = 0; k < D; k++) {
                     for (int i = 0; i < D; i++) L.sim(k + 1, i) = L.sim(0, i);
-                    const double step = (cur.c && k == D - 1) ? (wsd > 0.0 ? 0.1 * wsd : 1.0e-4) : 0.25;
+                    const double step = (cur.c && k == D - 1) ? (wsd > 0.0 ? 0.1 * wsd : 1.0e-4) : (polish ? 0.1 : 0.25);
                     L.sim(k + 1, k) = L.sim(0, k) + step;
                 }
                 nm_evals = 0; nm_iters = 1; vi = 0; passes = 0;
@@ -898,7 +925,8 @@ __global__ __launch_bounds__(NM_BLOCK) void arima_fit_spec_kernel(const ArimaArg
         bool mine = false;                      // this lane's evaluation is a real one
         if (!fin) {
             if (ph == PH_ITER) {
-                bool stop = !(nm_evals < 200 * D && nm_iters < 200 * D);
+                const int cap = polish ? ar_polish_cap(D) : ar_search_cap(D);
+                bool stop = !(nm_evals < cap && nm_iters < cap);
                 if (!stop) {
                     bool small = true;
                     for (int k = 1; k <= D; k++) {
@@ -963,10 +991,16 @@ __global__ __launch_bounds__(NM_BLOCK) void arima_fit_spec_kernel(const ArimaArg
                 if (!(fabs(aicc) <= 1.7976931348623157e308)) aicc = __builtin_huge_val();
             }
             if (g == 0) {
-                const size_t ci = (size_t)s * AR_KEYS + key;
-                ws.cache_aicc[ci] = aicc;
-                ws.cache_evals[ci] = nm_evals;
-                for (int i = 0; i < AR_MAXDIM; i++) ws.cache_x[ci * AR_MAXDIM + i] = i < D ? L.sim(0, i) : 0.0;
+                if (polish) {
+                    a.aicc[s] = aicc;
+                    a.evals[s] += nm_evals;
+                    for (int i = 0; i < D; i++) a.xbest[(size_t)i * a.ld + s] = L.sim(0, i);
+                } else {
+                    const size_t ci = (size_t)s * AR_KEYS + key;
+                    ws.cache_aicc[ci] = aicc;
+                    ws.cache_evals[ci] = nm_evals;
+                    for (int i = 0; i < AR_MAXDIM; i++) ws.cache_x[ci * AR_MAXDIM + i] = i < D ? L.sim(0, i) : 0.0;
+                }
                 atomicAdd(&a.passes[s], passes);
             }
             ph = PH_NEXT;
@@ -1554,15 +1588,29 @@ int launch_arima(const ArimaArgs &a, hipStream_t stream)
     hipLaunchKernelGGL(arima_skip_kernel, dim3(grid256), dim3(256), 0, stream, a);
     int launches = 2;
     long prev_total = -1;
+    auto launch_fit = [&](long total, int polish) {
+        const double spec_factor = a.spec_factor;   // (ANOFOX_HIP_ARIMA_SPEC_FACTOR, default 8)
+        if ((double)total <= spec_factor * (double)max_waves * (NM_BLOCK / 4)) {
+            // short queue (up to a few problems per resident 4-lane group): four lanes per problem, one pass per Nelder-Mead
+            // iteration -- such a launch is bound by its slowest fit, not by throughput
+            long waves = (total * 4 + NM_BLOCK - 1) / NM_BLOCK;
+            if (waves > max_waves) waves = max_waves;
+            hipLaunchKernelGGL(arima_fit_spec_kernel, dim3((int)waves), dim3(NM_BLOCK), fit_lds, stream, a, ws, (int)total, polish);
+        } else {
+            const long waves = (total + NM_BLOCK - 1) / NM_BLOCK;
+            const int fit_grid = (int)(waves < max_waves ? waves : max_waves);
+            hipLaunchKernelGGL(arima_fit_kernel, dim3(fit_grid), dim3(NM_BLOCK), fit_lds, stream, a, ws, (int)total, polish);
+        }
+    };
     for (int sweep = 0; sweep < 4 * AR_MAXMODELS; sweep++) {
         AR_HIPCHECK(hipMemsetAsync(ws.counts, 0, 16 * sizeof(int32_t), stream));
         // look one sweep ahead once the previous sweep's queue times the fan-out (~18 candidates per series) fits the
         // resident lanes `la_factor` times over: the extra fits cost idle lanes, the saved sweeps cost ~0.1-0.2 s each
-        static const double la_factor = [] { const char *e = std::getenv("ANOFOX_HIP_ARIMA_LOOKAHEAD"); return e ? std::atof(e) : 12.0; }();   // measured 0 / 0.25 / 1 / 4 / 16: 2.16 / 2.03 / 1.93 / 1.92 / 1.90 s on the M5 batch (round 1); with the refit 4 / 8 / 12 / 16 / 24 / 32 / 64: 2.23 / 2.23 / 2.14 / 2.14 / 2.17 / 2.17 / 2.92 s
+        const double la_factor = a.lookahead;   // (ANOFOX_HIP_ARIMA_LOOKAHEAD, default 12) measured 0 / 0.25 / 1 / 4 / 16: 2.16 / 2.03 / 1.93 / 1.92 / 1.90 s on the M5 batch (round 1); with the refit 4 / 8 / 12 / 16 / 24 / 32 / 64: 2.23 / 2.23 / 2.14 / 2.14 / 2.17 / 2.17 / 2.92 s
         int lookahead = (prev_total >= 0 && (double)prev_total * (AR_SWEEP + 1) <= la_factor * (double)max_waves * NM_BLOCK) ? 1 : 0;
         // ... and two sweeps ahead once even that fan-out squared fits the resident lanes (the late sweeps of a few hundred series are
         // each bound by their slowest fit, ~0.1 s: 5 of them on the M5 batch)
-        static const int la_depth = [] { const char *e = std::getenv("ANOFOX_HIP_ARIMA_LOOKAHEAD_DEPTH"); return e ? std::atoi(e) : 2; }();
+        const int la_depth = a.lookahead_depth;   // (ANOFOX_HIP_ARIMA_LOOKAHEAD_DEPTH, default 2)
         if (lookahead && la_depth >= 2 && (double)prev_total * (AR_SWEEP + 1) * (AR_SWEEP + 1) <= la_factor * (double)max_waves * NM_BLOCK) lookahead = 2;
         hipLaunchKernelGGL(arima_advance_kernel, dim3(grid256), dim3(256), 0, stream, a, ws, lookahead);
         int32_t counts[8];
@@ -1574,21 +1622,23 @@ int launch_arima(const ArimaArgs &a, hipStream_t stream)
         if (total == 0) break;
         if (a.trace) std::fprintf(stderr, "[anofox-hip] AutoARIMA sweep %d: %ld problems queued (lookahead %d)\n", sweep, total, lookahead);
         prev_total = total;
-        static const double spec_factor = [] { const char *e = std::getenv("ANOFOX_HIP_ARIMA_SPEC_FACTOR"); return e ? std::atof(e) : 8.0; }();   // measured 1 / 2 / 2.5 / 3 / 4: 1.83 / 1.83 / 1.74 / 1.74 / 1.73 s (round 1); with the refit and the longer lookahead 2 / 4 / 6 / 8 / 10 / 12 / 16: 2.31 / 2.14 / 2.12 / 2.10 / 2.10 / 2.19 / 2.35 s
-        if ((double)total <= spec_factor * (double)max_waves * (NM_BLOCK / 4)) {
-            // short queue (up to three problems per resident 4-lane group): four lanes per problem, one pass per Nelder-Mead
-            // iteration -- such a sweep is bound by its slowest fit, not by throughput
-            long waves = (total * 4 + NM_BLOCK - 1) / NM_BLOCK;
-            if (waves > max_waves) waves = max_waves;
-            hipLaunchKernelGGL(arima_fit_spec_kernel, dim3((int)waves), dim3(NM_BLOCK), fit_lds, stream, a, ws, (int)total);
-        } else {
-            const long waves = (total + NM_BLOCK - 1) / NM_BLOCK;
-            const int fit_grid = (int)(waves < max_waves ? waves : max_waves);
-            hipLaunchKernelGGL(arima_fit_kernel, dim3(fit_grid), dim3(NM_BLOCK), fit_lds, stream, a, ws, (int)total);
-        }
+        launch_fit(total, 0);
         launches++;
     }
-    // final estimates of the selected models: exact Gaussian likelihood (a.ml_scratch == NULL keeps the CSS estimates)
+    // the selected models' CSS estimates, to convergence (one problem per series)
+    {
+        AR_HIPCHECK(hipMemsetAsync(ws.counts, 0, 16 * sizeof(int32_t), stream));
+        hipLaunchKernelGGL(arima_polish_queue_kernel, dim3(grid256), dim3(256), 0, stream, a, ws);
+        int32_t counts[8];
+        AR_HIPCHECK(hipMemcpyAsync(counts, ws.counts, sizeof counts, hipMemcpyDeviceToHost, stream));
+        AR_HIPCHECK(hipStreamSynchronize(stream));
+        long total = 0;
+        for (int i = 0; i <= AR_MAXDIM; i++) total += counts[i];
+        if (a.trace) std::fprintf(stderr, "[anofox-hip] AutoARIMA polish: %ld selected models\n", total);
+        if (total > 0) { launch_fit(total, 1); launches++; }
+        launches++;
+    }
+    // on request (ANOFOX_ARIMA_CSS_ML): final estimates of the selected models on the exact Gaussian likelihood
     if (a.ml_refit) {
         const size_t lds_b = sizeof(double) * ar_ml_lds_doubles(a.m) * NM_BLOCK;
         if (lds_b > 48 * 1024) AR_HIPCHECK(hipFuncSetAttribute((const void *)arima_refit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));

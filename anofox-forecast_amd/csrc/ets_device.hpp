@@ -41,8 +41,6 @@ struct SeriesView {
     int rows;          // rows the block holds (row indices are clamped to rows - 1 by the streaming loads)
     const double *yb;  // the block itself (wave-uniform) and this lane's column: y == yb + col.  The streaming loads
     int col;           // address rows from the scalar base so the per-load address work stays on the scalar unit
-    const double *row; // ROWS passes (work-pool kernel): this lane's own series, contiguous in time, 16-byte aligned, with
-                       // >= 2 * 32 readable doubles past its end (the prefetch runs ahead of the series)
 };
 
 __device__ __forceinline__ int wave_max_i32(int v)
@@ -189,9 +187,7 @@ struct EtsFinalOut {
 
 // The pass.  MS > 0: compile-time period, ring in VGPRs.  MS == 0: no seasonality.
 // MS == -1: run-time period, ring in LDS (`ring`, K * m * 64 doubles).  MS == -2: run-time period, `ring` points to HBM scratch.
-// ROWS: every lane streams its OWN series from a series-major copy (v.row) with 128-bit loads instead of the wave's 64
-// adjacent columns of the time-major block -- the lanes of a work-pool wave hold unrelated series (ets_pool_kernel.hpp).
-template <class Cfg, int MS, int K, bool FINAL, bool ROWS = false>
+template <class Cfg, int MS, int K, bool FINAL>
 __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
                                          const double (&cand)[K][Cfg::DIM], double (&fout)[K],
                                          double *ring, const EtsFinalOut *fin)
@@ -221,9 +217,7 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
     // a step holds a reciprocal, a quarter when it holds a pow (damped multiplicative trend) -- those are long enough to
     // cover the latency with fewer rows in flight, and their own register needs leave less room for the buffers
     constexpr int S_TARGET = Cfg::ADDITIVE ? 32 : ((Cfg::T == C_MUL && Cfg::D) ? 8 : 16);
-    constexpr int S_COL = (MS > 0) ? ((S_TARGET / MS > 0 ? S_TARGET / MS : 1) * MS) : S_TARGET;
-    constexpr int S = (ROWS && (S_COL % 2)) ? 2 * S_COL : S_COL;       // 128-bit row loads take the steps in pairs
-    static_assert(S <= 32, "the row copy keeps 2 * 32 doubles of slack behind every series");
+    constexpr int S = (MS > 0) ? ((S_TARGET / MS > 0 ? S_TARGET / MS : 1) * MS) : S_TARGET;
     double cur[S], nxt[S];
     // One loader, no branch (a conditional load in the loop makes the compiler wait for every outstanding load at once)
     // and no per-load address arithmetic on the vector unit: the rows of a block are fetched with buffer loads whose
@@ -234,19 +228,7 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
     typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
     const size_t row_bytes = ld * 8;
     const size_t total_bytes = (size_t)(row_max + 1) * row_bytes;
-    const double *rowp = v.row;
     auto load_block = [&](double (&buf)[S], const int row0) __attribute__((always_inline)) {
-        if constexpr (ROWS) {
-            typedef double d2_t __attribute__((ext_vector_type(2)));
-            const d2_t *p = reinterpret_cast<const d2_t *>(rowp + row0);
-#pragma unroll
-            for (int j = 0; j < S / 2; j++) {
-                const d2_t w = p[j];
-                buf[2 * j] = w.x;
-                buf[2 * j + 1] = w.y;
-            }
-            return;
-        }
         const size_t off = (size_t)row0 * row_bytes;
         const size_t rem = off < total_bytes ? total_bytes - off : 0;
         const unsigned nrec = rem > 0xffffffffull ? 0xffffffffu : (unsigned)rem;

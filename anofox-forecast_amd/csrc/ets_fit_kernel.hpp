@@ -45,9 +45,6 @@ __global__ __launch_bounds__(NM_BLOCK, ANOFOX_ROUND_WAVES) void ets_round_kernel
     }
     const int LPP = mode == 0 ? 1 : (mode == 1 ? NM_K : NM_BLOCK);         // lanes per problem (a constant unless SPEC == 3)
     const int PPB = NM_BLOCK / LPP;                                         // problems per workgroup
-    // fused compaction: this round appends its unfinished problems to the next round's list; the counter of the round
-    // after that is cleared here (three counters rotate), by the round's owner even when nothing is left to run
-    if (a.clear_cnt && blockIdx.x == 0 && lane == 0) *a.clear_cnt = 0;
     if ((int)blockIdx.x * PPB >= n_act) return;
     const int p = blockIdx.x * PPB + lane / LPP;
     const bool valid = p < n_act;
@@ -85,7 +82,7 @@ __global__ __launch_bounds__(NM_BLOCK, ANOFOX_ROUND_WAVES) void ets_round_kernel
     }
 
     SeriesView v;
-    const bool gathered = a.gathered && n_act > a.gather_min && n_act <= a.gather_max;      // outside, the gather kernel did nothing
+    const bool gathered = a.gathered != 0;
     v.col = valid ? (gathered ? p : s) : 0;
     v.yb = gathered ? a.y_round : a.y;
     v.y = v.yb + v.col;
@@ -123,9 +120,8 @@ __global__ __launch_bounds__(NM_BLOCK, ANOFOX_ROUND_WAVES) void ets_round_kernel
         r.done = !active;
     }
 
-    // few problems left (they no longer fill the chip): run them to completion now instead of paying a compaction +
-    // gather + launch gap per remaining round -- the later rounds then find nothing to do
-    const int budget = (n_act <= a.tail_below || mode == 2) ? (1 << 30) : ((SPEC == 3 && mode == 0) ? a.budget_seq : a.budget);
+    // one problem per wave (the last problems of a spec) runs to completion
+    const int budget = mode == 2 ? (1 << 30) : ((SPEC == 3 && mode == 0) ? a.budget_seq : a.budget);
     if constexpr (SPEC == 3) {
         if (mode == 2) nm_advance_spec2(mdl, lds, r, budget);
         else if (mode == 1) nm_advance_spec(mdl, lds, r, budget);
@@ -146,29 +142,6 @@ __global__ __launch_bounds__(NM_BLOCK, ANOFOX_ROUND_WAVES) void ets_round_kernel
         a.st.iters[s] = r.iters;
         a.st.passes[s] = r.passes;
         a.st.done[s] = r.done ? 1 : 0;
-    }
-    if (a.next_map) {
-        // Fused compaction + gather: every problem that is still running reserves a column of the next round's dense block
-        // (one ballot + one atomic per wave, consecutive columns within the wave) and copies its series there -- reads of
-        // this round's column, writes of 512 contiguous bytes per row and wave -- so no compaction or gather kernel sits
-        // between two rounds of a spec.
-        const bool push = active && !r.done;
-        const bool lead = push && (lane % LPP) == 0;
-        const unsigned long long bal = __ballot(lead);
-        const int cnt = __popcll(bal);
-        if (cnt) {
-            int base = 0;
-            if (lane == 0) base = atomicAdd(a.next_cnt, cnt);
-            base = __shfl(base, 0);
-            int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
-            if (LPP != 1) pos = __shfl(pos, lane & ~(LPP - 1));
-            if (lead) a.next_map[pos] = s;
-            if (push && a.next_y) {
-                const double *src = v.y;
-                double *dst = a.next_y + pos;
-                for (int t = lane % LPP; t < len; t += LPP) dst[(size_t)t * a.ld] = src[(size_t)t * v.ld];
-            }
-        }
     }
 }
 

@@ -56,17 +56,105 @@ void report_hip_failure(AnofoxError *out_error, const HipFail &f)
 // INTERNAL_ERROR instead of a success with uninitialised forecasts
 constexpr int32_t STATUS_NOT_COMPUTED = -1;
 
+// Every environment variable the library reads, in ONE place (INTEGRATION.md "Environment" is the user-facing list).  The schedule
+// knobs are read when a batch is created (tests and the sweep scripts under tools/ vary them between batches of one process);
+// the process-wide ones (caches, devices, priority streams) once.  None of them changes a result: every schedule walks the same
+// Nelder-Mead iterates (tests/test_gpu_parity.py::test_schedule_variants_are_bit_identical).
+struct Tunables {
+    std::vector<int> budgets{24, 24, 24, 24, 24, 24, 48, 48, 96, 96, 192, 1024};   // ANOFOX_HIP_BUDGETS: Nelder-Mead iterations per round (last = to completion)
+    int seq_rounds = -1;        // ANOFOX_HIP_SEQ_ROUNDS: rounds run by the sequential driver (-1: decided from the live problems)
+    int gather = -1;            // ANOFOX_HIP_GATHER: dense re-gather of the running problems between rounds (-1: on while it fits 96 GiB)
+    int spec_below = 8192;      // ANOFOX_HIP_SPEC_BELOW[_MD]: four lanes per problem once this few problems of a spec still run
+    int spec_below_md = 8192;   //   (_MD: the damped multiplicative-trend specs, whose pass is ~10x longer)
+    int spec2_below = 1024;     // ANOFOX_HIP_SPEC2_BELOW[_MD]: one wave per problem, two iterations per pass, for the last problems
+    int spec2_below_md = 2048;  //   (tools/spec2_sweep.sh: 0 / 256 / 1024 / 2048 / 4096 / 8192 -> 579 / 575 / 565 / 562 / 594 / 736 ms on the 30-spec M5 batch)
+    bool merge_periods = true;  // ANOFOX_HIP_MERGE_PERIODS: auto-detected periods run as merged batches (0: one batch per period)
+    int pack_threads = 0;       // ANOFOX_HIP_PACK_THREADS: host threads of the packer (0: all, at most 32)
+    bool timing = false;        // ANOFOX_HIP_TIMING: phase times of the batch entry on stderr
+    bool arima_trace = false;   // ANOFOX_HIP_ARIMA_TRACE: per-sweep queue lengths / per-wave refit timings on stderr
+    double arima_lookahead = 12.0;   // ANOFOX_HIP_ARIMA_LOOKAHEAD, _LOOKAHEAD_DEPTH, _SPEC_FACTOR: see arima.hip launch_arima
+    int arima_lookahead_depth = 2;
+    double arima_spec_factor = 8.0;
+    static Tunables from_env()
+    {
+        Tunables t;
+        auto geti = [](const char *k, int &v) { if (const char *e = std::getenv(k)) v = std::atoi(e); };
+        if (const char *e = std::getenv("ANOFOX_HIP_BUDGETS")) {
+            std::vector<int> v;
+            for (const char *q = e; *q;) {
+                char *end = nullptr;
+                long x = std::strtol(q, &end, 10);
+                if (end == q) break;
+                if (x > 0) v.push_back((int)x);
+                q = (*end == ',') ? end + 1 : end;
+            }
+            if (!v.empty()) t.budgets = v;
+        }
+        geti("ANOFOX_HIP_SEQ_ROUNDS", t.seq_rounds);
+        geti("ANOFOX_HIP_GATHER", t.gather);
+        if (const char *e = std::getenv("ANOFOX_HIP_SPEC_BELOW")) t.spec_below = t.spec_below_md = std::atoi(e);
+        geti("ANOFOX_HIP_SPEC_BELOW_MD", t.spec_below_md);
+        if (const char *e = std::getenv("ANOFOX_HIP_SPEC2_BELOW")) t.spec2_below = t.spec2_below_md = std::atoi(e);
+        geti("ANOFOX_HIP_SPEC2_BELOW_MD", t.spec2_below_md);
+        if (const char *e = std::getenv("ANOFOX_HIP_MERGE_PERIODS")) t.merge_periods = std::atoi(e) != 0;
+        if (const char *e = std::getenv("ANOFOX_HIP_PACK_THREADS")) t.pack_threads = std::max(1, std::atoi(e));
+        t.timing = std::getenv("ANOFOX_HIP_TIMING") != nullptr;
+        t.arima_trace = std::getenv("ANOFOX_HIP_ARIMA_TRACE") != nullptr;
+        if (const char *e = std::getenv("ANOFOX_HIP_ARIMA_LOOKAHEAD")) t.arima_lookahead = std::atof(e);
+        geti("ANOFOX_HIP_ARIMA_LOOKAHEAD_DEPTH", t.arima_lookahead_depth);
+        if (const char *e = std::getenv("ANOFOX_HIP_ARIMA_SPEC_FACTOR")) t.arima_spec_factor = std::atof(e);
+        return t;
+    }
+};
+// process-wide settings, read once: ANOFOX_HIP_CACHE_GB (idle device blocks kept, default 1/8 of the device), ANOFOX_HIP_PINNED_CACHE_GB
+// (idle pinned staging blocks, default 2), ANOFOX_HIP_PRIO_STREAMS (high-priority streams of the first stream set, default from
+// GPU_MAX_HW_QUEUES), ANOFOX_HIP_DEVICES (devices the batch entry shards over, default: the caller's current device only)
+struct ProcessTunables {
+    double cache_gb = -1.0, pinned_cache_gb = 2.0;
+    int prio_streams = -1;
+    std::string devices;
+    static const ProcessTunables &get()
+    {
+        static const ProcessTunables t = [] {
+            ProcessTunables p;
+            if (const char *e = std::getenv("ANOFOX_HIP_CACHE_GB")) p.cache_gb = std::atof(e);
+            if (const char *e = std::getenv("ANOFOX_HIP_PINNED_CACHE_GB")) p.pinned_cache_gb = std::atof(e);
+            if (const char *e = std::getenv("ANOFOX_HIP_PRIO_STREAMS")) p.prio_streams = std::atoi(e);
+            if (const char *e = std::getenv("ANOFOX_HIP_DEVICES")) p.devices = e;
+            return p;
+        }();
+        return t;
+    }
+};
+
+// RAII: make `dev` current for a scope (the device is a per-thread setting)
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+};
+
 // Device memory comes from a small caching allocator: a batch of the M5 shape is ~300 hipMalloc calls (25 spec chains x state,
 // maps and two gather blocks) = 380-400 ms to create and 50-65 ms to destroy, as long as its fit on the intermittent batch four
 // times over; a statement that forecasts chunk after chunk of the same shape pays that once.  Blocks are keyed by (device, size
-// rounded to 512 B / 2 MiB) and handed back as they are -- nothing in the library relies on fresh memory being zero.  At most
-// ANOFOX_HIP_CACHE_GB (default: a quarter of the device) stays cached; an out-of-memory hipMalloc empties the cache and retries.
+// rounded to 512 B / 2 MiB) and handed back as they are -- nothing in the library relies on fresh memory being zero.  Per device
+// at most ANOFOX_HIP_CACHE_GB (default: an eighth of the device -- an M5-shape AutoETS batch is ~14 GB) stays cached: a block
+// handed back over the cap evicts the OLDEST idle blocks of its device first, so shapes that are no longer used age out instead
+// of pinning the cache; an out-of-memory hipMalloc empties the cache and retries; anofox_hip_release_caches() (header block 2)
+// gives everything back on request -- a co-resident allocator (torch's, another library's) cannot reach these blocks otherwise.
 struct DevCache {
+    struct Idle { int dev; size_t size; void *ptr; };
     std::mutex mu;
-    std::multimap<std::pair<int, size_t>, void *> idle;
+    std::map<uint64_t, Idle> by_age;                                   // idle blocks, oldest first
+    std::multimap<std::pair<int, size_t>, uint64_t> by_key;            // (device, size) -> age
+    std::unordered_map<void *, uint64_t> idle_ptr;                     // guards against a second free of a cached block
     std::unordered_map<void *, std::pair<int, size_t>> live;
-    size_t idle_bytes = 0, cap = 0;
-    bool cap_known = false;
+    std::map<int, size_t> idle_bytes, cap;                             // per device
+    uint64_t next_age = 0;
 };
 DevCache &dev_cache() { static DevCache *c = new DevCache; return *c; }     // never destroyed: no HIP calls at process exit
 
@@ -74,6 +162,23 @@ size_t dev_round(size_t bytes)
 {
     const size_t g = bytes < (1u << 20) ? 512 : (2u << 20);
     return (std::max<size_t>(bytes, 1) + g - 1) / g * g;
+}
+
+// (lock held) take idle blocks of `dev` out of the cache, oldest first, until `need` more bytes fit under the cap (all of them
+// when need == SIZE_MAX); the caller frees them outside the lock
+void dev_cache_evict_locked(DevCache &c, int dev, size_t need, std::vector<void *> &drop)
+{
+    for (auto it = c.by_age.begin(); it != c.by_age.end();) {
+        if (need != SIZE_MAX && c.idle_bytes[dev] + need <= c.cap[dev]) break;
+        if (it->second.dev != dev) { ++it; continue; }
+        const DevCache::Idle b = it->second;
+        auto range = c.by_key.equal_range({b.dev, b.size});
+        for (auto k = range.first; k != range.second; ++k) if (k->second == it->first) { c.by_key.erase(k); break; }
+        c.idle_ptr.erase(b.ptr);
+        c.idle_bytes[dev] -= b.size;
+        drop.push_back(b.ptr);
+        it = c.by_age.erase(it);
+    }
 }
 
 void *dev_alloc_bytes(size_t bytes)
@@ -84,17 +189,20 @@ void *dev_alloc_bytes(size_t bytes)
     const size_t sz = dev_round(bytes);
     {
         std::lock_guard<std::mutex> lock(c.mu);
-        if (!c.cap_known) {
-            c.cap_known = true;
+        if (!c.cap.count(dev)) {
             size_t free_b = 0, total_b = 0;
-            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) c.cap = total_b / 4;
-            if (const char *e = std::getenv("ANOFOX_HIP_CACHE_GB")) c.cap = (size_t)(std::atof(e) * 1073741824.0);
+            c.cap[dev] = hipMemGetInfo(&free_b, &total_b) == hipSuccess ? total_b / 8 : 0;
+            const double gb = ProcessTunables::get().cache_gb;
+            if (gb >= 0.0) c.cap[dev] = (size_t)(gb * 1073741824.0);
         }
-        auto it = c.idle.find({dev, sz});
-        if (it != c.idle.end()) {
-            void *p = it->second;
-            c.idle.erase(it);
-            c.idle_bytes -= sz;
+        auto it = c.by_key.find({dev, sz});
+        if (it != c.by_key.end()) {
+            const uint64_t age = it->second;
+            void *p = c.by_age[age].ptr;
+            c.by_age.erase(age);
+            c.by_key.erase(it);
+            c.idle_ptr.erase(p);
+            c.idle_bytes[dev] -= sz;
             c.live[p] = {dev, sz};
             return p;
         }
@@ -106,9 +214,7 @@ void *dev_alloc_bytes(size_t bytes)
         std::vector<void *> drop;
         {
             std::lock_guard<std::mutex> lock(c.mu);
-            for (auto &kv : c.idle) drop.push_back(kv.second);
-            c.idle.clear();
-            c.idle_bytes = 0;
+            dev_cache_evict_locked(c, dev, SIZE_MAX, drop);
         }
         for (void *q : drop) (void)hipFree(q);
         err = hipMalloc(&p, sz);
@@ -119,34 +225,68 @@ void *dev_alloc_bytes(size_t bytes)
     return p;
 }
 
-// `quiesced`: the caller has already waited for every stream that may touch the block (batch destruction); otherwise the device
-// is synchronised first, which is what hipFree does implicitly
+// `quiesced`: the caller has already waited for every stream that may touch the block (batch destruction); otherwise the block's
+// device is synchronised first, which is what hipFree does implicitly
 void dev_free(void *p, bool quiesced = false)
 {
     if (!p) return;
-    if (!quiesced) (void)hipDeviceSynchronize();
     DevCache &c = dev_cache();
+    int dev = -1;
     {
         std::lock_guard<std::mutex> lock(c.mu);
         auto it = c.live.find(p);
-        if (it != c.live.end()) {
-            const std::pair<int, size_t> key = it->second;
-            c.live.erase(it);
-            if (c.idle_bytes + key.second <= c.cap) {
-                c.idle.insert({key, p});
-                c.idle_bytes += key.second;
-                return;
-            }
+        if (it != c.live.end()) dev = it->second.first;
+        else if (c.idle_ptr.count(p)) return;          // already handed back: a second free must not reach hipFree while the block sits in the cache
+    }
+    if (dev < 0) { (void)hipFree(p); return; }         // not one of ours
+    if (!quiesced) { DeviceGuard g(dev); (void)hipDeviceSynchronize(); }
+    std::vector<void *> drop;
+    bool cached = false;
+    {
+        std::lock_guard<std::mutex> lock(c.mu);
+        auto it = c.live.find(p);
+        if (it == c.live.end()) return;
+        const size_t sz = it->second.second;
+        c.live.erase(it);
+        if (sz <= c.cap[dev]) {
+            dev_cache_evict_locked(c, dev, sz, drop);
+            const uint64_t age = c.next_age++;
+            c.by_age[age] = DevCache::Idle{dev, sz, p};
+            c.by_key.insert({{dev, sz}, age});
+            c.idle_ptr[p] = age;
+            c.idle_bytes[dev] += sz;
+            cached = true;
         }
     }
-    (void)hipFree(p);
+    for (void *q : drop) (void)hipFree(q);
+    if (!cached) (void)hipFree(p);
+}
+
+void dev_cache_release_all()
+{
+    DevCache &c = dev_cache();
+    std::vector<void *> drop;
+    {
+        std::lock_guard<std::mutex> lock(c.mu);
+        for (auto &kv : c.by_age) drop.push_back(kv.second.ptr);
+        c.by_age.clear(); c.by_key.clear(); c.idle_ptr.clear();
+        for (auto &kv : c.idle_bytes) kv.second = 0;
+    }
+    for (void *q : drop) (void)hipFree(q);
 }
 
 template <class T> T *dalloc(size_t n) { return (T *)dev_alloc_bytes(std::max<size_t>(n, 1) * sizeof(T)); }
 
 // ... and the pinned staging blocks of the host packer (page-locking 467 MB is ~20 ms, unlocking it ~40 ms): the same scheme,
-// sizes rounded to 2 MiB, at most ANOFOX_HIP_PINNED_CACHE_GB (default 4) kept
-struct PinCache { std::mutex mu; std::multimap<size_t, void *> idle; std::unordered_map<void *, size_t> live; size_t idle_bytes = 0; };
+// sizes rounded to 2 MiB, at most ANOFOX_HIP_PINNED_CACHE_GB (default 2) kept, oldest evicted first
+struct PinCache {
+    std::mutex mu;
+    std::map<uint64_t, std::pair<size_t, void *>> by_age;
+    std::multimap<size_t, uint64_t> by_size;
+    std::unordered_map<void *, size_t> live;
+    size_t idle_bytes = 0;
+    uint64_t next_age = 0;
+};
 PinCache &pin_cache() { static PinCache *c = new PinCache; return *c; }
 void *pin_alloc_bytes(size_t bytes)
 {
@@ -154,10 +294,11 @@ void *pin_alloc_bytes(size_t bytes)
     PinCache &c = pin_cache();
     {
         std::lock_guard<std::mutex> lock(c.mu);
-        auto it = c.idle.find(sz);
-        if (it != c.idle.end()) {
-            void *p = it->second;
-            c.idle.erase(it);
+        auto it = c.by_size.find(sz);
+        if (it != c.by_size.end()) {
+            void *p = c.by_age[it->second].second;
+            c.by_age.erase(it->second);
+            c.by_size.erase(it);
             c.idle_bytes -= sz;
             c.live[p] = sz;
             return p;
@@ -172,37 +313,84 @@ void *pin_alloc_bytes(size_t bytes)
 void pin_free(void *p)
 {
     if (!p) return;
-    static const size_t cap = [] { const char *e = std::getenv("ANOFOX_HIP_PINNED_CACHE_GB"); return (size_t)((e ? std::atof(e) : 4.0) * 1073741824.0); }();
+    const size_t cap = (size_t)(std::max(0.0, ProcessTunables::get().pinned_cache_gb) * 1073741824.0);
     PinCache &c = pin_cache();
+    std::vector<void *> drop;
+    bool cached = false;
     {
         std::lock_guard<std::mutex> lock(c.mu);
         auto it = c.live.find(p);
-        if (it != c.live.end()) {
-            const size_t sz = it->second;
-            c.live.erase(it);
-            if (c.idle_bytes + sz <= cap) { c.idle.insert({sz, p}); c.idle_bytes += sz; return; }
+        if (it == c.live.end()) return;                 // not live: already handed back (or never ours)
+        const size_t sz = it->second;
+        c.live.erase(it);
+        if (sz <= cap) {
+            while (c.idle_bytes + sz > cap && !c.by_age.empty()) {
+                auto old = c.by_age.begin();
+                auto range = c.by_size.equal_range(old->second.first);
+                for (auto k = range.first; k != range.second; ++k) if (k->second == old->first) { c.by_size.erase(k); break; }
+                c.idle_bytes -= old->second.first;
+                drop.push_back(old->second.second);
+                c.by_age.erase(old);
+            }
+            const uint64_t age = c.next_age++;
+            c.by_age[age] = {sz, p};
+            c.by_size.insert({sz, age});
+            c.idle_bytes += sz;
+            cached = true;
         }
     }
-    (void)hipHostFree(p);
+    for (void *q : drop) (void)hipHostFree(q);
+    if (!cached) (void)hipHostFree(p);
+}
+void pin_cache_release_all()
+{
+    PinCache &c = pin_cache();
+    std::vector<void *> drop;
+    {
+        std::lock_guard<std::mutex> lock(c.mu);
+        for (auto &kv : c.by_age) drop.push_back(kv.second.second);
+        c.by_age.clear(); c.by_size.clear(); c.idle_bytes = 0;
+    }
+    for (void *q : drop) (void)hipHostFree(q);
 }
 
 // ... and the streams and events of a batch: 33 streams + 37 events are ~10 ms to create, and -- measured -- the streams a
 // process creates FIRST get the better mapping onto the 16 hardware queues: the same 30-spec batch runs in 580 ms on the first
 // batch of a process and in 690-700 ms on every batch created after that one was destroyed (tools/time_run_variants.py).  A
-// batch borrows a set and hands it back (synchronised) when it is destroyed; sets are never destroyed.
+// batch borrows a set and hands it back (synchronised) when it is destroyed or parked in the single-series pool; idle sets are
+// destroyed only by anofox_hip_release_caches().
 struct StreamSet {
     int dev = 0;
     unsigned long id = 0;              // creation order
+    bool prio = false;                 // holds the process's high-priority streams
     hipStream_t own = nullptr, aux[N_AUX_STREAMS] = {};
     hipEvent_t ev_start = nullptr, ev_stop = nullptr, ev_fit0 = nullptr, ev_fit1 = nullptr, ev_fork = nullptr, ev_join[N_AUX_STREAMS] = {};
 };
-struct StreamPool { std::mutex mu; std::vector<StreamSet *> idle; unsigned long created = 0; };
+struct StreamPool { std::mutex mu; std::vector<StreamSet *> idle; unsigned long created = 0; std::map<int, bool> prio_taken; };
 StreamPool &stream_pool() { static StreamPool *p = new StreamPool; return *p; }
+void stream_set_destroy(StreamSet *s)
+{
+    DeviceGuard g(s->dev);
+    if (s->own) (void)hipStreamDestroy(s->own);
+    for (auto &q : s->aux) if (q) (void)hipStreamDestroy(q);
+    for (hipEvent_t e : {s->ev_start, s->ev_stop, s->ev_fit0, s->ev_fit1, s->ev_fork}) if (e) (void)hipEventDestroy(e);
+    for (auto &e : s->ev_join) if (e) (void)hipEventDestroy(e);
+    delete s;
+}
 StreamSet *stream_set_take()
 {
     int dev = 0;
     HIPCHECK(hipGetDevice(&dev));
     StreamPool &p = stream_pool();
+    // The first streams of a device's FIRST set carry the most expensive specs of a fit (launch_fit_slots orders the specs by
+    // work) and get the highest priority: the command processor then dispatches their workgroups first whenever slots free up, the
+    // cheap specs fill in behind -- longest chains first: 571 -> 536-545 ms on the 30-spec M5 batch, neutral elsewhere.  Every
+    // priority level has its own hardware queues and the chip multiplexes well only up to ~23 of them in total (16 normal + 7
+    // high: 541 ms, + 8: 747 ms; 13 + 10, 14 + 9, 15 + 8: 544 ms; 20 + 7: 785 ms), so the count follows GPU_MAX_HW_QUEUES (none
+    // when the host has not set it: the runtime's default of 4 queues leaves no room) and later sets (concurrent batches of other
+    // host threads) stay at normal priority.  ANOFOX_HIP_PRIO_STREAMS overrides the count.  The priority set is RESERVED under
+    // the lock before any stream exists, so two threads creating their first sets at once cannot both take it.
+    bool want_prio = false;
     {
         std::lock_guard<std::mutex> lock(p.mu);
         // the OLDEST idle set of this device first: that is the one with the favourable queue mapping
@@ -210,37 +398,36 @@ StreamSet *stream_set_take()
         for (size_t i = 0; i < p.idle.size(); i++)
             if (p.idle[i]->dev == dev && (best < 0 || p.idle[i]->id < p.idle[(size_t)best]->id)) best = (long)i;
         if (best >= 0) { StreamSet *s = p.idle[(size_t)best]; p.idle.erase(p.idle.begin() + best); return s; }
+        if (!p.prio_taken[dev]) { p.prio_taken[dev] = true; want_prio = true; }
     }
-    std::unique_ptr<StreamSet> s(new StreamSet);
-    s->dev = dev;
-    HIPCHECK(hipStreamCreateWithFlags(&s->own, hipStreamNonBlocking));
-    // The first streams of the process's FIRST set carry the most expensive specs of a fit (launch_fit_slots orders the specs by
-    // work) and get the highest priority: the command processor then dispatches their workgroups first whenever slots free up, the
-    // cheap specs fill in behind -- longest chains first: 571 -> 536-545 ms on the 30-spec M5 batch, neutral elsewhere.  Every
-    // priority level has its own hardware queues and the chip multiplexes well only up to ~23 of them in total (16 normal + 7
-    // high: 541 ms, + 8: 747 ms; 13 + 10, 14 + 9, 15 + 8: 544 ms; 20 + 7: 785 ms), so the count follows GPU_MAX_HW_QUEUES and
-    // later sets (concurrent batches of other host threads) stay at normal priority.  ANOFOX_HIP_PRIO_STREAMS overrides the count.
     int n_prio = 0;
-    {
-        std::lock_guard<std::mutex> lock(p.mu);
-        if (p.created == 0) {
-            const char *q = std::getenv("GPU_MAX_HW_QUEUES");
-            const int hwq = q ? std::atoi(q) : 4;
-            n_prio = std::max(0, std::min(7, 23 - hwq));
-            if (const char *e = std::getenv("ANOFOX_HIP_PRIO_STREAMS")) n_prio = std::max(0, std::min(std::atoi(e), N_AUX_STREAMS));
+    if (want_prio) {
+        const char *q = std::getenv("GPU_MAX_HW_QUEUES");
+        n_prio = q ? std::max(0, std::min(7, 23 - std::atoi(q))) : 0;
+        const int forced = ProcessTunables::get().prio_streams;
+        if (forced >= 0) n_prio = std::min(forced, N_AUX_STREAMS);
+    }
+    StreamSet *s = new StreamSet;
+    try {
+        s->dev = dev;
+        s->prio = want_prio;
+        HIPCHECK(hipStreamCreateWithFlags(&s->own, hipStreamNonBlocking));
+        int prio_least = 0, prio_greatest = 0;
+        if (n_prio > 0) (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+        for (int i = 0; i < N_AUX_STREAMS; i++) {
+            if (i < n_prio) HIPCHECK(hipStreamCreateWithPriority(&s->aux[i], hipStreamNonBlocking, prio_greatest));
+            else HIPCHECK(hipStreamCreateWithFlags(&s->aux[i], hipStreamNonBlocking));
         }
+        for (hipEvent_t *e : {&s->ev_start, &s->ev_stop, &s->ev_fit0, &s->ev_fit1}) HIPCHECK(hipEventCreate(e));
+        HIPCHECK(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
+        for (auto &e : s->ev_join) HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    } catch (...) {
+        stream_set_destroy(s);
+        if (want_prio) { std::lock_guard<std::mutex> lock(p.mu); p.prio_taken[dev] = false; }
+        throw;
     }
-    int prio_least = 0, prio_greatest = 0;
-    if (n_prio > 0) (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-    for (int i = 0; i < N_AUX_STREAMS; i++) {
-        if (i < n_prio) HIPCHECK(hipStreamCreateWithPriority(&s->aux[i], hipStreamNonBlocking, prio_greatest));
-        else HIPCHECK(hipStreamCreateWithFlags(&s->aux[i], hipStreamNonBlocking));
-    }
-    for (hipEvent_t *e : {&s->ev_start, &s->ev_stop, &s->ev_fit0, &s->ev_fit1}) HIPCHECK(hipEventCreate(e));
-    HIPCHECK(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
-    for (auto &e : s->ev_join) HIPCHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     { std::lock_guard<std::mutex> lock(p.mu); s->id = p.created++; }
-    return s.release();        // (a set whose creation failed half way leaks its few handles: the process is out of resources anyway)
+    return s;
 }
 void stream_set_give(StreamSet *s)
 {
@@ -248,6 +435,17 @@ void stream_set_give(StreamSet *s)
     StreamPool &p = stream_pool();
     std::lock_guard<std::mutex> lock(p.mu);
     p.idle.push_back(s);
+}
+void stream_pool_release_all()
+{
+    StreamPool &p = stream_pool();
+    std::vector<StreamSet *> drop;
+    {
+        std::lock_guard<std::mutex> lock(p.mu);
+        drop.swap(p.idle);
+        for (StreamSet *s : drop) if (s->prio) p.prio_taken[s->dev] = false;     // the next set created on that device takes the priority streams again
+    }
+    for (StreamSet *s : drop) stream_set_destroy(s);
 }
 
 struct Plan {
@@ -259,9 +457,15 @@ struct Plan {
     double z = 1.645;
 };
 
+thread_local unsigned tl_host_thread_share = 1;   // > 1 while this thread runs one of several device shards of a batch call (the packer takes its share of the host threads)
+std::atomic<int> g_default_arima_method{0};      // ANOFOX_ARIMA_CSS (anofox_hip_set_default_arima_method)
+
 } // namespace
 
 struct AnofoxHipBatch {
+    int dev = 0;                       // the device the batch lives on (the caller's current device when it was created): every
+                                       // entry point makes it current for its own duration, so a host thread may drive batches of
+                                       // several devices
     size_t n = 0, t_max = 0, ld = 0;
     int h = 0;
     ForecastOptions opt;
@@ -306,7 +510,8 @@ struct AnofoxHipBatch {
     int insp_m = 1;
     int32_t live_pos = -1, live_all = -1;   // usable strictly positive / usable series of the current group (-1: not counted)
     // AutoARIMA workspace
-    bool arima_ml = true;            // exact-likelihood refit of the selected model (ANOFOX_HIP_ARIMA_ML=0: keep the CSS estimates)
+    int arima_method = 0;            // ANOFOX_ARIMA_CSS: the search's own estimates; ANOFOX_ARIMA_CSS_ML: exact-likelihood refit of the
+                                     // selected model (anofox_hip_batch_set_arima_method / anofox_hip_set_default_arima_method)
     size_t ar_ws_bytes = 0;
     double *ar_w = nullptr, *ar_wmean = nullptr, *ar_wsd = nullptr, *ar_l0 = nullptr, *ar_l1 = nullptr, *ar_x = nullptr, *ar_aicc = nullptr;
     int32_t *ar_wlen = nullptr, *ar_d = nullptr, *ar_D = nullptr, *ar_order = nullptr, *ar_status = nullptr, *ar_evals = nullptr, *ar_passes = nullptr, *ar_models = nullptr;
@@ -319,7 +524,6 @@ struct AnofoxHipBatch {
     // per aux stream: gathered block of the running problems, ping-pong column maps + counts, parked NM state
     struct Lane {
         double *ybuf = nullptr;
-        double *ybuf2 = nullptr;         // fused compaction: the rounds alternate between the two dense blocks
         int32_t *map[2] = {nullptr, nullptr};
         int32_t *cnt = nullptr;          // [2]
         anofox::NmStateBuf st{};
@@ -328,15 +532,9 @@ struct AnofoxHipBatch {
     bool ran = false, timed_fit = false;
     uint32_t fit_launches = 0;
     uint64_t n_problems = 0;
+    Tunables tun;            // the environment knobs, read when the batch was created
     int seq_rounds = 3;      // rounds run by the sequential Nelder-Mead driver before switching to the speculative one
     int seq_rounds_env = -1; // ANOFOX_HIP_SEQ_ROUNDS override (-1 = decide from the number of live problems)
-    bool fused = false;      // ANOFOX_HIP_FUSED=1: compaction + gather fused into the end of every round kernel (measured 3-8 % slower
-                             // than the separate kernels: the gaps between a spec's rounds are queueing, not those kernels)
-    double gather_max_frac = 1.0;    // per spec: no gather while more than this share of the series is still running (1.0 = always gather:
-                                     // tools/gather_sweep.sh, 1.0 / 0.9 / 0.75 / 0.5 / 0.25 -> 85.6 / 85.9 / 86.5 / 88.5 / 94.7 ms on the intermittent
-                                     // M5 batch, 150 / 152 / 159 / 184 / 233 ms on the stress batch: the gather pays at every count)
-    int gather_min = 0;      // per spec: stop gathering columns once this few problems are still running (measured: the gather pays at every count, 0 = always gather)
-    int tail_below = 0;      // per spec: run the remaining problems to completion once this few are left (measured: rounds + compaction win at every threshold, 0 = off)
     int spec_below_md = 8192; // same, for the damped multiplicative-trend specs (their pass is ~10x longer: the stragglers matter more)
     // the SES / Holt / Holt-Winters / SeasonalES family on the round kernels: its own Nelder-Mead state, status and compaction lists
     // (the spec lanes keep the optima an inspection call re-reads)
@@ -347,26 +545,15 @@ struct AnofoxHipBatch {
                                   // (freeing them on the spot needs a device-wide synchronisation, which couples every host thread's batch)
     int merged_m_max = 0;         // ... and its largest period (sizes)
     int32_t *d_m_col = nullptr;   // merged batch of several seasonal periods (auto-detected): period of every column, constant within 64 columns
-    bool one_launch = true;    // the three Nelder-Mead drivers of a later round in ONE kernel (ANOFOX_HIP_ONE_LAUNCH=0: one launch each, two of them empty)
     int spec2_below_md = 2048; // per spec: the last problems run one per wave, two iterations per pass (0 = never); damped multiplicative
                                // trend.  Measured on the 30-spec M5 batch (tools/spec2_sweep.sh): 0 / 256 / 1024 / 2048 / 4096 / 8192 -> 579 / 575 / 565 / 562 / 594 / 736 ms
     int spec2_below = 1024;    // same, other specs (single-spec ETS(A,A,A) fit: 22.5 -> 18.2 ms; all specs at 2048 / 4096: 588 / 673 ms)
     int spec_below = 8192;   // per spec: switch to the speculative driver once this few problems are still running
     bool use_gather = false; // rebuild a dense block of the running problems between rounds (else index y by series)
-    // work-pool schedule (ets_pool_kernel.hpp): persistent waves, lanes refill from a queue, slow problems take four lanes
-    bool pool_sched = false; // ANOFOX_HIP_SCHED=pool selects the work-pool schedule; the round schedule (resumable rounds + compaction + gather)
-                             // is the default: measured 590 ms against 700-800 ms per 30-spec M5 step
-    int pool_waves = 2048;   // persistent waves over all candidate specs of a group (the chip holds 2 x 1,024 waves of these kernels)
-    int pool_promote = 128;  // iterations after which a problem asks for four lanes
     double *d_ring = nullptr;        // seasonal rings of periods above the LDS limit: one area per (candidate spec, workgroup)
     size_t ring_elems = 0;
     double *d_prep_scratch = nullptr;   // prep kernel's window ring + per-phase accumulators for such periods
     size_t prep_scratch_elems = 0;
-    double *d_ys = nullptr;  // series-major copy of the block [n x pool_tw] (+ one row of slack)
-    size_t pool_tw = 0;
-    int32_t *d_pool_head = nullptr;   // [N_AUX_STREAMS] queue cursors
-    unsigned long long *d_pool_trace = nullptr;   // ANOFOX_HIP_POOL_TRACE=1: [N_AUX_STREAMS x 8] diagnostics, printed to stderr by the next stats call
-    std::vector<int> pool_trace_spec;
     // BASELINE config 2: ETS(spec) with GIVEN smoothing parameters -- no optimiser, one streamed pass per series
     bool fixed_params = false;
     double fixed_x[4] = {0.0, 0.0, 0.0, 0.0};   // optimiser coordinates (alpha, beta*, gamma*, phi) of the given parameters
@@ -503,6 +690,24 @@ int detect_seasonality_first(const double *v, size_t n)
     return best;
 }
 
+// a batch borrows its streams and events from the process-wide pool (and hands them back while it is parked, see pool_give)
+void batch_attach_streams(AnofoxHipBatch *b)
+{
+    if (b->sset) return;
+    b->sset = stream_set_take();
+    b->own_stream = b->sset->own;
+    for (int i = 0; i < N_AUX_STREAMS; i++) { b->aux[i] = b->sset->aux[i]; b->ev_join[i] = b->sset->ev_join[i]; }
+    b->ev_start = b->sset->ev_start; b->ev_stop = b->sset->ev_stop; b->ev_fit0 = b->sset->ev_fit0; b->ev_fit1 = b->sset->ev_fit1;
+    b->ev_fork = b->sset->ev_fork;
+}
+void batch_detach_streams(AnofoxHipBatch *b)           // the caller has synchronised the set's streams (or nothing was ever launched on them)
+{
+    if (!b->sset) return;
+    stream_set_give(b->sset);
+    b->sset = nullptr; b->own_stream = nullptr; b->last_stream = nullptr; b->ran = false;
+    for (auto &q : b->aux) q = nullptr;
+}
+
 void free_batch_buffers(AnofoxHipBatch *b)
 {
     auto F = [](void *p) { dev_free(p, true); };             // the caller has synchronised the batch's streams
@@ -517,18 +722,13 @@ void free_batch_buffers(AnofoxHipBatch *b)
     F(b->d_classic_ybuf); F(b->d_classic_status); F(b->classic_map[0]); F(b->classic_map[1]); F(b->classic_cnt);
     for (void *p : b->retired) F(p);
     b->retired.clear();
-    F(b->d_m_col); F(b->d_ys); F(b->d_pool_head); F(b->d_pool_trace); F(b->d_ring); F(b->d_prep_scratch);
+    F(b->d_m_col); F(b->d_ring); F(b->d_prep_scratch);
     F(b->d_passes_total); F(b->d_evals_total); F(b->d_mask); F(b->d_len_group); F(b->d_count); F(b->d_pos_map); F(b->d_pos_cnt); F(b->d_notpos); F(b->d_ypos);
     F(b->ar_w); F(b->ar_wmean); F(b->ar_wsd); F(b->ar_l0); F(b->ar_l1); F(b->ar_x); F(b->ar_aicc); F(b->ar_wlen); F(b->ar_d); F(b->ar_D);
     F(b->ar_order); F(b->ar_status); F(b->ar_evals); F(b->ar_passes); F(b->ar_models);
-    if (b->sset) {
-        // the caller has synchronised the set's streams (or nothing was ever launched on them)
-        stream_set_give(b->sset);
-        b->sset = nullptr; b->own_stream = nullptr;
-        for (auto &s : b->aux) s = nullptr;
-    }
+    batch_detach_streams(b);
     for (auto &l : b->lanes) {
-        F(l.ybuf); F(l.ybuf2); F(l.map[0]); F(l.map[1]); F(l.cnt);
+        F(l.ybuf); F(l.map[0]); F(l.map[1]); F(l.cnt);
         F(l.st.sim); F(l.st.fs); F(l.st.phase); F(l.st.evals); F(l.st.iters); F(l.st.passes); F(l.st.done);
     }
 }
@@ -593,7 +793,6 @@ void alloc_common(AnofoxHipBatch *b)
         for (int q = 0; q < n_lanes; q++) {
             auto &l = b->lanes[q];
             if (b->use_gather) l.ybuf = dalloc<double>(T * ld);
-            if (b->use_gather && b->fused) l.ybuf2 = dalloc<double>(T * ld);
             l.map[0] = dalloc<int32_t>(ld);
             l.map[1] = dalloc<int32_t>(ld);
             l.cnt = dalloc<int32_t>(3);
@@ -606,11 +805,7 @@ void alloc_common(AnofoxHipBatch *b)
             l.st.done = dalloc<int32_t>(ld);
         }
     }
-    b->sset = stream_set_take();
-    b->own_stream = b->sset->own;
-    for (int i = 0; i < N_AUX_STREAMS; i++) { b->aux[i] = b->sset->aux[i]; b->ev_join[i] = b->sset->ev_join[i]; }
-    b->ev_start = b->sset->ev_start; b->ev_stop = b->sset->ev_stop; b->ev_fit0 = b->sset->ev_fit0; b->ev_fit1 = b->sset->ev_fit1;
-    b->ev_fork = b->sset->ev_fork;
+    batch_attach_streams(b);
 }
 
 void ensure_fig(AnofoxHipBatch *b, int m)
@@ -618,6 +813,7 @@ void ensure_fig(AnofoxHipBatch *b, int m)
     if (m <= b->fig_m) return;
     if (b->d_fig_add) b->retired.push_back(b->d_fig_add);
     if (b->d_fig_mul) b->retired.push_back(b->d_fig_mul);
+    b->d_fig_add = nullptr; b->d_fig_mul = nullptr; b->fig_m = 0;      // (an allocation below may throw: the retired blocks must not be freed twice)
     b->d_fig_add = dalloc<double>((size_t)m * b->ld);
     b->d_fig_mul = dalloc<double>((size_t)m * b->ld);
     b->fig_m = m;
@@ -674,8 +870,7 @@ void run_classic(AnofoxHipBatch *b, int kind, const int32_t *d_len, int m, int o
     a.ring_scratch = nullptr;
     a.m_col = (kind == CK_HW || kind == CK_SEASONAL_ES) ? b->d_m_col : nullptr;
     const bool optimise = kind == CK_HOLT || kind == CK_HW || optimized != 0;
-    static const bool on_rounds = [] { const char *e = std::getenv("ANOFOX_HIP_CLASSIC_ROUNDS"); return e ? std::atoi(e) != 0 : true; }();
-    if (optimise && on_rounds) {
+    if (optimise) {
         // The optimised members of the family run on the ETS round kernels (ClassicCfg<KIND>, fit_classic.hip): resumable rounds
         // with compaction, the drivers picked from the device-side count, then one final pass.  One chain on `st`.
         const size_t n = b->n, ld = b->ld;
@@ -711,10 +906,9 @@ void run_classic(AnofoxHipBatch *b, int kind, const int32_t *d_len, int m, int o
         const int n_rounds = merged ? (n > 4096 ? 4 : 3) : (int)(sizeof BUDGET / sizeof BUDGET[0]);
         for (int r = 0; r < n_rounds; r++) {
             f.first_round = (r == 0);
-            f.spec_below = -1; f.spec2_below = -1; f.tail_below = 0;
-            f.gathered = 0; f.gather_min = 0; f.gather_max = 0x7fffffff;
+            f.spec_below = -1; f.spec2_below = -1;
+            f.gathered = 0;
             f.y_round = b->d_y; f.ld_round = ld; f.series_of = nullptr; f.n_active = nullptr;
-            f.next_map = nullptr; f.next_cnt = nullptr; f.clear_cnt = nullptr; f.next_y = nullptr;
             if (merged) {
                 // several periods in one block: every launch sweeps all columns in place (see launch_fit_slots)
                 f.budget = r == 0 ? 64 : (r == 1 ? 128 : 256); f.budget_seq = f.budget;
@@ -731,7 +925,7 @@ void run_classic(AnofoxHipBatch *b, int kind, const int32_t *d_len, int m, int o
                 launch_compact(prev_map, prev_cnt, (int)n, b->classic_st.done, map[r & 1], cnt + (r % 3), st, cnt + ((r + 1) % 3));
                 f.series_of = map[r & 1]; f.n_active = cnt + (r % 3);
                 if (ybuf) {
-                    launch_gather_columns(b->d_y, ld, map[r & 1], cnt + (r % 3), (int)n, (int)b->t_max, ybuf, ld, st, 0, 0x7fffffff);
+                    launch_gather_columns(b->d_y, ld, map[r & 1], cnt + (r % 3), (int)n, (int)b->t_max, ybuf, ld, st);
                     f.y_round = ybuf; f.gathered = 1;
                 }
                 f.spec_below = 8192; f.spec2_below = 1024;
@@ -808,7 +1002,7 @@ __global__ void retire_nonpositive_kernel(int n, const int32_t *len, const int32
     if (s >= n || !notpos[s]) return;
     status[s] = len[s] > 0 ? FIT_NONPOSITIVE : FIT_SKIPPED;
     done[s] = 1; passes[s] = 0; evals[s] = 0; iters[s] = 0;
-    // work-pool schedule: there is no final kernel to leave these behind
+    // a spec without a launch chain: there is no final kernel to leave these behind
     if (aicc && len[s] > 0) { aicc[s] = __builtin_huge_val(); f_passes[s] = 0; f_evals[s] = 0; f_iters[s] = 0; }
 }
 
@@ -863,50 +1057,14 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
     // Round budgets (streamed passes per launch).  Geometric, so every round retires roughly half of the
     // still-running problems and the compaction + gather in between stays a few percent of the passes.
     // iteration budgets of the rounds (the last one runs everything left to completion); ANOFOX_HIP_BUDGETS overrides
-    std::vector<int> BUDGET = {24, 24, 24, 24, 24, 24, 48, 48, 96, 96, 192, 1024};   // measured best of five schedules (5-12 rounds)
-    if (const char *e = std::getenv("ANOFOX_HIP_BUDGETS")) {
-        std::vector<int> v;
-        for (const char *q = e; *q;) {
-            char *end = nullptr;
-            long x = std::strtol(q, &end, 10);
-            if (end == q) break;
-            if (x > 0) v.push_back((int)x);
-            q = (*end == ',') ? end + 1 : end;
-        }
-        if (!v.empty()) BUDGET = v;
-    }
+    const std::vector<int> &BUDGET = b->tun.budgets;
     const int n_rounds = (int)BUDGET.size();
     const int n_lanes = std::min<int>(N_AUX_STREAMS, b->n_slots_cap);
     // fork: aux streams wait for everything queued on `st` so far
     HIPCHECK(hipEventRecord(b->ev_fit0, st));
     const bool merged = b->d_m_col != nullptr;           // several periods in one block: no compaction (a wave's columns share a period)
-    const bool pool = b->pool_sched && !b->fixed_params && m <= ETS_LDS_PERIOD && !merged;      // long periods: round schedule only
-    const int n_fork = pool ? POOL_UNITS : n_lanes;      // streams that carry work: one per unit kernel / one per spec
-    if (pool) {
-        // the work-pool kernels stream every lane's own series: series-major copy of the block, once per group
-        const size_t T = std::max<size_t>(b->t_max, 1);
-        const size_t tw = (T + 1) / 2 * 2 + 64;
-        if (!b->d_ys || b->pool_tw != tw) {
-            if (b->d_ys) b->retired.push_back(b->d_ys);
-            b->d_ys = nullptr;
-            b->d_ys = dalloc<double>((n + 1) * tw);
-            HIPCHECK(hipMemsetAsync(b->d_ys, 0, (n + 1) * tw * sizeof(double), st));
-            b->pool_tw = tw;
-        }
-        if (!b->d_pool_head) b->d_pool_head = dalloc<int32_t>(N_AUX_STREAMS);
-        if (std::getenv("ANOFOX_HIP_POOL_TRACE") && !b->d_pool_trace) b->d_pool_trace = dalloc<unsigned long long>(N_AUX_STREAMS * 8);
-        if (b->d_pool_trace) {
-            std::vector<unsigned long long> init(N_AUX_STREAMS * 8, 0ull);
-            for (int i = 0; i < N_AUX_STREAMS; i++) init[i * 8 + 3] = ~0ull;
-            HIPCHECK(hipMemcpy(b->d_pool_trace, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice));
-            b->pool_trace_spec.assign(N_AUX_STREAMS, -1);
-        }
-        launch_transpose_rows(b->d_y, ld, (int)n, (int)T, b->d_ys, tw, st);
-        HIPCHECK(hipMemsetAsync(b->d_pool_head, 0, N_AUX_STREAMS * sizeof(int32_t), st));
-        HIPCHECK(hipEventRecord(b->ev_fork, st));
-        for (int i = 0; i < n_fork; i++) HIPCHECK(hipStreamWaitEvent(b->aux[i], b->ev_fork, 0));
-    } else
-        for (int i = 0; i < n_fork; i++) HIPCHECK(hipStreamWaitEvent(b->aux[i], b->ev_fit0, 0));
+    const int n_fork = n_lanes;                          // streams that carry work: one per spec
+    for (int i = 0; i < n_fork; i++) HIPCHECK(hipStreamWaitEvent(b->aux[i], b->ev_fit0, 0));
     // enqueue order: most expensive specs first, dealt round-robin over the streams, so the long
     // multiplicative / damped / seasonal fits start together instead of queueing behind each other
     std::vector<size_t> order(specs.size());
@@ -929,9 +1087,7 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
     // one stream per spec (the runtime maps them onto the hardware queues; two explicit pairing schemes -- dedicated
     // queues for the heaviest specs, heaviest-with-lightest -- both measured 14 % slower on the 30-spec batch)
     std::vector<int> stream_of(order.size());
-    int n_streams = n_lanes;
-    if (const char *e = std::getenv("ANOFOX_HIP_STREAMS")) { const int v = std::atoi(e); if (v > 0) n_streams = std::min(v, n_lanes); }
-    for (size_t oi = 0; oi < order.size(); oi++) stream_of[oi] = (int)(oi % (size_t)n_streams);
+    for (size_t oi = 0; oi < order.size(); oi++) stream_of[oi] = (int)(oi % (size_t)n_lanes);
     std::vector<FitArgs> args(order.size());
     std::vector<FitLaunchers> fns(order.size());
     for (size_t oi = 0; oi < order.size(); oi++) {
@@ -994,7 +1150,7 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
             if (args[oi].need_positive) {
                 dead[oi] = 1;
                 const FitArgs &a = args[oi];
-                hipLaunchKernelGGL(retire_nonpositive_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, b->aux[pool ? 0 : stream_of[oi]], (int)n, d_len,
+                hipLaunchKernelGGL(retire_nonpositive_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, b->aux[stream_of[oi]], (int)n, d_len,
                                    b->d_notpos, a.status, a.st.done, a.st.passes, a.st.evals, a.st.iters, a.aicc, a.passes, a.evals, a.iters);
             }
     if (b->fixed_params) {
@@ -1014,86 +1170,6 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
                                a.st.sim, a.st.evals, a.st.iters, a.st.passes, a.st.done);
         }
         LAUNCHCHECK("ETS fixed-parameter setup");
-    }
-    if (pool) {
-        // One persistent kernel per compile unit; a unit's waves walk its specs in priority order (most expensive first), so
-        // the slow problems of one spec overlap with the bulk of the next and nothing waits for a hardware queue.  The grids
-        // are oversubscribed (every unit may fill the chip): slots freed by a unit that runs dry go to the others.  With few
-        // problems (four lanes each fit the chip) every problem runs speculatively from its first pass.
-        double total_live = 0.0;
-        std::vector<double> live(order.size());
-        for (size_t oi = 0; oi < order.size(); oi++) {
-            const int id = specs[order[oi]];
-            live[oi] = (b->live_all >= 0) ? (spec_has_mult(id) ? (double)b->live_pos : (double)b->live_all) : (double)n;
-            total_live += live[oi];
-        }
-        const bool start_spec = total_live * 4.0 <= (double)b->pool_waves * 64.0;
-        PoolUnitArgs units[POOL_UNITS];
-        size_t unit_lds[POOL_UNITS] = {0, 0, 0, 0};
-        double unit_live[POOL_UNITS] = {0, 0, 0, 0};
-        std::vector<double> unit_work[POOL_UNITS];
-        for (auto &u : units) {
-            u = PoolUnitArgs{};
-            u.ys = b->d_ys; u.tw = b->pool_tw; u.ld = ld; u.fig_ld = ld; u.len = d_len; u.flags = b->d_flags;
-            u.n_series = (int)n; u.h = b->h; u.promote = b->pool_promote; u.start_spec = start_spec ? 1 : 0;
-            u.skip_constant = skip_constant ? 1 : 0; u.n_specs = 0;
-        }
-        for (size_t oi = 0; oi < order.size(); oi++) {
-            if (dead[oi]) continue;
-            const int id = specs[order[oi]];
-            const FitArgs &a = args[oi];
-            const int ui = pool_unit_of(id);
-            if (ui < 0 || units[ui].n_specs >= POOL_MAX_SPECS) throw HipFail{"no work-pool kernel for ETS spec id " + std::to_string(id)};
-            PoolSpec &ps = units[ui].spec[units[ui].n_specs++];
-            ps = PoolSpec{};
-            ps.head = b->d_pool_head + oi;
-            ps.trace = b->d_pool_trace ? b->d_pool_trace + oi * 8 : nullptr;
-            if (b->d_pool_trace) b->pool_trace_spec[oi] = id;
-            ps.status = a.status; ps.st = a.st; ps.aicc = a.aicc; ps.evals = a.evals; ps.iters = a.iters; ps.passes = a.passes;
-            ps.l0 = a.l0; ps.b0 = a.b0; ps.fig = a.fig; ps.yhat = a.yhat;
-            ps.m = a.m; ps.n_param = a.n_param; ps.need_positive = a.need_positive;
-            ps.key = id * 4 + pool_period_variant(id, a.m);
-            if (b->use_pos && a.need_positive) {
-                // mixed batch: a spec with a multiplicative component only queues the strictly positive series; the others
-                // get here what the pool would have written for an inadmissible problem
-                hipLaunchKernelGGL(retire_nonpositive_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, b->aux[ui], (int)n, d_len, b->d_notpos,
-                                   a.status, a.st.done, a.st.passes, a.st.evals, a.st.iters, a.aicc, a.passes, a.evals, a.iters);
-                ps.series_of = b->d_pos_map; ps.n_active = b->d_pos_cnt;
-            }
-            const int D = spec_dim(id);
-            size_t lds_bytes = sizeof(double) * (size_t)((D + 1) * D + (D + 1)) * 64;
-            if (ps.key % 4 == 3) lds_bytes += sizeof(double) * (size_t)a.m * 64;
-            unit_lds[ui] = std::max(unit_lds[ui], lds_bytes);
-            unit_live[ui] += live[oi];
-            unit_work[ui].push_back((double)cost(id) * (live[oi] + 1.0));
-        }
-        // deal the waves of a unit to its specs: 64 slots in proportion to the expected work (at least one each), interleaved
-        for (int ui = 0; ui < POOL_UNITS; ui++) {
-            PoolUnitArgs &u = units[ui];
-            if (u.n_specs == 0) continue;
-            std::vector<double> w(u.n_specs), given(u.n_specs, 0.0);
-            double wsum = 0.0;
-            for (int k = 0; k < u.n_specs; k++) { w[k] = unit_work[ui][k]; wsum += w[k]; }
-            for (int slot = 0; slot < 64; slot++) {
-                // largest deficit first: spec k should hold w[k] / wsum of the slots dealt so far
-                int best = 0;
-                double best_def = -1.0e300;
-                for (int k = 0; k < u.n_specs; k++) {
-                    const double def = (slot + 1) * w[k] / wsum - given[k];
-                    if (def > best_def) { best_def = def; best = k; }
-                }
-                given[best] += 1.0;
-                u.first[slot] = (unsigned char)best;
-            }
-        }
-        for (int ui = 0; ui < POOL_UNITS; ui++) {
-            if (units[ui].n_specs == 0) continue;
-            const double per_wave = start_spec ? 16.0 : 64.0;
-            const int grid = (int)std::max(1.0, std::min((double)b->pool_waves, std::ceil((unit_live[ui] + 1.0) / per_wave)));
-            launch_pool_unit(ui, units[ui], grid, unit_lds[ui], b->aux[ui]);
-            b->fit_launches++;
-        }
-        LAUNCHCHECK("ETS work pool");
     }
     if (merged && !b->fixed_params) {
         // Three launches per spec, every one over all columns in place (finished problems are skipped in the kernel): 64 and 128
@@ -1118,10 +1194,9 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
                 hipStream_t sq = b->aux[stream_of[oi]];
                 FitArgs &a = args[oi];
                 a.first_round = (r == 0);
-                a.spec_below = -1; a.spec2_below = -1; a.tail_below = 0;
-                a.gathered = 0; a.gather_min = 0; a.gather_max = 0x7fffffff;
+                a.spec_below = -1; a.spec2_below = -1;
+                a.gathered = 0;
                 a.y_round = b->d_y; a.ld_round = ld; a.series_of = nullptr; a.n_active = nullptr;
-                a.next_map = nullptr; a.next_cnt = nullptr; a.clear_cnt = nullptr; a.next_y = nullptr;
                 a.budget = plan_r[r].budget; a.budget_seq = a.budget;
                 (plan_r[r].driver == 0 ? fns[oi].round_seq : (plan_r[r].driver == 1 ? fns[oi].round_spec : fns[oi].round_spec2))(a, sq);
                 b->fit_launches++;
@@ -1129,7 +1204,7 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
             LAUNCHCHECK("ETS fit round (merged periods)");
         }
     }
-    for (int r = 0; r < ((b->fixed_params || pool || merged) ? 0 : n_rounds); r++) {
+    for (int r = 0; r < ((b->fixed_params || merged) ? 0 : n_rounds); r++) {
         for (size_t oi = 0; oi < order.size(); oi++) {
             if (dead[oi]) continue;
             const int q = (int)(oi % (size_t)n_lanes);
@@ -1139,9 +1214,7 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
             const bool spec_mode = r >= b->seq_rounds;
             a.first_round = (r == 0);
             a.spec_below = -1; a.spec2_below = -1;
-            a.tail_below = (r == 0) ? 0 : b->tail_below;
-            a.gathered = 0; a.gather_min = 0; a.gather_max = 0x7fffffff;
-            const int gather_max = b->gather_max_frac >= 1.0 ? 0x7fffffff : (int)(b->gather_max_frac * (double)n);
+            a.gathered = 0;
             if (r == 0 && b->use_pos && a.need_positive) {
                 // mixed batch: this spec is admissible for the strictly positive series only -- its first round runs on
                 // their dense list (built once per group) instead of sweeping every wave for a few live lanes
@@ -1152,10 +1225,6 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
                 else { a.y_round = b->d_y; a.ld_round = ld; }
             } else if (r == 0) {
                 a.y_round = b->d_y; a.ld_round = ld; a.series_of = nullptr; a.n_active = nullptr;
-            } else if (b->fused) {
-                // the previous round left its unfinished problems, densely, in map / ybuf [r & 1] with their count in cnt[r % 3]
-                a.series_of = lane.map[r & 1]; a.n_active = lane.cnt + (r % 3);
-                a.y_round = (r & 1) ? lane.ybuf2 : lane.ybuf; a.ld_round = ld; a.gathered = 1; a.gather_min = 0; a.gather_max = 0x7fffffff;
             } else {
                 const int32_t *prev_map = (r == 1) ? nullptr : lane.map[(r - 1) & 1];
                 const int32_t *prev_cnt = (r == 1) ? nullptr : lane.cnt + ((r - 1) % 3);
@@ -1163,17 +1232,11 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
                 launch_compact(prev_map, prev_cnt, (int)n, lane.st.done, lane.map[r & 1], lane.cnt + (r % 3), sq, lane.cnt + ((r + 1) % 3));
                 a.series_of = lane.map[r & 1]; a.n_active = lane.cnt + (r % 3);
                 if (b->use_gather && lane.ybuf) {
-                    launch_gather_columns(b->d_y, ld, lane.map[r & 1], lane.cnt + (r % 3), (int)n, (int)b->t_max, lane.ybuf, ld, sq, b->gather_min, gather_max);
-                    a.y_round = lane.ybuf; a.ld_round = ld; a.gathered = 1; a.gather_min = b->gather_min; a.gather_max = gather_max;
+                    launch_gather_columns(b->d_y, ld, lane.map[r & 1], lane.cnt + (r % 3), (int)n, (int)b->t_max, lane.ybuf, ld, sq);
+                    a.y_round = lane.ybuf; a.ld_round = ld; a.gathered = 1;
                 } else {
                     a.y_round = b->d_y; a.ld_round = ld;
                 }
-            }
-            a.next_map = nullptr; a.next_cnt = nullptr; a.clear_cnt = nullptr; a.next_y = nullptr;
-            if (b->fused && r + 1 < n_rounds) {
-                if (r == 0) HIPCHECK(hipMemsetAsync(lane.cnt, 0, 3 * sizeof(int32_t), sq));      // once; afterwards the counters rotate
-                a.next_map = lane.map[(r + 1) & 1]; a.next_cnt = lane.cnt + ((r + 1) % 3); a.clear_cnt = lane.cnt + ((r + 2) % 3);
-                a.next_y = ((r + 1) & 1) ? lane.ybuf2 : lane.ybuf;
             }
             const int s2 = (spec_trend_idx(specs[order[oi]]) == 4) ? b->spec2_below_md : b->spec2_below;
             if (r == 0 || b->seq_rounds_env >= 0 || b->seq_rounds == 0) {
@@ -1182,8 +1245,7 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
                 if (spec_mode && r > 0 && s2 > 0) {
                     // ... but the last s2 problems still go one per wave (device-side count), in the same launch
                     a.spec_below = 0x7fffffff; a.spec2_below = s2; a.budget_seq = a.budget;
-                    if (b->one_launch) fns[oi].round_auto(a, sq);
-                    else { fns[oi].round_spec(a, sq); fns[oi].round_spec2(a, sq); }
+                    fns[oi].round_auto(a, sq);
                 } else
                     (spec_mode ? fns[oi].round_spec : fns[oi].round_seq)(a, sq);
             } else {
@@ -1192,29 +1254,20 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
                 // speculative (one problem per wave, two iterations per pass)
                 a.spec_below = (spec_trend_idx(specs[order[oi]]) == 4) ? b->spec_below_md : b->spec_below;
                 a.spec2_below = s2 > 0 ? s2 : -1;
+                // ONE launch: a launch whose workgroups only find out that another driver owns the round still has to be dispatched
                 a.budget_seq = (BUDGET[r] * 7) / 4;
-                if (b->one_launch) {
-                    a.budget = BUDGET[r];
-                    fns[oi].round_auto(a, sq);
-                } else {
-                    a.budget = a.budget_seq;
-                    fns[oi].round_seq(a, sq);
-                    a.budget = BUDGET[r];
-                    fns[oi].round_spec(a, sq);
-                    if (s2 > 0) fns[oi].round_spec2(a, sq);
-                }
+                a.budget = BUDGET[r];
+                fns[oi].round_auto(a, sq);
             }
             b->fit_launches++;
         }
         LAUNCHCHECK("ETS fit round");
     }
-    if (!pool) {
-        // fixed parameters: the one streamed pass IS the workload -- the fit events bracket exactly that launch, on its stream
-        if (b->fixed_params && order.size() == 1) HIPCHECK(hipEventRecord(b->ev_fit0, b->aux[stream_of[0]]));
-        for (size_t oi = 0; oi < order.size(); oi++) if (!dead[oi]) fns[oi].final(args[oi], b->aux[stream_of[oi]]);
-        if (b->fixed_params && order.size() == 1) HIPCHECK(hipEventRecord(b->ev_fit1, b->aux[stream_of[0]]));
-        LAUNCHCHECK("ETS final pass");
-    }
+    // fixed parameters: the one streamed pass IS the workload -- the fit events bracket exactly that launch, on its stream
+    if (b->fixed_params && order.size() == 1) HIPCHECK(hipEventRecord(b->ev_fit0, b->aux[stream_of[0]]));
+    for (size_t oi = 0; oi < order.size(); oi++) if (!dead[oi]) fns[oi].final(args[oi], b->aux[stream_of[oi]]);
+    if (b->fixed_params && order.size() == 1) HIPCHECK(hipEventRecord(b->ev_fit1, b->aux[stream_of[0]]));
+    LAUNCHCHECK("ETS final pass");
     for (int i = 0; i < n_fork; i++) {
         HIPCHECK(hipEventRecord(b->ev_join[i], b->aux[i]));
         HIPCHECK(hipStreamWaitEvent(st, b->ev_join[i], 0));
@@ -1349,8 +1402,7 @@ void run_group(AnofoxHipBatch *b, int period, const int32_t *d_len, hipStream_t 
             size_t n_add = 0;
             for (int id : specs) if (!spec_has_mult(id)) n_add++;
             const double live = (double)cnt[0] * (double)specs.size() + (double)(cnt[1] - cnt[0]) * (double)n_add;
-            static const double seq_live = [] { const char *e = std::getenv("ANOFOX_HIP_SEQ_LIVE"); return e ? std::atof(e) : 8.0 * 65536.0; }();
-            b->seq_rounds = live >= seq_live ? 4 : 0;         // >= 8 problems per SIMD lane-slot: VALU-bound, go sequential
+            b->seq_rounds = live >= 8.0 * 65536.0 ? 4 : 0;         // >= 8 problems per SIMD lane-slot: VALU-bound, go sequential
             b->use_pos = cnt[0] > 0 && (double)cnt[0] < 0.7 * (double)cnt[1] && !b->d_m_col;     // (a dense list of the positive series would mix periods)
             b->live_pos = cnt[0]; b->live_all = cnt[1];
         } else {
@@ -1393,8 +1445,9 @@ void run_group(AnofoxHipBatch *b, int period, const int32_t *d_len, hipStream_t 
         aa.last_d0 = b->ar_l0; aa.last_d1 = b->ar_l1; aa.order = b->ar_order; aa.xbest = b->ar_x; aa.aicc = b->ar_aicc;
         aa.status = b->d_detail; aa.evals = b->d_evals_total; aa.passes = b->d_passes_total; aa.models = b->ar_models;
         aa.yhat = b->d_yhat; aa.model_code = b->d_model_code;
-        aa.ml_refit = b->arima_ml ? 1 : 0;
-        aa.trace = std::getenv("ANOFOX_HIP_ARIMA_TRACE") ? 1 : 0;
+        aa.ml_refit = b->arima_method == ANOFOX_ARIMA_CSS_ML ? 1 : 0;
+        aa.trace = b->tun.arima_trace ? 1 : 0;
+        aa.lookahead = b->tun.arima_lookahead; aa.lookahead_depth = b->tun.arima_lookahead_depth; aa.spec_factor = b->tun.arima_spec_factor;
         HIPCHECK(hipEventRecord(b->ev_fit0, st));
         try { b->fit_launches += launch_arima(aa, st); }
         catch (const std::exception &e) { throw HipFail{e.what()}; }
@@ -1531,6 +1584,49 @@ bool device_ready(AnofoxError *err)
     return true;
 }
 
+// Route A (the shipped macro) calls anofox_ts_forecast once per group from every DuckDB worker thread
+// (ts_forecast_scalar.cpp:298-523).  Creating a device batch costs ~30 ms of allocator / stream calls that serialise across
+// threads -- far more than a single-series fit -- so idle single-series batches are kept in a small process-wide pool, keyed
+// by the option block and the device: a call takes a matching batch (or creates one with room for 2x its length), re-packs
+// it, runs, fetches and gives it back.  Entries are never destroyed at process exit (the HIP runtime may be gone by then).
+struct PooledBatch { ForecastOptions opt; int device; AnofoxHipBatch *b; };
+std::mutex g_pool_mu;
+std::vector<PooledBatch> g_pool;
+constexpr size_t POOL_MAX_IDLE = 32;
+
+AnofoxHipBatch *pool_take(const ForecastOptions &o, size_t length, int device)
+{
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    for (size_t i = 0; i < g_pool.size(); i++)
+        if (g_pool[i].device == device && g_pool[i].b->t_max >= length && std::memcmp(&g_pool[i].opt, &o, sizeof o) == 0) {
+            AnofoxHipBatch *b = g_pool[i].b;
+            g_pool.erase(g_pool.begin() + (long)i);
+            return b;                                   // (the caller attaches a stream set again)
+        }
+    return nullptr;
+}
+
+void pool_give(const ForecastOptions &o, int device, AnofoxHipBatch *b)
+{
+    // a parked batch keeps its device blocks but not its 33 streams: an early single-series call would otherwise sit on the
+    // process's first (favourably mapped, high-priority) stream set for as long as it stays in the pool
+    batch_detach_streams(b);
+    AnofoxHipBatch *evict = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mu);
+        if (g_pool.size() >= POOL_MAX_IDLE) { evict = g_pool.front().b; g_pool.erase(g_pool.begin()); }
+        g_pool.push_back(PooledBatch{o, device, b});
+    }
+    if (evict) anofox_hip_batch_destroy(evict);
+}
+
+void pool_drain(std::vector<AnofoxHipBatch *> &out)
+{
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    for (auto &e : g_pool) out.push_back(e.b);
+    g_pool.clear();
+}
+
 } // namespace
 
 // =============================================================================================
@@ -1549,6 +1645,36 @@ int anofox_hip_device_count(void)
 
 int anofox_hip_set_device(int device) { return hipSetDevice(device) == hipSuccess ? 0 : -1; }
 
+void anofox_hip_release_caches(void)
+{
+    // parked single-series batches first (their blocks go back to the caches), then the caches themselves
+    std::vector<AnofoxHipBatch *> parked;
+    pool_drain(parked);
+    for (AnofoxHipBatch *b : parked) anofox_hip_batch_destroy(b);
+    dev_cache_release_all();
+    pin_cache_release_all();
+    stream_pool_release_all();
+}
+
+bool anofox_hip_set_default_arima_method(int method)
+{
+    if (method != ANOFOX_ARIMA_CSS && method != ANOFOX_ARIMA_CSS_ML) return false;
+    g_default_arima_method.store(method);
+    return true;
+}
+
+bool anofox_hip_batch_set_arima_method(AnofoxHipBatch *b, int method, AnofoxError *out_error)
+{
+    if (out_error) { out_error->code = SUCCESS; std::memset(out_error->message, 0, sizeof out_error->message); }
+    if (!b) { set_error(out_error, NULL_POINTER, "Null pointer argument"); return false; }
+    if (method != ANOFOX_ARIMA_CSS && method != ANOFOX_ARIMA_CSS_ML) {
+        set_error(out_error, INVALID_INPUT, "Invalid input: unknown ARIMA estimation method (0 = CSS, 1 = CSS-ML)");
+        return false;
+    }
+    b->arima_method = method;
+    return true;
+}
+
 bool anofox_hip_batch_create(size_t n_series, size_t t_max, const ForecastOptions *options, AnofoxHipBatch **out_batch,
                              AnofoxError *out_error)
 {
@@ -1559,6 +1685,7 @@ bool anofox_hip_batch_create(size_t n_series, size_t t_max, const ForecastOption
     if (!device_ready(out_error)) return false;
     AnofoxHipBatch *b = new AnofoxHipBatch();
     try {
+        HIPCHECK(hipGetDevice(&b->dev));
         b->n = n_series;
         b->t_max = t_max;
         b->ld = (n_series + 63) / 64 * 64;
@@ -1568,26 +1695,15 @@ bool anofox_hip_batch_create(size_t n_series, size_t t_max, const ForecastOption
         b->h = options->horizon;
         b->opt = *options;
         b->plan = plan;
-        if (const char *e = std::getenv("ANOFOX_HIP_SEQ_ROUNDS")) { b->seq_rounds_env = std::atoi(e); b->seq_rounds = b->seq_rounds_env; }
+        b->tun = Tunables::from_env();
+        if (b->tun.seq_rounds >= 0) { b->seq_rounds_env = b->tun.seq_rounds; b->seq_rounds = b->seq_rounds_env; }
         // dense re-gather of the running problems between rounds (up to 2x on a large batch) costs one block copy per
         // candidate spec: on by default while that stays under 96 GiB of the 288 GB HBM
         b->use_gather = (double)max_slots_for(plan) * (double)std::max<size_t>(t_max, 1) * (double)b->ld * 8.0 <= 96.0 * 1073741824.0;
-        if (const char *e = std::getenv("ANOFOX_HIP_GATHER")) b->use_gather = std::atoi(e) != 0;
-        if (const char *e = std::getenv("ANOFOX_HIP_SPEC_BELOW")) b->spec_below = b->spec_below_md = std::atoi(e);
-        if (const char *e = std::getenv("ANOFOX_HIP_SPEC_BELOW_MD")) b->spec_below_md = std::atoi(e);
-        if (const char *e = std::getenv("ANOFOX_HIP_SPEC2_BELOW")) b->spec2_below = b->spec2_below_md = std::atoi(e);
-        if (const char *e = std::getenv("ANOFOX_HIP_SPEC2_BELOW_MD")) b->spec2_below_md = std::atoi(e);
-        if (const char *e = std::getenv("ANOFOX_HIP_ONE_LAUNCH")) b->one_launch = std::atoi(e) != 0;
-        if (const char *e = std::getenv("ANOFOX_HIP_TAIL_BELOW")) b->tail_below = std::atoi(e);
-        if (const char *e = std::getenv("ANOFOX_HIP_GATHER_MIN")) b->gather_min = std::atoi(e);
-        if (const char *e = std::getenv("ANOFOX_HIP_GATHER_MAX_FRAC")) b->gather_max_frac = std::atof(e);
-        if (const char *e = std::getenv("ANOFOX_HIP_FUSED")) b->fused = std::atoi(e) != 0;
-        if (!b->use_gather) b->fused = false;
-        if (const char *e = std::getenv("ANOFOX_HIP_ARIMA_ML")) b->arima_ml = std::atoi(e) != 0;
-        if (const char *e = std::getenv("ANOFOX_HIP_SCHED")) b->pool_sched = std::string(e) == "pool";
-        if (const char *e = std::getenv("ANOFOX_HIP_POOL_WAVES")) b->pool_waves = std::max(1, std::atoi(e));
-        if (const char *e = std::getenv("ANOFOX_HIP_PROMOTE")) b->pool_promote = std::max(1, std::atoi(e));
-        if (b->pool_sched) b->use_gather = false;          // no gather buffers: the pool streams a series-major copy
+        if (b->tun.gather >= 0) b->use_gather = b->tun.gather != 0;
+        b->spec_below = b->tun.spec_below; b->spec_below_md = b->tun.spec_below_md;
+        b->spec2_below = b->tun.spec2_below; b->spec2_below_md = b->tun.spec2_below_md;
+        b->arima_method = g_default_arima_method.load();
         alloc_common(b);
     } catch (const HipFail &f) {
         report_hip_failure(out_error, f);
@@ -1607,6 +1723,7 @@ bool anofox_hip_batch_create(size_t n_series, size_t t_max, const ForecastOption
 void anofox_hip_batch_destroy(AnofoxHipBatch *b)
 {
     if (!b) return;
+    DeviceGuard guard(b->dev);
     // wait for this batch's own work only (other batches may be running from other host threads)
     if (b->last_stream) (void)hipStreamSynchronize(b->last_stream);
     if (b->own_stream) (void)hipStreamSynchronize(b->own_stream);
@@ -1652,6 +1769,7 @@ bool anofox_hip_batch_pack_host(AnofoxHipBatch *b, const double *const *values, 
                                 const size_t *lengths, AnofoxError *out_error)
 {
     if (!b || !values || !lengths) { set_error(out_error, NULL_POINTER, "Null pointer argument"); return false; }
+    DeviceGuard guard(b->dev);
     try {
         const size_t n = b->n, ld = b->ld, T = std::max<size_t>(b->t_max, 1);
         for (size_t s = 0; s < n; s++)
@@ -1704,7 +1822,8 @@ bool anofox_hip_batch_pack_host(AnofoxHipBatch *b, const double *const *values, 
             }
         };
         unsigned n_thr = std::thread::hardware_concurrency();
-        if (const char *e = std::getenv("ANOFOX_HIP_PACK_THREADS")) n_thr = (unsigned)std::max(1, std::atoi(e));
+        if (tl_host_thread_share > 1) n_thr = std::max(1u, n_thr / tl_host_thread_share);     // one of several device shards packing side by side
+        if (b->tun.pack_threads > 0) n_thr = (unsigned)b->tun.pack_threads;
         n_thr = (unsigned)std::min<size_t>(std::max(1u, std::min(n_thr, 32u)), std::max<size_t>(n_tiles, 1));
         if (n_thr <= 1 || n_tiles < 8) do_tiles(0, n_tiles);
         else {
@@ -1742,6 +1861,7 @@ bool anofox_hip_batch_set_device_block(AnofoxHipBatch *b, const void *d_y, size_
         set_error(out_error, INVALID_INPUT, "Invalid input: a device-resident block requires an explicit seasonal_period");
         return false;
     }
+    DeviceGuard guard(b->dev);
     try {
         if (b->owns_y && b->d_y) { dev_free(b->d_y); }
         b->d_y = (double *)d_y;
@@ -1765,6 +1885,7 @@ bool anofox_hip_batch_run(AnofoxHipBatch *b, void *stream, AnofoxError *out_erro
 {
     if (!b) { set_error(out_error, NULL_POINTER, "Null pointer argument"); return false; }
     if (!b->has_block) { set_error(out_error, INVALID_INPUT, "Invalid input: batch has no series block"); return false; }
+    DeviceGuard guard(b->dev);
     try {
         run_batch(b, stream ? (hipStream_t)stream : b->own_stream);
     } catch (const HipFail &f) {
@@ -1780,27 +1901,12 @@ bool anofox_hip_batch_run(AnofoxHipBatch *b, void *stream, AnofoxError *out_erro
 bool anofox_hip_batch_stats(AnofoxHipBatch *b, AnofoxHipStats *out)
 {
     if (!b || !out || !b->ran) return false;
+    DeviceGuard guard(b->dev);
     std::memset(out, 0, sizeof *out);
     if (hipEventSynchronize(b->ev_stop) != hipSuccess) return false;
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, b->ev_start, b->ev_stop) == hipSuccess) out->total_device_ms = ms;
     if (b->timed_fit && hipEventElapsedTime(&ms, b->ev_fit0, b->ev_fit1) == hipSuccess) out->fit_kernel_ms = ms;
-    if (b->d_pool_trace) {
-        std::vector<unsigned long long> tr(N_AUX_STREAMS * 8);
-        if (hipMemcpy(tr.data(), b->d_pool_trace, tr.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
-            unsigned long long t0 = ~0ull;
-            for (int i = 0; i < N_AUX_STREAMS; i++) if (tr[i * 8] && tr[i * 8 + 3] < t0) t0 = tr[i * 8 + 3];
-            for (int i = 0; i < N_AUX_STREAMS; i++) {
-                if (!tr[i * 8]) continue;
-                char nm[64];
-                auto_ets_name(b->pool_trace_spec[i], nm);
-                std::fprintf(stderr, "pooltrace %-28s unit %d waves %5llu wave-passes %8llu lane-util %.3f spec-lane-frac %.3f ms/pass %.3f start %7.1f end %7.1f ms\n", nm,
-                             pool_unit_of(b->pool_trace_spec[i]), tr[i * 8 + 6], tr[i * 8], (double)tr[i * 8 + 1] / (64.0 * (double)tr[i * 8]),
-                             (double)tr[i * 8 + 5] / (double)std::max<unsigned long long>(tr[i * 8 + 1], 1), (double)tr[i * 8 + 2] / (double)tr[i * 8] / 1e5,
-                             (double)(tr[i * 8 + 3] - t0) / 1e5, (double)(tr[i * 8 + 4] - t0) / 1e5);
-            }
-        }
-    }
     std::vector<int32_t> passes(b->n), evals(b->n);
     if (hipMemcpy(passes.data(), b->d_passes_total, b->n * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) return false;
     if (hipMemcpy(evals.data(), b->d_evals_total, b->n * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) return false;
@@ -1845,6 +1951,7 @@ void anofox_hip_model_name(const ForecastOptions *options, int32_t model_code, c
 bool anofox_hip_batch_fetch(AnofoxHipBatch *b, ForecastResult *out_results, AnofoxError *out_errors)
 {
     if (!b || !out_results || !b->ran) return false;
+    DeviceGuard guard(b->dev);
     const size_t n = b->n, h = (size_t)std::max(b->h, 0);
     if (hipStreamSynchronize(b->last_stream) != hipSuccess) return false;
     std::vector<double> yhat(n * h), lo(n * h), hi(n * h);
@@ -1921,6 +2028,7 @@ bool anofox_hip_batch_inspect(AnofoxHipBatch *b, AnofoxHipInspection *out, doubl
 {
     if (!b || !out) { set_error(out_error, NULL_POINTER, "Null pointer argument"); return false; }
     if (!b->ran) { set_error(out_error, INVALID_INPUT, "Invalid input: the batch has not been run"); return false; }
+    DeviceGuard guard(b->dev);
     const size_t n = b->n, ld = b->ld, T = std::max<size_t>(b->t_max, 1);
     try {
         HIPCHECK(hipStreamSynchronize(b->last_stream));
@@ -2024,7 +2132,7 @@ static bool forecast_batch_uniform(const double *const *values, const uint64_t *
         if (out_errors) for (size_t s = 0; s < n_series; s++) out_errors[s] = e;
         return false;
     }
-    static const bool timing = std::getenv("ANOFOX_HIP_TIMING") != nullptr;     // phase times of the batch entry on stderr
+    const bool timing = b->tun.timing;     // ANOFOX_HIP_TIMING: phase times of the batch entry on stderr
     const auto t1 = std::chrono::steady_clock::now();
     bool ok = anofox_hip_batch_pack_host(b, values, validity, lengths, &e);
     const auto t2 = std::chrono::steady_clock::now();
@@ -2056,16 +2164,11 @@ static bool forecast_batch_uniform(const double *const *values, const uint64_t *
     return ok;
 }
 
-bool anofox_ts_forecast_batch(const double *const *values, const uint64_t *const *validity, const size_t *lengths, size_t n_series,
-                              const ForecastOptions *options, const int *horizons, ForecastResult *out_results,
-                              AnofoxError *out_errors, AnofoxError *out_batch_error)
+// the batch entry on the calling thread's current device
+static bool forecast_batch_one_device(const double *const *values, const uint64_t *const *validity, const size_t *lengths, size_t n_series,
+                                      const ForecastOptions *options, const int *horizons, ForecastResult *out_results,
+                                      AnofoxError *out_errors, AnofoxError *out_batch_error)
 {
-    if (out_batch_error) { out_batch_error->code = SUCCESS; std::memset(out_batch_error->message, 0, sizeof out_batch_error->message); }
-    if (!values || !lengths || !options || !out_results) { set_error(out_batch_error, NULL_POINTER, "Null pointer argument"); return false; }
-    for (size_t s = 0; s < n_series; s++) {
-        std::memset(&out_results[s], 0, sizeof(ForecastResult));
-        if (!values[s]) { set_error(out_batch_error, NULL_POINTER, "Null pointer argument"); return false; }
-    }
     // Per-series period detection (params := MAP{}): every distinct period a model uses is its own run of the pipeline,
     // latency bound and tiny (~140 distinct periods per thousand M5-like series).  Detect the periods here, split the batch
     // by used period and run the parts side by side from a few host threads, each part as an ordinary batch that names
@@ -2146,8 +2249,8 @@ bool anofox_ts_forecast_batch(const double *const *values, const uint64_t *const
         };
         // AutoETS: the small parts with periods 2..48 run as ONE batch whose columns are grouped by period in blocks of 64 (the
         // kernels read the period per block): 138 tiny batches x 25 spec chains on 16 hardware queues were latency bound end to end
-        static const bool merge_periods = [] { const char *e = std::getenv("ANOFOX_HIP_MERGE_PERIODS"); return e ? std::atoi(e) != 0 : true; }();
-        const bool do_merge = merge_periods && (plan.model == M_AutoETS || plan.model == M_HoltWinters || plan.model == M_SeasonalES || plan.model == M_SeasonalESOptimized ||
+        const Tunables tun = Tunables::from_env();
+        const bool do_merge = tun.merge_periods && (plan.model == M_AutoETS || plan.model == M_HoltWinters || plan.model == M_SeasonalES || plan.model == M_SeasonalESOptimized ||
                                                 (plan.model == M_ETS && plan.ets_spec_id >= 0 && spec_season(plan.ets_spec_id) != 0));
             // one merged batch per ring class (seasonal ring in LDS up to 64, in an HBM scratch above; the scratch is sized by the
             // class's largest period, hence a few classes)
@@ -2199,7 +2302,7 @@ bool anofox_ts_forecast_batch(const double *const *values, const uint64_t *const
                     ok = ok && anofox_hip_batch_run(mb, nullptr, &be) && anofox_hip_batch_fetch(mb, res.data(), errs.data());
                     anofox_hip_batch_destroy(mb);
                 }
-                if (std::getenv("ANOFOX_HIP_TIMING"))
+                if (tun.timing)
                     std::fprintf(stderr, "[anofox-hip] merged batch: %zu parts with periods %d..%d in %zu columns: %.1f ms\n", take.size(), take.front().first, m_max, nc,
                                  std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tm0).count());
                 if (!ok) {
@@ -2289,7 +2392,7 @@ bool anofox_ts_forecast_batch(const double *const *values, const uint64_t *const
             if (!grp_hbm.empty()) cls_threads.emplace_back(run_cls, grp_hbm);
             parts = std::move(keep);
             std::sort(parts.begin(), parts.end(), [](const Part &x, const Part &y) { return x.second.size() > y.second.size(); });
-        if (std::getenv("ANOFOX_HIP_TIMING")) {
+        if (tun.timing) {
             std::string desc;
             for (auto &part : parts) desc += " " + std::to_string(part.first) + "x" + std::to_string(part.second.size());
             std::fprintf(stderr, "[anofox-hip] remaining parts (period x series):%s\n", desc.c_str());
@@ -2391,37 +2494,168 @@ bool anofox_ts_forecast_batch(const double *const *values, const uint64_t *const
     }
 }
 
-// Route A (the shipped macro) calls anofox_ts_forecast once per group from every DuckDB worker thread
-// (ts_forecast_scalar.cpp:298-523).  Creating a device batch costs ~30 ms of allocator / stream calls that serialise across
-// threads -- far more than a single-series fit -- so idle single-series batches are kept in a small process-wide pool, keyed
-// by the option block and the device: a call takes a matching batch (or creates one with room for 2x its length), re-packs
-// it, runs, fetches and gives it back.  Entries are never destroyed at process exit (the HIP runtime may be gone by then).
-struct PooledBatch { ForecastOptions opt; int device; AnofoxHipBatch *b; };
-static std::mutex g_pool_mu;
-static std::vector<PooledBatch> g_pool;
-constexpr size_t POOL_MAX_IDLE = 32;
+// ---------------------------------------------------------------------------------------------
+// Multi-device batch entry (north star: "series-id ranges shard trivially across the 8 GPUs of one node", behind ts_forecast_by;
+// replaces the ONE-thread finalize loop of ts_forecast_native.cpp:559-800 with one host thread per device)
+// ---------------------------------------------------------------------------------------------
+struct DeviceList { std::mutex mu; bool env_read = false; std::vector<int> devs; size_t min_series = 2048; };
+static DeviceList &device_list() { static DeviceList *d = new DeviceList; return *d; }
 
-static AnofoxHipBatch *pool_take(const ForecastOptions &o, size_t length, int device)
+// "0,1,2,3" / "all" -> ordinals; false when an entry is not a visible device
+static bool parse_device_list(const std::string &spec, std::vector<int> &out)
 {
-    std::lock_guard<std::mutex> lock(g_pool_mu);
-    for (size_t i = 0; i < g_pool.size(); i++)
-        if (g_pool[i].device == device && g_pool[i].b->t_max >= length && std::memcmp(&g_pool[i].opt, &o, sizeof o) == 0) {
-            AnofoxHipBatch *b = g_pool[i].b;
-            g_pool.erase(g_pool.begin() + (long)i);
-            return b;
-        }
-    return nullptr;
+    out.clear();
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) return spec.empty();
+    if (spec == "all" || spec == "ALL") { for (int i = 0; i < cnt; i++) out.push_back(i); return true; }
+    for (const char *q = spec.c_str(); *q;) {
+        while (*q == ',' || *q == ' ') q++;
+        if (!*q) break;
+        char *end = nullptr;
+        const long v = std::strtol(q, &end, 10);
+        if (end == q || v < 0 || v >= cnt) return false;
+        out.push_back((int)v);
+        q = end;
+    }
+    return true;
 }
 
-static void pool_give(const ForecastOptions &o, int device, AnofoxHipBatch *b)
+static std::vector<int> devices_in_use(size_t *min_series)
 {
-    AnofoxHipBatch *evict = nullptr;
-    {
-        std::lock_guard<std::mutex> lock(g_pool_mu);
-        if (g_pool.size() >= POOL_MAX_IDLE) { evict = g_pool.front().b; g_pool.erase(g_pool.begin()); }
-        g_pool.push_back(PooledBatch{o, device, b});
+    DeviceList &d = device_list();
+    std::lock_guard<std::mutex> lock(d.mu);
+    if (!d.env_read) {
+        d.env_read = true;
+        const std::string &spec = ProcessTunables::get().devices;
+        std::vector<int> v;
+        if (!spec.empty() && parse_device_list(spec, v)) d.devs = v;
+        else if (!spec.empty()) std::fprintf(stderr, "[anofox-hip] ANOFOX_HIP_DEVICES=%s names a device that is not visible: ignored\n", spec.c_str());
     }
-    if (evict) anofox_hip_batch_destroy(evict);
+    if (min_series) *min_series = d.min_series;
+    return d.devs;
+}
+
+bool anofox_hip_set_devices(const int *devices, size_t n_devices)
+{
+    std::vector<int> v;
+    if (n_devices) {
+        if (!devices) return false;
+        int cnt = 0;
+        if (hipGetDeviceCount(&cnt) != hipSuccess) return false;
+        for (size_t i = 0; i < n_devices; i++) { if (devices[i] < 0 || devices[i] >= cnt) return false; v.push_back(devices[i]); }
+    }
+    DeviceList &d = device_list();
+    std::lock_guard<std::mutex> lock(d.mu);
+    d.env_read = true;
+    d.devs = v;
+    return true;
+}
+
+size_t anofox_hip_get_devices(int *devices, size_t capacity)
+{
+    const std::vector<int> v = devices_in_use(nullptr);
+    for (size_t i = 0; i < v.size() && i < capacity && devices; i++) devices[i] = v[i];
+    return v.size();
+}
+
+void anofox_hip_set_min_series_per_device(size_t min_series)
+{
+    DeviceList &d = device_list();
+    std::lock_guard<std::mutex> lock(d.mu);
+    d.min_series = std::max<size_t>(min_series, 1);
+}
+
+// contiguous ranges [g * ceil(N / G), (g + 1) * ceil(N / G)) -- SURVEY.md section 8(e), the same rule as dist.shard_range
+void anofox_hip_shard_range(size_t n_series, size_t n_shards, size_t shard, size_t *begin, size_t *end)
+{
+    const size_t per = n_shards ? (n_series + n_shards - 1) / n_shards : n_series;
+    const size_t lo = std::min(n_series, shard * per), hi = std::min(n_series, lo + per);
+    if (begin) *begin = lo;
+    if (end) *end = hi;
+}
+
+bool anofox_ts_forecast_batch(const double *const *values, const uint64_t *const *validity, const size_t *lengths, size_t n_series,
+                              const ForecastOptions *options, const int *horizons, ForecastResult *out_results,
+                              AnofoxError *out_errors, AnofoxError *out_batch_error)
+{
+    if (out_batch_error) { out_batch_error->code = SUCCESS; std::memset(out_batch_error->message, 0, sizeof out_batch_error->message); }
+    if (!values || !lengths || !options || !out_results) { set_error(out_batch_error, NULL_POINTER, "Null pointer argument"); return false; }
+    for (size_t s = 0; s < n_series; s++) {
+        std::memset(&out_results[s], 0, sizeof(ForecastResult));
+        if (!values[s]) { set_error(out_batch_error, NULL_POINTER, "Null pointer argument"); return false; }
+    }
+    size_t min_series = 2048;
+    const std::vector<int> devs = devices_in_use(&min_series);
+    // as many shards as there are listed devices, but none smaller than min_series (a shard that does not fill its device
+    // finishes no sooner than a larger one: the fit is bound by its slowest problems)
+    const size_t G = devs.empty() ? 1 : std::max<size_t>(1, std::min(devs.size(), n_series / std::max<size_t>(min_series, 1)));
+    if (devs.empty())
+        return forecast_batch_one_device(values, validity, lengths, n_series, options, horizons, out_results, out_errors, out_batch_error);
+    if (G == 1) {
+        DeviceGuard guard(devs[0]);
+        return forecast_batch_one_device(values, validity, lengths, n_series, options, horizons, out_results, out_errors, out_batch_error);
+    }
+    // one host thread per shard: its device made current, its own batch (stream set, allocator cache entries and pinned
+    // staging block of that device), its slice of the caller's arrays -- the shards share nothing but the option block
+    std::vector<AnofoxError> berr(G);
+    std::vector<char> ok(G, 1);
+    std::vector<std::thread> threads;
+    const bool timing = std::getenv("ANOFOX_HIP_TIMING") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto shard = [&](size_t g) {
+        berr[g].code = SUCCESS; berr[g].message[0] = 0;
+        try {
+            size_t lo = 0, hi = 0;
+            anofox_hip_shard_range(n_series, G, g, &lo, &hi);
+            if (hi <= lo) return;
+            if (hipSetDevice(devs[g]) != hipSuccess) { set_error(&berr[g], INTERNAL_ERROR, "Internal error: cannot select device " + std::to_string(devs[g])); ok[g] = 0; return; }
+            tl_host_thread_share = (unsigned)G;
+            ok[g] = forecast_batch_one_device(values + lo, validity ? validity + lo : nullptr, lengths + lo, hi - lo, options, horizons ? horizons + lo : nullptr,
+                                              out_results + lo, out_errors ? out_errors + lo : nullptr, &berr[g]) ? 1 : 0;
+            tl_host_thread_share = 1;
+        } catch (const std::exception &e) {           // nothing may leave a worker thread
+            set_error(&berr[g], INTERNAL_ERROR, std::string("Internal error: ") + e.what()); ok[g] = 0;
+        } catch (...) { set_error(&berr[g], INTERNAL_ERROR, "Internal error: device shard failed"); ok[g] = 0; }
+    };
+    int caller_dev = 0;
+    (void)hipGetDevice(&caller_dev);
+    for (size_t g = 1; g < G; g++) threads.emplace_back(shard, g);
+    shard(0);
+    for (auto &t : threads) t.join();
+    (void)hipSetDevice(caller_dev);
+    if (timing)
+        std::fprintf(stderr, "[anofox-hip] batch of %zu over %zu device shards: %.1f ms\n", n_series, G,
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    bool all_ok = true;
+    for (size_t g = 0; g < G; g++)
+        if (!ok[g] || berr[g].code != SUCCESS) {
+            // the option errors (INVALID_MODEL / INVALID_INPUT) are uniform across the shards: the first one speaks for the batch
+            if (out_batch_error && out_batch_error->code == SUCCESS) *out_batch_error = berr[g];
+            if (!ok[g]) all_ok = false;
+        }
+    return all_ok;
+}
+
+// Block 3 counterpart: run several device-resident batches -- typically one per device, each created after
+// anofox_hip_set_device(d) -- side by side, one host thread per batch (a run synchronises its stream a few times, so one thread
+// cannot drive several devices concurrently).  Returns false if any run failed; out_errors (may be NULL) is per batch.
+bool anofox_hip_batch_run_many(AnofoxHipBatch *const *batches, size_t n_batches, AnofoxError *out_errors)
+{
+    if (!batches && n_batches) return false;
+    std::vector<char> ok(n_batches, 1);
+    std::vector<std::thread> threads;
+    auto one = [&](size_t i) {
+        AnofoxError e;
+        e.code = SUCCESS; e.message[0] = 0;
+        try { ok[i] = anofox_hip_batch_run(batches[i], nullptr, &e) ? 1 : 0; }
+        catch (...) { ok[i] = 0; set_error(&e, INTERNAL_ERROR, "Internal error: batch run failed"); }
+        if (out_errors) out_errors[i] = e;
+    };
+    for (size_t i = 1; i < n_batches; i++) threads.emplace_back(one, i);
+    if (n_batches) one(0);
+    for (auto &t : threads) t.join();
+    for (size_t i = 0; i < n_batches; i++) if (!ok[i]) return false;
+    return true;
 }
 
 bool anofox_ts_forecast(const double *values, const uint64_t *validity, size_t length, const ForecastOptions *options,
@@ -2470,6 +2704,10 @@ bool anofox_ts_forecast(const double *values, const uint64_t *validity, size_t l
     int device = 0;
     (void)hipGetDevice(&device);
     AnofoxHipBatch *b = pool_take(key, length, device);
+    if (b) {
+        try { batch_attach_streams(b); }
+        catch (const HipFail &f) { report_hip_failure(out_error, f); anofox_hip_batch_destroy(b); return false; }
+    }
     if (!b) {
         size_t cap = 256;
         while (cap < 2 * length) cap *= 2;

@@ -232,33 +232,6 @@ void launch_intervals(const IntervalArgs &a, hipStream_t stream)
 }
 
 // ------------------------------------------------------------------------------------------
-// series-major copy of the block (work-pool schedule): 64 x 64 tiles through LDS, 512-byte reads along the series axis,
-// 512-byte writes along the time axis.  HBM bound: 16 bytes per element.
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void transpose_rows_kernel(const double *y, size_t ld, int n_series, int t_rows, double *ys, size_t tw)
-{
-    __shared__ double tile[64][65];
-    const int s0 = blockIdx.x * 64, t0 = blockIdx.y * 64;
-    const int c = threadIdx.x & 63, r4 = threadIdx.x >> 6;
-    for (int r = r4; r < 64; r += 4) {
-        const int t = t0 + r, s = s0 + c;
-        tile[r][c] = (t < t_rows && s < n_series) ? y[(size_t)t * ld + s] : 0.0;
-    }
-    __syncthreads();
-    for (int r = r4; r < 64; r += 4) {
-        const int s = s0 + r, t = t0 + c;
-        if (s < n_series && t < t_rows) ys[(size_t)s * tw + t] = tile[c][r];
-    }
-}
-
-void launch_transpose_rows(const double *y, size_t ld, int n_series, int t_rows, double *ys, size_t tw, hipStream_t stream)
-{
-    if (n_series <= 0 || t_rows <= 0) return;
-    dim3 grid((unsigned)((n_series + 63) / 64), (unsigned)((t_rows + 63) / 64));
-    hipLaunchKernelGGL(transpose_rows_kernel, grid, dim3(256), 0, stream, y, ld, n_series, t_rows, ys, tw);
-}
-
-// ------------------------------------------------------------------------------------------
 FitLaunchers ets_fit_launcher(int spec_id, int m)
 {
     FitLaunchers f = fit_unit_nonseasonal(spec_id, m);
@@ -266,26 +239,6 @@ FitLaunchers ets_fit_launcher(int spec_id, int m)
     if (!f.final) f = fit_unit_seasonal_gen_a(spec_id, m);
     if (!f.final) f = fit_unit_seasonal_gen_m(spec_id, m);
     return f;
-}
-
-int pool_unit_of(int spec_id)
-{
-    if (fit_unit_nonseasonal(spec_id, 7).final) return 0;
-    if (fit_unit_seasonal_add(spec_id, 7).final) return 1;
-    if (fit_unit_seasonal_gen_a(spec_id, 7).final) return 2;
-    if (fit_unit_seasonal_gen_m(spec_id, 7).final) return 3;
-    return -1;
-}
-
-void launch_pool_unit(int unit, const PoolUnitArgs &u, int grid, size_t lds_bytes, hipStream_t stream)
-{
-    switch (unit) {
-    case 0: launch_pool_unit_nonseasonal(u, grid, lds_bytes, stream); break;
-    case 1: launch_pool_unit_seasonal_add(u, grid, lds_bytes, stream); break;
-    case 2: launch_pool_unit_seasonal_gen_a(u, grid, lds_bytes, stream); break;
-    case 3: launch_pool_unit_seasonal_gen_m(u, grid, lds_bytes, stream); break;
-    default: throw std::runtime_error("no work-pool unit " + std::to_string(unit));
-    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -333,11 +286,10 @@ void launch_compact(const int32_t *series_prev, const int32_t *n_prev, int n_ser
 // ------------------------------------------------------------------------------------------
 constexpr int GATHER_TB = 32;
 __global__ __launch_bounds__(NM_BLOCK) void gather_columns_kernel(const double *y, size_t ld, const int32_t *series_of,
-                                                                  const int32_t *n_active, int t_max, double *out, size_t ld_out, int min_active, int max_active)
+                                                                  const int32_t *n_active, int t_max, double *out, size_t ld_out)
 {
     const int n_act = *n_active;
-    // few problems left, or nearly all of them (the block is still dense): the round reads y in place
-    if ((int)blockIdx.x * NM_BLOCK >= n_act || n_act <= min_active || n_act > max_active) return;
+    if ((int)blockIdx.x * NM_BLOCK >= n_act) return;
     const int p = blockIdx.x * NM_BLOCK + threadIdx.x;
     const int s = series_of[p < n_act ? p : n_act - 1];
     const int t0 = blockIdx.y * GATHER_TB;
@@ -346,11 +298,11 @@ __global__ __launch_bounds__(NM_BLOCK) void gather_columns_kernel(const double *
 }
 
 void launch_gather_columns(const double *y, size_t ld, const int32_t *series_of, const int32_t *n_active, int n_series,
-                           int t_max, double *out, size_t ld_out, hipStream_t stream, int min_active, int max_active)
+                           int t_max, double *out, size_t ld_out, hipStream_t stream)
 {
     if (n_series <= 0 || t_max <= 0) return;          // a batch of empty series: nothing to copy (and no zero-sized grid)
     dim3 grid((n_series + NM_BLOCK - 1) / NM_BLOCK, (t_max + GATHER_TB - 1) / GATHER_TB);
-    hipLaunchKernelGGL(gather_columns_kernel, grid, dim3(NM_BLOCK), 0, stream, y, ld, series_of, n_active, t_max, out, ld_out, min_active, max_active);
+    hipLaunchKernelGGL(gather_columns_kernel, grid, dim3(NM_BLOCK), 0, stream, y, ld, series_of, n_active, t_max, out, ld_out);
 }
 
 } // namespace anofox

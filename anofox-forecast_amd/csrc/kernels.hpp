@@ -59,22 +59,9 @@ struct FitArgs {
     int min_len;                 // ... and fail shorter series (Holt-Winters and SeasonalES derive theirs from the period)
     int budget_seq;              // passes per round when the device-side choice (round_auto) lands on the sequential driver
     int spec2_below;             // ... and the one-problem-per-wave driver (two iterations per pass) iff n_active <= spec2_below
-    int tail_below;              // run to completion once this few problems are still running (0 = never)
-    int gather_min;              // the gather (and the gathered view) only applies while more than this many problems run
-    int gather_max;              // ... and no more than this many (nearly all still running: the block is dense as it is)
     int gathered;                // y_round holds the running problems' columns densely (column p), else index by series
-    // fused compaction + gather at the end of a round (NULL: the host runs compact / gather kernels instead)
-    int32_t *next_map, *next_cnt, *clear_cnt;
-    double *next_y;              // next round's dense block [t_rows x ld] (NULL: the next round reads y in place)
     NmStateBuf st;
     double *ring_scratch;        // periods above ETS_LDS_PERIOD: m * 64 doubles per workgroup of the launch (seasonal ring in HBM)
-    // work-pool schedule (ets_pool_kernel.hpp): series-major copy of the block (row s at ys + s * tw, 64 doubles of slack
-    // behind every row), the queue cursor (zeroed before the launch), the iteration count after which a problem asks for
-    // four lanes, whether every problem runs speculatively from its first pass, and the number of persistent waves
-    const double *ys; size_t tw;
-    int32_t *head;
-    int promote, start_spec;
-    unsigned long long *trace;   // work pool, diagnostics only: wave passes, active lane passes, pass clocks, first / last wall clock, speculative lane passes
     int m, h;
     const double *l0, *b0;       // [ld] for this spec's (season, trend) class
     const double *fig; size_t fig_ld;
@@ -153,44 +140,13 @@ FitLaunchers classic_fit_launcher(int kind, int m);          // fit_classic.hip:
 struct ClassicArgs;
 void launch_classic_final(int kind, const FitArgs &a, const ClassicArgs &c, hipStream_t stream);
 
-// Work-pool schedule (ets_pool_kernel.hpp): ONE persistent kernel per compile unit serves the unit's candidate specs in
-// priority order.  The arguments travel by value (kernel argument segment: uniform, read-only), per-spec part + common part.
-constexpr int POOL_MAX_SPECS = 10;
-constexpr int POOL_UNITS = 4;     // nonseasonal, seasonal additive class, additive error general, multiplicative error general
-struct PoolSpec {
-    const int32_t *series_of, *n_active;   // the spec's queue: problem -> series (NULL = identity), device count (NULL = n_series)
-    int32_t *head;                         // queue cursor, zeroed before the launch
-    int32_t *status;
-    NmStateBuf st;                         // only vertex 0 (the optimum) and the counters are written: what the inspection pass reads
-    double *aicc;
-    int32_t *evals, *iters, *passes;
-    const double *l0, *b0, *fig;
-    double *yhat;
-    unsigned long long *trace;             // NULL, or 8 counters (ANOFOX_HIP_POOL_TRACE: tools/pool_trace.py prints them)
-    int key;                               // spec id * 4 + period variant (0 none, 1 m = 7, 2 m = 12, 3 run-time period)
-    int m, n_param, need_positive;
-};
-struct PoolUnitArgs {
-    const double *ys; size_t tw, ld, fig_ld;
-    const int32_t *len; const uint32_t *flags;
-    int n_series, h, promote, start_spec, skip_constant, n_specs;
-    unsigned char first[64];               // spec a wave starts with, by blockIdx % 64: the specs' shares of the waves follow their
-                                           // expected work, so that a spec's queue outlasts its waves' first fill (lanes REFILL)
-    PoolSpec spec[POOL_MAX_SPECS];
-};
-int pool_unit_of(int spec_id);              // which unit holds the spec's kernels
-inline int pool_period_variant(int spec_id, int m) { return (spec_id % 3) == 0 ? 0 : (m == 7 ? 1 : ((m == 12 && spec_id < 15 && (spec_id % 3) == 1 && (spec_id % 15) / 3 <= 2) ? 2 : 3)); }
-void launch_pool_unit(int unit, const PoolUnitArgs &, int grid, size_t lds_bytes, hipStream_t);
-
 // compaction of the unfinished problems: series_next[0..n_next) = the series of the previous map whose done flag
 // is 0 (one ballot + one atomic per wave; the order of the survivors is not preserved, results do not depend on it)
 void launch_compact(const int32_t *series_prev, const int32_t *n_prev, int n_series, const int32_t *done,
                     int32_t *series_next, int32_t *n_next, hipStream_t, int32_t *n_clear = nullptr);
 // out[t * ld_out + p] = y[t * ld + series_of[p]] for p < *n_active, t < t_max
-// series-major copy of the time-major block for the work-pool kernels: ys[s * tw + t] = y[t * ld + s], t < t_rows
-void launch_transpose_rows(const double *y, size_t ld, int n_series, int t_rows, double *ys, size_t tw, hipStream_t);
 void launch_gather_columns(const double *y, size_t ld, const int32_t *series_of, const int32_t *n_active, int n_series,
-                           int t_max, double *out, size_t ld_out, hipStream_t, int min_active = 0, int max_active = 0x7fffffff);
+                           int t_max, double *out, size_t ld_out, hipStream_t);
 
 // AutoARIMA (arima.hip): prep (D, d, differenced block), stepwise CSS search (advance / fit sweeps), forecast + integration
 struct ArimaArgs {
@@ -207,6 +163,8 @@ struct ArimaArgs {
     double *yhat;                       // [n_series x h]
     int32_t *model_code;                // 1000000 + p*1e5 + d*1e4 + q*1e3 + P*100 + D*10 + Q
     int trace;                          // debugging: the refit kernel prints per-wave timings (ANOFOX_HIP_ARIMA_TRACE)
+    double lookahead, spec_factor;      // schedule knobs of the search (host_api.hip Tunables: lookahead once the queue fits the resident lanes
+    int lookahead_depth;                //   this many times over; four lanes per problem below spec_factor x the resident groups)
     int ml_refit;                       // exact-likelihood (Kalman / Chandrasekhar) refit of the selected models; 0 keeps the CSS estimates
 };
 size_t arima_workspace_bytes(int n_series, int t_max);

@@ -60,6 +60,12 @@ class DeviceBatch:
         if not self.L.anofox_hip_batch_set_fixed_params(self.handle, float(alpha), float(beta), float(gamma), float(phi), C.byref(err)):
             raise RuntimeError(f"set_fixed_params failed: [{err.code}] {err.message.decode()}")
 
+    def set_arima_method(self, method: int):
+        """AutoARIMA estimation method of this batch: lib.ARIMA_CSS (default) or lib.ARIMA_CSS_ML (exact-likelihood refit)."""
+        err = _lib.AnofoxError()
+        if not self.L.anofox_hip_batch_set_arima_method(self.handle, int(method), C.byref(err)):
+            raise RuntimeError(f"set_arima_method failed: [{err.code}] {err.message.decode()}")
+
     def run(self, stream: torch.cuda.Stream | None = None):
         st = stream if stream is not None else torch.cuda.current_stream(self.device)
         err = _lib.AnofoxError()

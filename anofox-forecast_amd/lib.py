@@ -93,7 +93,12 @@ EXPORTED_SYMBOLS = [
     "anofox_hip_ingest_group_keys", "anofox_hip_ingest_last_dates", "anofox_hip_ingest_lengths", "anofox_hip_ingest_values",
     "anofox_hip_ingest_validity", "anofox_hip_batch_pack_ingest", "anofox_hip_batch_inspect",
     "anofox_hip_batch_n_series", "anofox_hip_batch_set_fixed_params",
+    "anofox_hip_set_devices", "anofox_hip_get_devices", "anofox_hip_set_min_series_per_device", "anofox_hip_shard_range",
+    "anofox_hip_set_default_arima_method", "anofox_hip_batch_set_arima_method", "anofox_hip_release_caches",
+    "anofox_hip_batch_run_many",
 ]
+
+ARIMA_CSS, ARIMA_CSS_ML = 0, 1     # include/anofox_fcst_hip.h: ANOFOX_ARIMA_CSS / ANOFOX_ARIMA_CSS_ML
 
 _lib = None
 
@@ -148,6 +153,19 @@ def load():
     L.anofox_hip_model_name.argtypes = [P(ForecastOptions), C.c_int32, C.c_char * 64]
     L.anofox_hip_batch_inspect.restype = C.c_bool
     L.anofox_hip_batch_inspect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, P(AnofoxError)]
+    L.anofox_hip_set_devices.restype = C.c_bool
+    L.anofox_hip_set_devices.argtypes = [C.c_void_p, C.c_size_t]
+    L.anofox_hip_get_devices.restype = C.c_size_t
+    L.anofox_hip_get_devices.argtypes = [C.c_void_p, C.c_size_t]
+    L.anofox_hip_set_min_series_per_device.argtypes = [C.c_size_t]
+    L.anofox_hip_shard_range.argtypes = [C.c_size_t, C.c_size_t, C.c_size_t, P(C.c_size_t), P(C.c_size_t)]
+    L.anofox_hip_set_default_arima_method.restype = C.c_bool
+    L.anofox_hip_set_default_arima_method.argtypes = [C.c_int]
+    L.anofox_hip_batch_set_arima_method.restype = C.c_bool
+    L.anofox_hip_batch_set_arima_method.argtypes = [C.c_void_p, C.c_int, P(AnofoxError)]
+    L.anofox_hip_release_caches.argtypes = []
+    L.anofox_hip_batch_run_many.restype = C.c_bool
+    L.anofox_hip_batch_run_many.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
     # block 4: columnar ingest (host side only; usable without a GPU up to pack_ingest)
     L.anofox_hip_ingest_create.restype = C.c_void_p
     L.anofox_hip_ingest_destroy.argtypes = [C.c_void_p]
@@ -187,3 +205,17 @@ def make_options(model, horizon, *, ets_model="", seasonal_period=0, confidence_
     o.seasonal_periods_str = seasonal_periods_str.encode()[:63]
     o.model_pool = model_pool.encode()[:31]
     return o
+
+
+def set_devices(devices):
+    """Devices the batch entry shards series ranges over (include/anofox_fcst_hip.h block 2); [] = the current device only."""
+    L = load()
+    arr = (C.c_int * len(devices))(*devices) if devices else None
+    if not L.anofox_hip_set_devices(arr, len(devices)):
+        raise ValueError(f"not visible devices: {devices!r}")
+
+
+def shard_range(n_series, n_shards, shard):
+    lo, hi = C.c_size_t(), C.c_size_t()
+    load().anofox_hip_shard_range(n_series, n_shards, shard, C.byref(lo), C.byref(hi))
+    return lo.value, hi.value

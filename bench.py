@@ -23,7 +23,9 @@ Workloads (--workload):
                           gamma 0.1): one streamed pass per series, 15,976 algorithmic bytes per series
     ets_aaa_m5            ETS(A,A,A) fitted (Nelder-Mead over alpha, beta*, gamma*) on the same batch
     autoets_stress        n x 1,024 AutoETS (use --n-series; the 1M config shards over 8 GPUs)
-    autoarima_m5          AutoARIMA stepwise search, m = 7, on the M5-shape batch (BASELINE config 4)
+    autoarima_m5          AutoARIMA stepwise search, m = 7, on the M5-shape batch, selected model refitted on the exact Gaussian
+                          likelihood (BASELINE config 4: "(Kalman kernel)"; estimation method ANOFOX_ARIMA_CSS_ML)
+    autoarima_css_m5      the same with the library's default method (ANOFOX_ARIMA_CSS: the search's estimates, the reference's cost envelope)
 
 The JSON line also carries, on rank 0 at N = 1: `e2e` (the same workload through anofox_ts_forecast_batch: host
 buffers in, results on host -- pack + H2D + fit + D2H, SURVEY.md 8(d) metric (ii); never `value`) and
@@ -66,8 +68,9 @@ def parse_args():
 CPU_TARGET_S = 12.0      # CPU work of the baseline leg (the contract asks for 10-30 s)
 
 
-def W(model, ets_model, n, T, m, positive, seed, cpu_sample, fixed=None):
-    return dict(model=model, ets_model=ets_model, n=n, T=T, m=m, positive=positive, seed=seed, cpu_sample=cpu_sample, fixed=fixed)
+def W(model, ets_model, n, T, m, positive, seed, cpu_sample, fixed=None, arima_method=0):
+    return dict(model=model, ets_model=ets_model, n=n, T=T, m=m, positive=positive, seed=seed, cpu_sample=cpu_sample, fixed=fixed,
+                arima_method=arima_method)
 
 
 WORKLOADS = {
@@ -76,7 +79,8 @@ WORKLOADS = {
     "ets_aaa_fixed_m5": W("ETS", "AAA", 30490, 1913, 7, False, 20260101, 30490, fixed=(0.2, 0.05, 0.1, 1.0)),
     "ets_aaa_m5": W("ETS", "AAA", 30490, 1913, 7, False, 20260101, 8192),
     "autoets_stress": W("AutoETS", "", 125000, 1024, 7, False, 20260102, 8192),
-    "autoarima_m5": W("AutoARIMA", "", 30490, 1913, 7, False, 20260101, 512),
+    "autoarima_m5": W("AutoARIMA", "", 30490, 1913, 7, False, 20260101, 2048, arima_method=1),
+    "autoarima_css_m5": W("AutoARIMA", "", 30490, 1913, 7, False, 20260101, 2048, arima_method=0),
     # single-spec probes (kernel efficiency without cross-kernel effects)
     "ets_amdn_stress": W("ETS", "AMdN", 125000, 1024, 7, True, 20260102, 256),
     "ets_mam_stress": W("ETS", "MAM", 125000, 1024, 7, True, 20260102, 256),
@@ -152,6 +156,9 @@ def main():
     batch = DeviceBatch(n, T, opts, dev)
     if wl["fixed"]:
         batch.set_fixed_params(*wl["fixed"])
+    if model == "AutoARIMA":
+        batch.set_arima_method(wl["arima_method"])
+        lib.load().anofox_hip_set_default_arima_method(wl["arima_method"])      # the host-buffer entry of the e2e leg
     y_dev = torch.from_numpy(pack_time_major(Y, batch.ld)).to(dev)
     len_dev = torch.full((batch.ld,), T, dtype=torch.int32, device=dev)
     len_dev[n:] = 0
@@ -203,11 +210,18 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = n_total * args.steps / elapsed
         fit_ms_avg = float(np.mean(fit_ms))
+        final_pass_ms = None
+        if wl["fixed"]:
+            # config 2: the timed unit is the STEP (HIP events around everything the run enqueues), not the final pass alone
+            final_pass_ms, fit_ms_avg = fit_ms_avg, float(np.mean(dev_ms))
         achieved = float(np.mean(alg_bytes)) / (fit_ms_avg * 1e-3) / 1e9 if fit_ms_avg > 0 else 0.0
         if model == "AutoARIMA":
-            kernel = "arima_fit_kernel + arima_fit_spec_kernel + arima_refit_kernel (all sweeps of one step and the exact-likelihood refit)"
+            kernel = ("arima_fit_kernel + arima_fit_spec_kernel (all sweeps of one step + the selected models' polish)" +
+                      (" + arima_refit_kernel (exact-likelihood refit)" if wl["arima_method"] else ""))
         elif wl["fixed"]:
-            kernel = "ets_final_kernel<spec,period> (one streamed pass per series)"
+            # the whole step is the unit here: prep_kernel (means, decomposition, initial states: two streamed passes) dominates it,
+            # the one-pass ets_final_kernel is reported beside it
+            kernel = "prep_kernel + ets_fixed_setup_kernel + ets_final_kernel + interval_kernel (the whole one-pass step; prep_kernel dominant)"
         else:
             kernel = "ets_round_kernel<spec,period,driver> + ets_final_kernel (all spec launches of one step, concurrent streams)"
         out = {
@@ -231,28 +245,45 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                          "kernel": kernel, "kernel_ms": round(fit_ms_avg, 3), "algorithmic_bytes": int(np.mean(alg_bytes))},
         }
-        # HBM traffic and VALU issue of the fit kernels come from separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE
-        # corrected as MI355X_MICROARCH.md prescribes; SQ_INSTS_VALU / SQ_ACTIVE_INST_VALU); the committed summary of the
-        # newest round is quoted when it was taken on this workload and shape, else the fields stay null.
-        for fn in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        if final_pass_ms:
+            out["roofline"]["final_pass"] = {"kernel": "ets_final_kernel<spec,period> alone", "kernel_ms": round(final_pass_ms, 4),
+                                             "achieved": round(float(np.mean(alg_bytes)) / (final_pass_ms * 1e-3) / 1e9, 1),
+                                             "frac": round(float(np.mean(alg_bytes)) / (final_pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        # HBM traffic and VALU issue of the fit kernels come from separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE corrected
+        # as MI355X_MICROARCH.md prescribes; SQ_INSTS_VALU): tools/profile_round.sh writes profiles/rNN_pmc_traffic*.json STAMPED with
+        # the sha256 of the library they were taken on.  The figures are quoted only when the stamp is the library that just ran
+        # and the workload / shape agree -- anything else leaves the fields null and says why.
+        import glob
+        import hashlib
+        lib_sha = hashlib.sha256(open(lib.LIB_PATH, "rb").read()).hexdigest()
+        out["roofline"]["lib_sha256"] = lib_sha[:16]
+        stale = None
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")), reverse=True):
             try:
-                tr = json.load(open(os.path.join(ROOT, "profiles", fn)))
+                tr = json.load(open(path))
             except (OSError, ValueError):
                 continue
-            if tr.get("workload") == args.workload and n == wl["n"] and T == wl["T"]:
-                try:
-                    out["roofline"]["traffic"] = int(tr["ets_round_kernel_traffic_bytes_per_step"])
-                    out["roofline"]["traffic_source"] = f"profiles/{fn} (PMC passes, per step)"
-                    if "valu_insts_per_step" in tr:
-                        issued = float(tr["valu_insts_per_step"])
-                        rate = issued / (fit_ms_avg * 1e-3)
-                        out["roofline"]["valu"] = {"issued_insts": int(issued), "peak_issue": FP64_VALU_PEAK_WAVE_INSTS,
-                                                   "frac": round(rate / FP64_VALU_PEAK_WAVE_INSTS, 4),
-                                                   "unit": "wave-level VALU instructions per second against one fp64 issue per SIMD per 4 cycles",
-                                                   "source": f"profiles/{fn} (SQ_INSTS_VALU per step) / this run's kernel_ms"}
-                except (KeyError, ValueError):
-                    pass
-                break
+            if not (tr.get("workload") == args.workload and n == wl["n"] and T == wl["T"]):
+                continue
+            fn = os.path.basename(path)
+            if tr.get("lib_sha256", "")[:16] != lib_sha[:16]:
+                stale = stale or f"profiles/{fn} was taken on another build of the library ({tr.get('lib_sha256', 'unstamped')[:16]}): not quoted"
+                continue
+            try:
+                out["roofline"]["traffic"] = int(tr["fit_kernel_traffic_bytes_per_step"])
+                out["roofline"]["traffic_source"] = f"profiles/{fn} (PMC passes on this build, per step)"
+                if "valu_insts_per_step" in tr:
+                    issued = float(tr["valu_insts_per_step"])
+                    rate = issued / (fit_ms_avg * 1e-3)
+                    out["roofline"]["valu"] = {"issued_insts": int(issued), "peak_issue": FP64_VALU_PEAK_WAVE_INSTS,
+                                               "frac": round(rate / FP64_VALU_PEAK_WAVE_INSTS, 4),
+                                               "unit": "wave-level VALU instructions per second against one fp64 issue per SIMD per 4 cycles",
+                                               "source": f"profiles/{fn} (SQ_INSTS_VALU per step, this build) / this run's kernel_ms"}
+            except (KeyError, ValueError):
+                pass
+            break
+        if out["roofline"]["traffic"] is None and stale:
+            out["roofline"]["traffic_source"] = stale
         yhat_host = res["yhat"].cpu().numpy().copy()
         batch.close()       # the host-buffer entry below is what a binding calls on its own: no second resident batch (and its streams) beside it
         # ---- end to end: host buffers in, results on host (never `value`) -----------------------------
@@ -279,6 +310,7 @@ def main():
                 if wl["fixed"]:
                     r = O.ets_fixed_batch(vals, offs, ets_model, m, *wl["fixed"], h)
                 else:
+                    C.c_int.in_dll(O.lib(), "oracle_arima_ml_refit").value = wl["arima_method"]     # the checker runs the same estimation method
                     r = O.forecast_batch(vals, offs, O.make_options(model, h, ets_model=ets_model, seasonal_period=m), 0)
                 return r, time.perf_counter() - t0
 

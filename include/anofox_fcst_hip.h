@@ -130,6 +130,44 @@ bool anofox_ts_forecast_batch(const double *const *values,
                               struct AnofoxError *out_errors,
                               struct AnofoxError *out_batch_error);
 
+/*
+ * Multi-device execution of the batch entry.  The reference's finalize loop is ONE process walking all groups
+ * (src/table_functions/ts_forecast_native.cpp:559-800); series are independent, so anofox_ts_forecast_batch shards
+ * contiguous series-id ranges [g * ceil(N / G), (g + 1) * ceil(N / G)) over the G devices named here: one host thread,
+ * stream set and allocator cache per device, each range packed into its device's own pinned staging block, results
+ * written straight into the caller's arrays (host side: no RCCL involved).  Default: the caller's current device only.
+ * `devices` = ordinal list (a device may be listed more than once: its ranges then run as separate batches on it);
+ * n_devices = 0 restores the default.  The environment variable ANOFOX_HIP_DEVICES ("0,1,2,3" or "all"), read once at
+ * the first batch call, gives the initial list.  Batches smaller than `min_series_per_device` (default 2,048) per
+ * device use fewer devices.  Returns false (nothing changed) when an ordinal is not a visible device.
+ */
+bool anofox_hip_set_devices(const int *devices, size_t n_devices);
+size_t anofox_hip_get_devices(int *devices, size_t capacity);      /* returns the number of devices in use (0 = default) */
+void anofox_hip_set_min_series_per_device(size_t min_series);
+/* The range of shard `shard` of `n_shards`: [shard * ceil(N / n_shards), ...) clipped to N. */
+void anofox_hip_shard_range(size_t n_series, size_t n_shards, size_t shard, size_t *begin, size_t *end);
+
+/*
+ * AutoARIMA estimation method -- a caller-visible choice (the reference's `AutoARIMAConfig::default()`,
+ * forecast.rs:1447-1455, exposes none, and its measured cost, benchmark/README.md:55, leaves no room for an exact-likelihood
+ * refit: DESIGN.md section 3).  ANOFOX_ARIMA_CSS (default): the selected model keeps the conditional-sum-of-squares
+ * estimates of the search.  ANOFOX_ARIMA_CSS_ML: the selected model is re-estimated on the exact Gaussian likelihood
+ * (Kalman filter of the Harvey state space, evaluated through the Chandrasekhar recursions: BASELINE.json's "Kalman
+ * kernel").  The process default applies to anofox_ts_forecast / anofox_ts_forecast_batch and to batches created afterwards;
+ * anofox_hip_batch_set_arima_method (block 3) overrides it per batch.
+ */
+enum { ANOFOX_ARIMA_CSS = 0, ANOFOX_ARIMA_CSS_ML = 1 };
+bool anofox_hip_set_default_arima_method(int method);
+
+/*
+ * The library keeps idle device blocks (per device at most ANOFOX_HIP_CACHE_GB, default an eighth of the device, oldest
+ * evicted first), pinned staging blocks (ANOFOX_HIP_PINNED_CACHE_GB, default 2), stream / event sets and up to 32 parked
+ * single-series batches for re-use (a batch of the M5 shape is ~300 hipMalloc calls = 0.4 s without them).  This gives all of
+ * it back: call it when the host wants the memory (another allocator in the process is short of HBM) or before unloading.
+ * Safe while other threads run batches: only idle resources are touched.
+ */
+void anofox_hip_release_caches(void);
+
 /* ------------------------------------------------------------------------- */
 /* Block 3: device-resident batch (series block already in HBM)               */
 /* ------------------------------------------------------------------------- */
@@ -181,6 +219,9 @@ size_t anofox_hip_batch_n_series(const AnofoxHipBatch *batch);
 bool anofox_hip_batch_set_fixed_params(AnofoxHipBatch *batch, double alpha, double beta, double gamma, double phi,
                                        struct AnofoxError *out_error);
 
+/* AutoARIMA estimation method of this batch: ANOFOX_ARIMA_CSS / ANOFOX_ARIMA_CSS_ML (see block 2). */
+bool anofox_hip_batch_set_arima_method(AnofoxHipBatch *batch, int method, struct AnofoxError *out_error);
+
 /* Host series -> HBM block (NULL interpolation, imputation.rs:61-114, then pack + H2D). */
 bool anofox_hip_batch_pack_host(AnofoxHipBatch *batch,
                                 const double *const *values,
@@ -200,6 +241,14 @@ bool anofox_hip_batch_set_device_block(AnofoxHipBatch *batch,
 /* Asynchronous fit + forecast on `stream` (a hipStream_t, may be NULL). */
 bool anofox_hip_batch_run(AnofoxHipBatch *batch, void *stream,
                           struct AnofoxError *out_error);
+
+/*
+ * Run several batches side by side, one host thread each -- the device-resident counterpart of the multi-device batch
+ * entry: create one batch per device (anofox_hip_set_device(d) before each create; a batch remembers its device and every
+ * entry point makes it current for its own duration), adopt each device's block, run them together.  out_errors may be
+ * NULL; returns false if any run failed.
+ */
+bool anofox_hip_batch_run_many(AnofoxHipBatch *const *batches, size_t n_batches, struct AnofoxError *out_errors);
 
 /* Waits for the run, then fills `out_stats`. */
 bool anofox_hip_batch_stats(AnofoxHipBatch *batch, AnofoxHipStats *out_stats);

@@ -8,9 +8,12 @@
  *   D  : seasonal strength of the classical decomposition > 0.64            (max D = 1)
  *   d  : KPSS level test, lag trunc(3 sqrt(n)/13), 5% critical value 0.463  (max d = 2)
  *   fit: conditional sum of squares over tanh-PACF transformed coefficients, Nelder-Mead
- *   search: stepwise over (p,q,P,Q,constant), p,q <= 5, P,Q <= 2, p+q+P+Q <= 5, AICc
- *   final estimates of the selected model: exact Gaussian likelihood (Kalman filter of the Harvey state space through
- *        the Chandrasekhar recursions, stationary start), Nelder-Mead from the CSS optimum
+ *   search: stepwise over (p,q,P,Q,constant), p,q <= 5, P,Q <= 2, p+q+P+Q <= 5, AICc; every candidate gets a bounded
+ *        optimiser run (ARIMA_SEARCH_EVALS evaluations: an approximate criterion, as the lineage's approximation = TRUE),
+ *        which keeps the whole search within the reference's measured cost (benchmark/README.md:55)
+ *   final estimates of the selected model: CSS to convergence; on request (oracle_arima_ml_refit = ANOFOX_ARIMA_CSS_ML) the
+ *        exact Gaussian likelihood (Kalman filter of the Harvey state space through the Chandrasekhar recursions,
+ *        stationary start), Nelder-Mead from the CSS optimum
  * The only numeric pin in the reference tree is the 6-decimal KAT 18.014537 of
  * test/sql/ts_model_distinctness.test:164; it is NOT reproduced to that precision (parity unpinned).
  */
@@ -27,6 +30,8 @@ extern "C" {
 #define ARIMA_MAX_DIM 6            /* p+q+P+Q <= 5, plus the constant */
 #define ARIMA_MAX_LAG (ARIMA_MAX_P + ARIMA_MAX_SP * ARIMA_MAX_PERIOD)
 #define ARIMA_MAX_MODELS 94
+#define ARIMA_SEARCH_EVALS(dim) (20 + 10 * (dim))   /* Nelder-Mead evaluations / iterations of a candidate in the search stage */
+#define ARIMA_POLISH_NM_CAP 200     /* ... of the selected model's CSS estimates: 200 x dim (the optimiser's usual budget) */
 #define ARIMA_ML_NM_CAP 100         /* Nelder-Mead budget of the refit: 100 x dim evaluations / iterations */
 #define ARIMA_ML_MAX_R 32          /* state dimension of the exact likelihood; larger models keep their CSS estimates */
 

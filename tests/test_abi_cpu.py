@@ -66,6 +66,38 @@ def test_no_gpu_fails_loudly(hiplib):
     assert not ok and err.code == hiplib.NULL_POINTER
 
 
+def test_shard_ranges_of_the_multi_device_batch_entry(hiplib):
+    """anofox_hip_shard_range is the rule the batch entry cuts a batch by (contiguous
+    [g ceil(N / G), (g + 1) ceil(N / G)) clipped to N) -- the same rule as dist.shard_range: the ranges tile [0, N) in order,
+    none is larger than ceil(N / G), trailing shards may be empty.  Host logic only: no GPU needed."""
+    from anofox_forecast_amd import dist
+    for n in (0, 1, 7, 64, 1000, 30490, 1000003):
+        for g in (1, 2, 3, 4, 8, 16):
+            per = -(-n // g) if g else n
+            pos = 0
+            for k in range(g):
+                lo, hi = hiplib.shard_range(n, g, k)
+                assert lo == min(n, k * per) and hi == min(n, lo + per) and lo == pos, (n, g, k, lo, hi)
+                assert (lo, hi) == dist.shard_range(n, k, g)
+                pos = hi
+            assert pos == n
+
+
+def test_device_list_api_without_a_gpu(hiplib):
+    """The device list is validated against the visible devices: without a GPU no ordinal is acceptable, the empty list (the
+    default: the caller's current device) always is; release_caches and the ARIMA method setter are safe to call on an idle library."""
+    import torch
+    L = hiplib.load()
+    if not torch.cuda.is_available():
+        assert not L.anofox_hip_set_devices((C.c_int * 1)(0), 1)
+    assert L.anofox_hip_set_devices(None, 0) and L.anofox_hip_get_devices(None, 0) == 0
+    L.anofox_hip_release_caches()
+    assert L.anofox_hip_set_default_arima_method(1) and L.anofox_hip_set_default_arima_method(0) and not L.anofox_hip_set_default_arima_method(2)
+    err = hiplib.AnofoxError()
+    assert not L.anofox_hip_batch_set_arima_method(None, 0, C.byref(err)) and err.code == hiplib.NULL_POINTER
+    assert not L.anofox_hip_batch_run_many(None, 1, None)
+
+
 def test_product_never_imports_oracle():
     """The oracle is test infrastructure: nothing under the package may import, link or call it."""
     pkg = os.path.join(ROOT, "anofox-forecast_amd")

@@ -393,55 +393,18 @@ def test_ts_cv_forecast_by_operator(env):
         api.ts_cv_forecast_by(fold, split, grp, ds, yv, "NoSuchModel", {})
 
 
-def test_fused_compaction_variant_is_bit_identical(env, monkeypatch):
-    """ANOFOX_HIP_FUSED=1 (compaction + gather fused into the end of every round kernel) and the 6-round schedule walk the
-    same trajectories as the default schedule."""
-    api, O, lib, synth = env
-    monkeypatch.setenv("ANOFOX_HIP_SCHED", "rounds")
-    monkeypatch.setenv("ANOFOX_HIP_FUSED", "1")
-    monkeypatch.setenv("ANOFOX_HIP_BUDGETS", "32,32,64,128,256,1024")
-    Y = synth.gen_series(synth.SEED_M5, 5200, 130, 160, 7, positive=True)
-    series = [Y[s, : 160 - (s % 5) * 9] for s in range(130)]
-    _compare(api, O, lib, series, "AutoETS", 14, seasonal_period=7)
-    Yi = synth.gen_series(synth.SEED_M5, 5400, 130, 160, 7)
-    _compare(api, O, lib, list(Yi), "AutoETS", 14, seasonal_period=7)
-
-
 @pytest.mark.parametrize("seq_rounds", ["0", "2", "6"])
 @pytest.mark.parametrize("gather", ["0", "1"])
 def test_schedule_variants_are_bit_identical(env, monkeypatch, seq_rounds, gather):
     """The sequential and the speculative Nelder-Mead drivers, with or without the column gather between
     rounds, must walk the same trajectory: every schedule reproduces the oracle bit for bit."""
     api, O, lib, synth = env
-    monkeypatch.setenv("ANOFOX_HIP_SCHED", "rounds")
     monkeypatch.setenv("ANOFOX_HIP_SEQ_ROUNDS", seq_rounds)
     monkeypatch.setenv("ANOFOX_HIP_GATHER", gather)
     Y = synth.gen_series(synth.SEED_M5, 5000, 130, 160, 7, positive=True)
     series = [Y[s, : 160 - (s % 5) * 9] for s in range(130)]          # ragged lengths
     _compare(api, O, lib, series, "AutoETS", 12, seasonal_period=7)
     _compare(api, O, lib, series, "ETS", 12, ets_model="MAdM", seasonal_period=7)
-
-
-@pytest.mark.parametrize("waves", ["3", "40", "2048"])
-@pytest.mark.parametrize("promote", ["1", "9", "100000"])
-def test_work_pool_variants_are_bit_identical(env, monkeypatch, waves, promote):
-    """The work-pool schedule (persistent waves, lanes refilling from a queue, slow problems promoted to four lanes) walks
-    the same trajectories whatever the number of waves (3: every lane refills many times; 2,048: few problems per wave,
-    every problem speculative from its first pass) and whenever a problem is promoted (at once, after 9 iterations,
-    never): every variant reproduces the oracle bit for bit -- ragged lengths, a mixed batch (multiplicative specs queue
-    the strictly positive series only) and a run-time period (seasonal ring in LDS) included."""
-    api, O, lib, synth = env
-    monkeypatch.setenv("ANOFOX_HIP_SCHED", "pool")
-    monkeypatch.setenv("ANOFOX_HIP_POOL_WAVES", waves)
-    monkeypatch.setenv("ANOFOX_HIP_PROMOTE", promote)
-    Y = synth.gen_series(synth.SEED_M5, 5000, 130, 160, 7, positive=True)
-    series = [Y[s, : 160 - (s % 5) * 9] for s in range(130)]          # ragged lengths
-    _compare(api, O, lib, series, "AutoETS", 12, seasonal_period=7)
-    _compare(api, O, lib, series, "ETS", 12, ets_model="MAdM", seasonal_period=7)
-    Yi = synth.gen_series(synth.SEED_M5, 5400, 130, 160, 7)
-    mixed = [Yi[s] if s % 3 else Y[s] for s in range(130)] + [np.full(30, 4.0), np.arange(5.0), np.zeros(40)]
-    _compare(api, O, lib, mixed, "AutoETS", 12, seasonal_period=7)
-    _compare(api, O, lib, series[:40], "AutoETS", 6, seasonal_period=5)
 
 
 @pytest.mark.parametrize("below", ["20", "100000"])
@@ -451,7 +414,6 @@ def test_two_level_speculation_is_bit_identical(env, monkeypatch, below):
     evaluation counts, same forecasts as the oracle -- for every parameter dimension (1..4: the AutoETS grid), ragged
     lengths, a mixed batch, a run-time period (ring in LDS) and a long one (ring in HBM scratch)."""
     api, O, lib, synth = env
-    monkeypatch.setenv("ANOFOX_HIP_SCHED", "rounds")
     monkeypatch.setenv("ANOFOX_HIP_SPEC2_BELOW", below)
     Y = synth.gen_series(synth.SEED_M5, 5000, 130, 160, 7, positive=True)
     series = [Y[s, : 160 - (s % 5) * 9] for s in range(130)]          # ragged lengths
@@ -517,10 +479,10 @@ def test_auto_detected_periods_merge_into_one_batch(env, monkeypatch, model):
     _compare(api, O, lib, series, model, 9, **kw)
 
 
-@pytest.mark.parametrize("envset", [{"ANOFOX_HIP_CACHE_GB": "0", "ANOFOX_HIP_PINNED_CACHE_GB": "0"}, {"ANOFOX_HIP_PRIO_STREAMS": "0", "ANOFOX_HIP_ONE_LAUNCH": "0"},
+@pytest.mark.parametrize("envset", [{"ANOFOX_HIP_CACHE_GB": "0", "ANOFOX_HIP_PINNED_CACHE_GB": "0"}, {"ANOFOX_HIP_PRIO_STREAMS": "0", "ANOFOX_HIP_BUDGETS": "32,32,64,128,256,1024"},
                                     {"ANOFOX_HIP_PRIO_STREAMS": "3", "GPU_MAX_HW_QUEUES": "8"}])
 def test_process_wide_switches(envset):
-    """The allocation caches, the stream priorities and the one-launch rounds are decided once per process: a fresh process
+    """The allocation caches and the stream priorities are decided once per process (a round schedule rides along): a fresh process
     with each of them switched off (or sized differently) reproduces the oracle like the defaults do -- three batches in a
     row, so that blocks and stream sets are handed back and taken again."""
     import os, subprocess, sys, textwrap
@@ -766,6 +728,122 @@ def test_auto_arima_matches_oracle(env):
     _compare(api, O, lib, series, "AutoARIMA", 10)                        # auto-detected periods (host packer)
     r = api.forecast_series(KAT_SERIES, lib.make_options("AutoARIMA", 3, auto_detect=False))
     assert r["ok"] and r["model_name"].startswith("AutoARIMA(") and abs(r["point"][0] - 18.014537) / 18.014537 < 2e-3
+
+
+def test_auto_arima_estimation_method_is_a_caller_choice(env):
+    """ANOFOX_ARIMA_CSS (default) keeps the selected model's CSS estimates, ANOFOX_ARIMA_CSS_ML refits it on the exact Gaussian
+    likelihood (the Kalman / Chandrasekhar kernel): per batch (anofox_hip_batch_set_arima_method) and as the process default
+    (anofox_hip_set_default_arima_method, what the one-series and host-buffer entries use) -- each against the oracle in the
+    same mode, bit for bit; the two modes select the same orders and differ in the forecasts."""
+    import ctypes as C
+    import torch
+    api, O, lib, synth = env
+    from anofox_forecast_amd.device import DeviceBatch, pack_time_major
+    L = lib.load()
+    flag = C.c_int.in_dll(O.lib(), "oracle_arima_ml_refit")
+    n, T, h, m = 48, 150, 10, 7
+    Y = synth.gen_series(synth.SEED_M5, 9100, n, T, m)
+    Y[5] = 20 + 5 * np.sin(2 * np.pi * np.arange(T) / 7) + np.random.default_rng(3).normal(0, 0.3, T)
+    opts = lib.make_options("AutoARIMA", h, seasonal_period=m)
+    oo = O.make_options("AutoARIMA", h, seasonal_period=m)
+    outs = {}
+    try:
+        for method in (lib.ARIMA_CSS, lib.ARIMA_CSS_ML):
+            b = DeviceBatch(n, T, opts, "cuda:0")
+            err = lib.AnofoxError()
+            assert L.anofox_hip_batch_set_arima_method(b.handle, method, C.byref(err)), err.message
+            assert not L.anofox_hip_batch_set_arima_method(b.handle, 7, C.byref(err)) and err.code == lib.INVALID_INPUT
+            y = torch.from_numpy(pack_time_major(Y, b.ld)).cuda()
+            ln = torch.full((b.ld,), T, dtype=torch.int32, device="cuda")
+            ln[n:] = 0
+            b.set_block(y, ln)
+            b.run()
+            torch.cuda.synchronize()
+            r = b.results()
+            outs[method] = (r["yhat"].cpu().numpy()[:n].copy(), r["model_code"].cpu().numpy()[:n].copy())
+            b.close()
+            flag.value = method
+            for s in range(n):
+                ref = O.forecast(Y[s], oo)
+                assert ref["ok"] and np.array_equal(outs[method][0][s], ref["point"]), (method, s)
+            # the process default drives the entries that only carry a ForecastOptions block
+            assert L.anofox_hip_set_default_arima_method(method)
+            got, berr = api.forecast_batch(list(Y[:8]), opts)
+            assert berr["ok"] and all(np.array_equal(got[s]["point"], outs[method][0][s]) for s in range(8))
+            one = api.forecast_series(Y[5], opts)
+            assert one["ok"] and np.array_equal(one["point"], outs[method][0][5])
+        assert not L.anofox_hip_set_default_arima_method(9)
+    finally:
+        flag.value = 0
+        L.anofox_hip_set_default_arima_method(lib.ARIMA_CSS)
+    assert np.array_equal(outs[0][1], outs[1][1])                      # same orders: the refit only re-estimates
+    assert not np.array_equal(outs[0][0], outs[1][0])
+
+
+@pytest.mark.parametrize("model,kw", [("AutoETS", {"seasonal_period": 7}), ("AutoARIMA", {"seasonal_period": 7}), ("HoltWinters", {}), ("Naive", {})])
+def test_batch_entry_shards_over_the_listed_devices(env, model, kw):
+    """anofox_hip_set_devices / ANOFOX_HIP_DEVICES: the batch entry cuts contiguous series ranges (ceil(N / G) each) and runs
+    them on the listed devices from one host thread each.  One GPU is visible here, so it is listed twice and three times
+    (two / three concurrent shard batches on it): every series' result -- forecasts, intervals, names, per-series errors,
+    per-series horizons -- is bit for bit what the single-device call returns, also when periods are auto-detected."""
+    api, O, lib, synth = env
+    L = lib.load()
+    Y = synth.gen_series(synth.SEED_M5, 8800, 150, 120, 7, positive=True)
+    series = [Y[s, : 120 - (s % 6) * 9] for s in range(150)] + [np.array([1.0, 2.0]), np.array([]), np.full(30, 4.0)]
+    horizons = [5 + (s % 4) for s in range(len(series))]
+    opts = lib.make_options(model, 8, **kw)
+    L.anofox_hip_set_min_series_per_device(16)
+    try:
+        lib.set_devices([])
+        base, berr0 = api.forecast_batch(series, opts, horizons=horizons)
+        assert berr0["ok"]
+        for devs in ([0, 0], [0, 0, 0]):
+            lib.set_devices(devs)
+            assert L.anofox_hip_get_devices(None, 0) == len(devs)
+            got, berr = api.forecast_batch(series, opts, horizons=horizons)
+            assert berr["ok"] == berr0["ok"]
+            for s in range(len(series)):
+                assert got[s]["ok"] == base[s]["ok"] and got[s]["code"] == base[s]["code"] and got[s]["message"] == base[s]["message"], (devs, s)
+                if base[s]["ok"]:
+                    assert got[s]["model_name"] == base[s]["model_name"]
+                    for k in ("point", "lower", "upper"):
+                        assert np.array_equal(got[s][k], base[s][k]), (devs, s, k)
+        # a device that is not there is refused and nothing changes; an unknown model fails the whole statement like before
+        with pytest.raises(ValueError):
+            lib.set_devices([0, 99])
+        assert L.anofox_hip_get_devices(None, 0) == 3
+        bad, berr = api.forecast_batch(series, lib.make_options("NoSuchModel", 8))
+        assert not berr["ok"] and berr["code"] == lib.INVALID_MODEL
+    finally:
+        lib.set_devices([])
+        L.anofox_hip_set_min_series_per_device(2048)
+
+
+def test_release_caches_and_double_free_guard(env):
+    """anofox_hip_release_caches gives the idle device blocks, pinned staging blocks, stream sets and parked one-series batches
+    back (hipMemGetInfo shows the memory again) and the library keeps working afterwards -- twice over, with single-series calls
+    in between, so parked batches and their stream sets are taken, handed back and destroyed."""
+    import torch
+    api, O, lib, synth = env
+    L = lib.load()
+    Y = synth.gen_series(synth.SEED_M5, 8300, 400, 300, 7, positive=True)
+    opts = lib.make_options("AutoETS", 7, seasonal_period=7)
+    ref, _ = api.forecast_batch(list(Y[:40]), opts)
+    for rep in range(2):
+        got, berr = api.forecast_batch(list(Y), opts)
+        assert berr["ok"]
+        one = api.forecast_series(Y[3], opts)
+        assert one["ok"] and np.array_equal(one["point"], got[3]["point"])
+        torch.cuda.synchronize()
+        free_before, _ = torch.cuda.mem_get_info()
+        L.anofox_hip_release_caches()
+        free_after, _ = torch.cuda.mem_get_info()
+        assert free_after > free_before + 50 * 2**20, (free_before, free_after)      # the 25 gather blocks alone are 25 x 1 MB x ... > 50 MB here
+        for s in range(40):
+            assert np.array_equal(got[s]["point"], ref[s]["point"])
+    L.anofox_hip_release_caches()                                                      # nothing idle: a no-op
+    again, berr = api.forecast_batch(list(Y[:40]), opts)
+    assert berr["ok"] and all(np.array_equal(again[s]["point"], ref[s]["point"]) for s in range(40))
 
 
 @pytest.mark.parametrize("model,kw", [("AutoETS", dict(seasonal_period=7)), ("AutoETS", dict(seasonal_period=1)),

@@ -6,7 +6,8 @@ Status of the pin (stated in DESIGN.md section 3 as well):
     Naive, SMA, RandomWalkDrift, SeasonalNaive, toy ARIMA (bit-exact closed form);
   * within the north star's 1e-5 relative tolerance: AutoETS (3.7e-8), SeasonalESOptimized (7.9e-6);
   * AutoARIMA: restated (Hyndman-Khandakar, CSS) but NOT pinned: 18.000000 vs the KAT 18.014537 (8e-4 relative);
-    the test only guards that distance (2e-3) so that a regression of the restatement is noticed.
+    the test only guards that distance (2e-3) so that a regression of the restatement is noticed.  The search for an
+    estimator that lands on the KAT is tools/arima_kat_search/ (committed negative result: DESIGN.md section 3).
 """
 import json
 import os
@@ -243,21 +244,31 @@ def test_exact_likelihood_equals_the_kalman_filter(oracle):
     assert checked > 100 and worst < 1e-9, (checked, worst)
 
 
-def test_exact_likelihood_refit_improves_the_likelihood(oracle):
-    """The refit never makes the exact likelihood worse than the CSS start, and on an MA(1) with a root near the unit circle --
-    where conditional and exact estimates differ visibly -- it moves the coefficient towards the exact optimum."""
+def test_exact_likelihood_refit_is_a_choice_and_moves_the_estimates(oracle):
+    """The selected model keeps its CSS estimates by default (ANOFOX_ARIMA_CSS); with the exact-likelihood refit switched on
+    (ANOFOX_ARIMA_CSS_ML: oracle_arima_ml_refit, the checker of anofox_hip_batch_set_arima_method) the same model is selected and,
+    where it has coefficients and the sample is short -- conditional and exact estimates differ visibly on 60 points of an MA(1)
+    with a root near the unit circle -- its forecasts move."""
     import ctypes as C
     L = oracle.lib()
     flag = C.c_int.in_dll(L, "oracle_arima_ml_refit")
-    rng = np.random.default_rng(5)
-    e = rng.normal(0, 1, 61)
-    y = np.cumsum(e[1:] - 0.95 * e[:-1]) + 10.0          # ARIMA(0,1,1), theta near the invertibility boundary, n = 60
+    assert flag.value == 0                                   # the default
+    moved = 0
     try:
-        flag.value = 0
-        css = oracle.forecast(y, oracle.make_options("AutoARIMA", 3, auto_detect=False))
-        flag.value = 1
-        ml = oracle.forecast(y, oracle.make_options("AutoARIMA", 3, auto_detect=False))
+        for seed in range(5, 13):
+            rng = np.random.default_rng(seed)
+            e = rng.normal(0, 1, 61)
+            y = np.cumsum(e[1:] - 0.95 * e[:-1]) + 10.0          # ARIMA(0,1,1), theta near the invertibility boundary, n = 60
+            flag.value = 0
+            css = oracle.forecast(y, oracle.make_options("AutoARIMA", 3, auto_detect=False))
+            flag.value = 1
+            ml = oracle.forecast(y, oracle.make_options("AutoARIMA", 3, auto_detect=False))
+            assert css["ok"] and ml["ok"] and css["model_name"] == ml["model_name"]
+            if css["model_name"] == "AutoARIMA(0,0,0)":
+                assert np.array_equal(css["point"], ml["point"])        # nothing but the mean: nothing to refit
+            elif not np.array_equal(css["point"], ml["point"]):
+                moved += 1
+                assert np.max(np.abs(css["point"] - ml["point"])) < 1.0
     finally:
-        flag.value = 1
-    assert css["ok"] and ml["ok"] and css["model_name"] == ml["model_name"]
-    assert not np.array_equal(css["point"], ml["point"])
+        flag.value = 0
+    assert moved >= 2
