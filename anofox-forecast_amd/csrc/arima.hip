@@ -35,7 +35,7 @@ constexpr int AR_MAXP = 5, AR_MAXSP = 2, AR_MAXORDER = 5, AR_MAXDIM = 6, AR_MAXM
 // (ARIMA_SEARCH_EVALS: an approximate criterion, which keeps the whole search inside the reference's measured cost), the
 // selected model's CSS estimates then run to convergence (ARIMA_POLISH_NM_CAP x dim)
 __host__ __device__ inline int ar_search_cap(int dim) { return 20 + 10 * dim; }
-__host__ __device__ inline int ar_polish_cap(int dim) { return 200 * dim; }
+__host__ __device__ inline int ar_polish_cap(int dim) { return 100 * dim; }
 constexpr int AR_KEYS = 6 * 6 * 3 * 3 * 2;            // order keys (p, q, P, Q, constant)
 constexpr int AR_KEYWORDS = (AR_KEYS + 31) / 32;      // bitmap words
 constexpr int AR_SWEEP = 17;                          // candidates of one sweep (8 seasonal, 8 non-seasonal, constant)

@@ -13,6 +13,7 @@
 #include <unordered_map>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <mutex>
 #include <cstdlib>
 #include <cstring>
@@ -111,6 +112,7 @@ struct Tunables {
 // GPU_MAX_HW_QUEUES), ANOFOX_HIP_DEVICES (devices the batch entry shards over, default: the caller's current device only)
 struct ProcessTunables {
     double cache_gb = -1.0, pinned_cache_gb = 2.0;
+    double coalesce_us = 200.0;       // ANOFOX_HIP_COALESCE_US: how long the first of several concurrent anofox_ts_forecast calls waits for the others (0: never)
     int prio_streams = -1;
     std::string devices;
     static const ProcessTunables &get()
@@ -120,6 +122,7 @@ struct ProcessTunables {
             if (const char *e = std::getenv("ANOFOX_HIP_CACHE_GB")) p.cache_gb = std::atof(e);
             if (const char *e = std::getenv("ANOFOX_HIP_PINNED_CACHE_GB")) p.pinned_cache_gb = std::atof(e);
             if (const char *e = std::getenv("ANOFOX_HIP_PRIO_STREAMS")) p.prio_streams = std::atoi(e);
+            if (const char *e = std::getenv("ANOFOX_HIP_COALESCE_US")) p.coalesce_us = std::atof(e);
             if (const char *e = std::getenv("ANOFOX_HIP_DEVICES")) p.devices = e;
             return p;
         }();
@@ -2658,27 +2661,13 @@ bool anofox_hip_batch_run_many(AnofoxHipBatch *const *batches, size_t n_batches,
     return true;
 }
 
-bool anofox_ts_forecast(const double *values, const uint64_t *validity, size_t length, const ForecastOptions *options,
-                        ForecastResult *out_result, AnofoxError *out_error)
+// one series on a parked one-series device batch (or a new one): pack, run, fetch, park again
+static bool forecast_one_pooled(const double *values, const uint64_t *validity, size_t length, const ForecastOptions *options, const ForecastOptions &key,
+                                ForecastResult *out_result, AnofoxError *out_error)
 {
-    if (out_error) { out_error->code = SUCCESS; std::memset(out_error->message, 0, sizeof out_error->message); }
-    if (!values || !options || !out_result) { set_error(out_error, NULL_POINTER, "Null pointer argument"); return false; }
-    // argument errors come first, exactly like the reference (lib.rs:3368-3380, forecast.rs:514-565)
-    Plan plan;
     AnofoxError e;
     e.code = SUCCESS;
     std::memset(e.message, 0, sizeof e.message);
-    {
-        std::string mname = cstr_field(options->model, sizeof options->model);
-        ModelType mt;
-        if (!parse_model(mname, mt)) { set_error(out_error, INVALID_MODEL, "Invalid model: Unknown model: '" + mname + "'"); return false; }
-        if (options->horizon < 0) { set_error(out_error, PANIC_CAUGHT, "Panic in Rust code"); return false; }
-        if (length == 0) { set_error(out_error, INSUFFICIENT_DATA, "Insufficient data: need at least 1 observations, got 0"); return false; }
-        if (length < 3) {
-            set_error(out_error, INSUFFICIENT_DATA, "Insufficient data: need at least 3 observations, got " + std::to_string(length));
-            return false;
-        }
-    }
     AnofoxError se;
     se.code = SUCCESS;
     std::memset(se.message, 0, sizeof se.message);
@@ -2687,26 +2676,15 @@ bool anofox_ts_forecast(const double *values, const uint64_t *validity, size_t l
     size_t lens[1] = {length};
     ForecastResult r;
     std::memset(&r, 0, sizeof r);
-    // a pooled single-series batch: the option block is the key (every byte of it: callers memset it first,
-    // ts_forecast_scalar.cpp:440), the capacity covers series up to twice this length
-    ForecastOptions key;                       // normalised copy: padding and the bytes behind a string's NUL do not take part
-    std::memset(&key, 0, sizeof key);
-    auto copy_str = [](char *dst, const char *src, size_t cap) { for (size_t i = 0; i + 1 < cap && src[i]; i++) dst[i] = src[i]; };
-    copy_str(key.model, options->model, sizeof key.model);
-    copy_str(key.ets_model, options->ets_model, sizeof key.ets_model);
-    copy_str(key.seasonal_periods_str, options->seasonal_periods_str, sizeof key.seasonal_periods_str);
-    copy_str(key.model_pool, options->model_pool, sizeof key.model_pool);
-    copy_str(key.laplace_variant, options->laplace_variant, sizeof key.laplace_variant);
-    key.horizon = options->horizon; key.confidence_level = options->confidence_level; key.seasonal_period = options->seasonal_period;
-    key.auto_detect_seasonality = options->auto_detect_seasonality; key.include_fitted = options->include_fitted;
-    key.include_residuals = options->include_residuals; key.window = options->window;
-    key.laplace_seasonal_batch_init = options->laplace_seasonal_batch_init;
+    // a pooled single-series batch: the option block is the key, the capacity covers series up to twice this length
     int device = 0;
     (void)hipGetDevice(&device);
     AnofoxHipBatch *b = pool_take(key, length, device);
     if (b) {
         try { batch_attach_streams(b); }
         catch (const HipFail &f) { report_hip_failure(out_error, f); anofox_hip_batch_destroy(b); return false; }
+        b->arima_method = g_default_arima_method.load();      // a parked batch predates the process default of this call
+        b->tun = Tunables::from_env();
     }
     if (!b) {
         size_t cap = 256;
@@ -2727,6 +2705,146 @@ bool anofox_ts_forecast(const double *values, const uint64_t *validity, size_t l
     pool_give(key, device, b);
     if (se.code != SUCCESS) { if (out_error) *out_error = se; return false; }
     *out_result = r;
+    return true;
+}
+
+// Route A coalescing (ts_forecast_scalar.cpp:298-523: every DuckDB worker thread calls anofox_ts_forecast once per group of its
+// chunk, concurrently): a one-series fit is latency bound -- 5 ms for AutoETS, the chip all but idle -- so calls that are inside the
+// library AT THE SAME TIME with an equal option block join ONE multi-series batch.  The first caller of a key opens a group and
+// leads it: it waits until every call currently inside the library has joined or at most ANOFOX_HIP_COALESCE_US (default 200 us;
+// a lone caller does not wait at all), closes the group and runs it through the batch entry; the followers sleep on the group and
+// pick up their own result and their own error (per-series isolation is the batch entry's: out_errors).  Results are those of
+// single calls bit for bit -- a series' result does not depend on the batch it is in (test_concurrent_single_series_calls).
+struct CoalesceReq { const double *values; const uint64_t *validity; size_t length; ForecastResult res; AnofoxError err; bool ok = false; };
+struct CoalesceGroup {
+    ForecastOptions key; int device = 0; int method = 0;
+    std::vector<CoalesceReq *> reqs;
+    bool closed = false, done = false;
+    std::condition_variable cv;
+};
+static std::mutex g_co_mu;
+static std::vector<std::shared_ptr<CoalesceGroup>> g_co_open;
+static int g_co_inflight = 0;                     // calls inside anofox_ts_forecast past their argument checks (under g_co_mu)
+static int g_co_recent_width = 1;                 // the largest number of concurrent calls seen in the last 20 ms, and when: workers that call
+static std::chrono::steady_clock::time_point g_co_recent_time;   // again and again arrive a few microseconds apart, so the first one back waits for its peers
+constexpr size_t COALESCE_MAX = 256;
+
+bool anofox_ts_forecast(const double *values, const uint64_t *validity, size_t length, const ForecastOptions *options,
+                        ForecastResult *out_result, AnofoxError *out_error)
+{
+    if (out_error) { out_error->code = SUCCESS; std::memset(out_error->message, 0, sizeof out_error->message); }
+    if (!values || !options || !out_result) { set_error(out_error, NULL_POINTER, "Null pointer argument"); return false; }
+    // argument errors come first, exactly like the reference (lib.rs:3368-3380, forecast.rs:514-565)
+    {
+        std::string mname = cstr_field(options->model, sizeof options->model);
+        ModelType mt;
+        if (!parse_model(mname, mt)) { set_error(out_error, INVALID_MODEL, "Invalid model: Unknown model: '" + mname + "'"); return false; }
+        if (options->horizon < 0) { set_error(out_error, PANIC_CAUGHT, "Panic in Rust code"); return false; }
+        if (length == 0) { set_error(out_error, INSUFFICIENT_DATA, "Insufficient data: need at least 1 observations, got 0"); return false; }
+        if (length < 3) {
+            set_error(out_error, INSUFFICIENT_DATA, "Insufficient data: need at least 3 observations, got " + std::to_string(length));
+            return false;
+        }
+    }
+    // the option block is the key (every byte of it: callers memset it first, ts_forecast_scalar.cpp:440)
+    ForecastOptions key;                       // normalised copy: padding and the bytes behind a string's NUL do not take part
+    std::memset(&key, 0, sizeof key);
+    auto copy_str = [](char *dst, const char *src, size_t cap) { for (size_t i = 0; i + 1 < cap && src[i]; i++) dst[i] = src[i]; };
+    copy_str(key.model, options->model, sizeof key.model);
+    copy_str(key.ets_model, options->ets_model, sizeof key.ets_model);
+    copy_str(key.seasonal_periods_str, options->seasonal_periods_str, sizeof key.seasonal_periods_str);
+    copy_str(key.model_pool, options->model_pool, sizeof key.model_pool);
+    copy_str(key.laplace_variant, options->laplace_variant, sizeof key.laplace_variant);
+    key.horizon = options->horizon; key.confidence_level = options->confidence_level; key.seasonal_period = options->seasonal_period;
+    key.auto_detect_seasonality = options->auto_detect_seasonality; key.include_fitted = options->include_fitted;
+    key.include_residuals = options->include_residuals; key.window = options->window;
+    key.laplace_seasonal_batch_init = options->laplace_seasonal_batch_init;
+
+    const double window_us = ProcessTunables::get().coalesce_us;
+    if (!(window_us > 0.0)) return forecast_one_pooled(values, validity, length, options, key, out_result, out_error);
+    int device = 0;
+    (void)hipGetDevice(&device);
+    const int method = g_default_arima_method.load();
+    CoalesceReq req;
+    req.values = values; req.validity = validity; req.length = length;
+    std::memset(&req.res, 0, sizeof req.res);
+    req.err.code = SUCCESS; req.err.message[0] = 0;
+    std::shared_ptr<CoalesceGroup> grp;
+    bool leader = false;
+    {
+        std::unique_lock<std::mutex> lock(g_co_mu);
+        g_co_inflight++;
+        const auto now = std::chrono::steady_clock::now();
+        const bool recent = now - g_co_recent_time < std::chrono::milliseconds(20);
+        if (g_co_inflight > 1 && (g_co_inflight >= g_co_recent_width || !recent)) { g_co_recent_width = g_co_inflight; g_co_recent_time = now; }
+        else if (g_co_inflight > 1 && recent) g_co_recent_time = now;
+        for (auto &g : g_co_open)
+            if (!g->closed && g->device == device && g->method == method && g->reqs.size() < COALESCE_MAX && std::memcmp(&g->key, &key, sizeof key) == 0) { grp = g; break; }
+        if (grp) {
+            grp->reqs.push_back(&req);
+            grp->cv.notify_all();                                  // the leader re-checks "has everyone inside joined?"
+            grp->cv.wait(lock, [&] { return grp->done; });
+            g_co_inflight--;
+        } else {
+            leader = true;
+            grp = std::make_shared<CoalesceGroup>();
+            grp->key = key; grp->device = device; grp->method = method;
+            grp->reqs.push_back(&req);
+            g_co_open.push_back(grp);
+            const int expect = recent ? std::max(g_co_inflight, g_co_recent_width) : g_co_inflight;
+            if (expect > 1) {
+                // other calls are inside the library right now, or were a moment ago: give them the window to join (those of another
+                // key never will: the window bounds what their presence costs; a caller that has always been alone never waits)
+                const auto deadline = now + std::chrono::nanoseconds((long long)(window_us * 1000.0));
+                grp->cv.wait_until(lock, deadline, [&] { return (int)grp->reqs.size() >= std::max(expect, g_co_inflight) || grp->reqs.size() >= COALESCE_MAX; });
+            }
+            grp->closed = true;
+            g_co_open.erase(std::find(g_co_open.begin(), g_co_open.end(), grp));
+        }
+    }
+    if (!leader) {
+        if (!req.ok) { if (out_error) *out_error = req.err; return false; }
+        *out_result = req.res;
+        return true;
+    }
+    // ---- the leader runs the group (its members are blocked on the group; their request records live on their stacks) ----
+    const size_t k = grp->reqs.size();
+    bool my_ok = false;
+    if (k == 1) {
+        my_ok = forecast_one_pooled(values, validity, length, options, key, &req.res, &req.err);
+        req.ok = my_ok;
+    } else {
+        std::vector<const double *> v(k);
+        std::vector<const uint64_t *> m(k);
+        std::vector<size_t> len(k);
+        bool any_mask = false;
+        for (size_t j = 0; j < k; j++) { v[j] = grp->reqs[j]->values; m[j] = grp->reqs[j]->validity; len[j] = grp->reqs[j]->length; any_mask |= m[j] != nullptr; }
+        std::vector<ForecastResult> res(k);
+        std::vector<AnofoxError> errs(k);
+        for (size_t j = 0; j < k; j++) { std::memset(&res[j], 0, sizeof(ForecastResult)); errs[j].code = SUCCESS; errs[j].message[0] = 0; }
+        AnofoxError be;
+        be.code = SUCCESS; be.message[0] = 0;
+        bool ok = false;
+        try {
+            ok = forecast_batch_one_device(v.data(), any_mask ? m.data() : nullptr, len.data(), k, options, nullptr, res.data(), errs.data(), &be);
+        } catch (...) { ok = false; }
+        if (!ok && be.code == SUCCESS) set_error(&be, INTERNAL_ERROR, "Internal error: device batch failed");
+        for (size_t j = 0; j < k; j++) {
+            CoalesceReq *q = grp->reqs[j];
+            if (!ok) { anofox_free_forecast_result(&res[j]); q->ok = false; q->err = be; }
+            else if (errs[j].code != SUCCESS) { anofox_free_forecast_result(&res[j]); q->ok = false; q->err = errs[j]; }
+            else { q->ok = true; q->res = res[j]; }
+        }
+        my_ok = req.ok;
+    }
+    {
+        std::lock_guard<std::mutex> lock(g_co_mu);
+        grp->done = true;
+        g_co_inflight--;
+        grp->cv.notify_all();
+    }
+    if (!my_ok) { if (out_error) *out_error = req.err; return false; }
+    *out_result = req.res;
     return true;
 }
 

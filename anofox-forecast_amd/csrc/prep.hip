@@ -34,9 +34,14 @@ struct RowLoader {
         }
     }
 };
-// block length of the streamed rows: 16, or two revolutions of a compile-time period MR (ring slots and phases of a block are
-// compile-time constants then)
-template <int MR> constexpr int prep_block() { return MR > 0 ? 2 * MR : 16; }
+// block length of the streamed rows: 16, or four revolutions of a compile-time period MR (ring slots and phases of a block are
+// compile-time constants then).  One wave per 64 series is all the parallelism this kernel has (477 waves for the M5 block: every
+// sum is sequential in time, and the mean / sd are the reference's own in-tree arithmetic, forecast.rs:2558-2591, so the time axis
+// is not split), which makes it a question of bytes in flight: with 14 rows (7 KB) per wave in flight the two passes ran at
+// 2.0-2.7 TB/s (249 + 182 us per 487 MB, rocprofv3), whatever the arithmetic per step -- dealing the accumulators of a step to
+// three waves changed nothing (431 us against 454: three waves read every row three times).  28 rows per block, two blocks
+// alternating without a copy, is what the one-pass ets_final_kernel streams the same block with at 5.5 TB/s.
+template <int MR> constexpr int prep_block() { return MR > 0 ? 4 * MR : 16; }
 
 // GSCR: the decomposition's window ring and per-phase accumulators live in an HBM scratch area of the workgroup instead of
 // LDS (periods above ETS_LDS_PERIOD: (2 (m / 2) + 1 + 3 m) * 512 bytes no longer fit)
@@ -90,8 +95,7 @@ __global__ __launch_bounds__(NM_BLOCK) void prep_kernel(const PrepArgs a)
     int slot = 0;                       // t % L
     int ph = 0;                         // (t - half) % m, phase of the window centre
     if (want_season) ph = ((-half) % m + m) % m;
-    for (int base = 0; base < wave_rows; base += PREP_S) {
-      rows.load(nxt, base + PREP_S);
+    auto pass_a_block = [&](const double (&buf)[PREP_S], const int base) __attribute__((always_inline)) {
       // the multiplicative figure (one IEEE division per step) only matters for strictly positive series: once every series of
       // the wave has shown a value <= 0 (intermittent demand: within the first blocks) the wave stops computing it
       const bool wave_pos = __any(positive && base < n);
@@ -99,7 +103,7 @@ __global__ __launch_bounds__(NM_BLOCK) void prep_kernel(const PrepArgs a)
       for (int jj = 0; jj < PREP_S; jj++) {
         const int t = base + jj;
         if (t < n) {
-            const double v = cur[jj];
+            const double v = buf[jj];
             sum += v;
             if (!(v > 0.0)) positive = false;
             if (v != y0) constant = false;
@@ -153,8 +157,13 @@ __global__ __launch_bounds__(NM_BLOCK) void prep_kernel(const PrepArgs a)
         slot = slot + 1 == L ? 0 : slot + 1;
         if (want_season) ph = ph + 1 == m ? 0 : ph + 1;
       }
-#pragma unroll
-      for (int jj = 0; jj < PREP_S; jj++) cur[jj] = nxt[jj];
+    };
+    // two blocks per iteration on alternating buffers: the rows of the block after next are requested before a block is consumed
+    for (int base = 0; base < wave_rows; base += 2 * PREP_S) {
+        rows.load(nxt, base + PREP_S);
+        pass_a_block(cur, base);
+        rows.load(cur, base + 2 * PREP_S);
+        if (base + PREP_S < wave_rows) pass_a_block(nxt, base + PREP_S);
     }
     if (n <= 0) return;
     const double mean = sum / (double)n;
@@ -225,13 +234,12 @@ __global__ __launch_bounds__(NM_BLOCK) void prep_kernel(const PrepArgs a)
     if (Km > n) Km = n;
     int j = 0;
     rows.load(cur, 0);
-    for (int base = 0; base < wave_rows; base += PREP_S) {
-      rows.load(nxt, base + PREP_S);
+    auto pass_b_block = [&](const double (&buf)[PREP_S], const int base) __attribute__((always_inline)) {
 #pragma unroll
       for (int jj = 0; jj < PREP_S; jj++) {
         const int t = base + jj;
         if (t >= n) continue;
-        const double v = cur[jj];
+        const double v = buf[jj];
         const double dv = v - mean;
         var += dv * dv;
         if (states) {
@@ -257,8 +265,12 @@ __global__ __launch_bounds__(NM_BLOCK) void prep_kernel(const PrepArgs a)
             if (want_season) j = j + 1 == m ? 0 : j + 1;
         }
       }
-#pragma unroll
-      for (int jj = 0; jj < PREP_S; jj++) cur[jj] = nxt[jj];
+    };
+    for (int base = 0; base < wave_rows; base += 2 * PREP_S) {
+        rows.load(nxt, base + PREP_S);
+        pass_b_block(cur, base);
+        rows.load(cur, base + 2 * PREP_S);
+        if (base + PREP_S < wave_rows) pass_b_block(nxt, base + PREP_S);
     }
     a.sd[s] = sqrt(var / (double)n);
     if (!states) return;
@@ -296,214 +308,6 @@ __global__ __launch_bounds__(NM_BLOCK) void prep_kernel(const PrepArgs a)
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// The weekly period (m = 7, every BASELINE shape) split by ROLE over three waves per 64 series and two launches.
-// prep_kernel above runs ~55-70 fp64 operations per time step on ONE wave per 64 series -- 477 waves on 1,024 SIMDs for the
-// M5 block, issue bound at a wave per SIMD: 0.45 ms, three quarters of the one-pass step of BASELINE config 2.  The work of a
-// step is several independent accumulations, so it is dealt to three waves (grid.y = role) and the dependency between the
-// passes (B needs A's mean and figures) becomes a launch boundary:
-//   pass A   role 0: additive figure (window ring, centred moving average, per-phase sums)
-//            role 1: multiplicative figure (the same window + one division per step; stops once no series of the wave is positive)
-//            role 2: sum -> mean, positivity / constancy / NaN flags
-//   pass B   role 0: variance -> sd, and the states of the unadjusted series
-//            role 1: states of the additively adjusted series       role 2: ... of the multiplicatively adjusted series
-// Every accumulator is still ONE sequential sum in time order -- the split is by quantity, never along t -- so each value is
-// bit for bit what prep_kernel (and oracle/ets.c, oracle/forecast.c, and for mean / sd the reference's own
-// forecast.rs:2558-2591) computes.  A split along t would buy more waves but changes the rounding of the in-tree mean / sd.
-// ------------------------------------------------------------------------------------------------------------
-template <int MR>
-__global__ __launch_bounds__(NM_BLOCK) void prep_a_split_kernel(const PrepArgs a)
-{
-    constexpr int PREP_S = 2 * MR;
-    constexpr int HALF = MR / 2;
-    const int role = blockIdx.y;
-    const int lane = threadIdx.x;
-    const int s = blockIdx.x * NM_BLOCK + lane;
-    const bool valid = s < a.n_series;
-    const int n = valid ? a.len[s] : 0;
-    const int wave_n = wave_max_i32(n);
-    if (wave_n == 0) return;
-    const size_t ld = a.ld;
-    const int wave_rows = __builtin_amdgcn_readfirstlane(wave_n);
-    RowLoader<PREP_S> rows;
-    rows.base = (const char *)a.y;
-    rows.col_bytes = (unsigned)(valid ? s : 0) * 8u;
-    rows.row_bytes = ld * 8;
-    rows.total_bytes = (size_t)wave_rows * rows.row_bytes;
-    double cur[PREP_S], nxt[PREP_S];
-    const int m = MR;
-    const double w = 1.0 / (double)m;
-    const bool seasonal = n >= 2 * m;
-    rows.load(cur, 0);
-    if (role == 2) {
-        double sum = 0.0;
-        bool positive = true, constant = true, has_nan = false;
-        const double y0 = n > 0 ? cur[0] : 0.0;
-        for (int base = 0; base < wave_rows; base += PREP_S) {
-            rows.load(nxt, base + PREP_S);
-#pragma unroll
-            for (int jj = 0; jj < PREP_S; jj++) {
-                if (base + jj < n) {
-                    const double v = cur[jj];
-                    sum += v;
-                    if (!(v > 0.0)) positive = false;
-                    if (v != y0) constant = false;
-                    if (v != v) has_nan = true;
-                }
-            }
-#pragma unroll
-            for (int jj = 0; jj < PREP_S; jj++) cur[jj] = nxt[jj];
-        }
-        if (n <= 0) return;
-        a.mean[s] = sum / (double)n;
-        a.flags[s] = (positive ? SF_POSITIVE : 0u) | (constant ? SF_CONSTANT : 0u) | (has_nan ? SF_HAS_NAN : 0u);
-        return;
-    }
-    // roles 0 / 1: one seasonal figure each (the multiplicative one tracks positivity itself: it is defined for strictly positive series only)
-    const bool mul = role == 1;
-    double rR[MR], acR[MR], cNR[MR];
-#pragma unroll
-    for (int j = 0; j < MR; j++) { rR[j] = 0.0; acR[j] = 0.0; cNR[j] = 0.0; }
-    bool positive = true;
-    for (int base = 0; base < wave_rows; base += PREP_S) {
-        rows.load(nxt, base + PREP_S);
-        const bool wave_pos = __any(positive && base < n);
-        if (mul && !wave_pos) break;                    // no strictly positive series left in the wave: nothing to compute (wave-uniform)
-#pragma unroll
-        for (int jj = 0; jj < PREP_S; jj++) {
-            const int t = base + jj;
-            if (t < n) {
-                const double v = cur[jj];
-                if (!(v > 0.0)) positive = false;
-                if (seasonal) {
-                    const int sl = jj % MR;
-#pragma unroll
-                    for (int q = 0; q < MR; q++) rR[q] = (q == sl) ? v : rR[q];
-                    if (t >= MR - 1) {
-                        double acc = 0.0;
-#pragma unroll
-                        for (int k = 0; k < MR; k++) acc = acc + w * rR[(sl + 1 + k) % MR];
-                        const double yc = rR[(sl + 1 + HALF) % MR];
-                        const int phc = ((jj - HALF) % MR + MR) % MR;
-                        const double term = mul ? yc / acc : yc - acc;
-#pragma unroll
-                        for (int q = 0; q < MR; q++) {
-                            acR[q] = (q == phc) ? acR[q] + term : acR[q];
-                            cNR[q] = (q == phc) ? cNR[q] + 1.0 : cNR[q];
-                        }
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int jj = 0; jj < PREP_S; jj++) cur[jj] = nxt[jj];
-    }
-    if (n <= 0 || !seasonal) return;
-    if (mul && !positive) return;
-    double tot = 0.0;
-#pragma unroll
-    for (int j = 0; j < MR; j++) {
-        const double fj = acR[j] / cNR[j];
-        acR[j] = fj;
-        tot = tot + fj;
-    }
-    const double fmean = tot / (double)m;
-    double *fig = (mul ? a.fig_mul : a.fig_add) + s;
-#pragma unroll
-    for (int j = 0; j < MR; j++) {
-        double fj = acR[j];
-        if (!mul) fj = fj - fmean;
-        else {
-            fj = fj / fmean;
-            if (!(fj >= 1.0e-2)) fj = 1.0e-2;
-        }
-        fig[(size_t)j * ld] = fj;
-    }
-}
-
-template <int MR>
-__global__ __launch_bounds__(NM_BLOCK) void prep_b_split_kernel(const PrepArgs a)
-{
-    constexpr int PREP_S = 2 * MR;
-    const int st = blockIdx.y;                         // 0 unadjusted (+ variance), 1 additively, 2 multiplicatively adjusted
-    const int lane = threadIdx.x;
-    const int s = blockIdx.x * NM_BLOCK + lane;
-    const bool valid = s < a.n_series;
-    const int n = valid ? a.len[s] : 0;
-    const int m = MR;
-    const bool seasonal = n >= 2 * m;
-    const bool positive = n > 0 && (a.flags[s] & SF_POSITIVE) != 0;
-    const bool use = st == 0 ? n > 0 : (st == 1 ? seasonal : seasonal && positive);
-    const int wave_n = wave_max_i32(use ? n : 0);
-    if (wave_n == 0) return;                           // (e.g. the multiplicative role of a wave without strictly positive series)
-    const size_t ld = a.ld;
-    const int wave_rows = __builtin_amdgcn_readfirstlane(wave_n);
-    RowLoader<PREP_S> rows;
-    rows.base = (const char *)a.y;
-    rows.col_bytes = (unsigned)(valid ? s : 0) * 8u;
-    rows.row_bytes = ld * 8;
-    rows.total_bytes = (size_t)wave_rows * rows.row_bytes;
-    double cur[PREP_S], nxt[PREP_S];
-    double fg[MR];
-#pragma unroll
-    for (int j = 0; j < MR; j++) fg[j] = (use && st > 0) ? (st == 1 ? a.fig_add : a.fig_mul)[(size_t)j * ld + s] : 1.0;
-    const double mean = (use && st == 0) ? a.mean[s] : 0.0;
-    const int nn = use ? n : 0;
-    double var = 0.0, sy = 0.0, sxy = 0.0, sk = 0.0, ysa0 = 0.0, ysa1 = 0.0;
-    const int K0 = 10 > n ? n : 10;
-    int Km = 2 * m > 10 ? 2 * m : 10;
-    if (Km > n) Km = n;
-    const int K = st == 0 ? K0 : Km;
-    rows.load(cur, 0);
-    for (int base = 0; base < wave_rows; base += PREP_S) {
-        rows.load(nxt, base + PREP_S);
-#pragma unroll
-        for (int jj = 0; jj < PREP_S; jj++) {
-            const int t = base + jj;
-            if (t >= nn) continue;
-            const double v = cur[jj];
-            if (st == 0) { const double dv = v - mean; var += dv * dv; }
-            const double vs = st == 0 ? v : (st == 1 ? v - fg[jj % MR] : v / fg[jj % MR]);
-            sy = sy + vs;
-            sxy = sxy + (double)(t + 1) * vs;
-            if (t < K) sk = sk + vs;
-            if (t == 0) ysa0 = vs;
-            if (t == 1) ysa1 = vs;
-        }
-#pragma unroll
-        for (int jj = 0; jj < PREP_S; jj++) cur[jj] = nxt[jj];
-    }
-    if (!use) return;
-    if (st == 0) a.sd[s] = sqrt(var / (double)n);
-    const double dn = (double)n;
-    const double sx = dn * (dn + 1.0) / 2.0;
-    const double sxx = dn * (dn + 1.0) * (2.0 * dn + 1.0) / 6.0;
-    const double slope = (dn * sxy - sx * sy) / (dn * sxx - sx * sx);
-    const double icpt = (sy - slope * sx) / dn;
-    a.l0[(size_t)(st * 3 + 0) * ld + s] = sk / (double)K;
-    a.b0[(size_t)(st * 3 + 0) * ld + s] = 0.0;
-    {
-        double l0 = icpt, b0 = slope;
-        if (fabs(l0 + b0) < 1.0e-8) { l0 = l0 * (1.0 + 1.0e-3); b0 = b0 * (1.0 - 1.0e-3); }
-        a.l0[(size_t)(st * 3 + 1) * ld + s] = l0;
-        a.b0[(size_t)(st * 3 + 1) * ld + s] = b0;
-    }
-    {
-        double l0 = icpt + slope;
-        if (fabs(l0) < 1.0e-8) l0 = 1.0e-7;
-        double b0 = (icpt + 2.0 * slope) / l0;
-        l0 = l0 / b0;
-        if (fabs(b0) > 1.0e10) b0 = (b0 < 0.0 ? -1.0e10 : 1.0e10);
-        if (l0 < 1.0e-8 || b0 < 1.0e-8) {
-            l0 = ysa0 > 1.0e-3 ? ysa0 : 1.0e-3;
-            double r = ysa1 / ysa0;
-            b0 = r > 1.0e-3 ? r : 1.0e-3;
-        }
-        a.l0[(size_t)(st * 3 + 2) * ld + s] = l0;
-        a.b0[(size_t)(st * 3 + 2) * ld + s] = b0;
-    }
-}
-
 void launch_prep(const PrepArgs &a, hipStream_t stream)
 {
     const int grid = (a.n_series + NM_BLOCK - 1) / NM_BLOCK;
@@ -513,9 +317,8 @@ void launch_prep(const PrepArgs &a, hipStream_t stream)
         hipLaunchKernelGGL((prep_kernel<true, 0>), dim3(grid), dim3(NM_BLOCK), 0, stream, a);
         return;
     }
-    if (a.l0 != nullptr && a.m == 7 && !a.m_col) {        // the M5 / weekly period: ring and accumulators in registers, three waves per 64 series
-        hipLaunchKernelGGL((prep_a_split_kernel<7>), dim3(grid, 3), dim3(NM_BLOCK), 0, stream, a);
-        hipLaunchKernelGGL((prep_b_split_kernel<7>), dim3(grid, 3), dim3(NM_BLOCK), 0, stream, a);
+    if (a.l0 != nullptr && a.m == 7 && !a.m_col) {        // the M5 / weekly period: ring and accumulators in registers
+        hipLaunchKernelGGL((prep_kernel<false, 7>), dim3(grid), dim3(NM_BLOCK), 0, stream, a);
         return;
     }
     if (a.l0 != nullptr && a.m >= 2 && a.m <= ETS_LDS_PERIOD) lds_bytes = sizeof(double) * (size_t)((2 * (a.m / 2) + 1) + 3 * a.m) * NM_BLOCK;

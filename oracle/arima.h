@@ -31,7 +31,11 @@ extern "C" {
 #define ARIMA_MAX_LAG (ARIMA_MAX_P + ARIMA_MAX_SP * ARIMA_MAX_PERIOD)
 #define ARIMA_MAX_MODELS 94
 #define ARIMA_SEARCH_EVALS(dim) (20 + 10 * (dim))   /* Nelder-Mead evaluations / iterations of a candidate in the search stage */
-#define ARIMA_POLISH_NM_CAP 200     /* ... of the selected model's CSS estimates: 200 x dim (the optimiser's usual budget) */
+#ifndef ARIMA_POLISH_NM_CAP
+#define ARIMA_POLISH_NM_CAP 100     /* ... of the selected model's CSS estimates: 100 x dim, like the exact-likelihood refit (the run starts where
+                                     * the search stopped: 4 % of the M5-like series need more than that, and on the device the longest
+                                     * of these runs is the critical path of the whole stage) */
+#endif
 #define ARIMA_ML_NM_CAP 100         /* Nelder-Mead budget of the refit: 100 x dim evaluations / iterations */
 #define ARIMA_ML_MAX_R 32          /* state dimension of the exact likelihood; larger models keep their CSS estimates */
 
