@@ -8,6 +8,7 @@
 //           K values (level-only start).
 // Same operations in the same order as oracle/ets.c (ets_init_states) and oracle/forecast.c (intervals), so the
 // results are bit-identical; only the number of times y is streamed changed (2 instead of ~22).
+#include <type_traits>
 #include "ets_device.hpp"
 #include "kernels.hpp"
 
@@ -158,12 +159,51 @@ __global__ __launch_bounds__(NM_BLOCK) void prep_kernel(const PrepArgs a)
         if (want_season) ph = ph + 1 == m ? 0 : ph + 1;
       }
     };
+    // Full blocks of the register variant run as STRAIGHT-LINE code: once every series of the wave is inside its sample for the whole
+    // block (and past the first one, so the window is full) no step needs a per-lane branch -- flags become mask operations, the
+    // per-phase updates have compile-time targets -- and the 28 steps of a block form ONE basic block.  The per-lane `if (t < n)` of
+    // the gated form made every step its own basic block, so the seven dependent additions of a step's window mean (same order as
+    // the oracle: the sum is sequential by definition) could not overlap with the neighbouring steps' chains: a wave alone on its
+    // SIMD then waits out every fp64 latency -- 283 cycles per step measured (453 us for the two passes of the M5 block, whatever
+    // the number of rows in flight).  Same operations on the same values: a lane without a series (padding) computes into
+    // registers nobody reads.
+    const int wave_min_n = __builtin_amdgcn_readfirstlane(wave_min_i32(n > 0 ? n : 0x7fffffff));
+    auto pass_a_fast = [&](const double (&buf)[PREP_S], auto pos_tag) __attribute__((always_inline)) {
+        constexpr bool POS = decltype(pos_tag)::value;
+        if constexpr (MR > 0) {
+            constexpr int HALF = MR / 2;
+#pragma unroll
+            for (int jj = 0; jj < PREP_S; jj++) {
+                const double v = buf[jj];
+                sum += v;
+                positive = positive & (v > 0.0);
+                constant = constant & (v == y0);
+                has_nan = has_nan | (v != v);
+                const int sl = jj % MR;
+                rR[sl] = v;
+                double acc = 0.0;
+#pragma unroll
+                for (int k = 0; k < MR; k++) acc = acc + w * rR[(sl + 1 + k) % MR];
+                const double yc = rR[(sl + 1 + HALF) % MR];
+                const int phc = ((jj - HALF) % MR + MR) % MR;
+                sAR[phc] = sAR[phc] + (yc - acc);
+                cNR[phc] = cNR[phc] + 1.0;
+                if constexpr (POS) sMR[phc] = sMR[phc] + yc / acc;
+            }
+        }
+    };
+    auto pass_a_any = [&](const double (&buf)[PREP_S], const int base) __attribute__((always_inline)) {
+        if (MR > 0 && base >= PREP_S && base + PREP_S <= wave_min_n) {
+            if (__any(positive && base < n)) pass_a_fast(buf, std::true_type{});
+            else pass_a_fast(buf, std::false_type{});
+        } else pass_a_block(buf, base);
+    };
     // two blocks per iteration on alternating buffers: the rows of the block after next are requested before a block is consumed
     for (int base = 0; base < wave_rows; base += 2 * PREP_S) {
         rows.load(nxt, base + PREP_S);
-        pass_a_block(cur, base);
+        pass_a_any(cur, base);
         rows.load(cur, base + 2 * PREP_S);
-        if (base + PREP_S < wave_rows) pass_a_block(nxt, base + PREP_S);
+        if (base + PREP_S < wave_rows) pass_a_any(nxt, base + PREP_S);
     }
     if (n <= 0) return;
     const double mean = sum / (double)n;
@@ -266,11 +306,41 @@ __global__ __launch_bounds__(NM_BLOCK) void prep_kernel(const PrepArgs a)
         }
       }
     };
+    // ... and the same for pass B: past the first block no step takes part in the level-only start (t < K <= 2 m) or is t = 0, 1
+    auto pass_b_fast = [&](const double (&buf)[PREP_S], const int base, auto m_tag) __attribute__((always_inline)) {
+        constexpr bool USEM = decltype(m_tag)::value;
+        if constexpr (MR > 0) {
+#pragma unroll
+            for (int jj = 0; jj < PREP_S; jj++) {
+                const double v = buf[jj];
+                const double dv = v - mean;
+                var += dv * dv;
+                const double tt = (double)(base + jj + 1);
+                double vs[3];
+                vs[0] = v;
+                vs[1] = v - sAR[jj % MR];
+                vs[2] = 0.0;
+                if constexpr (USEM) vs[2] = useM ? v / sMR[jj % MR] : 0.0;
+#pragma unroll
+                for (int st = 0; st < (USEM ? 3 : 2); st++) {
+                    sy[st] = sy[st] + vs[st];
+                    sxy[st] = sxy[st] + tt * vs[st];
+                }
+            }
+        }
+    };
+    auto pass_b_any = [&](const double (&buf)[PREP_S], const int base) __attribute__((always_inline)) {
+        // (every series of such a block is seasonal: n >= base + PREP_S >= 8 m)
+        if (MR > 0 && states && base >= PREP_S && base + PREP_S <= wave_min_n && __all(n <= 0 || useA)) {
+            if (wave_useM) pass_b_fast(buf, base, std::true_type{});
+            else pass_b_fast(buf, base, std::false_type{});
+        } else pass_b_block(buf, base);
+    };
     for (int base = 0; base < wave_rows; base += 2 * PREP_S) {
         rows.load(nxt, base + PREP_S);
-        pass_b_block(cur, base);
+        pass_b_any(cur, base);
         rows.load(cur, base + 2 * PREP_S);
-        if (base + PREP_S < wave_rows) pass_b_block(nxt, base + PREP_S);
+        if (base + PREP_S < wave_rows) pass_b_any(nxt, base + PREP_S);
     }
     a.sd[s] = sqrt(var / (double)n);
     if (!states) return;

@@ -62,6 +62,9 @@ def parse_args():
     ap.add_argument("--horizon", type=int, default=28)
     ap.add_argument("--cpu-sample", type=int, default=-1, help="series for the CPU baseline (-1 auto, 0 skip)")
     ap.add_argument("--e2e-steps", type=int, default=-1, help="timed passes of the host-buffer entry (-1 auto, 0 skip)")
+    ap.add_argument("--simulate-world", type=int, default=0,
+                    help="ONE process, ONE GPU: run rank 0's share of an N-GPU job (strong: shard 0 of N; weak: one full batch) and report the "
+                         "per-GPU figure an N-GPU run would start from -- what can be known about 8 GPUs on a 1-GPU box (no collective runs)")
     return ap.parse_args()
 
 
@@ -141,9 +144,10 @@ def main():
     n_arg = args.n_series or wl["n"]
     T = args.t or wl["T"]
     h = args.horizon
+    sim = args.simulate_world if (args.simulate_world > 1 and world == 1) else 0
     if args.scaling == "strong":
         n_total = n_arg
-        lo, hi = shard_range(n_total, rank, world)        # this rank's series-id range of the ONE batch
+        lo, hi = shard_range(n_total, rank, sim or world)        # this rank's series-id range of the ONE batch
     else:
         n_total = n_arg * world
         lo, hi = rank * n_arg, (rank + 1) * n_arg          # every rank a full batch of its own
@@ -208,7 +212,7 @@ def main():
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        value = n_total * args.steps / elapsed
+        value = (n if sim else n_total) * args.steps / elapsed          # (simulated world: only this rank's series were processed)
         fit_ms_avg = float(np.mean(fit_ms))
         final_pass_ms = None
         if wl["fixed"]:
@@ -237,6 +241,7 @@ def main():
                        "fixed_params": list(wl["fixed"]) if wl["fixed"] else None,
                        "series_total": n_total, "series_per_gpu": n, "T": T, "horizon": h, "seasonal_period": m, "positive": positive,
                        "parallelism": f"series-sharded x{world} ({args.scaling}), gather of yhat chunks to rank 0",
+                       "simulated_world": sim or None,
                        "series_ok": n_ok, "mean_passes_per_series": round(st["total_passes"] / max(n, 1), 1),
                        "max_passes_per_series": st["max_passes"], "mean_evals_per_series": round(st["total_evals"] / max(n, 1), 1),
                        "problems": st["n_problems"], "fit_kernel_launches": st["fit_kernel_launches"],
@@ -284,6 +289,12 @@ def main():
             break
         if out["roofline"]["traffic"] is None and stale:
             out["roofline"]["traffic_source"] = stale
+        if sim:
+            # rank 0's shard alone: `value` is what THIS GPU did; the N-GPU job cannot be faster than its slowest rank, so the
+            # projection is N x value at best (shards are equal sized up to one series; the gather adds < 1 ms)
+            out["projection"] = {"world": sim, "scaling": args.scaling, "per_gpu_series": n, "per_gpu_ms_per_step": round(ms_per_step, 3),
+                                 "job_series_per_s_upper_bound": round(sim * value, 1),
+                                 "note": "one rank of the job measured alone on one GPU; no RCCL gather in the timed region"}
         yhat_host = res["yhat"].cpu().numpy().copy()
         batch.close()       # the host-buffer entry below is what a binding calls on its own: no second resident batch (and its streams) beside it
         # ---- end to end: host buffers in, results on host (never `value`) -----------------------------

@@ -4,6 +4,8 @@ Tolerance: the north star allows 1e-5 relative (fp64); oracle and kernels are wr
 sequence of IEEE operations (fma only where stated, -ffp-contract=off), so we assert 1e-12 relative
 and report the worst case.  Model names, error codes and selected specs must match exactly.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -280,6 +282,27 @@ def test_concurrent_single_series_calls(env):
     for a, b in zip(serial, got):
         assert a["ok"] and b["ok"] and a["model_name"] == b["model_name"]
         assert np.array_equal(a["point"], b["point"]) and np.array_equal(a["upper"], b["upper"])
+
+
+@pytest.mark.parametrize("model,period", [("AutoETS", 7), ("HoltWinters", 7), ("AutoARIMA", 7), ("SES", 0)])
+def test_concurrent_c_workers_coalesce_bit_identically(env, model, period):
+    """tests/c_abi/concurrent.c: 8 pthreads calling anofox_ts_forecast back to back, the way the reference's scalar binding does from
+    every DuckDB worker (ts_forecast_scalar.cpp:298-523).  The coalescing window of the library puts concurrent calls with an equal
+    option block into one multi-series batch: every result equals its serial call bit for bit, the too-short series among them fail
+    alone, and the threaded run needs less wall time per call than the serial one."""
+    import subprocess, tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "anofox-forecast_amd")
+    with tempfile.TemporaryDirectory() as d:
+        exe = os.path.join(d, "concurrent")
+        subprocess.check_call(["gcc", "-std=c11", "-O2", "-pthread", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
+                               os.path.join(root, "tests", "c_abi", "concurrent.c"), "-L", pkg, "-lanofox_fcst_hip", "-Wl,-rpath," + pkg, "-o", exe])
+        out = subprocess.run([exe, model, str(period), "8", "8", "160"], capture_output=True, text=True, timeout=600,
+                             env=dict(os.environ, GPU_MAX_HW_QUEUES="16"))
+    assert out.returncode == 0 and out.stdout.startswith("OK "), (out.stdout, out.stderr[-1500:])
+    serial_us, threaded_us, bad, failed = out.stdout.split()[1:5]
+    assert int(bad) == 0 and int(failed) == 4                      # calls 12, 25, 38, 51 are two observations long
+    assert float(threaded_us) < float(serial_us), out.stdout
 
 
 def test_ts_forecast_agg_caller(env):
