@@ -93,7 +93,7 @@ struct ArLds {
 // the fit kernels need the two seasonal lags of a 4-step sub-block only: 2 m + 4 slots (39 KB per wave at m = 7 with the
 // 42 simplex coordinates: four waves per CU, one per SIMD); the function values of the simplex stay in registers
 __host__ __device__ inline int ar_fit_ring_slots(int m) { return 2 * m + 4 < 8 ? 8 : 2 * m + 4; }
-static size_t ar_lds_bytes(int m) { return sizeof(double) * (size_t)(2 * ar_fit_ring_slots(m) + (AR_MAXDIM + 1) * AR_MAXDIM) * NM_BLOCK; }
+static size_t ar_lds_bytes(int m) { return sizeof(double) * (size_t)((m == 7 ? 0 : 2 * ar_fit_ring_slots(m)) + (AR_MAXDIM + 1) * AR_MAXDIM) * NM_BLOCK; }
 
 // simplex function values in registers; run-time index by select chains (a handful of v_cndmask per access, against
 // tens of thousands of instructions per pass)
@@ -185,6 +185,10 @@ struct ArBlockLen { static constexpr int R = 2 * M + 4; static constexpr int val
 template <>
 struct ArBlockLen<0> { static constexpr int R = 0; static constexpr int value = AR_S; };
 
+// MODE 3 block length in revolutions of the 2 M ring: ONE (14 steps at m = 7: 56 VGPRs of row buffers instead of 112) so that the
+// fit kernels of the weekly period fit 256 registers and two waves share a SIMD -- the pass is a chain of dependent fp64
+// operations, and a second wave is what fills the issue slots the first one leaves (371 registers and one wave per SIMD before)
+constexpr int AR_MODE3_REVS = 1;
 template <int MODE, int M>
 __device__ __noinline__ double ar_css_pass_impl(const double *wrow, int len, int wave_len_v, bool live, const ArFac &fin, int m_v,
                                                 const ArLds &L)
@@ -218,9 +222,9 @@ __device__ __noinline__ double ar_css_pass_impl(const double *wrow, int len, int
         for (int k = 0; k < R; k++) ring[k * NM_BLOCK] = ar_ev_t{0.0, 0.0};
     // MODE 3: compile-time period with BOTH seasonal lags in registers (shift rings of 2 M values of e and of v, block =
     // two revolutions so every ring index is a constant): no LDS traffic in the pass at all
-    constexpr int S = (MODE == 3) ? 4 * M : ArBlockLen<M>::value;
+    constexpr int S = (MODE == 3) ? AR_MODE3_REVS * 2 * M : ArBlockLen<M>::value;
     constexpr int RR = (MODE == 3) ? 2 * M : 1;
-    static_assert(S % 4 == 0 && 2 * S <= AR_SPARE, "block length");
+    static_assert(S % 2 == 0 && 2 * S <= AR_SPARE, "block length");
     double er[RR], vr[RR];
 #pragma unroll
     for (int k = 0; k < RR; k++) { er[k] = 0.0; vr[k] = 0.0; }
@@ -246,12 +250,14 @@ __device__ __noinline__ double ar_css_pass_impl(const double *wrow, int len, int
             if (MODE == 1) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
+                    if (sb + j >= S) continue;
                     l1[j] = ring[slot1(sb + j, j) * NM_BLOCK];
                     l2[j] = ring[slot2(sb + j, j) * NM_BLOCK];
                 }
             }
 #pragma unroll
             for (int j = 0; j < 4; j++) {
+                if (sb + j >= S) continue;              // (a block length that is not a multiple of four: the last sub-block is short)
                 const int t = t0 + j;
                 const double wv = ((sb + j) & 1) ? cur[(sb + j) / 2].y : cur[(sb + j) / 2].x;
                 const double wp = wv - mu;
@@ -304,7 +310,7 @@ __device__ __noinline__ double ar_css_pass_impl(const double *wrow, int len, int
             if (MODE == 1 || MODE == 2) {
 #pragma unroll
                 for (int j = 0; j < 4; j++)
-                    if (!GATED || t0 + j < lim) ring[slot0(sb + j, j) * NM_BLOCK] = ar_ev_t{enew[j], vnew[j]};
+                    if (sb + j < S && (!GATED || t0 + j < lim)) ring[slot0(sb + j, j) * NM_BLOCK] = ar_ev_t{enew[j], vnew[j]};
             }
             if (!CT) { s0 = wrap(s0 + 4); s1 = wrap(s1 + 4); s2 = wrap(s2 + 4); }
         }
@@ -726,11 +732,15 @@ __device__ __forceinline__ void ar_sort(const LT &L, FT &F, int D)
 
 // `polish`: the problems are the SELECTED models (one per series, queued by arima_polish_queue_kernel): start at the search's
 // estimates (a.xbest) with steps of 0.1, run to convergence, write the estimates and their criterion back (oracle polish_css)
-__global__ __launch_bounds__(NM_BLOCK) void arima_fit_kernel(const ArimaArgs a, const ArWs ws, const int total, const int polish)
+// One instantiation per pass variant (MODE, M as in ar_css_pass_impl: the launch picks it from the period), so that a kernel carries
+// the registers of ITS pass only; the weekly variant is bounded to 256 registers = two waves per SIMD.
+constexpr int ar_fit_waves(int mode) { return mode == 3 ? 2 : 1; }
+template <int MODE, int M>
+__global__ __launch_bounds__(NM_BLOCK, ar_fit_waves(MODE)) void arima_fit_kernel(const ArimaArgs a, const ArWs ws, const int total, const int polish)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int m = a.m;
-    ArLds L{lds, ar_fit_ring_slots(m), (int)threadIdx.x};
+    ArLds L{lds, MODE == 3 ? 0 : ar_fit_ring_slots(m), (int)threadIdx.x};       // MODE 3: both seasonal lags live in registers, LDS holds the simplex only
     ArFs F;
     for (int k = 0; k <= AR_MAXDIM; k++) F.v[k] = 0.0;
     // queue: dimension 6 first (longest fits first, so the tail of the launch is made of short ones)
@@ -806,7 +816,7 @@ __global__ __launch_bounds__(NM_BLOCK) void arima_fit_kernel(const ArimaArgs a, 
 
         // ---- 3. one streamed pass -------------------------------------------------------------------
         const int wave_len = ar_wave_max(fin ? 0 : len);
-        const double css = ar_css_pass(wrow, len, wave_len, !fin, fac, m, L);
+        const double css = ar_css_pass_impl<MODE, M>(wrow, len, wave_len, !fin, fac, m, L);
         if (fin) continue;
         passes++;
         const int nu = len - fac.nc;
@@ -872,12 +882,13 @@ __global__ __launch_bounds__(NM_BLOCK) void arima_fit_kernel(const ArimaArgs a, 
 // sequential method would have made, so iterates, evaluation counts and the stopping point are those of the sequential
 // fit.  An iteration costs one pass instead of ~1.7: the critical path of a sweep's slowest fit shortens accordingly.
 // The simplex lives in the group leader's LDS column; all four lanes run the same bookkeeping on it (identical values).
-__global__ __launch_bounds__(NM_BLOCK) void arima_fit_spec_kernel(const ArimaArgs a, const ArWs ws, const int total, const int polish)
+template <int MODE, int M>
+__global__ __launch_bounds__(NM_BLOCK, ar_fit_waves(MODE)) void arima_fit_spec_kernel(const ArimaArgs a, const ArWs ws, const int total, const int polish)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int m = a.m;
     const int lane = threadIdx.x, g = lane & 3, leader = lane & ~3;
-    ArLds L{lds, ar_fit_ring_slots(m), leader};
+    ArLds L{lds, MODE == 3 ? 0 : ar_fit_ring_slots(m), leader};
     ArFs F;
     for (int k = 0; k <= AR_MAXDIM; k++) F.v[k] = 0.0;
     int qoff[8];
@@ -948,7 +959,7 @@ __global__ __launch_bounds__(NM_BLOCK) void arima_fit_spec_kernel(const ArimaArg
         if (__all(fin)) break;
 
         const int wave_len = ar_wave_max(fin ? 0 : len);
-        const double css = ar_css_pass(wrow, len, wave_len, !fin, fac, m, L);
+        const double css = ar_css_pass_impl<MODE, M>(wrow, len, wave_len, !fin, fac, m, L);
         if (fin) continue;
         passes++;
         const int nu = len - fac.nc;
@@ -1571,17 +1582,31 @@ int launch_arima(const ArimaArgs &a, hipStream_t stream)
     const int grid256 = (a.n_series + 255) / 256;
     const size_t fit_lds = ar_lds_bytes(a.m);
     const size_t fc_lds = sizeof(double) * (size_t)(2 * ar_ring_slots(a.m) + 2 * (AR_MAXP + AR_MAXSP * a.m + 1)) * NM_BLOCK;
+    // the pass variant of the period (ar_css_pass: the fit kernels' ring has 2 m + 4 slots)
+    typedef void (*fit_fn_t)(const ArimaArgs, const ArWs, const int, const int);
+    fit_fn_t fit_seq, fit_spec;
+    int fit_waves = 1;
+    if (a.m == 7) { fit_seq = arima_fit_kernel<3, 7>; fit_spec = arima_fit_spec_kernel<3, 7>; fit_waves = ar_fit_waves(3); }
+    else if (a.m == 12) { fit_seq = arima_fit_kernel<1, 12>; fit_spec = arima_fit_spec_kernel<1, 12>; }
+    else if (a.m == 4) { fit_seq = arima_fit_kernel<1, 4>; fit_spec = arima_fit_spec_kernel<1, 4>; }
+    else if (a.m >= 4) { fit_seq = arima_fit_kernel<1, 0>; fit_spec = arima_fit_spec_kernel<1, 0>; }
+    else if (a.m <= 1) { fit_seq = arima_fit_kernel<2, 0>; fit_spec = arima_fit_spec_kernel<2, 0>; }
+    else { fit_seq = arima_fit_kernel<0, 0>; fit_spec = arima_fit_spec_kernel<0, 0>; }
     if (fit_lds > 48 * 1024) {
-        AR_HIPCHECK(hipFuncSetAttribute((const void *)arima_fit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fit_lds));
-        AR_HIPCHECK(hipFuncSetAttribute((const void *)arima_fit_spec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fit_lds));
+        AR_HIPCHECK(hipFuncSetAttribute((const void *)fit_seq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fit_lds));
+        AR_HIPCHECK(hipFuncSetAttribute((const void *)fit_spec, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fit_lds));
     }
     if (fc_lds > 48 * 1024) AR_HIPCHECK(hipFuncSetAttribute((const void *)arima_forecast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fc_lds));
     int dev = 0, cus = 256;
     AR_HIPCHECK(hipGetDevice(&dev));
     AR_HIPCHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     int per_cu = (int)((160 * 1024) / fit_lds);
-    per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);         // one wave per SIMD is enough: the pass is issue bound
+    per_cu = per_cu < 1 ? 1 : (per_cu > 4 * fit_waves ? 4 * fit_waves : per_cu);         // waves per SIMD the kernel's registers allow
     const int max_waves = cus * per_cu;
+    // the schedule thresholds (four lanes per problem, lookahead) were measured in units of one wave per SIMD: they stay in those units
+    // when a variant fits two waves per SIMD (with twice the resident waves the same thresholds sent nine of eleven sweeps to the
+    // four-lane kernel, 2.35x the lane-passes: 358 -> 410 ms on the M5 batch)
+    const int sched_waves = cus * (per_cu > 4 ? 4 : per_cu);
 
     const size_t prep_lds = sizeof(double) * (size_t)(a.m > 1 ? a.m : 1) * NM_BLOCK;
     hipLaunchKernelGGL(arima_prep_kernel, dim3(grid), dim3(NM_BLOCK), prep_lds, stream, a, ws);
@@ -1590,16 +1615,16 @@ int launch_arima(const ArimaArgs &a, hipStream_t stream)
     long prev_total = -1;
     auto launch_fit = [&](long total, int polish) {
         const double spec_factor = a.spec_factor;   // (ANOFOX_HIP_ARIMA_SPEC_FACTOR, default 8)
-        if ((double)total <= spec_factor * (double)max_waves * (NM_BLOCK / 4)) {
+        if ((double)total <= spec_factor * (double)sched_waves * (NM_BLOCK / 4)) {
             // short queue (up to a few problems per resident 4-lane group): four lanes per problem, one pass per Nelder-Mead
             // iteration -- such a launch is bound by its slowest fit, not by throughput
             long waves = (total * 4 + NM_BLOCK - 1) / NM_BLOCK;
             if (waves > max_waves) waves = max_waves;
-            hipLaunchKernelGGL(arima_fit_spec_kernel, dim3((int)waves), dim3(NM_BLOCK), fit_lds, stream, a, ws, (int)total, polish);
+            hipLaunchKernelGGL(fit_spec, dim3((int)waves), dim3(NM_BLOCK), fit_lds, stream, a, ws, (int)total, polish);
         } else {
             const long waves = (total + NM_BLOCK - 1) / NM_BLOCK;
             const int fit_grid = (int)(waves < max_waves ? waves : max_waves);
-            hipLaunchKernelGGL(arima_fit_kernel, dim3(fit_grid), dim3(NM_BLOCK), fit_lds, stream, a, ws, (int)total, polish);
+            hipLaunchKernelGGL(fit_seq, dim3(fit_grid), dim3(NM_BLOCK), fit_lds, stream, a, ws, (int)total, polish);
         }
     };
     for (int sweep = 0; sweep < 4 * AR_MAXMODELS; sweep++) {
@@ -1607,11 +1632,11 @@ int launch_arima(const ArimaArgs &a, hipStream_t stream)
         // look one sweep ahead once the previous sweep's queue times the fan-out (~18 candidates per series) fits the
         // resident lanes `la_factor` times over: the extra fits cost idle lanes, the saved sweeps cost ~0.1-0.2 s each
         const double la_factor = a.lookahead;   // (ANOFOX_HIP_ARIMA_LOOKAHEAD, default 12) measured 0 / 0.25 / 1 / 4 / 16: 2.16 / 2.03 / 1.93 / 1.92 / 1.90 s on the M5 batch (round 1); with the refit 4 / 8 / 12 / 16 / 24 / 32 / 64: 2.23 / 2.23 / 2.14 / 2.14 / 2.17 / 2.17 / 2.92 s
-        int lookahead = (prev_total >= 0 && (double)prev_total * (AR_SWEEP + 1) <= la_factor * (double)max_waves * NM_BLOCK) ? 1 : 0;
+        int lookahead = (prev_total >= 0 && (double)prev_total * (AR_SWEEP + 1) <= la_factor * (double)sched_waves * NM_BLOCK) ? 1 : 0;
         // ... and two sweeps ahead once even that fan-out squared fits the resident lanes (the late sweeps of a few hundred series are
         // each bound by their slowest fit, ~0.1 s: 5 of them on the M5 batch)
         const int la_depth = a.lookahead_depth;   // (ANOFOX_HIP_ARIMA_LOOKAHEAD_DEPTH, default 2)
-        if (lookahead && la_depth >= 2 && (double)prev_total * (AR_SWEEP + 1) * (AR_SWEEP + 1) <= la_factor * (double)max_waves * NM_BLOCK) lookahead = 2;
+        if (lookahead && la_depth >= 2 && (double)prev_total * (AR_SWEEP + 1) * (AR_SWEEP + 1) <= la_factor * (double)sched_waves * NM_BLOCK) lookahead = 2;
         hipLaunchKernelGGL(arima_advance_kernel, dim3(grid256), dim3(256), 0, stream, a, ws, lookahead);
         int32_t counts[8];
         AR_HIPCHECK(hipMemcpyAsync(counts, ws.counts, sizeof counts, hipMemcpyDeviceToHost, stream));

@@ -112,7 +112,10 @@ struct Tunables {
 // GPU_MAX_HW_QUEUES), ANOFOX_HIP_DEVICES (devices the batch entry shards over, default: the caller's current device only)
 struct ProcessTunables {
     double cache_gb = -1.0, pinned_cache_gb = 2.0;
-    double coalesce_us = 200.0;       // ANOFOX_HIP_COALESCE_US: how long the first of several concurrent anofox_ts_forecast calls waits for the others (0: never)
+    double coalesce_us = 1000.0;      // ANOFOX_HIP_COALESCE_US: how long the first of several concurrent anofox_ts_forecast calls waits for the others (0: never).
+                                      // Measured with 8 C worker threads (tests/c_abi/concurrent.c, wall / calls): AutoETS 9.7 ms without, 4.0 ms at 200 us,
+                                      // 2.3 ms at 1,000 us; SES 5.0 / 0.87 / 0.05 ms -- the leader leaves as soon as its peers have joined, so the
+                                      // window is only ever waited out when a peer has stopped calling
     int prio_streams = -1;
     std::string devices;
     static const ProcessTunables &get()
@@ -2711,7 +2714,7 @@ static bool forecast_one_pooled(const double *values, const uint64_t *validity, 
 // Route A coalescing (ts_forecast_scalar.cpp:298-523: every DuckDB worker thread calls anofox_ts_forecast once per group of its
 // chunk, concurrently): a one-series fit is latency bound -- 5 ms for AutoETS, the chip all but idle -- so calls that are inside the
 // library AT THE SAME TIME with an equal option block join ONE multi-series batch.  The first caller of a key opens a group and
-// leads it: it waits until every call currently inside the library has joined or at most ANOFOX_HIP_COALESCE_US (default 200 us;
+// leads it: it waits until every call currently inside the library has joined or at most ANOFOX_HIP_COALESCE_US (default 1,000 us;
 // a lone caller does not wait at all), closes the group and runs it through the batch entry; the followers sleep on the group and
 // pick up their own result and their own error (per-series isolation is the batch entry's: out_errors).  Results are those of
 // single calls bit for bit -- a series' result does not depend on the batch it is in (test_concurrent_single_series_calls).
