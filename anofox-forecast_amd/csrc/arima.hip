@@ -31,6 +31,11 @@
 namespace anofox {
 
 constexpr int AR_MAXP = 5, AR_MAXSP = 2, AR_MAXORDER = 5, AR_MAXDIM = 6, AR_MAXMODELS = 94;
+// Seasonal periods up to AR_LDS_PERIOD keep the ring of seasonal lags in LDS (2 m + 4 slots of {e, v} per lane: 52 KB per wave at
+// m = 24); longer ones -- weekly data with a yearly period of 52, hourly 168, daily 365: the reference takes any period,
+// forecast.rs:1447-1451 -- keep it in an HBM scratch area of the wave (same lane-minor layout: a slot is one coalesced 1 KB access),
+// as the ETS kernels do above ETS_LDS_PERIOD.  Above AR_MAX_PERIOD the host fails the series loudly (oracle: ARIMA_MAX_PERIOD).
+constexpr int AR_LDS_PERIOD = 24, AR_MAX_PERIOD = 2048;
 // Nelder-Mead budgets (evaluations / iterations), oracle/arima.h: every candidate of the stepwise search gets a bounded run
 // (ARIMA_SEARCH_EVALS: an approximate criterion, which keeps the whole search inside the reference's measured cost), the
 // selected model's CSS estimates then run to convergence (ARIMA_POLISH_NM_CAP x dim)
@@ -86,14 +91,26 @@ __host__ __device__ inline int ar_ring_slots(int m) { return 2 * m + 6; }
 struct ArLds {
     double *base; int R;
     int col;              // lane column holding this lane's simplex (its own, or its group leader's in the speculative fit)
-    __device__ double *smp() const { return base + (size_t)2 * R * NM_BLOCK; }
+    double *gring;        // the ring of R slots in HBM scratch (long periods), else NULL: the ring is the first 2 R x 64 doubles of `base`
+    __device__ double *smp() const { return gring ? base : base + (size_t)2 * R * NM_BLOCK; }
     __device__ double &sim(int k, int i) const { return smp()[(k * AR_MAXDIM + i) * NM_BLOCK + col]; }
-    __device__ double e_at(int t) const { return base[((size_t)(t % R) * NM_BLOCK + threadIdx.x) * 2]; }
+    __device__ double e_at(int t) const { return (gring ? gring : base)[((size_t)(t % R) * NM_BLOCK + threadIdx.x) * 2]; }
 };
 // the fit kernels need the two seasonal lags of a 4-step sub-block only: 2 m + 4 slots (39 KB per wave at m = 7 with the
 // 42 simplex coordinates: four waves per CU, one per SIMD); the function values of the simplex stay in registers
 __host__ __device__ inline int ar_fit_ring_slots(int m) { return 2 * m + 4 < 8 ? 8 : 2 * m + 4; }
-static size_t ar_lds_bytes(int m) { return sizeof(double) * (size_t)((m == 7 ? 0 : 2 * ar_fit_ring_slots(m)) + (AR_MAXDIM + 1) * AR_MAXDIM) * NM_BLOCK; }
+static size_t ar_lds_bytes(int m) { return sizeof(double) * (size_t)(((m == 7 || m > AR_LDS_PERIOD) ? 0 : 2 * ar_fit_ring_slots(m)) + (AR_MAXDIM + 1) * AR_MAXDIM) * NM_BLOCK; }
+// HBM scratch of a long period (doubles): the fit kernels' rings (one per resident wave), the forecast kernel's ring + expanded
+// polynomials and the prep kernel's seasonal figure (one per 64 series) -- the stages run one after the other and share it
+__host__ __device__ inline size_t ar_fc_scratch_doubles(int m) { return (size_t)(2 * ar_ring_slots(m) + 2 * (AR_MAXP + AR_MAXSP * m + 1)) * NM_BLOCK; }
+size_t arima_long_scratch_doubles(int n_series, int m, int max_fit_waves)
+{
+    if (m <= AR_LDS_PERIOD) return 0;
+    const size_t grid = (size_t)((n_series + NM_BLOCK - 1) / NM_BLOCK);
+    const size_t fit = (size_t)max_fit_waves * 2 * ar_fit_ring_slots(m) * NM_BLOCK;
+    const size_t fc = grid * ar_fc_scratch_doubles(m);
+    return fit > fc ? fit : fc;                  // (the prep kernel's m x 64 per workgroup is below the forecast kernel's need)
+}
 
 // simplex function values in registers; run-time index by select chains (a handful of v_cndmask per access, against
 // tens of thousands of instructions per pass)
@@ -185,10 +202,11 @@ struct ArBlockLen { static constexpr int R = 2 * M + 4; static constexpr int val
 template <>
 struct ArBlockLen<0> { static constexpr int R = 0; static constexpr int value = AR_S; };
 
-// MODE 3 block length in revolutions of the 2 M ring: ONE (14 steps at m = 7: 56 VGPRs of row buffers instead of 112) so that the
-// fit kernels of the weekly period fit 256 registers and two waves share a SIMD -- the pass is a chain of dependent fp64
-// operations, and a second wave is what fills the issue slots the first one leaves (371 registers and one wave per SIMD before)
-constexpr int AR_MODE3_REVS = 1;
+// MODE 3 block length in revolutions of the 2 M ring.  Two (28 steps at m = 7: 112 VGPRs of row buffers) with one wave per SIMD is
+// the measured best: ONE revolution brings the weekly fit kernels down to 256 registers and two waves per SIMD (371 registers
+// before; 17 doubles of spill), and the M5 batch then takes 381 ms against 358 ms -- the pass issues fp64 operations 68 % of the time
+// already (tools/pmc_arima.sh), a second wave only adds its spill traffic.  ar_fit_waves / AR_MODE3_REVS = 2 / 1 rebuilds that variant.
+constexpr int AR_MODE3_REVS = 2;
 template <int MODE, int M>
 __device__ __noinline__ double ar_css_pass_impl(const double *wrow, int len, int wave_len_v, bool live, const ArFac &fin, int m_v,
                                                 const ArLds &L)
@@ -213,9 +231,9 @@ __device__ __noinline__ double ar_css_pass_impl(const double *wrow, int len, int
     // explicit address spaces: through the call boundary the pointers are generic, and generic (flat) loads would make
     // every LDS wait also wait for the row prefetch in flight
     typedef const __attribute__((address_space(1))) ar_ev_t *gptr_t;
-    typedef __attribute__((address_space(3))) ar_ev_t *lptr_t;
+    typedef typename std::conditional<MODE == 5, __attribute__((address_space(1))) ar_ev_t *, __attribute__((address_space(3))) ar_ev_t *>::type lptr_t;
     gptr_t wp_next = (gptr_t)wrow;
-    const lptr_t ring = (lptr_t)(L.base) + threadIdx.x;        // slot k of this lane: ring[k * NM_BLOCK]
+    const lptr_t ring = (lptr_t)(MODE == 5 ? L.gring : L.base) + threadIdx.x;        // slot k of this lane: ring[k * NM_BLOCK]
     double css = 0.0;
     double wl[AR_MAXP] = {0, 0, 0, 0, 0}, ul[AR_MAXP] = {0, 0, 0, 0, 0};
     if (MODE != 3)
@@ -247,7 +265,7 @@ __device__ __noinline__ double ar_css_pass_impl(const double *wrow, int len, int
             const int t0 = base + sb;
             ar_ev_t l1[4], l2[4];                 // slots t - m and t - 2m: {e, v}
             double vnew[4], enew[4];
-            if (MODE == 1) {
+            if (MODE == 1 || MODE == 5) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     if (sb + j >= S) continue;
@@ -307,7 +325,7 @@ __device__ __noinline__ double ar_css_pass_impl(const double *wrow, int len, int
                 const double ec = (!GATED || t < lim) ? et : 0.0;
                 css = fma(ec, ec, css);
             }
-            if (MODE == 1 || MODE == 2) {
+            if (MODE == 1 || MODE == 2 || MODE == 5) {
 #pragma unroll
                 for (int j = 0; j < 4; j++)
                     if (sb + j < S && (!GATED || t0 + j < lim)) ring[slot0(sb + j, j) * NM_BLOCK] = ar_ev_t{enew[j], vnew[j]};
@@ -330,6 +348,7 @@ __device__ __noinline__ double ar_css_pass_impl(const double *wrow, int len, int
 
 __device__ __forceinline__ double ar_css_pass(const double *wrow, int len, int wave_len, bool live, const ArFac &f, int m, const ArLds &L)
 {
+    if (L.gring) return ar_css_pass_impl<5, 0>(wrow, len, wave_len, live, f, m, L);      // long period: ring in HBM scratch
     if (L.R == 2 * m + 4) {      // fit kernels: common periods compiled in
         if (m == 7) return ar_css_pass_impl<3, 7>(wrow, len, wave_len, live, f, m, L);
         if (m == 12) return ar_css_pass_impl<1, 12>(wrow, len, wave_len, live, f, m, L);
@@ -493,7 +512,8 @@ __global__ __launch_bounds__(NM_BLOCK) void arima_prep_kernel(const ArimaArgs a,
     const size_t ld = a.ld;
     const int m = a.m;
     int len = n, D = 0, d = 0;
-    if (m > 1 && ar_seasonal_strength(y, ld, n, m, lds + threadIdx.x) > 0.64 && n > m + 2) {
+    double *const fig = a.long_scratch ? a.long_scratch + (size_t)blockIdx.x * ar_fc_scratch_doubles(m) + threadIdx.x : lds + threadIdx.x;
+    if (m > 1 && ar_seasonal_strength(y, ld, n, m, fig) > 0.64 && n > m + 2) {
         D = 1;
         for (int t = m; t < n; t++) w[t - m] = y[(size_t)t * ld] - y[(size_t)(t - m) * ld];
         len = n - m;
@@ -733,14 +753,16 @@ __device__ __forceinline__ void ar_sort(const LT &L, FT &F, int D)
 // `polish`: the problems are the SELECTED models (one per series, queued by arima_polish_queue_kernel): start at the search's
 // estimates (a.xbest) with steps of 0.1, run to convergence, write the estimates and their criterion back (oracle polish_css)
 // One instantiation per pass variant (MODE, M as in ar_css_pass_impl: the launch picks it from the period), so that a kernel carries
-// the registers of ITS pass only; the weekly variant is bounded to 256 registers = two waves per SIMD.
-constexpr int ar_fit_waves(int mode) { return mode == 3 ? 2 : 1; }
+// the registers of ITS pass only (see AR_MODE3_REVS for the two-waves-per-SIMD experiment).
+constexpr int ar_fit_waves(int mode) { return (mode == 3 && AR_MODE3_REVS == 1) ? 2 : 1; }
 template <int MODE, int M>
 __global__ __launch_bounds__(NM_BLOCK, ar_fit_waves(MODE)) void arima_fit_kernel(const ArimaArgs a, const ArWs ws, const int total, const int polish)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int m = a.m;
-    ArLds L{lds, MODE == 3 ? 0 : ar_fit_ring_slots(m), (int)threadIdx.x};       // MODE 3: both seasonal lags live in registers, LDS holds the simplex only
+    // MODE 3: both seasonal lags live in registers, MODE 5: in the wave's HBM scratch ring -- LDS holds the simplex only
+    ArLds L{lds, MODE == 3 ? 0 : ar_fit_ring_slots(m), (int)threadIdx.x,
+            MODE == 5 ? a.long_scratch + (size_t)blockIdx.x * 2 * ar_fit_ring_slots(m) * NM_BLOCK : nullptr};
     ArFs F;
     for (int k = 0; k <= AR_MAXDIM; k++) F.v[k] = 0.0;
     // queue: dimension 6 first (longest fits first, so the tail of the launch is made of short ones)
@@ -888,7 +910,8 @@ __global__ __launch_bounds__(NM_BLOCK, ar_fit_waves(MODE)) void arima_fit_spec_k
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int m = a.m;
     const int lane = threadIdx.x, g = lane & 3, leader = lane & ~3;
-    ArLds L{lds, MODE == 3 ? 0 : ar_fit_ring_slots(m), leader};
+    ArLds L{lds, MODE == 3 ? 0 : ar_fit_ring_slots(m), leader,
+            MODE == 5 ? a.long_scratch + (size_t)blockIdx.x * 2 * ar_fit_ring_slots(m) * NM_BLOCK : nullptr};
     ArFs F;
     for (int k = 0; k <= AR_MAXDIM; k++) F.v[k] = 0.0;
     int qoff[8];
@@ -1031,8 +1054,10 @@ __global__ __launch_bounds__(NM_BLOCK) void arima_forecast_kernel(const ArimaArg
     const int len = valid ? a.wlen[s] : 0;
     const bool live = valid && len >= 3 && a.status[s] == FIT_OK;
     const int m = a.m;
-    ArLds L{lds, ar_ring_slots(m), (int)threadIdx.x};
-    ArPolyLds PL{lds + (size_t)2 * L.R * NM_BLOCK, AR_MAXP + AR_MAXSP * m + 1};
+    // long period: ring and polynomials in the workgroup's HBM scratch
+    double *const wg_scratch = a.long_scratch ? a.long_scratch + (size_t)blockIdx.x * ar_fc_scratch_doubles(m) : nullptr;
+    ArLds L{lds, ar_ring_slots(m), (int)threadIdx.x, wg_scratch};
+    ArPolyLds PL{(wg_scratch ? wg_scratch : lds) + (size_t)2 * L.R * NM_BLOCK, AR_MAXP + AR_MAXSP * m + 1};
     const double *w = ws.W + (size_t)(valid ? s : 0) * ws.tw;
     const size_t ld = a.ld;
     const int wave_len = ar_wave_max(live ? len : 0);
@@ -1400,7 +1425,7 @@ __device__ __noinline__ int ar_refit_body(const ArimaArgs &a, const ArWs &ws, co
     static_assert(AR_ML_CTX <= 64, "refit context slots");
     const ArSimG L{ws.ml_sim + (size_t)blockIdx.x * (size_t)64 * NM_BLOCK, lane};
     const ArSimG &F = L;                                   // the function values live next to the simplex
-    ArMlLds Q{lds, RM, ar_ml_l1(m)};
+    ArMlLds Q{lds, RM, ar_ml_l1(m > AR_LDS_PERIOD ? 1 : m)};        // (long period: only models without seasonal terms get here)
 
     // persistent lane pairs: a pair that has finished its series takes the next one from the cursor (evaluation counts differ
     // several-fold between series, so a wave tied to 32 fixed series would idle most of its lanes)
@@ -1430,6 +1455,7 @@ __device__ __noinline__ int ar_refit_body(const ArimaArgs &a, const ArWs &ws, co
                 const int la = o.p + m * o.P, lb1 = o.q + m * o.Q + 1;
                 const int rr = la > lb1 ? la : lb1;
                 if (rr <= r_lo || rr > RM) continue;              // another instantiation's series (or beyond AR_ML_MAX_R: CSS estimates stay)
+                if (m > AR_LDS_PERIOD && (o.P || o.Q)) continue;
             }
             w = ws.W + (size_t)s * ws.tw;
             L.wsd() = a.wsd[s];
@@ -1523,6 +1549,7 @@ __device__ __forceinline__ int ar_ml_class(const ArimaArgs &a, int s)
     const size_t ld = a.ld;
     const int p = a.order[(size_t)0 * ld + s], q = a.order[(size_t)1 * ld + s], P = a.order[(size_t)2 * ld + s], Qs = a.order[(size_t)3 * ld + s];
     if (p + q + P + Qs + a.order[(size_t)4 * ld + s] == 0) return -1;
+    if (a.m > AR_LDS_PERIOD && (P || Qs)) return -1;          // seasonal terms of a long period: CSS estimates stay (oracle refit_ml)
     const int la = p + a.m * P, lb1 = q + a.m * Qs + 1;
     const int rr = la > lb1 ? la : lb1;
     return rr <= 8 ? 0 : (rr <= 12 ? 1 : (rr <= 16 ? 2 : (rr <= 20 ? 3 : (rr <= AR_ML_MAX_R ? 4 : -1))));
@@ -1573,6 +1600,13 @@ __global__ __launch_bounds__(NM_BLOCK, 2) void arima_refit_kernel(const ArimaArg
 
 #define AR_HIPCHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) throw std::runtime_error(std::string("HIP: ") + hipGetErrorString(e_) + " at " #x); } while (0)
 
+int arima_max_fit_waves()
+{
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return cus * 8;                   // no variant of the fit kernels runs more than two waves per SIMD
+}
+
 int launch_arima(const ArimaArgs &a, hipStream_t stream)
 {
     ArWs ws;
@@ -1581,7 +1615,10 @@ int launch_arima(const ArimaArgs &a, hipStream_t stream)
     const int grid = (a.n_series + NM_BLOCK - 1) / NM_BLOCK;
     const int grid256 = (a.n_series + 255) / 256;
     const size_t fit_lds = ar_lds_bytes(a.m);
-    const size_t fc_lds = sizeof(double) * (size_t)(2 * ar_ring_slots(a.m) + 2 * (AR_MAXP + AR_MAXSP * a.m + 1)) * NM_BLOCK;
+    const bool long_m = a.m > AR_LDS_PERIOD;
+    if (a.m > AR_MAX_PERIOD) throw std::runtime_error("AutoARIMA: seasonal period above the cap");
+    if (long_m && !a.long_scratch) throw std::runtime_error("AutoARIMA: a period above the LDS limit needs the scratch area");
+    const size_t fc_lds = long_m ? 0 : sizeof(double) * ar_fc_scratch_doubles(a.m);
     // the pass variant of the period (ar_css_pass: the fit kernels' ring has 2 m + 4 slots)
     typedef void (*fit_fn_t)(const ArimaArgs, const ArWs, const int, const int);
     fit_fn_t fit_seq, fit_spec;
@@ -1589,6 +1626,7 @@ int launch_arima(const ArimaArgs &a, hipStream_t stream)
     if (a.m == 7) { fit_seq = arima_fit_kernel<3, 7>; fit_spec = arima_fit_spec_kernel<3, 7>; fit_waves = ar_fit_waves(3); }
     else if (a.m == 12) { fit_seq = arima_fit_kernel<1, 12>; fit_spec = arima_fit_spec_kernel<1, 12>; }
     else if (a.m == 4) { fit_seq = arima_fit_kernel<1, 4>; fit_spec = arima_fit_spec_kernel<1, 4>; }
+    else if (a.m > AR_LDS_PERIOD) { fit_seq = arima_fit_kernel<5, 0>; fit_spec = arima_fit_spec_kernel<5, 0>; }
     else if (a.m >= 4) { fit_seq = arima_fit_kernel<1, 0>; fit_spec = arima_fit_spec_kernel<1, 0>; }
     else if (a.m <= 1) { fit_seq = arima_fit_kernel<2, 0>; fit_spec = arima_fit_spec_kernel<2, 0>; }
     else { fit_seq = arima_fit_kernel<0, 0>; fit_spec = arima_fit_spec_kernel<0, 0>; }
@@ -1608,7 +1646,7 @@ int launch_arima(const ArimaArgs &a, hipStream_t stream)
     // four-lane kernel, 2.35x the lane-passes: 358 -> 410 ms on the M5 batch)
     const int sched_waves = cus * (per_cu > 4 ? 4 : per_cu);
 
-    const size_t prep_lds = sizeof(double) * (size_t)(a.m > 1 ? a.m : 1) * NM_BLOCK;
+    const size_t prep_lds = long_m ? 0 : sizeof(double) * (size_t)(a.m > 1 ? a.m : 1) * NM_BLOCK;
     hipLaunchKernelGGL(arima_prep_kernel, dim3(grid), dim3(NM_BLOCK), prep_lds, stream, a, ws);
     hipLaunchKernelGGL(arima_skip_kernel, dim3(grid256), dim3(256), 0, stream, a);
     int launches = 2;
@@ -1665,7 +1703,7 @@ int launch_arima(const ArimaArgs &a, hipStream_t stream)
     }
     // on request (ANOFOX_ARIMA_CSS_ML): final estimates of the selected models on the exact Gaussian likelihood
     if (a.ml_refit) {
-        const size_t lds_b = sizeof(double) * ar_ml_lds_doubles(a.m) * NM_BLOCK;
+        const size_t lds_b = sizeof(double) * ar_ml_lds_doubles(long_m ? 1 : a.m) * NM_BLOCK;
         if (lds_b > 48 * 1024) AR_HIPCHECK(hipFuncSetAttribute((const void *)arima_refit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
         int per = (int)((160 * 1024) / lds_b);
         per = per < 1 ? 1 : (per > 8 ? 8 : per);                            // 256 registers: two waves per SIMD at most

@@ -1318,7 +1318,7 @@ void run_group(AnofoxHipBatch *b, int period, const int32_t *d_len, hipStream_t 
     // non-seasonal fit.  The reference takes any period (forecast.rs:528-537); 2,048 covers every calendar period.
     const bool uses_period = p.model == M_AutoETS || p.model == M_HoltWinters || p.model == M_SeasonalES || p.model == M_SeasonalESOptimized ||
                              (p.model == M_ETS && (p.ets_spec_id < 0 || spec_season(p.ets_spec_id) != 0));
-    const bool arima_period = p.model == M_AutoARIMA && period > 24;      // seasonal ARIMA terms: LDS rings of 2 m + 4 slots, m <= 24
+    const bool arima_period = p.model == M_AutoARIMA && period > ETS_MAX_PERIOD;      // seasonal ARIMA terms: LDS rings up to m = 24, an HBM scratch ring up to 2,048
     if ((uses_period && period > ETS_MAX_PERIOD) || arima_period) {
         prep(1, false);
         HIPCHECK(hipMemsetAsync(b->d_detail, 0, ld * sizeof(int32_t), st));
@@ -1445,7 +1445,9 @@ void run_group(AnofoxHipBatch *b, int period, const int32_t *d_len, hipStream_t 
         prep(1, false);
         ArimaArgs aa{};
         aa.y = b->d_y; aa.ld = ld; aa.len = d_len; aa.n_series = (int)n;
-        aa.m = period > 1 ? period : 1;                        // <= 24 here: longer periods failed loudly above
+        aa.m = period > 1 ? period : 1;                        // <= 2,048 here: longer periods failed loudly above
+        aa.long_scratch = nullptr;
+        if (aa.m > 24) aa.long_scratch = ensure_ring(b, arima_long_scratch_doubles((int)n, aa.m, arima_max_fit_waves()));
         aa.h = b->h;
         aa.ws = b->ar_w; aa.ws_bytes = b->ar_ws_bytes; aa.t_max = (int)std::max<size_t>(b->t_max, 1); aa.wlen = b->ar_wlen; aa.d = b->ar_d; aa.D = b->ar_D; aa.wmean = b->ar_wmean; aa.wsd = b->ar_wsd;
         aa.last_d0 = b->ar_l0; aa.last_d1 = b->ar_l1; aa.order = b->ar_order; aa.xbest = b->ar_x; aa.aicc = b->ar_aicc;
@@ -1497,10 +1499,11 @@ void run_batch(AnofoxHipBatch *b, hipStream_t st)
         switch (b->plan.model) {
         case M_Naive: case M_RandomWalkDrift: case M_ARIMA: case M_SES: case M_SESOptimized: case M_Holt: return 1;
         case M_AutoARIMA: {
-            // a DETECTED period above the cap of the seasonal ARIMA terms falls back to the non-seasonal search (the reference's
-            // documentation: AutoARIMA without seasonal_period is non-seasonal); an EXPLICIT one fails loudly in run_group
+            // a DETECTED period above 24 falls back to the non-seasonal search (the reference's documentation: AutoARIMA without
+            // seasonal_period is non-seasonal); an EXPLICIT one is used up to 2,048 (rings in HBM scratch) and fails loudly beyond
             const bool detected = b->opt.auto_detect_seasonality && b->opt.seasonal_period == 0;
-            return period > 24 ? (detected ? 1 : 25) : (period > 1 ? period : 1);
+            if (period > 24 && detected) return 1;
+            return period > ETS_MAX_PERIOD ? ETS_MAX_PERIOD + 1 : (period > 1 ? period : 1);
         }
         default: return period;
         }
@@ -1543,8 +1546,7 @@ std::string series_error_message(const AnofoxHipBatch *b, size_t s, int code, in
     const char *why = detail == FIT_SHORT ? "not enough observations for this model"
                       : detail == FIT_NONPOSITIVE ? "multiplicative components require strictly positive data"
                       : detail == FIT_NONFINITE ? "likelihood is not finite"
-                      : (b->plan.model == M_AutoARIMA ? "unsupported seasonal period (seasonal ARIMA terms are supported up to period 24)"
-                                                      : "unsupported seasonal period (periods above 2048 are not supported)");
+                      : "unsupported seasonal period (periods above 2048 are not supported)";
     switch (b->plan.model) {
     case M_ETS:
         if (b->plan.ets_spec_id >= 0) {

@@ -153,7 +153,7 @@ inline void auto_arima_name(int code, int period, char out[64])
 {
     int v = code - 1000000;
     int p = v / 100000, d = (v / 10000) % 10, q = (v / 1000) % 10, P = (v / 100) % 10, D = (v / 10) % 10, Q = v % 10;
-    int s = (period > 1 && period <= 24) ? period : 1;
+    int s = (period > 1 && period <= 2048) ? period : 1;
     if (s > 1 && (P || D || Q)) std::snprintf(out, 64, "AutoARIMA(%d,%d,%d)(%d,%d,%d)[%d]", p, d, q, P, D, Q, s);
     else std::snprintf(out, 64, "AutoARIMA(%d,%d,%d)", p, d, q);
 }

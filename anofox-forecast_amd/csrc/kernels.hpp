@@ -165,9 +165,12 @@ struct ArimaArgs {
     int trace;                          // debugging: the refit kernel prints per-wave timings (ANOFOX_HIP_ARIMA_TRACE)
     double lookahead, spec_factor;      // schedule knobs of the search (host_api.hip Tunables: lookahead once the queue fits the resident lanes
     int lookahead_depth;                //   this many times over; four lanes per problem below spec_factor x the resident groups)
+    double *long_scratch;               // seasonal period above 24: HBM scratch of arima_long_scratch_doubles() doubles (rings, polynomials), else NULL
     int ml_refit;                       // exact-likelihood (Kalman / Chandrasekhar) refit of the selected models; 0 keeps the CSS estimates
 };
 size_t arima_workspace_bytes(int n_series, int t_max);
+size_t arima_long_scratch_doubles(int n_series, int m, int max_fit_waves);   // 0 for periods whose rings live in LDS (m <= 24)
+int arima_max_fit_waves();                                                  // resident waves of the fit kernels (what the scratch is sized for)
 int launch_arima(const ArimaArgs &, hipStream_t);   // returns the number of kernel launches; synchronises the stream between sweeps
 
 void launch_prep(const PrepArgs &, hipStream_t);

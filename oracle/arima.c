@@ -55,7 +55,7 @@ double oracle_arima_seasonal_strength(const double *y, int n, int m)
     const int L = (m % 2 == 0) ? m + 1 : m;
     const double w = 1.0 / (double)m;
     const double wend = (m % 2 == 0) ? 0.5 / (double)m : w;
-    double fig[ARIMA_MAX_PERIOD];
+    double *fig = (double *)malloc(sizeof(double) * (size_t)m);
     double tot = 0.0;
     for (int j = 0; j < m; j++) {
         double sj = 0.0;
@@ -91,6 +91,7 @@ double oracle_arima_seasonal_strength(const double *y, int n, int m)
         vd = fma(d - md, d - md, vd);
         vr = fma(r - mr, r - mr, vr);
     }
+    free(fig);
     if (!(vd > 0.0)) return 0.0;
     double f = 1.0 - vr / vd;
     if (f < 0.0) f = 0.0;
@@ -159,9 +160,8 @@ static void build_poly(const ArimaOrder *o, const double *x, ArimaPoly *pl)
     pl->m = m;
     pl->La = expand_poly(pl->phi, o->p, pl->Phi, o->P, m, pl->a);
     /* MA polynomial (1 - theta(B))(1 - Theta(B^m)) with the same stationary-region transform: invertible */
-    double b[ARIMA_MAX_LAG + 1];
-    pl->Lb = expand_poly(pl->th, o->q, pl->Th, o->Q, m, b);
-    for (int i = 0; i <= pl->Lb; i++) pl->b[i] = -b[i];
+    pl->Lb = expand_poly(pl->th, o->q, pl->Th, o->Q, m, pl->b);
+    for (int i = 0; i <= pl->Lb; i++) pl->b[i] = -pl->b[i];
 }
 
 /*
@@ -503,6 +503,7 @@ static int refit_ml(ArimaFit *fit, const double *w, int n, double wsd)
     const ArimaOrder *o = &fit->ord;
     const int dim = o->p + o->q + o->P + o->Q + (o->with_constant ? 1 : 0);
     if (dim == 0) return 0;
+    if (o->s > ARIMA_ML_MAX_PERIOD && (o->P || o->Q)) return 0;       /* seasonal terms of a long period: the CSS estimates stay */
     CssCtx ctx = { o, w, n, NULL, NULL, ml_obj_fn, ARIMA_ML_NM_CAP * dim };
     const double f0 = ml_obj_fn(fit->x, &ctx);
     if (!(fabs(f0) <= DBL_MAX)) return 1;

@@ -26,7 +26,10 @@ extern "C" {
 #define ARIMA_MAX_P 5
 #define ARIMA_MAX_SP 2
 #define ARIMA_MAX_ORDER 5
-#define ARIMA_MAX_PERIOD 24        /* seasonal ARIMA terms only for m <= 24 (else non-seasonal search) */
+#define ARIMA_MAX_PERIOD 2048      /* an explicit seasonal period up to this is used (the reference takes any: forecast.rs:1447-1451);
+                                    * beyond it the series fails loudly, like the ETS family above ETS_MAX_PERIOD */
+#define ARIMA_DETECT_MAX_PERIOD 24 /* a DETECTED period above this falls back to the non-seasonal search */
+#define ARIMA_ML_MAX_PERIOD 24     /* seasonal terms of a longer period keep their CSS estimates in the exact-likelihood refit */
 #define ARIMA_MAX_DIM 6            /* p+q+P+Q <= 5, plus the constant */
 #define ARIMA_MAX_LAG (ARIMA_MAX_P + ARIMA_MAX_SP * ARIMA_MAX_PERIOD)
 #define ARIMA_MAX_MODELS 94

@@ -621,9 +621,9 @@ static int run_forecast(const double *y, size_t n, const ForecastOptions *o, Mod
     /* AutoARIMA: an EXPLICIT period above the cap fails loudly; a DETECTED one (the ACF heuristic of seasonality.rs:323-377 on a
      * call without seasonal_period) falls back to the non-seasonal search -- the reference's own documentation says AutoARIMA
      * without seasonal_period selects a non-seasonal model (docs/reference/models/state-space/auto_arima.md) */
-    if (model == M_AutoARIMA && period > ARIMA_MAX_PERIOD && o->auto_detect_seasonality && o->seasonal_period == 0) period = 1;
+    if (model == M_AutoARIMA && period > ARIMA_DETECT_MAX_PERIOD && o->auto_detect_seasonality && o->seasonal_period == 0) period = 1;
     if (model == M_AutoARIMA && period > ARIMA_MAX_PERIOD)
-        FAIL(err, COMPUTATION_ERROR, "Computation error: AutoARIMA fit failed: unsupported seasonal period (seasonal ARIMA terms are supported up to period %d)",
+        FAIL(err, COMPUTATION_ERROR, "Computation error: AutoARIMA fit failed: unsupported seasonal period (periods above %d are not supported)",
              ARIMA_MAX_PERIOD);
 
     name[0] = 0;

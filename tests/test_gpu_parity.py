@@ -914,13 +914,15 @@ def _run_device_batch(lib, Y, model, h, m, dev="cuda:0"):
     return out, again, names
 
 
-@pytest.mark.parametrize("m", [2, 3, 4, 12, 24, 30])
+@pytest.mark.parametrize("m", [2, 3, 4, 12, 24, 30, 52, 168, 365, 3000])
 def test_auto_arima_other_periods(env, m):
     """Every variant of the CSS pass: per-step ring access (m = 2, 3), compile-time ring slots (m = 4, 12), the generic
-    run-time ring (m = 24) and the loud failure of an explicit period above 24 -- each against the oracle."""
+    run-time ring in LDS (m = 24), the ring in HBM scratch for the long calendar periods the reference accepts like any other
+    (forecast.rs:1447-1451: weekly data with a yearly period 52, hourly 168, daily 365; prep figure, fit rings and the forecast
+    kernel's ring + polynomials all leave LDS) and the loud failure of an explicit period above 2,048 -- each against the oracle."""
     api, O, lib, synth = env
     rng = np.random.default_rng(100 + m)
-    T = 8 * m + 40
+    T = 8 * m + 40 if m <= 400 else 500
     t = np.arange(T)
     series = [10 + 3 * np.sin(2 * np.pi * t / m + k) + 0.02 * k * t + rng.normal(0, 0.5 + 0.1 * k, T) for k in range(12)]
     series += [np.cumsum(rng.normal(0.05, 1.0, T)) for _ in range(6)]

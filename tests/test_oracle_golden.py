@@ -138,6 +138,13 @@ def test_auto_arima_pieces(oracle):
     noise = rng.normal(5.0, 1.0, 200)
     r = oracle.forecast(noise, oracle.make_options("AutoARIMA", 5))
     assert r["ok"] and r["model_name"].split(",")[1] == "0" and abs(r["point"][-1] - 5.0) < 0.5
+    # a long explicit period is used like any other (the reference takes any period, forecast.rs:1447-1451): the name carries it
+    t = np.arange(52 * 7)
+    yearly = 50 + 10 * np.sin(2 * np.pi * t / 52) + rng.normal(0, 0.5, len(t))
+    r = oracle.forecast(yearly, oracle.make_options("AutoARIMA", 5, seasonal_period=52))
+    assert r["ok"] and r["model_name"].endswith("[52]"), r
+    r = oracle.forecast(yearly, oracle.make_options("AutoARIMA", 5, seasonal_period=4096))
+    assert not r["ok"] and r["code"] == 3 and "periods above 2048" in r["message"]
     r = oracle.forecast([1.0, 2.0], oracle.make_options("AutoARIMA", 2))
     assert not r["ok"] and r["code"] == 6
 
