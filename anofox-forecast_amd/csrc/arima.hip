@@ -1116,7 +1116,7 @@ __global__ __launch_bounds__(NM_BLOCK) void arima_forecast_kernel(const ArimaArg
 // the AR polynomial, then the MA filter) is O(r^2) per evaluation in a small LDS scratch.  Same sequence of IEEE operations
 // as the oracle, so the estimates are bit-identical.
 constexpr int AR_ML_MAX_R = 32;
-constexpr int AR_ML_NM_CAP = 100;       // the refit starts at the CSS optimum: 100 x dim evaluations / iterations at most (oracle: ARIMA_ML_NM_CAP)
+constexpr int AR_ML_NM_CAP = 50;        // the refit starts at the CSS optimum: 50 x dim evaluations / iterations at most (oracle: ARIMA_ML_NM_CAP)
 // LDS of the refit kernel per wave (lane-minor), in doubles per lane: rm + (l1 - 1) + (2 rm - 1), rm = the state-dimension class
 // of the launch's period, l1 = AR_MAXP + AR_MAXSP m + 1 -- 78 at m = 7 (39 KB per wave: FOUR waves per CU, one per SIMD; the
 // first version kept the simplex, both polynomials with their unused slot 0 and five scratch vectors there: 187, ONE wave

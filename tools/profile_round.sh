@@ -17,9 +17,15 @@ run trace_autoets_positive --steps 2 --warmup 1 --cpu-sample 0 --e2e-steps 0
 run trace_autoets_m5 --workload autoets_m5 --steps 3 --warmup 1 --cpu-sample 0 --e2e-steps 0
 run trace_ets_aaa_fixed --workload ets_aaa_fixed_m5 --steps 20 --warmup 2 --cpu-sample 0
 run trace_autoarima_m5 --workload autoarima_m5 --steps 1 --warmup 0 --cpu-sample 0 --e2e-steps 0
+run trace_autoarima_css_m5 --workload autoarima_css_m5 --steps 1 --warmup 0 --cpu-sample 0 --e2e-steps 0
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace -d $OUT/pmc_$c -o p -- python3 /root/repo/bench.py --steps 1 --warmup 0 --cpu-sample 0 --e2e-steps 0 > $OUT/pmc_$c.log 2>&1
   rocprofv3 --pmc $c --kernel-trace -d $OUT/pmcfixed_$c -o p -- python3 /root/repo/bench.py --workload ets_aaa_fixed_m5 --steps 4 --warmup 0 --cpu-sample 0 > $OUT/pmcfixed_$c.log 2>&1
+done
+# AutoARIMA (CSS method): HBM traffic of the row-per-lane W reads and the issue counters, per kernel
+for c in FETCH_SIZE WRITE_SIZE "SQ_INSTS_VALU SQ_WAVES SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY"; do
+  n=$(echo $c | cut -d' ' -f1)
+  rocprofv3 --pmc $c --kernel-trace -d $OUT/pmcarima_$n -o p -- python3 /root/repo/bench.py --workload autoarima_css_m5 --steps 1 --warmup 0 --cpu-sample 0 --e2e-steps 0 > $OUT/pmcarima_$n.log 2>&1
 done
 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_INSTS_SALU SQ_INSTS_LDS --kernel-trace -d $OUT/pmc_SQ_INSTS -o p -- python3 /root/repo/bench.py --steps 1 --warmup 0 --cpu-sample 0 --e2e-steps 0 > $OUT/pmc_SQ_INSTS.log 2>&1
 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY --kernel-trace -d $OUT/pmc_SQ_CYCLES -o p -- python3 /root/repo/bench.py --steps 1 --warmup 0 --cpu-sample 0 --e2e-steps 0 > $OUT/pmc_SQ_CYCLES.log 2>&1

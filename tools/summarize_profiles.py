@@ -9,6 +9,9 @@ import sqlite3
 import sys
 
 out = sys.argv[1]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+import hashlib
+LIB_SHA = hashlib.sha256(open(os.path.join(ROOT, "anofox-forecast_amd", "libanofox_fcst_hip.so"), "rb").read()).hexdigest()   # bench.py quotes a summary only on this build
 
 
 def family(name):
@@ -93,6 +96,7 @@ if traffic:
     js = {
         "command": "rocprofv3 --kernel-trace --pmc <FETCH_SIZE|WRITE_SIZE> -- python3 bench.py --steps 1 --warmup 0 --cpu-sample 0  (separate passes per counter)",
         "workload": "autoets_m5_positive",
+        "lib_sha256": LIB_SHA,
         "unit": "bytes per step (one bench step = all launches of the kernel family)",
         "calibration": "ets_final_kernel reads every series exactly once per spec; its FETCH_SIZE x 1024 is half of that algorithmic volume, "
                        "so fetch_correction = 2.0 (the gfx950 half-reporting of MI355X_MICROARCH.md, HBM section); WRITE_SIZE is taken as exact",
@@ -100,6 +104,7 @@ if traffic:
         "WRITE_SIZE_raw_bytes": {k: int(v) for k, v in write.items()},
         "hbm_bytes_corrected": {k: int(v) for k, v in corrected.items()},
         "ets_round_kernel_traffic_bytes_per_step": int(corrected.get("ets_round_kernel", 0)),
+        "fit_kernel_traffic_bytes_per_step": int(corrected.get("ets_round_kernel", 0) + corrected.get("ets_final_kernel", 0)),
     }
     # ---- SQ issue counters (separate passes): wave-level VALU instructions per step and how busy the SIMDs were ----
     sq = {}
@@ -138,7 +143,9 @@ if traffic:
                 n = max(fx[f].get("launches", 1), 1)
                 rep[f] = {"launches": n, "hbm_bytes_per_launch_corrected": int((2.0 * fx[f].get("FETCH_SIZE", 0.0) + fx[f].get("WRITE_SIZE", 0.0)) / n),
                           "FETCH_SIZE_raw_per_launch": int(fx[f].get("FETCH_SIZE", 0.0) / n), "WRITE_SIZE_raw_per_launch": int(fx[f].get("WRITE_SIZE", 0.0) / n)}
-        json.dump({"workload": "ets_aaa_fixed_m5", "algorithmic_bytes_per_launch_ets_final_kernel": 30490 * (8 * 1913 + 8 * 28),
+        json.dump({"workload": "ets_aaa_fixed_m5", "lib_sha256": LIB_SHA,
+                   "fit_kernel_traffic_bytes_per_step": int(sum(r["hbm_bytes_per_launch_corrected"] for r in rep.values())),
+                   "algorithmic_bytes_per_launch_ets_final_kernel": 30490 * (8 * 1913 + 8 * 28),
                    "correction": "fetch x 2 (gfx950 half-reporting, calibrated as in pmc_traffic.json)", "kernels": rep},
                   open(os.path.join(out, "pmc_traffic_fixed.json"), "w"), indent=1)
     for cname, agg in traffic.items():
@@ -146,4 +153,36 @@ if traffic:
             fh.write("kernel_family,raw_bytes\n")
             for k, v in sorted(agg.items(), key=lambda kv: -kv[1]):
                 fh.write(f"{k},{int(v)}\n")
+# ---- AutoARIMA: HBM traffic and issue counters per kernel (pmcarima_* passes of the autoarima_css_m5 workload) ----
+ar = {}
+for d in sorted(glob.glob(os.path.join(out, "pmcarima_*"))):
+    if not os.path.isdir(d):
+        continue
+    db = glob.glob(os.path.join(d, "*.db"))
+    if not db:
+        continue
+    c = sqlite3.connect(db[0])
+    for cname, name, val in c.execute("select counter_name, kernel_name, sum(value) from counters_collection group by 1, 2"):
+        ar.setdefault(family(name), {})
+        ar[family(name)][cname] = ar[family(name)].get(cname, 0) + val
+if ar:
+    rep = {}
+    for f, d in ar.items():
+        if not f.startswith("arima_"):
+            continue
+        e = {k: int(v) for k, v in d.items()}
+        if "FETCH_SIZE" in d or "WRITE_SIZE" in d:
+            e["hbm_bytes_corrected"] = int(2.0 * d.get("FETCH_SIZE", 0.0) * 1024.0 + d.get("WRITE_SIZE", 0.0) * 1024.0)
+        rep[f] = e
+    blog = [l for l in open(os.path.join(out, "pmcarima_FETCH_SIZE.log")).read().splitlines() if l.startswith('{"metric"')] if os.path.exists(os.path.join(out, "pmcarima_FETCH_SIZE.log")) else []
+    alg = json.loads(blog[-1])["roofline"]["algorithmic_bytes"] if blog else None
+    fit_bytes = sum(v.get("hbm_bytes_corrected", 0) for k, v in rep.items() if k.startswith(("arima_fit_kernel", "arima_fit_spec_kernel")))
+    json.dump({"workload": "autoarima_css_m5", "lib_sha256": LIB_SHA,
+               "command": "rocprofv3 --kernel-trace --pmc <group> -- python3 bench.py --workload autoarima_css_m5 --steps 1 --warmup 0 --cpu-sample 0 --e2e-steps 0 (one pass per counter group)",
+               "correction": "FETCH_SIZE x 1024 x 2 (gfx950 half-reporting, calibrated on ets_final_kernel) + WRITE_SIZE x 1024",
+               "fit_kernel_traffic_bytes_per_step": int(fit_bytes), "algorithmic_bytes_per_step": alg,
+               "traffic_over_algorithmic": (round(fit_bytes / alg, 3) if alg else None),
+               "note": "the fit lanes of a wave stream unrelated series: every lane reads its OWN row of the series-major block W with 128-bit loads "
+                       "(two steps per load), 8 T' bytes per evaluation and lane",
+               "kernels": rep}, open(os.path.join(out, "pmc_traffic_arima.json"), "w"), indent=1)
 print(open(os.path.join(out, "rocprof_summary.txt")).read())
