@@ -92,6 +92,7 @@ struct ArLds {
     double *base; int R;
     int col;              // lane column holding this lane's simplex (its own, or its group leader's in the speculative fit)
     double *gring;        // the ring of R slots in HBM scratch (long periods), else NULL: the ring is the first 2 R x 64 doubles of `base`
+    double *tile;         // fit kernels with the cooperative row loader: LDS tile behind the simplex (ArCoop), else NULL
     __device__ double *smp() const { return gring ? base : base + (size_t)2 * R * NM_BLOCK; }
     __device__ double &sim(int k, int i) const { return smp()[(k * AR_MAXDIM + i) * NM_BLOCK + col]; }
     __device__ double e_at(int t) const { return (gring ? gring : base)[((size_t)(t % R) * NM_BLOCK + threadIdx.x) * 2]; }
@@ -99,7 +100,13 @@ struct ArLds {
 // the fit kernels need the two seasonal lags of a 4-step sub-block only: 2 m + 4 slots (39 KB per wave at m = 7 with the
 // 42 simplex coordinates: four waves per CU, one per SIMD); the function values of the simplex stay in registers
 __host__ __device__ inline int ar_fit_ring_slots(int m) { return 2 * m + 4 < 8 ? 8 : 2 * m + 4; }
-static size_t ar_lds_bytes(int m) { return sizeof(double) * (size_t)(((m == 7 || m > AR_LDS_PERIOD) ? 0 : 2 * ar_fit_ring_slots(m)) + (AR_MAXDIM + 1) * AR_MAXDIM) * NM_BLOCK; }
+static size_t ar_lds_bytes(int m)
+{
+    const bool ring_in_lds = !(m == 7 || m > AR_LDS_PERIOD);
+    const bool coop = m == 7 || m <= 1 || m > AR_LDS_PERIOD;          // ar_fit_coop of the period's pass variant
+    // the tile of the longest block any cooperative variant uses (S = 32: 64 x 17 units of 16 bytes)
+    return sizeof(double) * ((size_t)((ring_in_lds ? 2 * ar_fit_ring_slots(m) : 0) + (AR_MAXDIM + 1) * AR_MAXDIM) * NM_BLOCK + (coop ? (size_t)2 * NM_BLOCK * 17 : 0));
+}
 // HBM scratch of a long period (doubles): the fit kernels' rings (one per resident wave), the forecast kernel's ring + expanded
 // polynomials and the prep kernel's seasonal figure (one per 64 series) -- the stages run one after the other and share it
 __host__ __device__ inline size_t ar_fc_scratch_doubles(int m) { return (size_t)(2 * ar_ring_slots(m) + 2 * (AR_MAXP + AR_MAXSP * m + 1)) * NM_BLOCK; }
@@ -207,7 +214,22 @@ struct ArBlockLen<0> { static constexpr int R = 0; static constexpr int value = 
 // before; 17 doubles of spill), and the M5 batch then takes 381 ms against 358 ms -- the pass issues fp64 operations 68 % of the time
 // already (tools/pmc_arima.sh), a second wave only adds its spill traffic.  ar_fit_waves / AR_MODE3_REVS = 2 / 1 rebuilds that variant.
 constexpr int AR_MODE3_REVS = 2;
-template <int MODE, int M>
+// COOP (fit kernels, where LDS has room): the rows of a block are fetched COOPERATIVELY.  The lanes of a fit wave hold unrelated
+// series, so "every lane streams its own row" makes each 128-bit load instruction touch 64 different cache lines: rocprofv3 showed the
+// sequential fit kernel waiting on memory 55 % of its time at 35 % VALU issue (profiles/r03_pmc_traffic_arima.json), the four-lanes-
+// per-problem kernel (16 distinct rows per wave) at 37 % / 55 % -- the address pipeline of the CU, not HBM (traffic is 1.1x the
+// algorithmic bytes), is what the scattered form saturates.  Cooperatively, one load instruction covers the block of 64 / (S / 2)
+// consecutive rows' S-step segments (for S = 28: four rows x 224 contiguous bytes = 18 lines instead of 64), the segments pass through
+// an LDS tile of 64 x (S / 2 + 1) 16-byte units (odd row stride: conflict-free 128-bit reads) and every lane reads its own row's
+// segment back into registers.  Same values, same arithmetic.
+template <int S_> struct ArCoop {
+    static constexpr int U = S_ / 2;                       // 16-byte units per row segment
+    static constexpr int RPI = NM_BLOCK / U;               // rows per load instruction
+    static constexpr int NI = (NM_BLOCK + RPI - 1) / RPI;  // load instructions per block
+    static constexpr int TS = (U % 2) ? U : U + 1;         // tile row stride in units
+    static constexpr int TILE_DOUBLES = 2 * NM_BLOCK * TS;
+};
+template <int MODE, int M, bool COOP = false>
 __device__ __noinline__ double ar_css_pass_impl(const double *wrow, int len, int wave_len_v, bool live, const ArFac &fin, int m_v,
                                                 const ArLds &L)
 {
@@ -246,9 +268,44 @@ __device__ __noinline__ double ar_css_pass_impl(const double *wrow, int len, int
     double er[RR], vr[RR];
 #pragma unroll
     for (int k = 0; k < RR; k++) { er[k] = 0.0; vr[k] = 0.0; }
-    ar_ev_t cur[S / 2], nxt[S / 2];
+    typedef ArCoop<S> CO;
+    ar_ev_t cur[S / 2], nxt[COOP ? CO::NI : S / 2];
+    // COOP: this lane loads unit `cu` of the segments of rows i * RPI + cr (i = 0 .. NI - 1); lanes past RPI * U and rows past 63
+    // repeat an in-range address and drop the value
+    typedef __attribute__((address_space(3))) ar_ev_t *tile_t;
+    const tile_t tile = (tile_t)(L.tile);
+    const int cr = (int)threadIdx.x / CO::U, cu = (int)threadIdx.x % CO::U;
+    gptr_t rowp[COOP ? CO::NI : 1];
+    if (COOP) {
+        // the row pointers of the rows this lane fetches from (wave shuffles of the 64-bit pointers, once per pass)
+        const unsigned long long mine = (unsigned long long)wrow;
 #pragma unroll
-    for (int j = 0; j < S / 2; j++) cur[j] = wp_next[j];
+        for (int i = 0; i < CO::NI; i++) {
+            int row = i * CO::RPI + cr;
+            row = row < NM_BLOCK ? row : NM_BLOCK - 1;
+            const unsigned lo = (unsigned)__shfl((int)(unsigned)(mine & 0xffffffffull), row);
+            const unsigned hi = (unsigned)__shfl((int)(unsigned)(mine >> 32), row);
+            rowp[i] = (gptr_t)(((unsigned long long)hi << 32) | lo) + cu;
+        }
+    }
+    auto coop_issue = [&](const int unit0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < CO::NI; i++) nxt[i] = rowp[i][unit0];
+    };
+    auto coop_commit = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < CO::NI; i++)
+            if (cr < CO::RPI && i * CO::RPI + cr < NM_BLOCK) tile[(i * CO::RPI + cr) * CO::TS + cu] = nxt[i];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < S / 2; j++) cur[j] = tile[(int)threadIdx.x * CO::TS + j];
+        __builtin_amdgcn_wave_barrier();
+    };
+    if (COOP) { coop_issue(0); coop_commit(); }
+    else {
+#pragma unroll
+        for (int j = 0; j < S / 2; j++) cur[j] = wp_next[j];
+    }
     wp_next += S / 2;
     // ring slots of t0, t0 - m, t0 - 2m (scalar, advanced by 4 per sub-block)
     int s0 = 0, s1 = (R - m % R) % R, s2 = (R - (2 * m) % R) % R;
@@ -335,13 +392,19 @@ __device__ __noinline__ double ar_css_pass_impl(const double *wrow, int len, int
     };
 
     for (int base = 0; base < wave_len; base += S) {
+        if (COOP) coop_issue((base + S) / 2);
+        else {
 #pragma unroll
-        for (int j = 0; j < S / 2; j++) nxt[j] = wp_next[j];
+            for (int j = 0; j < S / 2; j++) nxt[j] = wp_next[j];
+        }
         wp_next += S / 2;
         if (base >= nc_max && base + S <= len_min) block(base, std::false_type{});
         else block(base, std::true_type{});
+        if (COOP) coop_commit();
+        else {
 #pragma unroll
-        for (int j = 0; j < S / 2; j++) cur[j] = nxt[j];
+            for (int j = 0; j < S / 2; j++) cur[j] = nxt[j];
+        }
     }
     return css;
 }
@@ -754,6 +817,9 @@ __device__ __forceinline__ void ar_sort(const LT &L, FT &F, int D)
 // estimates (a.xbest) with steps of 0.1, run to convergence, write the estimates and their criterion back (oracle polish_css)
 // One instantiation per pass variant (MODE, M as in ar_css_pass_impl: the launch picks it from the period), so that a kernel carries
 // the registers of ITS pass only (see AR_MODE3_REVS for the two-waves-per-SIMD experiment).
+// the cooperative row loader needs an LDS tile (15-17 KB per wave): on where the ring is not in LDS -- the weekly period (registers),
+// no period (8 slots) and the long periods (HBM scratch); the LDS-ring periods keep per-lane row loads (the tile would halve their waves per CU)
+constexpr bool ar_fit_coop(int mode) { return mode == 3 || mode == 2 || mode == 5; }
 constexpr int ar_fit_waves(int mode) { return (mode == 3 && AR_MODE3_REVS == 1) ? 2 : 1; }
 template <int MODE, int M>
 __global__ __launch_bounds__(NM_BLOCK, ar_fit_waves(MODE)) void arima_fit_kernel(const ArimaArgs a, const ArWs ws, const int total, const int polish)
@@ -762,7 +828,8 @@ __global__ __launch_bounds__(NM_BLOCK, ar_fit_waves(MODE)) void arima_fit_kernel
     const int m = a.m;
     // MODE 3: both seasonal lags live in registers, MODE 5: in the wave's HBM scratch ring -- LDS holds the simplex only
     ArLds L{lds, MODE == 3 ? 0 : ar_fit_ring_slots(m), (int)threadIdx.x,
-            MODE == 5 ? a.long_scratch + (size_t)blockIdx.x * 2 * ar_fit_ring_slots(m) * NM_BLOCK : nullptr};
+            MODE == 5 ? a.long_scratch + (size_t)blockIdx.x * 2 * ar_fit_ring_slots(m) * NM_BLOCK : nullptr, nullptr};
+    if (ar_fit_coop(MODE)) L.tile = L.smp() + (size_t)(AR_MAXDIM + 1) * AR_MAXDIM * NM_BLOCK;
     ArFs F;
     for (int k = 0; k <= AR_MAXDIM; k++) F.v[k] = 0.0;
     // queue: dimension 6 first (longest fits first, so the tail of the launch is made of short ones)
@@ -838,7 +905,7 @@ __global__ __launch_bounds__(NM_BLOCK, ar_fit_waves(MODE)) void arima_fit_kernel
 
         // ---- 3. one streamed pass -------------------------------------------------------------------
         const int wave_len = ar_wave_max(fin ? 0 : len);
-        const double css = ar_css_pass_impl<MODE, M>(wrow, len, wave_len, !fin, fac, m, L);
+        const double css = ar_css_pass_impl<MODE, M, ar_fit_coop(MODE)>(wrow, len, wave_len, !fin, fac, m, L);
         if (fin) continue;
         passes++;
         const int nu = len - fac.nc;
@@ -911,7 +978,9 @@ __global__ __launch_bounds__(NM_BLOCK, ar_fit_waves(MODE)) void arima_fit_spec_k
     const int m = a.m;
     const int lane = threadIdx.x, g = lane & 3, leader = lane & ~3;
     ArLds L{lds, MODE == 3 ? 0 : ar_fit_ring_slots(m), leader,
-            MODE == 5 ? a.long_scratch + (size_t)blockIdx.x * 2 * ar_fit_ring_slots(m) * NM_BLOCK : nullptr};
+            MODE == 5 ? a.long_scratch + (size_t)blockIdx.x * 2 * ar_fit_ring_slots(m) * NM_BLOCK : nullptr, nullptr};
+    // (per-lane row loads here: the four lanes of a problem read the same row, 16 distinct rows per wave -- measured 173 ms with them
+    //  against 183 ms with the cooperative loader over the nine four-lane launches of the M5 batch; the sequential kernel 163 -> 132 ms)
     ArFs F;
     for (int k = 0; k <= AR_MAXDIM; k++) F.v[k] = 0.0;
     int qoff[8];
@@ -982,7 +1051,7 @@ __global__ __launch_bounds__(NM_BLOCK, ar_fit_waves(MODE)) void arima_fit_spec_k
         if (__all(fin)) break;
 
         const int wave_len = ar_wave_max(fin ? 0 : len);
-        const double css = ar_css_pass_impl<MODE, M>(wrow, len, wave_len, !fin, fac, m, L);
+        const double css = ar_css_pass_impl<MODE, M, false>(wrow, len, wave_len, !fin, fac, m, L);
         if (fin) continue;
         passes++;
         const int nu = len - fac.nc;
@@ -1056,7 +1125,7 @@ __global__ __launch_bounds__(NM_BLOCK) void arima_forecast_kernel(const ArimaArg
     const int m = a.m;
     // long period: ring and polynomials in the workgroup's HBM scratch
     double *const wg_scratch = a.long_scratch ? a.long_scratch + (size_t)blockIdx.x * ar_fc_scratch_doubles(m) : nullptr;
-    ArLds L{lds, ar_ring_slots(m), (int)threadIdx.x, wg_scratch};
+    ArLds L{lds, ar_ring_slots(m), (int)threadIdx.x, wg_scratch, nullptr};
     ArPolyLds PL{(wg_scratch ? wg_scratch : lds) + (size_t)2 * L.R * NM_BLOCK, AR_MAXP + AR_MAXSP * m + 1};
     const double *w = ws.W + (size_t)(valid ? s : 0) * ws.tw;
     const size_t ld = a.ld;
