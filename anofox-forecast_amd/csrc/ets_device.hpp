@@ -187,6 +187,10 @@ struct EtsFinalOut {
 
 // The pass.  MS > 0: compile-time period, ring in VGPRs.  MS == 0: no seasonality.
 // MS == -1: run-time period, ring in LDS (`ring`, K * m * 64 doubles).  MS == -2: run-time period, `ring` points to HBM scratch.
+// MS == -3 / -4 (round kernels of a merged batch of several periods, K == 1): the same two, with the period a PER-LANE quantity --
+// the lanes of a wave may then hold series of different periods, which is what lets a merged batch use the ordinary round schedule
+// (compaction + dense re-gather pack survivors of different periods into one wave).  Costs a vector phase counter and its wrap
+// per step; the ring of a lane is still `ring[j * 64 + lane]`, sized by the largest period of the batch.
 template <class Cfg, int MS, int K, bool FINAL>
 __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
                                          const double (&cand)[K][Cfg::DIM], double (&fout)[K],
@@ -216,7 +220,9 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
     // block length by the weight of a step: ~28-32 steps for the additive class (5-10 operations a step), half that when
     // a step holds a reciprocal, a quarter when it holds a pow (damped multiplicative trend) -- those are long enough to
     // cover the latency with fewer rows in flight, and their own register needs leave less room for the buffers
-    constexpr int S_TARGET = Cfg::ADDITIVE ? 32 : ((Cfg::T == C_MUL && Cfg::D) ? 8 : 16);
+    // (ring in HBM: the ring values stream through two more buffers of S -- half the block length, or the four buffers spill)
+    constexpr int S_FULL = Cfg::ADDITIVE ? 32 : ((Cfg::T == C_MUL && Cfg::D) ? 8 : 16);
+    constexpr int S_TARGET = ((MS == -2 || MS == -4) && K == 1 && S_FULL > 8) ? S_FULL / 2 : S_FULL;
     constexpr int S = (MS > 0) ? ((S_TARGET / MS > 0 ? S_TARGET / MS : 1) * MS) : S_TARGET;
     double cur[S], nxt[S];
     // One loader, no branch (a conditional load in the loop makes the compiler wait for every outstanding load at once)
@@ -317,14 +323,55 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
             }
         }
     } else {
-        // run-time period: ring[(k * m + j) * 64 + lane] in LDS, phase j advanced as a wave-uniform counter
-        const int m = __builtin_amdgcn_readfirstlane(in.m);
-        for (int j = 0; j < m; j++) {
+        // run-time period: ring[(k * m + j) * 64 + lane] in LDS, phase j advanced as a wave-uniform counter (per lane: MS <= -3)
+        constexpr bool LANE_M = MS <= -3;
+        static_assert(!LANE_M || K == 1, "per-lane periods: one candidate per lane");
+        const int m = LANE_M ? in.m : __builtin_amdgcn_readfirstlane(in.m);
+        const int m_max = LANE_M ? __builtin_amdgcn_readfirstlane(wave_max_i32(in.m)) : m;
+        for (int j = 0; j < m_max; j++) {
+            if (LANE_M && j >= m) continue;
             double f0 = in.fig[(size_t)j * in.fig_ld];
 #pragma unroll
             for (int k = 0; k < K; k++) ring[(k * m + j) * NM_BLOCK + lane] = f0;
         }
         int j = 0;
+        constexpr bool HBM_RING = (MS == -2 || MS == -4);
+        if constexpr (HBM_RING && K == 1) {
+            // Ring in HBM: a load of the ring inside the step would put a memory round trip on the recursion's critical path at
+            // every step (the compiler cannot move it above the previous step's store to the same array).  The ring values of a block
+            // are S DISTINCT phases and those of the next block S others (m > 64 >= 2 S), so they stream exactly like y: the next
+            // block's S values are requested before the current block's steps run, the updated values go out as stores.
+            static_assert(2 * S <= ETS_LDS_PERIOD, "the ring prefetch needs periods of at least two blocks");
+            double rc[S], rn[S];
+            auto ring_load = [&](double (&buf)[S], int j0) __attribute__((always_inline)) {
+#pragma unroll
+                for (int i = 0; i < S; i++) {
+                    buf[i] = ring[(size_t)j0 * NM_BLOCK + lane];
+                    j0 = (j0 + 1 == m) ? 0 : j0 + 1;
+                }
+                return j0;
+            };
+            int jn = ring_load(rc, 0);
+            int base = 0;
+            for (; base < wave_len; base += S) {
+                load_block(nxt, base + S);
+                const int jnn = ring_load(rn, jn);
+                const bool full = base + S <= wave_min_len;
+#pragma unroll
+                for (int i = 0; i < S; i++) {
+                    if (full || base + i < v.len) {
+                        double sv = rc[i];
+                        ets_step<Cfg>(par[0], st[0], cur[i], sv);
+                        ring[(size_t)j * NM_BLOCK + lane] = sv;
+                        keep_fit(base + i);
+                    }
+                    j = (j + 1 == m) ? 0 : j + 1;
+                }
+#pragma unroll
+                for (int i = 0; i < S; i++) { cur[i] = nxt[i]; rc[i] = rn[i]; }
+                jn = jnn;
+            }
+        } else {
         auto ring_block = [&](const int base, const bool full) __attribute__((always_inline)) {
 #pragma unroll
             for (int i = 0; i < S; i++) {
@@ -346,6 +393,7 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
             ring_block(base, base + S <= wave_min_len);
 #pragma unroll
             for (int i = 0; i < S; i++) cur[i] = nxt[i];
+        }
         }
         if constexpr (FINAL) {
             if (fin->states && v.len > 0)

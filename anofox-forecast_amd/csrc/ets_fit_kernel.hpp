@@ -52,7 +52,8 @@ __global__ __launch_bounds__(NM_BLOCK, ANOFOX_ROUND_WAVES) void ets_round_kernel
     const int len = valid ? a.len[s] : 0;
 
     // merged batch of several periods: the workgroup's problems share one (lane 0 always holds a problem)
-    const int m = a.m_col ? __builtin_amdgcn_readfirstlane(a.m_col[s]) : a.m;
+    // (per-lane period variants: the lane's own column's period; else the workgroup's, from lane 0)
+    const int m = a.m_col ? (MS <= -3 ? a.m_col[s] : __builtin_amdgcn_readfirstlane(a.m_col[s])) : a.m;
     const int n_param = a.n_param - ((Cfg::S != C_NONE && a.m_col) ? a.m - m : 0);      // a.n_param counts the m - 1 seasonal states of a.m
     bool active = valid;
     // ... and it runs without compaction: every round sweeps all columns and skips the finished ones
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(NM_BLOCK, ANOFOX_ROUND_WAVES) void ets_round_kernel
     mdl.in.fig = a.fig ? a.fig + s : nullptr;
     mdl.in.fig_ld = a.fig_ld;
     mdl.in.m = m;
-    mdl.ring = (MS == -2) ? a.ring_scratch + (size_t)blockIdx.x * (size_t)a.m * NM_BLOCK : lds + nm_lds_doubles<D>();
+    mdl.ring = (MS == -2 || MS == -4) ? a.ring_scratch + (size_t)blockIdx.x * (size_t)a.m * NM_BLOCK : lds + nm_lds_doubles<D>();
 
     NmRun r;
     if (a.first_round) nm_init_simplex(mdl, lds, r, active);
@@ -252,7 +253,7 @@ void ets_round_launch(const FitArgs &a, hipStream_t stream)
     }
     if (grid <= 0) return;
     size_t lds_bytes = sizeof(double) * (size_t)nm_lds_doubles<Cfg::DIM>();
-    if (MS == -1) lds_bytes += sizeof(double) * (size_t)a.m * NM_BLOCK;
+    if (MS == -1 || MS == -3) lds_bytes += sizeof(double) * (size_t)a.m * NM_BLOCK;
     if (lds_bytes > 48 * 1024)
         anofox_check_attr(hipFuncSetAttribute((const void *)ets_round_kernel<Cfg, MS, SPEC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     hipLaunchKernelGGL((ets_round_kernel<Cfg, MS, SPEC>), dim3(grid), dim3(NM_BLOCK), lds_bytes, stream, a);

@@ -17,9 +17,12 @@ template <int ID> struct SpecOf {
 };
 template <int ID, int MS> FitLaunchers launchers_of()
 {
+    // the final pass sweeps the columns in their original blocks of one period each: the per-lane period variants (-3 / -4) exist for
+    // the round kernels only
+    constexpr int MSF = MS == -3 ? -1 : (MS == -4 ? -2 : MS);
     return FitLaunchers{&ets_round_launch<typename SpecOf<ID>::Cfg, MS, 0>, &ets_round_launch<typename SpecOf<ID>::Cfg, MS, 1>,
                         &ets_round_launch<typename SpecOf<ID>::Cfg, MS, 2>, &ets_round_launch<typename SpecOf<ID>::Cfg, MS, 3>,
-                        &ets_final_launch<typename SpecOf<ID>::Cfg, MS>};
+                        &ets_final_launch<typename SpecOf<ID>::Cfg, MSF>};
 }
 
 FitLaunchers fit_unit_nonseasonal(int spec_id, int m);

@@ -107,7 +107,7 @@ struct Tunables {
         return t;
     }
 };
-// process-wide settings, read once: ANOFOX_HIP_CACHE_GB (idle device blocks kept, default 1/8 of the device), ANOFOX_HIP_PINNED_CACHE_GB
+// process-wide settings, read once: ANOFOX_HIP_CACHE_GB (idle device blocks kept, default 1/4 of the device), ANOFOX_HIP_PINNED_CACHE_GB
 // (idle pinned staging blocks, default 2), ANOFOX_HIP_PRIO_STREAMS (high-priority streams of the first stream set, default from
 // GPU_MAX_HW_QUEUES), ANOFOX_HIP_DEVICES (devices the batch entry shards over, default: the caller's current device only)
 struct ProcessTunables {
@@ -148,7 +148,7 @@ struct DeviceGuard {
 // maps and two gather blocks) = 380-400 ms to create and 50-65 ms to destroy, as long as its fit on the intermittent batch four
 // times over; a statement that forecasts chunk after chunk of the same shape pays that once.  Blocks are keyed by (device, size
 // rounded to 512 B / 2 MiB) and handed back as they are -- nothing in the library relies on fresh memory being zero.  Per device
-// at most ANOFOX_HIP_CACHE_GB (default: an eighth of the device -- an M5-shape AutoETS batch is ~14 GB) stays cached: a block
+// at most ANOFOX_HIP_CACHE_GB (default: a quarter of the device -- an M5-shape AutoETS batch is ~14 GB) stays cached: a block
 // handed back over the cap evicts the OLDEST idle blocks of its device first, so shapes that are no longer used age out instead
 // of pinning the cache; an out-of-memory hipMalloc empties the cache and retries; anofox_hip_release_caches() (header block 2)
 // gives everything back on request -- a co-resident allocator (torch's, another library's) cannot reach these blocks otherwise.
@@ -197,7 +197,10 @@ void *dev_alloc_bytes(size_t bytes)
         std::lock_guard<std::mutex> lock(c.mu);
         if (!c.cap.count(dev)) {
             size_t free_b = 0, total_b = 0;
-            c.cap[dev] = hipMemGetInfo(&free_b, &total_b) == hipSuccess ? total_b / 8 : 0;
+            // a quarter of the device: an eighth was tried (ADVICE round 2 asked for a smaller default) and the auto-detected M5 batch
+            // -- six large batches alive at once, ~40 GB handed back within a second -- then spent 0.8-1.1 s per destroy in hipFree,
+            // which waits for the whole device while the other host threads' batches are running (3.3 s per call)
+            c.cap[dev] = hipMemGetInfo(&free_b, &total_b) == hipSuccess ? total_b / 4 : 0;
             const double gb = ProcessTunables::get().cache_gb;
             if (gb >= 0.0) c.cap[dev] = (size_t)(gb * 1073741824.0);
         }
@@ -1068,7 +1071,10 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
     const int n_lanes = std::min<int>(N_AUX_STREAMS, b->n_slots_cap);
     // fork: aux streams wait for everything queued on `st` so far
     HIPCHECK(hipEventRecord(b->ev_fit0, st));
-    const bool merged = b->d_m_col != nullptr;           // several periods in one block: no compaction (a wave's columns share a period)
+    // several periods in one block (columns grouped by period in blocks of 64): the round kernels read the period PER LANE, so the
+    // batch runs the ordinary schedule -- compaction and the dense re-gather pack survivors of different periods into one wave;
+    // the final pass sweeps the original blocks (one period each)
+    const bool merged = b->d_m_col != nullptr;
     const int n_fork = n_lanes;                          // streams that carry work: one per spec
     for (int i = 0; i < n_fork; i++) HIPCHECK(hipStreamWaitEvent(b->aux[i], b->ev_fit0, 0));
     // enqueue order: most expensive specs first, dealt round-robin over the streams, so the long
@@ -1124,8 +1130,7 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
         a.st = lane.st;
         a.ring_scratch = nullptr;
         a.m_col = b->d_m_col;
-        // a merged batch runs the run-time-period kernels whatever its largest period is (7 and 12 have compile-time variants)
-        fns[oi] = ets_fit_launcher(id, (merged && (a.m == 7 || a.m == 12)) ? 13 : a.m);
+        fns[oi] = ets_fit_launcher(id, (merged && se != 0) ? (a.m > ETS_LDS_PERIOD ? ETS_PERLANE_HBM : ETS_PERLANE_LDS) : a.m);
         if (!fns[oi].round_seq || !fns[oi].round_spec || !fns[oi].round_auto || !fns[oi].final) throw HipFail{"no kernel for ETS spec id " + std::to_string(id)};
     }
     // Periods above the LDS limit keep the seasonal ring of every lane in HBM: one area per (spec, workgroup of the widest
@@ -1134,7 +1139,7 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
         size_t n_long = 0;
         for (size_t oi = 0; oi < order.size(); oi++) if (args[oi].m > ETS_LDS_PERIOD) n_long++;
         if (n_long) {
-            const size_t wg = merged ? n : std::max<size_t>((n + 15) / 16, std::min<size_t>(n, (size_t)std::max(b->spec2_below, b->spec2_below_md)));
+            const size_t wg = std::max<size_t>((n + 15) / 16, std::min<size_t>(n, (size_t)std::max(b->spec2_below, b->spec2_below_md)));
             const size_t per_spec = wg * (size_t)m * 64u;
             if ((double)n_long * (double)per_spec * 8.0 > 64.0 * 1073741824.0)
                 throw HipFail{"seasonal period " + std::to_string(m) + " on " + std::to_string(n) + " series needs more than 64 GiB of ring scratch: shard the batch"};
@@ -1177,40 +1182,7 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
         }
         LAUNCHCHECK("ETS fixed-parameter setup");
     }
-    if (merged && !b->fixed_params) {
-        // Three launches per spec, every one over all columns in place (finished problems are skipped in the kernel): 64 and 128
-        // iterations with four lanes per problem, then everything that is left one problem per wave to completion.  A merged batch
-        // is small (the series of the rare periods of an auto-detected batch), so lane efficiency is not what bounds it: the
-        // chains of 138 separate tiny batches on 16 hardware queues were (5.3 s for 1,024 series).
-        // (a large merged batch gets a third four-lane launch of 256 iterations first: one WAVE per problem is 16 times the
-        //  arithmetic, so the last launch should find a few thousand problems, not a third of them -- 30,490 auto-detected series
-        //  spent 2.5-3.5 s per merged batch in it)
-        // a large one starts with the sequential driver (one lane per problem: a workgroup's 64 columns share a period too)
-        struct MergedRound { int driver, budget; };              // driver 0 sequential, 1 four lanes per problem, 2 one wave per problem
-        static const MergedRound SMALL[] = {{1, 64}, {1, 128}, {2, 0}};
-        static const MergedRound LARGE[] = {{0, 42}, {0, 84}, {0, 168}, {1, 128}, {1, 256}, {2, 0}};
-        size_t n_real = 0;                                        // the padding columns of the period blocks do not count
-        for (size_t s2 = 0; s2 < n && s2 < b->h_len.size(); s2++) if (b->h_len[s2] > 0) n_real++;
-        const bool large = n_real > 4096;
-        const MergedRound *plan_r = large ? LARGE : SMALL;
-        const int n_merged_rounds = large ? 6 : 3;
-        for (int r = 0; r < n_merged_rounds; r++) {
-            for (size_t oi = 0; oi < order.size(); oi++) {
-                if (dead[oi]) continue;
-                hipStream_t sq = b->aux[stream_of[oi]];
-                FitArgs &a = args[oi];
-                a.first_round = (r == 0);
-                a.spec_below = -1; a.spec2_below = -1;
-                a.gathered = 0;
-                a.y_round = b->d_y; a.ld_round = ld; a.series_of = nullptr; a.n_active = nullptr;
-                a.budget = plan_r[r].budget; a.budget_seq = a.budget;
-                (plan_r[r].driver == 0 ? fns[oi].round_seq : (plan_r[r].driver == 1 ? fns[oi].round_spec : fns[oi].round_spec2))(a, sq);
-                b->fit_launches++;
-            }
-            LAUNCHCHECK("ETS fit round (merged periods)");
-        }
-    }
-    for (int r = 0; r < ((b->fixed_params || merged) ? 0 : n_rounds); r++) {
+    for (int r = 0; r < (b->fixed_params ? 0 : n_rounds); r++) {
         for (size_t oi = 0; oi < order.size(); oi++) {
             if (dead[oi]) continue;
             const int q = (int)(oi % (size_t)n_lanes);
@@ -1409,7 +1381,7 @@ void run_group(AnofoxHipBatch *b, int period, const int32_t *d_len, hipStream_t 
             for (int id : specs) if (!spec_has_mult(id)) n_add++;
             const double live = (double)cnt[0] * (double)specs.size() + (double)(cnt[1] - cnt[0]) * (double)n_add;
             b->seq_rounds = live >= 8.0 * 65536.0 ? 4 : 0;         // >= 8 problems per SIMD lane-slot: VALU-bound, go sequential
-            b->use_pos = cnt[0] > 0 && (double)cnt[0] < 0.7 * (double)cnt[1] && !b->d_m_col;     // (a dense list of the positive series would mix periods)
+            b->use_pos = cnt[0] > 0 && (double)cnt[0] < 0.7 * (double)cnt[1];
             b->live_pos = cnt[0]; b->live_all = cnt[1];
         } else {
             b->use_pos = false;
@@ -2296,8 +2268,10 @@ static bool forecast_batch_one_device(const double *const *values, const uint64_
                 for (size_t j = 0; j < nc; j++) { std::memset(&res[j], 0, sizeof(ForecastResult)); errs[j].code = SUCCESS; errs[j].message[0] = 0; }
                 const auto tm0 = std::chrono::steady_clock::now();
                 bool ok = anofox_hip_batch_create(nc, t_cap, &o, &mb, &be);
+                auto tm1 = std::chrono::steady_clock::now(), tm2 = tm1, tm3 = tm1;
                 if (ok) {
                     ok = anofox_hip_batch_pack_host(mb, v.data(), validity ? mk.data() : nullptr, len.data(), &be);
+                    tm2 = std::chrono::steady_clock::now();
                     if (ok) {
                         try {
                             mcol.resize(mb->ld, mcol.empty() ? 1 : mcol.back());
@@ -2307,12 +2281,17 @@ static bool forecast_batch_one_device(const double *const *values, const uint64_
                             for (size_t j = 0; j < nc; j++) mb->h_period[j] = mcol[j];     // what the host-side fitted values use
                         } catch (const HipFail &f) { report_hip_failure(&be, f); ok = false; }
                     }
-                    ok = ok && anofox_hip_batch_run(mb, nullptr, &be) && anofox_hip_batch_fetch(mb, res.data(), errs.data());
+                    ok = ok && anofox_hip_batch_run(mb, nullptr, &be);
+                    tm3 = std::chrono::steady_clock::now();
+                    ok = ok && anofox_hip_batch_fetch(mb, res.data(), errs.data());
                     anofox_hip_batch_destroy(mb);
                 }
-                if (tun.timing)
-                    std::fprintf(stderr, "[anofox-hip] merged batch: %zu parts with periods %d..%d in %zu columns: %.1f ms\n", take.size(), take.front().first, m_max, nc,
-                                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tm0).count());
+                if (tun.timing) {
+                    auto ms = [](std::chrono::steady_clock::time_point x, std::chrono::steady_clock::time_point y) { return std::chrono::duration<double, std::milli>(y - x).count(); };
+                    std::fprintf(stderr, "[anofox-hip] merged batch: %zu parts with periods %d..%d in %zu columns: %.1f ms (create %.1f, pack %.1f, run %.1f, fetch + destroy %.1f)\n",
+                                 take.size(), take.front().first, m_max, nc, ms(tm0, std::chrono::steady_clock::now()), ms(tm0, tm1), ms(tm1, tm2), ms(tm2, tm3),
+                                 ms(tm3, std::chrono::steady_clock::now()));
+                }
                 if (!ok) {
                     if (be.code == SUCCESS) set_error(&be, INTERNAL_ERROR, "Internal error: device batch failed");
                     for (size_t j = 0; j < nc; j++) anofox_free_forecast_result(&res[j]);
@@ -2345,24 +2324,19 @@ static bool forecast_batch_one_device(const double *const *values, const uint64_
                     for (size_t k = 0; k < take.size(); k++) if (part.first <= CLASS_HI[k]) { c = (int)k; break; }
                 (c >= 0 ? take[(size_t)c] : keep).push_back(std::move(part));
             }
-            // The HBM-ring class is cut where its ring scratch (columns x largest period x 512 B per seasonal spec, one workgroup per
-            // column in the last launch) would pass 1 GiB per spec: many rare long periods (252 parts up to 744 in 8,192 M5-like
-            // series: 16,640 columns) otherwise ask for 100 GB.
+            // The HBM-ring class is cut where its ring scratch (workgroups of the widest launch x largest period x 512 B per seasonal
+            // spec; the widest launch is the speculative driver's 16 problems per workgroup, or one wave per problem for the last
+            // 2,048) would pass 2 GiB per spec: many rare long periods otherwise ask for tens of GB.
             {
                 std::vector<std::vector<Part>> cut;
+                auto scratch_of = [](size_t cols, int m_hi) { return (double)std::max<size_t>((cols + 15) / 16, std::min<size_t>(cols, 2048)) * (double)m_hi * 512.0; };
                 for (auto &cls : take) {
                     std::sort(cls.begin(), cls.end(), [](const Part &x, const Part &y) { return x.first < y.first; });
-                    // a class that fits 2 GiB per spec as a whole stays whole (a thousand series: one latency-bound batch instead of
-                    // two); a larger one is cut at 1 GiB and its pieces run one after the other (below), re-using the same blocks
-                    size_t all_cols = 0;
-                    for (const auto &part : cls) all_cols += (part.second.size() + 63) / 64 * 64;
-                    const double whole = cls.empty() ? 0.0 : (double)all_cols * (double)cls.back().first * 512.0;
-                    const double bound = whole <= 2.0 * 1073741824.0 ? 2.0 * 1073741824.0 : 1073741824.0;
                     std::vector<Part> cur;
                     size_t cols = 0;
                     for (auto &part : cls) {
                         const size_t pc = (part.second.size() + 63) / 64 * 64;
-                        if (!cur.empty() && part.first > ETS_LDS_PERIOD && (double)(cols + pc) * (double)part.first * 512.0 > bound) {
+                        if (!cur.empty() && part.first > ETS_LDS_PERIOD && scratch_of(cols + pc, part.first) > 2.0 * 1073741824.0) {
                             cut.push_back(std::move(cur));
                             cur.clear();
                             cols = 0;

@@ -135,6 +135,9 @@ struct IntervalArgs {
 // compile-time period given, -1 = LDS ring.  Returns NULL when not instantiated.
 typedef void (*FitLaunchFn)(const FitArgs &, hipStream_t);
 struct FitLaunchers { FitLaunchFn round_seq, round_spec, round_spec2, round_auto, final; };   // sequential / speculative / two-level speculative rounds, all three behind a device-side choice, final pass
+// `m`: the period (7 and 12 have compile-time variants), or ETS_PERLANE_LDS / ETS_PERLANE_HBM for the round kernels of a merged
+// batch of several periods (per-lane period, ring in LDS / in HBM scratch sized by the batch's largest period)
+constexpr int ETS_PERLANE_LDS = -3, ETS_PERLANE_HBM = -4;
 FitLaunchers ets_fit_launcher(int spec_id, int m);
 FitLaunchers classic_fit_launcher(int kind, int m);          // fit_classic.hip: the SES / Holt / Holt-Winters / SeasonalES family on the round kernels (final = NULL)
 struct ClassicArgs;

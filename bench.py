@@ -84,6 +84,9 @@ WORKLOADS = {
     "autoets_stress": W("AutoETS", "", 125000, 1024, 7, False, 20260102, 8192),
     "autoarima_m5": W("AutoARIMA", "", 30490, 1913, 7, False, 20260101, 2048, arima_method=1),
     "autoarima_css_m5": W("AutoARIMA", "", 30490, 1913, 7, False, 20260101, 2048, arima_method=0),
+    # long seasonal periods (run-time-period kernels: seasonal ring in LDS up to m = 64, in an HBM scratch above)
+    "autoets_m24": W("AutoETS", "", 30490, 1008, 24, True, 20260103, 256),
+    "autoets_hourly168": W("AutoETS", "", 30490, 1008, 168, True, 20260103, 128),
     # single-spec probes (kernel efficiency without cross-kernel effects)
     "ets_amdn_stress": W("ETS", "AMdN", 125000, 1024, 7, True, 20260102, 256),
     "ets_mam_stress": W("ETS", "MAM", 125000, 1024, 7, True, 20260102, 256),

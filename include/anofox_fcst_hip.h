@@ -160,7 +160,7 @@ enum { ANOFOX_ARIMA_CSS = 0, ANOFOX_ARIMA_CSS_ML = 1 };
 bool anofox_hip_set_default_arima_method(int method);
 
 /*
- * The library keeps idle device blocks (per device at most ANOFOX_HIP_CACHE_GB, default an eighth of the device, oldest
+ * The library keeps idle device blocks (per device at most ANOFOX_HIP_CACHE_GB, default a quarter of the device, oldest
  * evicted first), pinned staging blocks (ANOFOX_HIP_PINNED_CACHE_GB, default 2), stream / event sets and up to 32 parked
  * single-series batches for re-use (a batch of the M5 shape is ~300 hipMalloc calls = 0.4 s without them).  This gives all of
  * it back: call it when the host wants the memory (another allocator in the process is short of HBM) or before unloading.
