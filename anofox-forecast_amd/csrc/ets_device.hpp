@@ -27,6 +27,7 @@ constexpr double ETS_TOL = 1.0e-10;
 constexpr double ETS_HUGEN = 1.0e10;
 constexpr double ETS_LN2 = 0.693147180559945309417232121458;
 constexpr double PAR_LO = 1.0e-4, PAR_HI = 0.9999, PHI_LO = 0.8, PHI_HI = 0.98;
+constexpr int ETS_MERGED_LDS_PERIOD = 16;   // ... of a merged batch of several periods: its LDS ring is sized by the largest period for EVERY wave
 constexpr int ETS_LDS_PERIOD = 64;      // run-time periods up to this keep the seasonal ring in LDS (MS == -1); longer ones
                                         // (weekly 52 fits, hourly 168, yearly-on-daily 365 do not) keep it in an HBM scratch
                                         // area of the wave (MS == -2: same code, the ring pointer is a global one)
@@ -222,7 +223,8 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
     // cover the latency with fewer rows in flight, and their own register needs leave less room for the buffers
     // (ring in HBM: the ring values stream through two more buffers of S -- half the block length, or the four buffers spill)
     constexpr int S_FULL = Cfg::ADDITIVE ? 32 : ((Cfg::T == C_MUL && Cfg::D) ? 8 : 16);
-    constexpr int S_TARGET = ((MS == -2 || MS == -4) && K == 1 && S_FULL > 8) ? S_FULL / 2 : S_FULL;
+    //  and at most 8 -- the ring prefetch needs periods of two blocks, a merged batch keeps periods from 17 up in HBM)
+    constexpr int S_TARGET = ((MS == -2 || MS == -4) && K == 1 && S_FULL > 8) ? 8 : S_FULL;
     constexpr int S = (MS > 0) ? ((S_TARGET / MS > 0 ? S_TARGET / MS : 1) * MS) : S_TARGET;
     double cur[S], nxt[S];
     // One loader, no branch (a conditional load in the loop makes the compiler wait for every outstanding load at once)
@@ -339,9 +341,9 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
         if constexpr (HBM_RING && K == 1) {
             // Ring in HBM: a load of the ring inside the step would put a memory round trip on the recursion's critical path at
             // every step (the compiler cannot move it above the previous step's store to the same array).  The ring values of a block
-            // are S DISTINCT phases and those of the next block S others (m > 64 >= 2 S), so they stream exactly like y: the next
+            // are S DISTINCT phases and those of the next block S others (m > 16 >= 2 S), so they stream exactly like y: the next
             // block's S values are requested before the current block's steps run, the updated values go out as stores.
-            static_assert(2 * S <= ETS_LDS_PERIOD, "the ring prefetch needs periods of at least two blocks");
+            static_assert(2 * S <= ETS_MERGED_LDS_PERIOD, "the ring prefetch needs periods of at least two blocks");
             double rc[S], rn[S];
             auto ring_load = [&](double (&buf)[S], int j0) __attribute__((always_inline)) {
 #pragma unroll

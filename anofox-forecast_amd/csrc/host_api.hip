@@ -161,8 +161,48 @@ struct DevCache {
     std::unordered_map<void *, std::pair<int, size_t>> live;
     std::map<int, size_t> idle_bytes, cap;                             // per device
     uint64_t next_age = 0;
+    int defer = 0;                                                     // > 0: evicted blocks wait in `deferred` (EvictionDeferral below)
+    std::vector<void *> deferred;
 };
 DevCache &dev_cache() { static DevCache *c = new DevCache; return *c; }     // never destroyed: no HIP calls at process exit
+
+// hipFree waits for the whole device.  A call that keeps several batches running from several host threads (auto-detected periods:
+// the merged batches beside the per-period ones) would stall a finishing thread in its evictions for as long as the other threads'
+// kernels run -- 0.5-1.1 s per destroy measured -- so inside such a call evicted blocks are parked and freed when the call ends
+// (nothing is running then), or when an allocation needs the memory.
+void dev_cache_free_blocks(std::vector<void *> &drop)
+{
+    if (drop.empty()) return;
+    DevCache &c = dev_cache();
+    {
+        std::lock_guard<std::mutex> lock(c.mu);
+        if (c.defer > 0) { c.deferred.insert(c.deferred.end(), drop.begin(), drop.end()); drop.clear(); return; }
+    }
+    for (void *q : drop) (void)hipFree(q);
+    drop.clear();
+}
+void dev_cache_flush_deferred()
+{
+    DevCache &c = dev_cache();
+    std::vector<void *> drop;
+    {
+        std::lock_guard<std::mutex> lock(c.mu);
+        drop.swap(c.deferred);
+    }
+    for (void *q : drop) (void)hipFree(q);
+}
+struct EvictionDeferral {
+    EvictionDeferral() { DevCache &c = dev_cache(); std::lock_guard<std::mutex> lock(c.mu); c.defer++; }
+    ~EvictionDeferral()
+    {
+        DevCache &c = dev_cache();
+        bool last;
+        { std::lock_guard<std::mutex> lock(c.mu); last = --c.defer == 0; }
+        if (last) dev_cache_flush_deferred();
+    }
+    EvictionDeferral(const EvictionDeferral &) = delete;
+    EvictionDeferral &operator=(const EvictionDeferral &) = delete;
+};
 
 size_t dev_round(size_t bytes)
 {
@@ -226,6 +266,7 @@ void *dev_alloc_bytes(size_t bytes)
             dev_cache_evict_locked(c, dev, SIZE_MAX, drop);
         }
         for (void *q : drop) (void)hipFree(q);
+        dev_cache_flush_deferred();
         err = hipMalloc(&p, sz);
     }
     HIPCHECK(err);
@@ -267,8 +308,8 @@ void dev_free(void *p, bool quiesced = false)
             cached = true;
         }
     }
-    for (void *q : drop) (void)hipFree(q);
-    if (!cached) (void)hipFree(p);
+    if (!cached) drop.push_back(p);
+    dev_cache_free_blocks(drop);
 }
 
 void dev_cache_release_all()
@@ -282,6 +323,7 @@ void dev_cache_release_all()
         for (auto &kv : c.idle_bytes) kv.second = 0;
     }
     for (void *q : drop) (void)hipFree(q);
+    dev_cache_flush_deferred();
 }
 
 template <class T> T *dalloc(size_t n) { return (T *)dev_alloc_bytes(std::max<size_t>(n, 1) * sizeof(T)); }
@@ -484,6 +526,7 @@ struct AnofoxHipBatch {
     int32_t *d_len = nullptr;          // lengths with unusable series zeroed
     bool owns_len = false;
     std::vector<int32_t> h_len;        // true lengths
+    bool quiesced = true;              // nothing of this batch is in flight (set by the fetch's wait, cleared by a run): destroy need not wait
     std::vector<int32_t> h_period;     // per-series period
     std::vector<int32_t> h_base_status;
     std::vector<int32_t> h_seed_status;  // what d_status is seeded with: base status, usable series = STATUS_NOT_COMPUTED
@@ -673,32 +716,6 @@ void fill_nulls_interpolate(const double *values, const uint64_t *validity, size
     }
 }
 
-// seasonality.rs:323-377: first (strongest) ACF peak or 0
-int detect_seasonality_first(const double *v, size_t n)
-{
-    if (n < 4) return 0;
-    size_t max_lag = n / 2;
-    if (max_lag < 2) return 0;
-    double mean = 0.0;
-    for (size_t i = 0; i < n; i++) mean += v[i];
-    mean /= (double)n;
-    double var = 0.0;
-    for (size_t i = 0; i < n; i++) { double d = v[i] - mean; var += d * d; }
-    if (std::fabs(var) < 2.220446049250313e-16) return 0;
-    std::vector<double> acf(max_lag);
-    for (size_t lag = 1; lag <= max_lag; lag++) {
-        double s = 0.0;
-        for (size_t i = 0; i < n - lag; i++) s += (v[i] - mean) * (v[i + lag] - mean);
-        acf[lag - 1] = s / var;
-    }
-    int best = 0;
-    double best_acf = 0.0;
-    for (size_t i = 1; i + 1 < max_lag; i++)
-        if (acf[i] > acf[i - 1] && acf[i] > acf[i + 1] && acf[i] > 0.1)
-            if (best == 0 || acf[i] > best_acf) { best = (int)(i + 1); best_acf = acf[i]; }
-    return best;
-}
-
 // a batch borrows its streams and events from the process-wide pool (and hands them back while it is parked, see pool_give)
 void batch_attach_streams(AnofoxHipBatch *b)
 {
@@ -850,6 +867,111 @@ double *ensure_prep_scratch(AnofoxHipBatch *b, size_t elems)
     return b->d_prep_scratch;
 }
 
+// Seasonal periods of the columns of a resident time-major block (kernels.hip detect_period_kernel): 0 = no autocorrelation peak.
+void detect_periods_block(const double *d_y, size_t ld, const int32_t *d_len, size_t n, size_t t_rows, int32_t *h_out, hipStream_t st)
+{
+    if (n == 0) return;
+    int32_t *d_per = dalloc<int32_t>(n);
+    const size_t sc = detect_scratch_doubles((int)n, (int)t_rows);
+    double *d_sc = sc ? dalloc<double>(sc) : nullptr;
+    try {
+        launch_detect_periods(d_y, ld, d_len, (int)n, (int)t_rows, d_sc, d_per, nullptr, st);
+        LAUNCHCHECK("seasonal period detection");
+        HIPCHECK(hipMemcpyAsync(h_out, d_per, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIPCHECK(hipStreamSynchronize(st));
+    } catch (...) { dev_free(d_per); dev_free(d_sc); throw; }
+    dev_free(d_per, true);
+    dev_free(d_sc, true);
+}
+
+// ... of host series (the batch entry with params := MAP{}, before the batch is split by period): packed 64 series per tile into
+// pinned blocks of ~128 MB, two in flight, so that the packer threads work on one block while the other is copied and scanned
+std::vector<int> detect_periods_host_series(const double *const *values, const uint64_t *const *validity, const size_t *lengths, size_t n_series)
+{
+    std::vector<int> out(n_series, 0);
+    size_t t_all = 0;
+    for (size_t s = 0; s < n_series; s++) t_all = std::max(t_all, lengths[s]);
+    if (t_all < 4 || n_series == 0) return out;
+    const size_t n_pad = (n_series + 63) / 64 * 64;
+    const size_t cols = std::min(n_pad, std::max<size_t>(64, (size_t)(134217728.0 / (8.0 * (double)t_all)) / 64 * 64));
+    struct Buf { double *h = nullptr, *d = nullptr, *sc = nullptr; int32_t *h_len = nullptr, *d_len = nullptr, *h_per = nullptr, *d_per = nullptr;
+                 size_t s0 = 0, cnt = 0; bool busy = false; } buf[2];
+    hipStream_t st = nullptr;
+    auto release = [&]() {
+        if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+        for (auto &b : buf) { pin_free(b.h); pin_free(b.h_len); dev_free(b.d, true); dev_free(b.sc, true); dev_free(b.d_len, true); dev_free(b.d_per, true); }
+    };
+    try {
+        HIPCHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        const size_t n_chunks = (n_series + cols - 1) / cols;
+        for (int k = 0; k < (n_chunks > 1 ? 2 : 1); k++) {
+            buf[k].h = (double *)pin_alloc_bytes(t_all * cols * sizeof(double));
+            buf[k].h_len = (int32_t *)pin_alloc_bytes(2 * cols * sizeof(int32_t));
+            buf[k].h_per = buf[k].h_len + cols;
+            buf[k].d = dalloc<double>(t_all * cols);
+            buf[k].d_len = dalloc<int32_t>(cols);
+            buf[k].d_per = dalloc<int32_t>(cols);
+            const size_t sc = detect_scratch_doubles((int)cols, (int)t_all);
+            if (sc) buf[k].sc = dalloc<double>(sc);
+        }
+        auto collect = [&](Buf &b) {
+            if (!b.busy) return;
+            HIPCHECK(hipStreamSynchronize(st));                   // (one stream: everything queued so far, i.e. this block's copy back)
+            for (size_t j = 0; j < b.cnt; j++) out[b.s0 + j] = b.h_per[j];
+            b.busy = false;
+        };
+        unsigned n_thr = std::max(1u, std::min(std::thread::hardware_concurrency(), 32u));
+        if (tl_host_thread_share > 1) n_thr = std::max(1u, n_thr / tl_host_thread_share);
+        for (size_t ck = 0; ck < n_chunks; ck++) {
+            Buf &b = buf[ck & 1];
+            collect(b);
+            b.s0 = ck * cols;
+            b.cnt = std::min(cols, n_series - b.s0);
+            size_t T = 0;
+            for (size_t j = 0; j < b.cnt; j++) T = std::max(T, lengths[b.s0 + j]);
+            T = std::max<size_t>(T, 1);
+            const size_t ld = (b.cnt + 63) / 64 * 64, n_tiles = ld / 64;
+            auto do_tiles = [&](size_t tile0, size_t tile1) {
+                std::vector<double> clean(64 * T);
+                for (size_t tile = tile0; tile < tile1; tile++) {
+                    size_t len_of[64];
+                    for (size_t j = 0; j < 64; j++) {
+                        const size_t c = tile * 64 + j;
+                        const size_t len = c < b.cnt ? lengths[b.s0 + c] : 0;
+                        len_of[j] = len;
+                        if (len) fill_nulls_interpolate(values[b.s0 + c], validity ? validity[b.s0 + c] : nullptr, len, clean.data() + j * T);
+                        b.h_len[c] = len >= 3 ? (int32_t)len : 0;
+                    }
+                    for (size_t t = 0; t < T; t++) {
+                        double *row = b.h + t * ld + tile * 64;
+                        for (size_t j = 0; j < 64; j++) row[j] = t < len_of[j] ? clean[j * T + t] : 0.0;
+                    }
+                }
+            };
+            const unsigned thr = (unsigned)std::min<size_t>(n_thr, n_tiles);
+            if (thr <= 1) do_tiles(0, n_tiles);
+            else {
+                std::vector<std::thread> pool;
+                std::atomic<bool> failed{false};
+                for (unsigned k = 0; k < thr; k++)
+                    pool.emplace_back([&, k] { try { do_tiles(n_tiles * k / thr, n_tiles * (k + 1) / thr); } catch (...) { failed = true; } });
+                for (auto &th : pool) th.join();
+                if (failed) throw HipFail{"period detection: packer thread failed (out of host memory)", true};
+            }
+            HIPCHECK(hipMemcpyAsync(b.d, b.h, T * ld * sizeof(double), hipMemcpyHostToDevice, st));
+            HIPCHECK(hipMemcpyAsync(b.d_len, b.h_len, ld * sizeof(int32_t), hipMemcpyHostToDevice, st));
+            launch_detect_periods(b.d, ld, b.d_len, (int)b.cnt, (int)T, b.sc, b.d_per, nullptr, st);
+            LAUNCHCHECK("seasonal period detection");
+            HIPCHECK(hipMemcpyAsync(b.h_per, b.d_per, b.cnt * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            b.busy = true;
+        }
+        collect(buf[0]);
+        collect(buf[1]);
+    } catch (...) { release(); throw; }
+    release();
+    return out;
+}
+
 // Series that cannot be forecast at all (forecast.rs:516-525) and per-series periods.
 void finalize_lengths(AnofoxHipBatch *b)
 {
@@ -862,6 +984,16 @@ void finalize_lengths(AnofoxHipBatch *b)
     }
     if (!b->d_len) { b->d_len = dalloc<int32_t>(b->ld); b->owns_len = true; }
     HIPCHECK(hipMemcpy(b->d_len, eff.data(), b->ld * sizeof(int32_t), hipMemcpyHostToDevice));
+}
+
+// auto-detected periods of a batch's own block (after finalize_lengths: series shorter than three observations read as empty)
+void batch_detect_periods(AnofoxHipBatch *b)
+{
+    std::vector<int32_t> per(b->n, 0);
+    batch_attach_streams(b);
+    detect_periods_block(b->d_y, b->ld, b->d_len, b->n, std::max<size_t>(b->t_max, 1), per.data(), b->own_stream);
+    b->h_period.assign(b->n, 1);
+    for (size_t s = 0; s < b->n; s++) b->h_period[s] = per[s] > 0 ? per[s] : 1;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1075,6 +1207,7 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
     // batch runs the ordinary schedule -- compaction and the dense re-gather pack survivors of different periods into one wave;
     // the final pass sweeps the original blocks (one period each)
     const bool merged = b->d_m_col != nullptr;
+    const int lds_limit = merged ? ETS_MERGED_LDS_PERIOD : ETS_LDS_PERIOD;      // largest period whose seasonal ring stays in LDS
     const int n_fork = n_lanes;                          // streams that carry work: one per spec
     for (int i = 0; i < n_fork; i++) HIPCHECK(hipStreamWaitEvent(b->aux[i], b->ev_fit0, 0));
     // enqueue order: most expensive specs first, dealt round-robin over the streams, so the long
@@ -1130,14 +1263,14 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
         a.st = lane.st;
         a.ring_scratch = nullptr;
         a.m_col = b->d_m_col;
-        fns[oi] = ets_fit_launcher(id, (merged && se != 0) ? (a.m > ETS_LDS_PERIOD ? ETS_PERLANE_HBM : ETS_PERLANE_LDS) : a.m);
+        fns[oi] = ets_fit_launcher(id, (merged && se != 0) ? (a.m > lds_limit ? ETS_PERLANE_HBM : ETS_PERLANE_LDS) : a.m);
         if (!fns[oi].round_seq || !fns[oi].round_spec || !fns[oi].round_auto || !fns[oi].final) throw HipFail{"no kernel for ETS spec id " + std::to_string(id)};
     }
     // Periods above the LDS limit keep the seasonal ring of every lane in HBM: one area per (spec, workgroup of the widest
     // launch = the speculative driver's 16 problems per workgroup)
     {
         size_t n_long = 0;
-        for (size_t oi = 0; oi < order.size(); oi++) if (args[oi].m > ETS_LDS_PERIOD) n_long++;
+        for (size_t oi = 0; oi < order.size(); oi++) if (args[oi].m > lds_limit) n_long++;
         if (n_long) {
             const size_t wg = std::max<size_t>((n + 15) / 16, std::min<size_t>(n, (size_t)std::max(b->spec2_below, b->spec2_below_md)));
             const size_t per_spec = wg * (size_t)m * 64u;
@@ -1145,7 +1278,7 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
                 throw HipFail{"seasonal period " + std::to_string(m) + " on " + std::to_string(n) + " series needs more than 64 GiB of ring scratch: shard the batch"};
             double *base = ensure_ring(b, n_long * per_spec);
             size_t k = 0;
-            for (size_t oi = 0; oi < order.size(); oi++) if (args[oi].m > ETS_LDS_PERIOD) args[oi].ring_scratch = base + (k++) * per_spec;
+            for (size_t oi = 0; oi < order.size(); oi++) if (args[oi].m > lds_limit) args[oi].ring_scratch = base + (k++) * per_spec;
         }
     }
     // Round-major submission: round r of every spec is enqueued before round r+1 of any, each spec on its
@@ -1273,7 +1406,11 @@ void run_group(AnofoxHipBatch *b, int period, const int32_t *d_len, hipStream_t 
         if (states) {
             if (m >= 2) ensure_fig(b, m);
             a.fig_add = b->d_fig_add; a.fig_mul = b->d_fig_mul; a.l0 = b->d_l0; a.b0 = b->d_b0;
-            if (m > ETS_LDS_PERIOD) a.scratch = ensure_prep_scratch(b, (size_t)((n + 63) / 64) * (size_t)((2 * (m / 2) + 1) + 3 * m) * 64u);
+            a.t_rows = (int)std::max<size_t>(b->t_max, 1);
+            if (m > ETS_LDS_PERIOD) {
+                const size_t sc = season_scratch_doubles((int)n, a.t_rows, m);
+                if (sc) a.scratch = ensure_prep_scratch(b, sc);
+            }
         }
         launch_prep(a, st);
     };
@@ -1450,6 +1587,8 @@ void run_batch(AnofoxHipBatch *b, hipStream_t st)
     b->n_problems = 0;
     b->timed_fit = false;
     b->insp_ok = false;
+    b->quiesced = false;         // (from here on, also when a launch below fails)
+    b->last_stream = st;
     HIPCHECK(hipEventRecord(b->ev_start, st));
     // usable series start as "not computed" and only a kernel turns that into success; the forecasts start as NaN
     b->h_seed_status.resize(n);
@@ -1504,6 +1643,7 @@ void run_batch(AnofoxHipBatch *b, hipStream_t st)
     HIPCHECK(hipEventRecord(b->ev_stop, st));
     b->last_stream = st;
     b->ran = true;
+    b->quiesced = false;
 }
 
 std::string series_error_message(const AnofoxHipBatch *b, size_t s, int code, int detail)
@@ -1705,15 +1845,37 @@ void anofox_hip_batch_destroy(AnofoxHipBatch *b)
     if (!b) return;
     DeviceGuard guard(b->dev);
     // wait for this batch's own work only (other batches may be running from other host threads)
-    if (b->last_stream) (void)hipStreamSynchronize(b->last_stream);
-    if (b->own_stream) (void)hipStreamSynchronize(b->own_stream);
-    for (auto &q : b->aux) if (q) (void)hipStreamSynchronize(q);
+    const bool timing = b->tun.timing;
+    const auto t0 = std::chrono::steady_clock::now();
+    // (a wait on an idle stream is not free either: with more streams than hardware queues it queues behind whatever other
+    //  batches run on the shared queue -- 200-550 ms per destroy measured beside two running batches -- so a batch whose last run
+    //  has been waited for skips them: its auxiliary streams had joined the run's stream before that wait returned)
+    if (!b->quiesced) {
+        if (b->last_stream) (void)hipStreamSynchronize(b->last_stream);
+        if (b->own_stream) (void)hipStreamSynchronize(b->own_stream);
+        for (auto &q : b->aux) if (q) (void)hipStreamSynchronize(q);
+    }
+    const auto t1 = std::chrono::steady_clock::now();
+    const size_t n = b->n;
     free_batch_buffers(b);
     delete b;
+    if (timing) {
+        const auto t2 = std::chrono::steady_clock::now();
+        if (std::chrono::duration<double, std::milli>(t2 - t0).count() > 20.0)
+            std::fprintf(stderr, "[anofox-hip] destroy of a batch of %zu: stream waits %.1f ms, buffers %.1f ms\n", n,
+                         std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t2 - t1).count());
+    }
 }
 
 size_t anofox_hip_batch_ld(const AnofoxHipBatch *b) { return b ? b->ld : 0; }
 size_t anofox_hip_batch_n_series(const AnofoxHipBatch *b) { return b ? b->n : 0; }
+
+bool anofox_hip_batch_periods(const AnofoxHipBatch *b, int32_t *out_periods)
+{
+    if (!b || !out_periods || !b->has_block || b->h_period.size() < b->n) return false;
+    for (size_t s = 0; s < b->n; s++) out_periods[s] = b->h_period[s];
+    return true;
+}
 
 bool anofox_hip_batch_set_fixed_params(AnofoxHipBatch *b, double alpha, double beta, double gamma, double phi, AnofoxError *out_error)
 {
@@ -1788,10 +1950,7 @@ bool anofox_hip_batch_pack_host(AnofoxHipBatch *b, const double *const *values, 
                     if (len) fill_nulls_interpolate(values[s], validity ? validity[s] : nullptr, len, c);
                     if (s < n) {
                         b->h_len[s] = (int32_t)len;
-                        int period = 1;
-                        if (detect) { int p = len >= 3 ? detect_seasonality_first(c, len) : 0; period = p > 0 ? p : 1; }
-                        else if (b->opt.seasonal_period > 0) period = b->opt.seasonal_period;
-                        b->h_period[s] = period;
+                        b->h_period[s] = (!detect && b->opt.seasonal_period > 0) ? b->opt.seasonal_period : 1;      // (detected periods: below, on the device)
                         if (keep && len) std::memcpy(b->h_clean.data() + b->h_clean_off[s], c, len * sizeof(double));
                     }
                 }
@@ -1821,6 +1980,7 @@ bool anofox_hip_batch_pack_host(AnofoxHipBatch *b, const double *const *values, 
         if (!b->d_y || !b->owns_y) { b->d_y = dalloc<double>(T * ld); b->owns_y = true; }
         HIPCHECK(hipMemcpy(b->d_y, block, T * ld * sizeof(double), hipMemcpyHostToDevice));
         finalize_lengths(b);
+        if (detect) batch_detect_periods(b);
         b->has_block = true;
     } catch (const HipFail &f) {
         report_hip_failure(out_error, f);
@@ -1836,11 +1996,6 @@ bool anofox_hip_batch_set_device_block(AnofoxHipBatch *b, const void *d_y, size_
 {
     if (!b || !d_y || !d_len) { set_error(out_error, NULL_POINTER, "Null pointer argument"); return false; }
     if (ld != b->ld) { set_error(out_error, INVALID_INPUT, "Invalid input: leading dimension must equal anofox_hip_batch_ld()"); return false; }
-    if (b->opt.auto_detect_seasonality && b->opt.seasonal_period == 0 && b->plan.model != M_Naive) {
-        // period detection runs in the host packer; a resident block must name its period
-        set_error(out_error, INVALID_INPUT, "Invalid input: a device-resident block requires an explicit seasonal_period");
-        return false;
-    }
     DeviceGuard guard(b->dev);
     try {
         if (b->owns_y && b->d_y) { dev_free(b->d_y); }
@@ -1850,6 +2005,7 @@ bool anofox_hip_batch_set_device_block(AnofoxHipBatch *b, const void *d_y, size_
         HIPCHECK(hipMemcpy(b->h_len.data(), d_len, b->n * sizeof(int32_t), hipMemcpyDeviceToHost));
         b->h_period.assign(b->n, b->opt.seasonal_period > 0 ? b->opt.seasonal_period : 1);
         finalize_lengths(b);
+        if (b->opt.auto_detect_seasonality && b->opt.seasonal_period == 0) batch_detect_periods(b);      // the block holds no NULLs: nothing to interpolate
         b->has_block = true;
     } catch (const HipFail &f) {
         report_hip_failure(out_error, f);
@@ -1934,6 +2090,7 @@ bool anofox_hip_batch_fetch(AnofoxHipBatch *b, ForecastResult *out_results, Anof
     DeviceGuard guard(b->dev);
     const size_t n = b->n, h = (size_t)std::max(b->h, 0);
     if (hipStreamSynchronize(b->last_stream) != hipSuccess) return false;
+    b->quiesced = true;
     std::vector<double> yhat(n * h), lo(n * h), hi(n * h);
     std::vector<int32_t> status(n), code(n), detail(n);
     bool ok = true;
@@ -2012,6 +2169,7 @@ bool anofox_hip_batch_inspect(AnofoxHipBatch *b, AnofoxHipInspection *out, doubl
     const size_t n = b->n, ld = b->ld, T = std::max<size_t>(b->t_max, 1);
     try {
         HIPCHECK(hipStreamSynchronize(b->last_stream));
+        b->quiesced = false;             // the inspection passes below run on the auxiliary streams
         std::vector<int32_t> code(n), status(n);
         HIPCHECK(hipMemcpy(code.data(), b->d_model_code, n * sizeof(int32_t), hipMemcpyDeviceToHost));
         HIPCHECK(hipMemcpy(status.data(), b->d_status, n * sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -2159,6 +2317,7 @@ static bool forecast_batch_one_device(const double *const *values, const uint64_
     if (!detect || !make_plan(options, plan, &pe))
         return forecast_batch_uniform(values, validity, lengths, n_series, options, horizons, out_results, out_errors, out_batch_error);
     try {
+        EvictionDeferral park_evictions;                 // several batches run side by side below
         auto used_period = [&](int period) {
             switch (plan.model) {
             case M_Naive: case M_RandomWalkDrift: case M_ARIMA: case M_SES: case M_SESOptimized: case M_Holt: return 1;
@@ -2168,26 +2327,12 @@ static bool forecast_batch_one_device(const double *const *values, const uint64_
         };
         std::vector<int> period(n_series, 1);
         {
-            std::atomic<size_t> next{0};
-            std::atomic<bool> failed{false};
-            auto work = [&]() {
-                try {                                   // nothing may leave a worker thread
-                    std::vector<double> clean;
-                    for (size_t s = next.fetch_add(1); s < n_series; s = next.fetch_add(1)) {
-                        if (lengths[s] < 3) continue;
-                        clean.resize(lengths[s]);
-                        fill_nulls_interpolate(values[s], validity ? validity[s] : nullptr, lengths[s], clean.data());
-                        const int p = detect_seasonality_first(clean.data(), lengths[s]);
-                        period[s] = used_period(p > 0 ? p : 1);
-                    }
-                } catch (...) { failed = true; }
-            };
-            unsigned n_thr = std::max(1u, std::min({std::thread::hardware_concurrency(), 32u, (unsigned)((n_series + 15) / 16)}));
-            std::vector<std::thread> pool;
-            for (unsigned i = 1; i < n_thr; i++) pool.emplace_back(work);
-            work();
-            for (auto &t : pool) t.join();
-            if (failed) throw std::runtime_error("period detection failed (out of host memory)");
+            const auto td0 = std::chrono::steady_clock::now();
+            const std::vector<int> raw = detect_periods_host_series(values, validity, lengths, n_series);
+            for (size_t s = 0; s < n_series; s++) period[s] = lengths[s] < 3 ? 1 : used_period(raw[s] > 0 ? raw[s] : 1);
+            if (Tunables::from_env().timing)
+                std::fprintf(stderr, "[anofox-hip] period detection of %zu series: %.1f ms\n", n_series,
+                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - td0).count());
         }
         std::map<int, std::vector<size_t>> groups;
         for (size_t s = 0; s < n_series; s++) groups[period[s]].push_back(s);
@@ -2315,7 +2460,10 @@ static bool forecast_batch_one_device(const double *const *values, const uint64_
                 }
                 return true;
             };
-            static const int CLASS_HI[] = {ETS_LDS_PERIOD, ETS_MAX_PERIOD};
+            // (the LDS ring of a round kernel is sized by the batch's largest period, for every wave: periods up to 64 in one batch
+            //  left three waves per CU -- a tenth of the uniform batch's rate per series -- so a merged batch keeps periods above 16
+            //  in the HBM ring, which streams like y; more, finer classes only multiply the streams that share the hardware queues)
+            static const int CLASS_HI[] = {ETS_MERGED_LDS_PERIOD, ETS_MAX_PERIOD};
             std::vector<Part> keep;
             std::vector<std::vector<Part>> take(sizeof CLASS_HI / sizeof CLASS_HI[0]);
             for (auto &part : parts) {
@@ -2336,7 +2484,7 @@ static bool forecast_batch_one_device(const double *const *values, const uint64_
                     size_t cols = 0;
                     for (auto &part : cls) {
                         const size_t pc = (part.second.size() + 63) / 64 * 64;
-                        if (!cur.empty() && part.first > ETS_LDS_PERIOD && scratch_of(cols + pc, part.first) > 2.0 * 1073741824.0) {
+                        if (!cur.empty() && part.first > ETS_MERGED_LDS_PERIOD && scratch_of(cols + pc, part.first) > 2.0 * 1073741824.0) {
                             cut.push_back(std::move(cur));
                             cur.clear();
                             cols = 0;
@@ -2357,8 +2505,7 @@ static bool forecast_batch_one_device(const double *const *values, const uint64_
             std::atomic<bool> merged_ok{true};
             int cur_dev_m = 0;
             (void)hipGetDevice(&cur_dev_m);
-            // one host thread for the LDS-ring batch, one for the HBM-ring batches (one after the other: each is latency bound by its
-            // slowest fit, side by side they take as long and hold several times the scratch)
+            // one host thread per LDS-ring batch, one for the HBM-ring batches (one after the other: they share the ring scratch)
             auto run_cls = [&](std::vector<std::vector<Part> *> group) {
                 try {
                     (void)hipSetDevice(cur_dev_m);
@@ -2368,9 +2515,11 @@ static bool forecast_batch_one_device(const double *const *values, const uint64_
             // ... and beside the parts that stay separate (below); joined before this function returns, whatever the way out
             std::vector<std::thread> cls_threads;
             struct Joiner { std::vector<std::thread> &t; ~Joiner() { for (auto &x : t) if (x.joinable()) x.join(); } } cls_joiner{cls_threads};
-            std::vector<std::vector<Part> *> grp_lds, grp_hbm;
-            for (auto *cls : todo) (cls->back().first <= ETS_LDS_PERIOD ? grp_lds : grp_hbm).push_back(cls);
-            if (!grp_lds.empty()) cls_threads.emplace_back(run_cls, grp_lds);
+            std::vector<std::vector<Part> *> grp_hbm;
+            for (auto *cls : todo) {
+                if (cls->back().first <= ETS_MERGED_LDS_PERIOD) cls_threads.emplace_back(run_cls, std::vector<std::vector<Part> *>{cls});
+                else grp_hbm.push_back(cls);
+            }
             if (!grp_hbm.empty()) cls_threads.emplace_back(run_cls, grp_hbm);
             parts = std::move(keep);
             std::sort(parts.begin(), parts.end(), [](const Part &x, const Part &y) { return x.second.size() > y.second.size(); });
@@ -2379,9 +2528,10 @@ static bool forecast_batch_one_device(const double *const *values, const uint64_
             for (auto &part : parts) desc += " " + std::to_string(part.first) + "x" + std::to_string(part.second.size());
             std::fprintf(stderr, "[anofox-hip] remaining parts (period x series):%s\n", desc.c_str());
         }
-        // the big parts fill the chip on their own and hold the most memory: one at a time; the small ones side by side
+        // the big parts fill the chip on their own and hold the most memory: one at a time on this thread (below), beside the small
+        // ones, which run side by side on the workers (a small part is a chain of latency-bound launches: it hardly slows a big one)
         size_t first_small = 0;
-        while (first_small < parts.size() && parts[first_small].second.size() >= 2048) run_part(parts[first_small++]);
+        while (first_small < parts.size() && parts[first_small].second.size() >= 2048) first_small++;
         // A worker keeps ONE device batch for all its parts (creating and destroying a batch costs ~30 ms of allocator calls
         // that serialise across threads -- as much as the part's own run): capacity = the largest small part, short parts are
         // padded with empty series, the period is set before every pack.
@@ -2390,6 +2540,7 @@ static bool forecast_batch_one_device(const double *const *values, const uint64_
         int h_cap = options->horizon;
         for (size_t s = 0; s < n_series; s++) { t_cap = std::max(t_cap, lengths[s]); if (horizons) h_cap = std::max(h_cap, horizons[s]); }
         std::atomic<size_t> next{first_small};
+        const auto t_small0 = std::chrono::steady_clock::now();
         int cur_dev = 0;
         (void)hipGetDevice(&cur_dev);                      // the device is a per-thread setting: the workers inherit the caller's
         auto work_body = [&]() {
@@ -2420,8 +2571,13 @@ static bool forecast_batch_one_device(const double *const *values, const uint64_
                     std::memset(&res[j], 0, sizeof(ForecastResult));
                     errs[j].code = SUCCESS; errs[j].message[0] = 0;
                 }
+                const auto tw0 = std::chrono::steady_clock::now();
                 const bool ok = anofox_hip_batch_pack_host(wb, v.data(), validity ? m.data() : nullptr, len.data(), &be) &&
                                 anofox_hip_batch_run(wb, nullptr, &be) && anofox_hip_batch_fetch(wb, res.data(), errs.data());
+                if (tun.timing)
+                    std::fprintf(stderr, "[anofox-hip] small part: period %d, %zu series: %.1f ms (started at %.1f ms)\n", parts[g].first, k,
+                                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count(),
+                                 std::chrono::duration<double, std::milli>(tw0 - t_small0).count());
                 if (!ok) {
                     if (be.code == SUCCESS) set_error(&be, INTERNAL_ERROR, "Internal error: device batch failed");
                     for (size_t j = 0; j < cap; j++) anofox_free_forecast_result(&res[j]);      // whatever the fetch had allocated
@@ -2460,8 +2616,27 @@ static bool forecast_batch_one_device(const double *const *values, const uint64_
         };
         const unsigned n_thr = (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)std::thread::hardware_concurrency(), 16, parts.size() - first_small}));
         std::vector<std::thread> pool;
-        for (unsigned i = 1; i < n_thr; i++) pool.emplace_back(work);
-        work();
+        struct PoolJoiner { std::vector<std::thread> &t; ~PoolJoiner() { for (auto &x : t) if (x.joinable()) x.join(); } } pool_joiner{pool};
+        const bool have_big = first_small > 0;
+        for (unsigned i = have_big ? 0 : 1; i < n_thr; i++) pool.emplace_back(work);
+        if (have_big) {
+            // the big parts: up to four side by side (one is throttled by whatever else runs; one after the other they were the
+            // critical path of the call), each on its own thread, largest first
+            std::atomic<size_t> next_big{0};
+            auto big_work = [&]() {
+                (void)hipSetDevice(cur_dev);
+                try {
+                    for (size_t g = next_big.fetch_add(1); g < first_small; g = next_big.fetch_add(1)) run_part(parts[g]);
+                } catch (...) {                          // nothing may leave a worker thread
+                    std::lock_guard<std::mutex> lock(err_mu);
+                    if (all_ok) set_error(&first_err, INTERNAL_ERROR, "Internal error: worker failed (out of host memory)");
+                    all_ok = false;
+                }
+            };
+            const size_t n_big_thr = std::min<size_t>(first_small, 4);
+            for (size_t i = 1; i < n_big_thr; i++) pool.emplace_back(big_work);
+            big_work();
+        } else work();
         for (auto &t : pool) t.join();
         for (auto &t : cls_threads) if (t.joinable()) t.join();
         if (!merged_ok) {

@@ -305,4 +305,92 @@ void launch_gather_columns(const double *y, size_t ld, const int32_t *series_of,
     hipLaunchKernelGGL(gather_columns_kernel, grid, dim3(NM_BLOCK), 0, stream, y, ld, series_of, n_active, t_max, out, ld_out);
 }
 
+// ------------------------------------------------------------------------------------------
+// seasonal period detection (seasonality.rs:323-377 detect_seasonality_first; oracle/forecast.c oracle_detect_seasonality_first):
+// the lag of the strongest local maximum above 0.1 of the autocorrelation over lags 1 .. n / 2, or 0.  O(n^2 / 2) multiply-adds
+// per series -- 1.8 M for an M5 series, 0.6 s of 32 host threads for the 30,490 of them -- so it runs here: one workgroup per
+// series, the centred series in LDS (a scratch block in HBM above DETECT_LDS_ROWS observations), one lag per lane (the lanes of a
+// wave read consecutive LDS words, the other factor is a broadcast), every sum in the order the scalar loop takes (separate
+// multiply and add, one accumulator), so the chosen lag is the oracle's bit for bit.  The mean, the variance and the final scan
+// are sequential sums / a sequential scan on one lane (2 n + n / 2 dependent steps against n^2 / 512 per lane for the lags).
+// ------------------------------------------------------------------------------------------
+constexpr int DETECT_THREADS = 256;
+template <bool USE_LDS>
+__global__ __launch_bounds__(DETECT_THREADS) void detect_period_kernel(const double *y, size_t ld, const int32_t *len, int n_series, int t_rows,
+                                                                       double *scratch, int32_t *period, double *best_acf_out)
+{
+    extern __shared__ double detect_lds[];
+    __shared__ double sh_mean, sh_var;
+    const int tid = threadIdx.x;
+    double *c = USE_LDS ? detect_lds : scratch + (size_t)blockIdx.x * ((size_t)t_rows + (size_t)t_rows / 2 + 2);
+    double *acf = c + t_rows;
+    for (int s = blockIdx.x; s < n_series; s += gridDim.x) {
+        const int n = len[s];
+        int best = 0;
+        double best_acf = 0.0;
+        const int max_lag = n / 2;
+        if (n >= 4 && max_lag >= 2) {
+            for (int i = tid; i < n; i += DETECT_THREADS) c[i] = y[(size_t)i * ld + s];
+            __syncthreads();
+            if (tid == 0) {
+                double mean = 0.0;
+                for (int i = 0; i < n; i++) mean += c[i];
+                mean /= (double)n;
+                double var = 0.0;
+                for (int i = 0; i < n; i++) { const double d = c[i] - mean; var += d * d; }
+                sh_mean = mean; sh_var = var;
+            }
+            __syncthreads();
+            const double mean = sh_mean, var = sh_var;
+            if (!(fabs(var) < 2.220446049250313e-16)) {
+                for (int i = tid; i < n; i += DETECT_THREADS) c[i] = c[i] - mean;
+                __syncthreads();
+                for (int lag = 1 + tid; lag <= max_lag; lag += DETECT_THREADS) {
+                    const double *q = c + lag;
+                    const int cnt = n - lag;
+                    double sum = 0.0;
+#pragma unroll 8
+                    for (int i = 0; i < cnt; i++) sum += c[i] * q[i];
+                    acf[lag - 1] = sum / var;
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    for (int i = 1; i + 1 < max_lag; i++) {
+                        const double v = acf[i];
+                        if (v > acf[i - 1] && v > acf[i + 1] && v > 0.1)
+                            if (best == 0 || v > best_acf) { best = i + 1; best_acf = v; }
+                    }
+                }
+            }
+            __syncthreads();            // the next series overwrites c
+        }
+        if (tid == 0) {
+            period[s] = best;
+            if (best_acf_out) best_acf_out[s] = best_acf;
+        }
+    }
+}
+
+size_t detect_scratch_doubles(int n_series, int t_rows)
+{
+    if (t_rows <= DETECT_LDS_ROWS) return 0;
+    return (size_t)std::min(n_series, DETECT_LONG_GRID) * ((size_t)t_rows + (size_t)t_rows / 2 + 2);
+}
+
+void launch_detect_periods(const double *y, size_t ld, const int32_t *len, int n_series, int t_rows, double *scratch, int32_t *period,
+                           double *best_acf, hipStream_t stream)
+{
+    if (n_series <= 0) return;
+    if (t_rows <= DETECT_LDS_ROWS) {
+        const size_t bytes = sizeof(double) * ((size_t)t_rows + (size_t)t_rows / 2 + 2);
+        if (bytes > 48 * 1024)
+            anofox_check_attr(hipFuncSetAttribute((const void *)detect_period_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        hipLaunchKernelGGL(detect_period_kernel<true>, dim3((unsigned)std::min(n_series, 65536)), dim3(DETECT_THREADS), bytes, stream, y, ld, len, n_series,
+                           t_rows, (double *)nullptr, period, best_acf);
+    } else {
+        hipLaunchKernelGGL(detect_period_kernel<false>, dim3((unsigned)std::min(n_series, DETECT_LONG_GRID)), dim3(DETECT_THREADS), 0, stream, y, ld, len,
+                           n_series, t_rows, scratch, period, best_acf);
+    }
+}
+
 } // namespace anofox

@@ -32,8 +32,15 @@ struct PrepArgs {
     uint32_t *flags;
     double *fig_add, *fig_mul;   // [m x ld] seasonal figures (additive / multiplicative)
     double *l0, *b0;       // [9 x ld]: index (season_type * 3 + trend_type)
-    double *scratch;       // periods above ETS_LDS_PERIOD: (2 (m / 2) + 1 + 3 m) * 64 doubles per workgroup instead of LDS
+    double *scratch;       // periods above ETS_LDS_PERIOD: season_figures scratch (season_scratch_doubles), else unused
+    int pre_fig;           // 1: fig_add / fig_mul already hold the figures (launch_season_figures): no decomposition in pass A
+    int t_rows;            // rows of the block (the figures kernel sizes its LDS by it)
 };
+
+// seasonal figures of long periods, one workgroup per series (prep.hip season_figures_kernel); `scratch`: season_scratch_doubles
+// doubles when the series and its trend do not fit LDS (else unused)
+size_t season_scratch_doubles(int n_series, int t_rows, int m_max);
+void launch_season_figures(const PrepArgs &a, hipStream_t stream);
 
 // Nelder-Mead state parked in HBM between rounds, indexed by series (stride ld)
 struct NmStateBuf {
@@ -148,6 +155,13 @@ void launch_classic_final(int kind, const FitArgs &a, const ClassicArgs &c, hipS
 void launch_compact(const int32_t *series_prev, const int32_t *n_prev, int n_series, const int32_t *done,
                     int32_t *series_next, int32_t *n_next, hipStream_t, int32_t *n_clear = nullptr);
 // out[t * ld_out + p] = y[t * ld + series_of[p]] for p < *n_active, t < t_max
+// seasonal period detection (first / strongest autocorrelation peak, 0 = none) of every column of a time-major block; series of up
+// to DETECT_LDS_ROWS observations are held in LDS, longer ones in `scratch` (detect_scratch_doubles doubles, else unused)
+constexpr int DETECT_LDS_ROWS = 8192;        // 1.5 x 8 B x 8,192 = 96 KB of the CU's 160 KB
+constexpr int DETECT_LONG_GRID = 1024;       // workgroups of the scratch variant (each owns 1.5 t_rows doubles of scratch)
+size_t detect_scratch_doubles(int n_series, int t_rows);
+void launch_detect_periods(const double *y, size_t ld, const int32_t *len, int n_series, int t_rows, double *scratch, int32_t *period,
+                           double *best_acf, hipStream_t stream);
 void launch_gather_columns(const double *y, size_t ld, const int32_t *series_of, const int32_t *n_active, int n_series,
                            int t_max, double *out, size_t ld_out, hipStream_t);
 

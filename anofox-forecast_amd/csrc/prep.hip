@@ -44,17 +44,116 @@ struct RowLoader {
 // alternating without a copy, is what the one-pass ets_final_kernel streams the same block with at 5.5 TB/s.
 template <int MR> constexpr int prep_block() { return MR > 0 ? 4 * MR : 16; }
 
-// GSCR: the decomposition's window ring and per-phase accumulators live in an HBM scratch area of the workgroup instead of
-// LDS (periods above ETS_LDS_PERIOD: (2 (m / 2) + 1 + 3 m) * 512 bytes no longer fit)
+// Long periods (above ETS_LDS_PERIOD): the classical decomposition costs T * (m + 1) multiply-adds per series (every centred
+// moving average is its own sequential sum, as the oracle writes it) -- 1.4 M for T = 1,913, m = 755 -- and with one wave per 64
+// series, window ring in an HBM scratch, prep_kernel spent 206 ms on the 36,000 columns of a merged batch before its first fit
+// could start.  season_figures_kernel gives a series a WORKGROUP instead: the series in LDS, one centre per thread (its window
+// summed in the oracle's order: acc = acc + w_k y_k, k ascending), then one phase per thread (the detrended values of a phase added
+// in time order), then the normalisation -- every sum keeps the order of oracle/ets.c ets_init_states, so the figures are the same
+// bits.  prep_kernel then runs with pre_fig = 1: pass A without the window, pass B reading the figures from fig_add / fig_mul.
+// The period is read PER SERIES (m_col), the block-of-64 grouping of a merged batch is not needed here.
+constexpr int SEASON_THREADS = 256;
+constexpr int SEASON_LDS_DOUBLES = 12288;        // 96 KB of the CU's 160
+constexpr int SEASON_LONG_GRID = 1024;
+template <bool USE_LDS>
+__global__ __launch_bounds__(SEASON_THREADS) void season_figures_kernel(const PrepArgs a, size_t scratch_stride)
+{
+    extern __shared__ double season_lds[];
+    __shared__ double sh_fmean[2];
+    const int tid = threadIdx.x;
+    double *x = USE_LDS ? season_lds : a.scratch + (size_t)blockIdx.x * scratch_stride;
+    double *tr = x + a.t_rows;
+    double *fa = tr + a.t_rows;
+    double *fm = fa + a.m;
+    for (int s = blockIdx.x; s < a.n_series; s += gridDim.x) {
+        const int n = a.len[s];
+        const int m = a.m_col ? a.m_col[s] : a.m;
+        if (n <= 0 || m < 2 || m > ETS_MAX_PERIOD || n < 2 * m) continue;          // (block-uniform) not seasonal: nobody reads its figures
+        const int half = m / 2, L = 2 * half + 1;
+        const double w = 1.0 / (double)m;
+        const double wend = (m % 2 == 0) ? 0.5 / (double)m : w;
+        int pos = 1;
+        for (int i = tid; i < n; i += SEASON_THREADS) {
+            const double v = a.y[(size_t)i * a.ld + s];
+            x[i] = v;
+            if (!(v > 0.0)) pos = 0;
+        }
+        const bool positive = __syncthreads_and(pos) != 0;
+        const int c_last = n - 1 - half;                                         // centres half .. c_last
+        for (int c = half + tid; c <= c_last; c += SEASON_THREADS) {
+            const double *q = x + (c - half);
+            double acc = 0.0;
+            acc = acc + wend * q[0];
+#pragma unroll 8
+            for (int k = 1; k < L - 1; k++) acc = acc + w * q[k];
+            acc = acc + wend * q[L - 1];
+            tr[c] = acc;
+        }
+        __syncthreads();
+        for (int p = tid; p < m; p += SEASON_THREADS) {
+            int c = p >= half ? p : p + ((half - p + m - 1) / m) * m;            // first centre of phase p (centre c has phase c mod m)
+            double sa = 0.0, sm = 0.0, cn = 0.0;
+            for (; c <= c_last; c += m) {
+                const double yc = x[c], t = tr[c];
+                sa = sa + (yc - t);
+                if (positive) sm = sm + (yc / t);
+                cn += 1.0;
+            }
+            fa[p] = sa / cn;
+            if (positive) fm[p] = sm / cn;
+        }
+        __syncthreads();
+        if (tid < 2 && (tid == 0 || positive)) {
+            const double *f = tid == 0 ? fa : fm;
+            double tot = 0.0;
+            for (int j = 0; j < m; j++) tot = tot + f[j];
+            sh_fmean[tid] = tot / (double)m;
+        }
+        __syncthreads();
+        const double mean_a = sh_fmean[0], mean_m = positive ? sh_fmean[1] : 1.0;
+        for (int p = tid; p < m; p += SEASON_THREADS) {
+            a.fig_add[(size_t)p * a.ld + s] = fa[p] - mean_a;
+            if (positive) {
+                double fj = fm[p] / mean_m;
+                if (!(fj >= 1.0e-2)) fj = 1.0e-2;
+                a.fig_mul[(size_t)p * a.ld + s] = fj;
+            }
+        }
+        __syncthreads();                    // the next series overwrites x
+    }
+}
+
+size_t season_scratch_doubles(int n_series, int t_rows, int m_max)
+{
+    const size_t per = 2 * (size_t)t_rows + 2 * (size_t)m_max;
+    if (per <= (size_t)SEASON_LDS_DOUBLES) return 0;
+    return (size_t)std::min(n_series, SEASON_LONG_GRID) * per;
+}
+
+void launch_season_figures(const PrepArgs &a, hipStream_t stream)
+{
+    if (a.n_series <= 0) return;
+    const size_t per = 2 * (size_t)a.t_rows + 2 * (size_t)a.m;
+    if (per <= (size_t)SEASON_LDS_DOUBLES) {
+        const size_t bytes = per * sizeof(double);
+        if (bytes > 48 * 1024)
+            anofox_check_attr(hipFuncSetAttribute((const void *)season_figures_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        hipLaunchKernelGGL(season_figures_kernel<true>, dim3((unsigned)std::min(a.n_series, 65536)), dim3(SEASON_THREADS), bytes, stream, a, (size_t)0);
+    } else {
+        if (!a.scratch) throw std::runtime_error("season figures: long series need the scratch area");
+        hipLaunchKernelGGL(season_figures_kernel<false>, dim3((unsigned)std::min(a.n_series, SEASON_LONG_GRID)), dim3(SEASON_THREADS), 0, stream, a, per);
+    }
+}
+
 // MR > 0: compile-time odd period (7): the window ring and the per-phase accumulators are VGPR arrays with compile-time
 // indices (the block is two revolutions long) -- no LDS traffic at all; same operations in the same order as the generic path.
-template <bool GSCR, int MR = 0>
+template <int MR = 0>
 __global__ __launch_bounds__(NM_BLOCK) void prep_kernel(const PrepArgs a)
 {
     constexpr int PREP_S = prep_block<MR>();
     static_assert(MR == 0 || (MR % 2 == 1 && MR >= 3), "register variant: odd periods");
     extern __shared__ double lds_dyn[];
-    double *lds = GSCR ? a.scratch + (size_t)blockIdx.x * (size_t)((2 * (a.m / 2) + 1) + 3 * a.m) * NM_BLOCK : lds_dyn;
+    double *lds = lds_dyn;
     const int lane = threadIdx.x;
     const int s = blockIdx.x * NM_BLOCK + lane;
     const bool valid = s < a.n_series;
@@ -82,11 +181,13 @@ __global__ __launch_bounds__(NM_BLOCK) void prep_kernel(const PrepArgs a)
     double rR[MRA], sAR[MRA], sMR[MRA], cNR[MRA];
 #pragma unroll
     for (int j = 0; j < MRA; j++) { rR[j] = 0.0; sAR[j] = 0.0; sMR[j] = 0.0; cNR[j] = 0.0; }
-    if (MR == 0 && want_season)
+    if (MR == 0 && want_season && !a.pre_fig)
         for (int j = 0; j < m; j++) { sumA[j * NM_BLOCK + lane] = 0.0; sumM[j * NM_BLOCK + lane] = 0.0; cnt[j * NM_BLOCK + lane] = 0.0; }
     const double w = want_season ? 1.0 / (double)m : 0.0;
     const double wend = (want_season && m % 2 == 0) ? 0.5 / (double)m : w;
     const bool seasonal = want_season && n >= 2 * m;
+    const bool pre_fig = a.pre_fig != 0;                        // figures already in fig_add / fig_mul (season_figures_kernel)
+    const bool decompose = seasonal && !pre_fig;
 
     // ---- pass A ----------------------------------------------------------------------------------------
     double sum = 0.0;
@@ -134,7 +235,7 @@ __global__ __launch_bounds__(NM_BLOCK) void prep_kernel(const PrepArgs a)
                     }
                 }
             } else
-            if (seasonal) {
+            if (decompose) {
                 ring[slot * NM_BLOCK + lane] = v;
                 if (t >= L - 1) {
                     double acc = 0.0;
@@ -239,7 +340,7 @@ __global__ __launch_bounds__(NM_BLOCK) void prep_kernel(const PrepArgs a)
             }
         }
     } else
-    if (seasonal) {
+    if (decompose) {
         for (int type = 1; type <= 2; type++) {
             if (type == 2 && !positive) break;
             double *acc = type == 1 ? sumA : sumM;
@@ -273,6 +374,9 @@ __global__ __launch_bounds__(NM_BLOCK) void prep_kernel(const PrepArgs a)
     int Km = 2 * m > 10 ? 2 * m : 10;
     if (Km > n) Km = n;
     int j = 0;
+    const double *figA = pre_fig ? a.fig_add + (valid ? s : 0) : sumA + lane;
+    const double *figM = pre_fig ? a.fig_mul + (valid ? s : 0) : sumM + lane;
+    const size_t fig_stride = pre_fig ? ld : (size_t)NM_BLOCK;
     rows.load(cur, 0);
     auto pass_b_block = [&](const double (&buf)[PREP_S], const int base) __attribute__((always_inline)) {
 #pragma unroll
@@ -290,9 +394,9 @@ __global__ __launch_bounds__(NM_BLOCK) void prep_kernel(const PrepArgs a)
                 vs[2] = 0.0;
                 if (wave_useM) vs[2] = useM ? v / sMR[jj % MR] : 0.0;
             } else {
-                vs[1] = useA ? v - sumA[j * NM_BLOCK + lane] : 0.0;
+                vs[1] = useA ? v - figA[(size_t)j * fig_stride] : 0.0;
                 vs[2] = 0.0;
-                if (wave_useM) vs[2] = useM ? v / sumM[j * NM_BLOCK + lane] : 0.0;
+                if (wave_useM) vs[2] = useM ? v / figM[(size_t)j * fig_stride] : 0.0;
             }
 #pragma unroll
             for (int st = 0; st < 3; st++) {
@@ -383,17 +487,20 @@ void launch_prep(const PrepArgs &a, hipStream_t stream)
     const int grid = (a.n_series + NM_BLOCK - 1) / NM_BLOCK;
     size_t lds_bytes = 0;
     if (a.l0 != nullptr && a.m > ETS_LDS_PERIOD && a.m <= ETS_MAX_PERIOD) {
-        if (!a.scratch) throw std::runtime_error("prep: a period above the LDS limit needs the scratch area");
-        hipLaunchKernelGGL((prep_kernel<true, 0>), dim3(grid), dim3(NM_BLOCK), 0, stream, a);
+        // long periods: the figures from one workgroup per series, then the two streamed passes without the decomposition
+        PrepArgs b = a;
+        launch_season_figures(b, stream);
+        b.pre_fig = 1;
+        hipLaunchKernelGGL((prep_kernel<0>), dim3(grid), dim3(NM_BLOCK), 0, stream, b);
         return;
     }
     if (a.l0 != nullptr && a.m == 7 && !a.m_col) {        // the M5 / weekly period: ring and accumulators in registers
-        hipLaunchKernelGGL((prep_kernel<false, 7>), dim3(grid), dim3(NM_BLOCK), 0, stream, a);
+        hipLaunchKernelGGL((prep_kernel<7>), dim3(grid), dim3(NM_BLOCK), 0, stream, a);
         return;
     }
     if (a.l0 != nullptr && a.m >= 2 && a.m <= ETS_LDS_PERIOD) lds_bytes = sizeof(double) * (size_t)((2 * (a.m / 2) + 1) + 3 * a.m) * NM_BLOCK;
-    if (lds_bytes > 48 * 1024) anofox_check_attr(hipFuncSetAttribute((const void *)prep_kernel<false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    hipLaunchKernelGGL((prep_kernel<false, 0>), dim3(grid), dim3(NM_BLOCK), lds_bytes, stream, a);
+    if (lds_bytes > 48 * 1024) anofox_check_attr(hipFuncSetAttribute((const void *)prep_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    hipLaunchKernelGGL((prep_kernel<0>), dim3(grid), dim3(NM_BLOCK), lds_bytes, stream, a);
 }
 
 } // namespace anofox

@@ -66,6 +66,13 @@ class DeviceBatch:
         if not self.L.anofox_hip_batch_set_arima_method(self.handle, int(method), C.byref(err)):
             raise RuntimeError(f"set_arima_method failed: [{err.code}] {err.message.decode()}")
 
+    def periods(self) -> np.ndarray:
+        """The seasonal period every series runs with (auto-detected on the device when the options ask for it)."""
+        out = np.zeros(self.n, dtype=np.int32)
+        if not self.L.anofox_hip_batch_periods(self.handle, out.ctypes.data):
+            raise RuntimeError("anofox_hip_batch_periods: no block set")
+        return out
+
     def run(self, stream: torch.cuda.Stream | None = None):
         st = stream if stream is not None else torch.cuda.current_stream(self.device)
         err = _lib.AnofoxError()

@@ -92,7 +92,7 @@ EXPORTED_SYMBOLS = [
     "anofox_hip_ingest_create", "anofox_hip_ingest_destroy", "anofox_hip_ingest_append", "anofox_hip_ingest_finish",
     "anofox_hip_ingest_group_keys", "anofox_hip_ingest_last_dates", "anofox_hip_ingest_lengths", "anofox_hip_ingest_values",
     "anofox_hip_ingest_validity", "anofox_hip_batch_pack_ingest", "anofox_hip_batch_inspect",
-    "anofox_hip_batch_n_series", "anofox_hip_batch_set_fixed_params",
+    "anofox_hip_batch_n_series", "anofox_hip_batch_periods", "anofox_hip_batch_set_fixed_params",
     "anofox_hip_set_devices", "anofox_hip_get_devices", "anofox_hip_set_min_series_per_device", "anofox_hip_shard_range",
     "anofox_hip_set_default_arima_method", "anofox_hip_batch_set_arima_method", "anofox_hip_release_caches",
     "anofox_hip_batch_run_many",
@@ -136,6 +136,8 @@ def load():
     L.anofox_hip_batch_ld.argtypes = [C.c_void_p]
     L.anofox_hip_batch_n_series.restype = C.c_size_t
     L.anofox_hip_batch_n_series.argtypes = [C.c_void_p]
+    L.anofox_hip_batch_periods.restype = C.c_bool
+    L.anofox_hip_batch_periods.argtypes = [C.c_void_p, C.c_void_p]
     L.anofox_hip_batch_set_fixed_params.restype = C.c_bool
     L.anofox_hip_batch_set_fixed_params.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, P(AnofoxError)]
     L.anofox_hip_batch_pack_host.restype = C.c_bool

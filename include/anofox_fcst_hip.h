@@ -231,12 +231,21 @@ bool anofox_hip_batch_pack_host(AnofoxHipBatch *batch,
 
 /*
  * Adopt a block that is already in HBM: `d_y` is [t_max x ld] fp64 time-major,
- * `d_len` is int32[n_series].  No copy; the caller keeps both alive.
+ * `d_len` is int32[n_series].  No copy; the caller keeps both alive.  The block
+ * holds no NULLs.  With auto_detect_seasonality and seasonal_period 0 the periods
+ * are detected here, on the device, as the host packer has them detected.
  */
 bool anofox_hip_batch_set_device_block(AnofoxHipBatch *batch,
                                        const void *d_y, size_t ld,
                                        const void *d_len,
                                        struct AnofoxError *out_error);
+
+/*
+ * The seasonal period every series of the packed / adopted block runs with: the caller's, or -- auto_detect_seasonality with
+ * seasonal_period 0 -- the lag of the strongest autocorrelation peak (seasonality.rs:323-377 detect_seasonality_first, 1 when
+ * there is none), found by detect_period_kernel on the resident block.  False before a block is set.
+ */
+bool anofox_hip_batch_periods(const AnofoxHipBatch *batch, int32_t *out_periods);
 
 /* Asynchronous fit + forecast on `stream` (a hipStream_t, may be NULL). */
 bool anofox_hip_batch_run(AnofoxHipBatch *batch, void *stream,

@@ -611,6 +611,61 @@ def test_device_resident_batch_and_stats(env):
     b.close()
 
 
+@pytest.mark.parametrize("T", [700, 9000])
+def test_period_detection_kernel_matches_oracle(env, T):
+    """auto_detect_seasonality on a RESIDENT block: detect_period_kernel (one workgroup per series, the centred series in LDS, in an
+    HBM scratch above 8,192 observations -- T = 9000 --, one lag per lane, every sum in the scalar loop's order) picks the lag
+    seasonality.rs:323-377 picks, for every series: clean seasonal ones, noise, constants, ramps, ragged and too-short ones, huge
+    values whose squares overflow, an infinity.  The forecasts then use those periods (sample against the oracle)."""
+    import ctypes as C
+    import torch
+    api, O, lib, synth = env
+    from anofox_forecast_amd.device import DeviceBatch
+    rng = np.random.default_rng(T)
+    series = []
+    for p in (2, 3, 7, 12, 24, 52, 168, 365):
+        for k in range(3):
+            L = int(rng.integers(min(max(3 * p, 20), T), T + 1))
+            t = np.arange(L)
+            series.append(20.0 + 0.01 * t + (3.0 + k) * np.sin(2 * np.pi * t / p) + rng.normal(0, 0.5 + k, L))
+    series += [rng.normal(0, 1, int(rng.integers(4, T + 1))) for _ in range(40)]                    # noise: spurious peaks
+    series += [np.floor(rng.gamma(0.3, 2.0, int(rng.integers(50, T + 1)))) for _ in range(40)]      # intermittent counts
+    series += [np.full(50, 3.0), np.arange(60.0), np.array([1.0, 2.0, 4.0]), np.array([1.0, 5.0, 2.0, 7.0]), np.array([1.0, 2.0]),
+               np.array([]), 1e200 * rng.normal(0, 1, 80), np.r_[rng.normal(0, 1, 30), np.inf, rng.normal(0, 1, 30)], rng.normal(0, 1, T)]
+    n = len(series)
+    opts = lib.make_options("AutoETS", 6)
+    assert opts.auto_detect_seasonality and opts.seasonal_period == 0
+    b = DeviceBatch(n, T, opts, "cuda:0")
+    y = np.zeros((T, b.ld))
+    ln = np.zeros(b.ld, dtype=np.int32)
+    for s, v in enumerate(series):
+        y[: len(v), s] = v
+        ln[s] = len(v)
+    b.set_block(torch.from_numpy(y).cuda(), torch.from_numpy(ln).cuda())
+    got = b.periods()
+    L = O.lib()
+    want = np.ones(n, dtype=np.int32)
+    for s, v in enumerate(series):
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        p = L.oracle_detect_seasonality_first(v.ctypes.data, len(v)) if len(v) >= 3 else 0
+        want[s] = p if p > 0 else 1
+    assert np.array_equal(got, want), [(s, int(got[s]), int(want[s])) for s in np.nonzero(got != want)[0][:10]]
+    assert len(set(want.tolist())) > 10
+    if T <= 1000:
+        b.run()
+        torch.cuda.synchronize()
+        out = b.results()
+        yhat = out["yhat"].cpu().numpy()
+        status = out["status"].cpu().numpy()
+        oo = O.make_options("AutoETS", 6)
+        for s in range(0, n, 9):
+            ref = O.forecast(series[s], oo)
+            assert (status[s] == 0) == ref["ok"], (s, status[s], ref)
+            if ref["ok"]:
+                assert _rel(yhat[s], ref["point"]) <= REL_TOL, s
+    b.close()
+
+
 def _fixed_batch(lib, Y, spec, m, h, params, lens=None):
     """ETS(spec) with given parameters over a resident block; returns host copies of the device results + stats."""
     import torch

@@ -14,7 +14,7 @@ lens = rng.integers(400, 1914, size=n)
 series = [Y[i, 1913 - lens[i]:].copy() for i in range(n)]
 opts = lib.make_options(model, 28)
 times = []
-for _ in range(2):
+for _ in range(int(os.environ.get('REPS', '2'))):
     t0 = time.time()
     got, berr = api.forecast_batch(series, opts)
     times.append(time.time() - t0)
@@ -25,4 +25,5 @@ for i in range(0, n, max(1, n // 24)):
     ref = O.forecast(series[i], O.make_options(model, 28))
     if ref["ok"] != got[i]["ok"] or (ref["ok"] and (ref["model_name"] != got[i]["model_name"] or not np.array_equal(ref["point"], got[i]["point"]))):
         bad += 1
+print("calls:", " ".join(f"{t:.2f}" for t in times))
 print(f"{model}: {dt:.2f} s for {n} series with auto-detected periods = {n / dt:.0f} series/s (second call; first {times[0]:.2f} s; Python marshalling included), {bad} mismatches in the sample")
