@@ -2746,8 +2746,14 @@ bool anofox_ts_forecast_batch(const double *const *values, const uint64_t *const
     // as many shards as there are listed devices, but none smaller than min_series (a shard that does not fill its device
     // finishes no sooner than a larger one: the fit is bound by its slowest problems)
     const size_t G = devs.empty() ? 1 : std::max<size_t>(1, std::min(devs.size(), n_series / std::max<size_t>(min_series, 1)));
-    if (devs.empty())
-        return forecast_batch_one_device(values, validity, lengths, n_series, options, horizons, out_results, out_errors, out_batch_error);
+    if (devs.empty()) {
+        const auto tb0 = std::chrono::steady_clock::now();
+        const bool r = forecast_batch_one_device(values, validity, lengths, n_series, options, horizons, out_results, out_errors, out_batch_error);
+        if (Tunables::from_env().timing)
+            std::fprintf(stderr, "[anofox-hip] anofox_ts_forecast_batch: %zu series in %.1f ms\n", n_series,
+                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count());
+        return r;
+    }
     if (G == 1) {
         DeviceGuard guard(devs[0]);
         return forecast_batch_one_device(values, validity, lengths, n_series, options, horizons, out_results, out_errors, out_batch_error);

@@ -1,5 +1,5 @@
 """AutoETS with auto-detected periods on the full M5 shape (30,490 ragged series): one call of the batch entry, a sample checked
-against the oracle.  python tools/time_autodetect_full.py [n_series] [model]"""
+against the oracle.  python tools/time_autodetect_full.py [n_series] [model] [positive|intermittent]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -8,8 +8,9 @@ from oracle import oracle as O
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 30490
 model = sys.argv[2] if len(sys.argv) > 2 else "AutoETS"
+positive = (sys.argv[3] != "intermittent") if len(sys.argv) > 3 else True
 rng = np.random.default_rng(5)
-Y = synth.gen_series(synth.SEED_M5 + 5, 4321, n, 1913, 7, True)
+Y = synth.gen_series(synth.SEED_M5 + 5, 4321, n, 1913, 7, positive)
 lens = rng.integers(400, 1914, size=n)
 series = [Y[i, 1913 - lens[i]:].copy() for i in range(n)]
 opts = lib.make_options(model, 28)
