@@ -18,6 +18,9 @@ run trace_autoets_m5 --workload autoets_m5 --steps 3 --warmup 1 --cpu-sample 0 -
 run trace_ets_aaa_fixed --workload ets_aaa_fixed_m5 --steps 20 --warmup 2 --cpu-sample 0
 run trace_autoarima_m5 --workload autoarima_m5 --steps 1 --warmup 0 --cpu-sample 0 --e2e-steps 0
 run trace_autoarima_css_m5 --workload autoarima_css_m5 --steps 1 --warmup 0 --cpu-sample 0 --e2e-steps 0
+run trace_autoets_hourly168 --workload autoets_hourly168 --steps 2 --warmup 1 --cpu-sample 0 --e2e-steps 0
+# the default call shape (params := MAP{}: periods detected per series) through the host-buffer batch entry, two calls
+rocprofv3 --kernel-trace --stats -d $OUT/trace_autodetect_autoets -o t -- python3 /root/repo/tools/time_autodetect_full.py 30490 AutoETS > $OUT/trace_autodetect_autoets.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace -d $OUT/pmc_$c -o p -- python3 /root/repo/bench.py --steps 1 --warmup 0 --cpu-sample 0 --e2e-steps 0 > $OUT/pmc_$c.log 2>&1
   rocprofv3 --pmc $c --kernel-trace -d $OUT/pmcfixed_$c -o p -- python3 /root/repo/bench.py --workload ets_aaa_fixed_m5 --steps 4 --warmup 0 --cpu-sample 0 > $OUT/pmcfixed_$c.log 2>&1
