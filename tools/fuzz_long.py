@@ -14,7 +14,11 @@ bad = total = 0
 for model, kw, positive, count in (("AutoETS", dict(seasonal_period=7), True, n), ("AutoETS", dict(seasonal_period=7), False, n),
                                    ("AutoETS", dict(seasonal_period=12, model_pool="reduced"), True, n // 2),
                                    ("AutoARIMA", dict(seasonal_period=7), False, n // 2), ("AutoARIMA", dict(), True, n // 4),
-                                   ("ETS", dict(ets_model="MAdM", seasonal_period=7), True, n // 2), ("HoltWinters", dict(seasonal_period=7), False, n // 2)):
+                                   ("ETS", dict(ets_model="MAdM", seasonal_period=7), True, n // 2), ("HoltWinters", dict(seasonal_period=7), False, n // 2),
+                                   # detected periods (merged batches: per-lane periods, LDS and HBM rings), long explicit periods
+                                   ("AutoETS", dict(), True, n // 2), ("AutoETS", dict(), False, n // 2), ("HoltWinters", dict(), True, n // 4),
+                                   ("AutoETS", dict(seasonal_period=30), True, n // 4), ("AutoETS", dict(seasonal_period=168), True, n // 4),
+                                   ("ETS", dict(ets_model="MAM", seasonal_period=365), True, n // 4)):
     Y = synth.gen_series(synth.SEED_M5 + seed, int(rng.integers(0, 100000)), count, 2000, 7, positive)
     lens = rng.integers(300, 2001, size=count)
     series = [Y[i, 2000 - lens[i]:].copy() for i in range(count)]          # ragged: the most recent lens[i] observations
