@@ -2005,7 +2005,12 @@ bool anofox_hip_batch_set_device_block(AnofoxHipBatch *b, const void *d_y, size_
         HIPCHECK(hipMemcpy(b->h_len.data(), d_len, b->n * sizeof(int32_t), hipMemcpyDeviceToHost));
         b->h_period.assign(b->n, b->opt.seasonal_period > 0 ? b->opt.seasonal_period : 1);
         finalize_lengths(b);
-        if (b->opt.auto_detect_seasonality && b->opt.seasonal_period == 0) batch_detect_periods(b);      // the block holds no NULLs: nothing to interpolate
+        if (b->opt.auto_detect_seasonality && b->opt.seasonal_period == 0) {
+            // the block holds no NULLs: nothing to interpolate.  The scan runs now, on the batch's own stream: whatever stream the
+            // caller filled the block on must have finished (the run itself is ordered by the stream the caller passes to it)
+            HIPCHECK(hipDeviceSynchronize());
+            batch_detect_periods(b);
+        }
         b->has_block = true;
     } catch (const HipFail &f) {
         report_hip_failure(out_error, f);
