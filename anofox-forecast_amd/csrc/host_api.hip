@@ -895,16 +895,20 @@ std::vector<int> detect_periods_host_series(const double *const *values, const u
     const size_t n_pad = (n_series + 63) / 64 * 64;
     const size_t cols = std::min(n_pad, std::max<size_t>(64, (size_t)(134217728.0 / (8.0 * (double)t_all)) / 64 * 64));
     struct Buf { double *h = nullptr, *d = nullptr, *sc = nullptr; int32_t *h_len = nullptr, *d_len = nullptr, *h_per = nullptr, *d_per = nullptr;
-                 size_t s0 = 0, cnt = 0; bool busy = false; } buf[2];
+                 size_t s0 = 0, cnt = 0; bool busy = false; hipEvent_t done = nullptr; } buf[2];
     hipStream_t st = nullptr;
     auto release = [&]() {
         if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
-        for (auto &b : buf) { pin_free(b.h); pin_free(b.h_len); dev_free(b.d, true); dev_free(b.sc, true); dev_free(b.d_len, true); dev_free(b.d_per, true); }
+        for (auto &b : buf) {
+            pin_free(b.h); pin_free(b.h_len); dev_free(b.d, true); dev_free(b.sc, true); dev_free(b.d_len, true); dev_free(b.d_per, true);
+            if (b.done) (void)hipEventDestroy(b.done);
+        }
     };
     try {
         HIPCHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         const size_t n_chunks = (n_series + cols - 1) / cols;
         for (int k = 0; k < (n_chunks > 1 ? 2 : 1); k++) {
+            HIPCHECK(hipEventCreateWithFlags(&buf[k].done, hipEventDisableTiming));
             buf[k].h = (double *)pin_alloc_bytes(t_all * cols * sizeof(double));
             buf[k].h_len = (int32_t *)pin_alloc_bytes(2 * cols * sizeof(int32_t));
             buf[k].h_per = buf[k].h_len + cols;
@@ -916,7 +920,7 @@ std::vector<int> detect_periods_host_series(const double *const *values, const u
         }
         auto collect = [&](Buf &b) {
             if (!b.busy) return;
-            HIPCHECK(hipStreamSynchronize(st));                   // (one stream: everything queued so far, i.e. this block's copy back)
+            HIPCHECK(hipEventSynchronize(b.done));                // this block's copy back (the other block may still be in flight)
             for (size_t j = 0; j < b.cnt; j++) out[b.s0 + j] = b.h_per[j];
             b.busy = false;
         };
@@ -963,6 +967,7 @@ std::vector<int> detect_periods_host_series(const double *const *values, const u
             launch_detect_periods(b.d, ld, b.d_len, (int)b.cnt, (int)T, b.sc, b.d_per, nullptr, st);
             LAUNCHCHECK("seasonal period detection");
             HIPCHECK(hipMemcpyAsync(b.h_per, b.d_per, b.cnt * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            HIPCHECK(hipEventRecord(b.done, st));
             b.busy = true;
         }
         collect(buf[0]);
