@@ -1983,7 +1983,10 @@ bool anofox_hip_batch_pack_host(AnofoxHipBatch *b, const double *const *values, 
             for (auto &f : fails) if (!f.empty()) throw HipFail{f};
         }
         if (!b->d_y || !b->owns_y) { b->d_y = dalloc<double>(T * ld); b->owns_y = true; }
-        HIPCHECK(hipMemcpy(b->d_y, block, T * ld * sizeof(double), hipMemcpyHostToDevice));
+        // on the batch's own stream: the legacy default stream of a synchronous hipMemcpy is shared by every host thread of the process
+        batch_attach_streams(b);
+        HIPCHECK(hipMemcpyAsync(b->d_y, block, T * ld * sizeof(double), hipMemcpyHostToDevice, b->own_stream));
+        HIPCHECK(hipStreamSynchronize(b->own_stream));
         finalize_lengths(b);
         if (detect) batch_detect_periods(b);
         b->has_block = true;
