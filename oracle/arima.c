@@ -243,7 +243,7 @@ static double css_obj_fn(const double *x, void *vc)
 
 static void nm_steps(CssCtx *ctx, int n, const double *x0, const double *step, double *xbest, double *fbest, int *iters_out, int *evals_out)
 {
-    double sim[ARIMA_MAX_DIM + 1][ARIMA_MAX_DIM], fs[ARIMA_MAX_DIM + 1], xb[ARIMA_MAX_DIM], xr[ARIMA_MAX_DIM], xt[ARIMA_MAX_DIM];
+    double sim[ARIMA_MAX_DIM + 1][ARIMA_MAX_DIM] = {{0}}, fs[ARIMA_MAX_DIM + 1] = {0}, xb[ARIMA_MAX_DIM] = {0}, xr[ARIMA_MAX_DIM] = {0}, xt[ARIMA_MAX_DIM] = {0};
     const int maxiter = ctx->cap, maxfun = ctx->cap;
     int evals = 0, iters = 1;
     if (n == 0) { *fbest = css_obj(x0, ctx); *iters_out = 0; *evals_out = 1; return; }
@@ -507,7 +507,7 @@ static int refit_ml(ArimaFit *fit, const double *w, int n, double wsd)
     CssCtx ctx = { o, w, n, NULL, NULL, ml_obj_fn, ARIMA_ML_NM_CAP * dim };
     const double f0 = ml_obj_fn(fit->x, &ctx);
     if (!(fabs(f0) <= DBL_MAX)) return 1;
-    double step[ARIMA_MAX_DIM], xb[ARIMA_MAX_DIM], fb;
+    double step[ARIMA_MAX_DIM] = {0}, xb[ARIMA_MAX_DIM] = {0}, fb;
     for (int i = 0; i < dim; i++) step[i] = 0.1;
     if (o->with_constant) step[dim - 1] = wsd > 0.0 ? 0.1 * wsd : 1.0e-4;
     int iters = 0, evals = 0;
@@ -564,7 +564,7 @@ static int polish_css(ArimaFit *fit, const double *w, int n, double wsd, double 
     const ArimaOrder *o = &fit->ord;
     const int dim = model_dim(o);
     if (dim == 0) return 0;
-    double step[ARIMA_MAX_DIM], xb[ARIMA_MAX_DIM], fb;
+    double step[ARIMA_MAX_DIM] = {0}, xb[ARIMA_MAX_DIM] = {0}, fb;
     for (int i = 0; i < dim; i++) step[i] = 0.1;
     if (o->with_constant) step[dim - 1] = wsd > 0.0 ? 0.1 * wsd : 1.0e-4;
     CssCtx ctx = { o, w, n, e, v, css_obj_fn, ARIMA_POLISH_NM_CAP * dim };

@@ -40,9 +40,9 @@ static double clipd(double v, double lo, double hi)
 void nm_minimize(nm_fn fn, void *ctx, int n, const double *x0,
                  const double *lo, const double *hi, NmResult *res)
 {
-    double sim[ETS_MAX_DIM + 1][ETS_MAX_DIM];
-    double fs[ETS_MAX_DIM + 1];
-    double xb[ETS_MAX_DIM], xt[ETS_MAX_DIM], xr[ETS_MAX_DIM];
+    double sim[ETS_MAX_DIM + 1][ETS_MAX_DIM] = {{0}};
+    double fs[ETS_MAX_DIM + 1] = {0};
+    double xb[ETS_MAX_DIM] = {0}, xt[ETS_MAX_DIM] = {0}, xr[ETS_MAX_DIM] = {0};
     const int maxiter = 200 * n, maxfun = 200 * n;
     int evals = 0, iters = 1;
 
