@@ -83,11 +83,11 @@ __global__ __launch_bounds__(NM_BLOCK, ANOFOX_ROUND_WAVES) void ets_round_kernel
     }
 
     SeriesView v;
-    const bool gathered = a.gathered != 0;
+    const bool gathered = a.gathered != 0 && n_act <= a.gather_cap;     // (else the gather kernel left y_round alone: no room)
     v.col = valid ? (gathered ? p : s) : 0;
     v.yb = gathered ? a.y_round : a.y;
     v.y = v.yb + v.col;
-    v.ld = a.ld_round;
+    v.ld = gathered ? a.ld_round : a.ld;
     v.len = active ? len : 0;
     v.wave_len = wave_max_i32(v.len);
     v.wave_min_len = wave_min_i32(active ? len : 0x7fffffff);

@@ -64,7 +64,8 @@ constexpr int32_t STATUS_NOT_COMPUTED = -1;
 struct Tunables {
     std::vector<int> budgets{24, 24, 24, 24, 24, 24, 48, 48, 96, 96, 192, 1024};   // ANOFOX_HIP_BUDGETS: Nelder-Mead iterations per round (last = to completion)
     int seq_rounds = -1;        // ANOFOX_HIP_SEQ_ROUNDS: rounds run by the sequential driver (-1: decided from the live problems)
-    int gather = -1;            // ANOFOX_HIP_GATHER: dense re-gather of the running problems between rounds (-1: on while it fits 96 GiB)
+    int gather_cols = 0;        // ANOFOX_HIP_GATHER_COLS (tests): columns of the per-spec gather blocks (0: as many as fit 55 % of the device, at most ld)
+    int gather = -1;            // ANOFOX_HIP_GATHER: dense re-gather of the running problems between rounds (-1: on, block size by memory)
     int spec_below = 8192;      // ANOFOX_HIP_SPEC_BELOW[_MD]: four lanes per problem once this few problems of a spec still run
     int spec_below_md = 8192;   //   (_MD: the damped multiplicative-trend specs, whose pass is ~10x longer)
     int spec2_below = 1024;     // ANOFOX_HIP_SPEC2_BELOW[_MD]: one wave per problem, two iterations per pass, for the last problems
@@ -95,6 +96,7 @@ struct Tunables {
         geti("ANOFOX_HIP_GATHER", t.gather);
         if (const char *e = std::getenv("ANOFOX_HIP_SPEC_BELOW")) t.spec_below = t.spec_below_md = std::atoi(e);
         geti("ANOFOX_HIP_SPEC_BELOW_MD", t.spec_below_md);
+        geti("ANOFOX_HIP_GATHER_COLS", t.gather_cols);
         if (const char *e = std::getenv("ANOFOX_HIP_SPEC2_BELOW")) t.spec2_below = t.spec2_below_md = std::atoi(e);
         geti("ANOFOX_HIP_SPEC2_BELOW_MD", t.spec2_below_md);
         if (const char *e = std::getenv("ANOFOX_HIP_MERGE_PERIODS")) t.merge_periods = std::atoi(e) != 0;
@@ -602,6 +604,8 @@ struct AnofoxHipBatch {
     int spec2_below = 1024;    // same, other specs (single-spec ETS(A,A,A) fit: 22.5 -> 18.2 ms; all specs at 2048 / 4096: 588 / 673 ms)
     int spec_below = 8192;   // per spec: switch to the speculative driver once this few problems are still running
     bool use_gather = false; // rebuild a dense block of the running problems between rounds (else index y by series)
+    size_t gather_cols = 0;  // columns of every spec's gather block: ld, or fewer when a block per spec would not fit (the gather then
+                             // starts once that few problems still run; until then the rounds index y by series)
     double *d_ring = nullptr;        // seasonal rings of periods above the LDS limit: one area per (candidate spec, workgroup)
     size_t ring_elems = 0;
     double *d_prep_scratch = nullptr;   // prep kernel's window ring + per-phase accumulators for such periods
@@ -816,9 +820,20 @@ void alloc_common(AnofoxHipBatch *b)
         b->d_slot_spec = dalloc<int32_t>(S);
         const int n_lanes = std::min<int>(N_AUX_STREAMS, b->n_slots_cap);
         const size_t T = std::max<size_t>(b->t_max, 1);
+        while (b->use_gather) {
+            try {
+                for (int q = 0; q < n_lanes; q++) b->lanes[q].ybuf = dalloc<double>(T * b->gather_cols);
+                break;
+            } catch (const HipFail &f) {
+                if (!f.oom) throw;
+                // no room for blocks of this size (a co-resident allocator holds memory): half the columns, or none at all
+                for (int q = 0; q < n_lanes; q++) { dev_free(b->lanes[q].ybuf, true); b->lanes[q].ybuf = nullptr; }
+                b->gather_cols = b->gather_cols / 2 / 64 * 64;
+                if (b->gather_cols < 1024) { b->use_gather = false; b->gather_cols = 0; }
+            }
+        }
         for (int q = 0; q < n_lanes; q++) {
             auto &l = b->lanes[q];
-            if (b->use_gather) l.ybuf = dalloc<double>(T * ld);
             l.map[0] = dalloc<int32_t>(ld);
             l.map[1] = dalloc<int32_t>(ld);
             l.cnt = dalloc<int32_t>(3);
@@ -1029,6 +1044,7 @@ void run_classic(AnofoxHipBatch *b, int kind, const int32_t *d_len, int m, int o
         }
         // dense re-gather between rounds: the spec lanes' block when there is one (free by now), else the family's own
         double *ybuf = (b->n_slots_cap > 0 && b->use_gather) ? b->lanes[0].ybuf : nullptr;
+        size_t ybuf_cols = ybuf ? b->gather_cols : ld;
         if (!ybuf && (double)std::max<size_t>(b->t_max, 1) * (double)ld * 8.0 <= 8.0 * 1073741824.0) {
             if (!b->d_classic_ybuf) b->d_classic_ybuf = dalloc<double>(std::max<size_t>(b->t_max, 1) * ld);
             ybuf = b->d_classic_ybuf;
@@ -1071,8 +1087,8 @@ void run_classic(AnofoxHipBatch *b, int kind, const int32_t *d_len, int m, int o
                 launch_compact(prev_map, prev_cnt, (int)n, b->classic_st.done, map[r & 1], cnt + (r % 3), st, cnt + ((r + 1) % 3));
                 f.series_of = map[r & 1]; f.n_active = cnt + (r % 3);
                 if (ybuf) {
-                    launch_gather_columns(b->d_y, ld, map[r & 1], cnt + (r % 3), (int)n, (int)b->t_max, ybuf, ld, st);
-                    f.y_round = ybuf; f.gathered = 1;
+                    launch_gather_columns(b->d_y, ld, map[r & 1], cnt + (r % 3), (int)n, (int)b->t_max, ybuf, ybuf_cols, st, (int)ybuf_cols);
+                    f.y_round = ybuf; f.ld_round = ybuf_cols; f.gathered = 1; f.gather_cap = (int)ybuf_cols;
                 }
                 f.spec_below = 8192; f.spec2_below = 1024;
                 f.budget = BUDGET[r]; f.budget_seq = (BUDGET[r] * 7) / 4;
@@ -1337,7 +1353,7 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
                 hipLaunchKernelGGL(retire_nonpositive_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, sq, (int)n, d_len, b->d_notpos,
                                    a.status, lane.st.done, lane.st.passes, lane.st.evals, lane.st.iters);
                 a.series_of = b->d_pos_map; a.n_active = b->d_pos_cnt;
-                if (b->d_ypos) { a.y_round = b->d_ypos; a.ld_round = ld; a.gathered = 1; }
+                if (b->d_ypos) { a.y_round = b->d_ypos; a.ld_round = ld; a.gathered = 1; a.gather_cap = (int)ld; }
                 else { a.y_round = b->d_y; a.ld_round = ld; }
             } else if (r == 0) {
                 a.y_round = b->d_y; a.ld_round = ld; a.series_of = nullptr; a.n_active = nullptr;
@@ -1348,8 +1364,9 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
                 launch_compact(prev_map, prev_cnt, (int)n, lane.st.done, lane.map[r & 1], lane.cnt + (r % 3), sq, lane.cnt + ((r + 1) % 3));
                 a.series_of = lane.map[r & 1]; a.n_active = lane.cnt + (r % 3);
                 if (b->use_gather && lane.ybuf) {
-                    launch_gather_columns(b->d_y, ld, lane.map[r & 1], lane.cnt + (r % 3), (int)n, (int)b->t_max, lane.ybuf, ld, sq);
-                    a.y_round = lane.ybuf; a.ld_round = ld; a.gathered = 1;
+                    launch_gather_columns(b->d_y, ld, lane.map[r & 1], lane.cnt + (r % 3), (int)n, (int)b->t_max, lane.ybuf, b->gather_cols, sq,
+                                          (int)b->gather_cols);
+                    a.y_round = lane.ybuf; a.ld_round = b->gather_cols; a.gathered = 1; a.gather_cap = (int)b->gather_cols;
                 } else {
                     a.y_round = b->d_y; a.ld_round = ld;
                 }
@@ -1536,7 +1553,7 @@ void run_group(AnofoxHipBatch *b, int period, const int32_t *d_len, hipStream_t 
             launch_compact(nullptr, nullptr, (int)n, b->d_notpos, b->d_pos_map, b->d_pos_cnt, st);
             if (b->use_gather) {
                 if (!b->d_ypos) b->d_ypos = dalloc<double>(std::max<size_t>(b->t_max, 1) * ld);
-                launch_gather_columns(b->d_y, ld, b->d_pos_map, b->d_pos_cnt, (int)n, (int)b->t_max, b->d_ypos, ld, st);
+                launch_gather_columns(b->d_y, ld, b->d_pos_map, b->d_pos_cnt, (int)n, (int)b->t_max, b->d_ypos, ld, st, (int)ld);
             }
         }
         launch_fit_slots(b, specs, d_len, m, true, st);
@@ -1823,9 +1840,20 @@ bool anofox_hip_batch_create(size_t n_series, size_t t_max, const ForecastOption
         b->tun = Tunables::from_env();
         if (b->tun.seq_rounds >= 0) { b->seq_rounds_env = b->tun.seq_rounds; b->seq_rounds = b->seq_rounds_env; }
         // dense re-gather of the running problems between rounds (up to 2x on a large batch) costs one block copy per
-        // candidate spec: on by default while that stays under 96 GiB of the 288 GB HBM
-        b->use_gather = (double)max_slots_for(plan) * (double)std::max<size_t>(t_max, 1) * (double)b->ld * 8.0 <= 96.0 * 1073741824.0;
-        if (b->tun.gather >= 0) b->use_gather = b->tun.gather != 0;
+        // candidate spec (sized below)
+        {
+            // one block per candidate spec: as many columns as fit 55 % of the device (158 GB of the MI355X's 288: the 1M x 1,024 stress
+            // configuration on ONE GPU gets 772k of its 1M columns -- 1.30 s per step against 1.64 s with 96 GiB of blocks and 2.75 s
+            // without any); halved below if the allocator refuses
+            size_t free_b = 0, total_b = 0;
+            const double budget = hipMemGetInfo(&free_b, &total_b) == hipSuccess ? std::max(96.0 * 1073741824.0, 0.55 * (double)total_b) : 96.0 * 1073741824.0;
+            const double per_col = (double)std::max(max_slots_for(plan), 1) * (double)std::max<size_t>(t_max, 1) * 8.0;
+            size_t cols = (size_t)std::min((double)b->ld, budget / per_col) / 64 * 64;
+            if (b->tun.gather_cols > 0) cols = std::min<size_t>(b->ld, (size_t)b->tun.gather_cols / 64 * 64);
+            b->gather_cols = cols;
+            b->use_gather = cols >= 1024 || cols >= b->ld;           // (a block for a few hundred stragglers is not worth its launches)
+        }
+        if (b->tun.gather >= 0) b->use_gather = b->tun.gather != 0 && b->gather_cols >= 64;
         b->spec_below = b->tun.spec_below; b->spec_below_md = b->tun.spec_below_md;
         b->spec2_below = b->tun.spec2_below; b->spec2_below_md = b->tun.spec2_below_md;
         b->arima_method = g_default_arima_method.load();

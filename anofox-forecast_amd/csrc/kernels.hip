@@ -286,10 +286,10 @@ void launch_compact(const int32_t *series_prev, const int32_t *n_prev, int n_ser
 // ------------------------------------------------------------------------------------------
 constexpr int GATHER_TB = 32;
 __global__ __launch_bounds__(NM_BLOCK) void gather_columns_kernel(const double *y, size_t ld, const int32_t *series_of,
-                                                                  const int32_t *n_active, int t_max, double *out, size_t ld_out)
+                                                                  const int32_t *n_active, int t_max, double *out, size_t ld_out, int cap)
 {
     const int n_act = *n_active;
-    if ((int)blockIdx.x * NM_BLOCK >= n_act) return;
+    if ((int)blockIdx.x * NM_BLOCK >= n_act || n_act > cap) return;       // (more running problems than `out` holds: the round kernel indexes y by series)
     const int p = blockIdx.x * NM_BLOCK + threadIdx.x;
     const int s = series_of[p < n_act ? p : n_act - 1];
     const int t0 = blockIdx.y * GATHER_TB;
@@ -298,11 +298,13 @@ __global__ __launch_bounds__(NM_BLOCK) void gather_columns_kernel(const double *
 }
 
 void launch_gather_columns(const double *y, size_t ld, const int32_t *series_of, const int32_t *n_active, int n_series,
-                           int t_max, double *out, size_t ld_out, hipStream_t stream)
+                           int t_max, double *out, size_t ld_out, hipStream_t stream, int cap)
 {
     if (n_series <= 0 || t_max <= 0) return;          // a batch of empty series: nothing to copy (and no zero-sized grid)
-    dim3 grid((n_series + NM_BLOCK - 1) / NM_BLOCK, (t_max + GATHER_TB - 1) / GATHER_TB);
-    hipLaunchKernelGGL(gather_columns_kernel, grid, dim3(NM_BLOCK), 0, stream, y, ld, series_of, n_active, t_max, out, ld_out);
+    const int n_cols = std::min(n_series, cap);
+    if (n_cols <= 0) return;
+    dim3 grid((n_cols + NM_BLOCK - 1) / NM_BLOCK, (t_max + GATHER_TB - 1) / GATHER_TB);
+    hipLaunchKernelGGL(gather_columns_kernel, grid, dim3(NM_BLOCK), 0, stream, y, ld, series_of, n_active, t_max, out, ld_out, cap);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -67,6 +67,7 @@ struct FitArgs {
     int budget_seq;              // passes per round when the device-side choice (round_auto) lands on the sequential driver
     int spec2_below;             // ... and the one-problem-per-wave driver (two iterations per pass) iff n_active <= spec2_below
     int gathered;                // y_round holds the running problems' columns densely (column p), else index by series
+    int gather_cap;              // columns y_round has room for: the gather (and this flag) only apply while n_active <= gather_cap
     NmStateBuf st;
     double *ring_scratch;        // periods above ETS_LDS_PERIOD: m * 64 doubles per workgroup of the launch (seasonal ring in HBM)
     int m, h;
@@ -162,8 +163,9 @@ constexpr int DETECT_LONG_GRID = 1024;       // workgroups of the scratch varian
 size_t detect_scratch_doubles(int n_series, int t_rows);
 void launch_detect_periods(const double *y, size_t ld, const int32_t *len, int n_series, int t_rows, double *scratch, int32_t *period,
                            double *best_acf, hipStream_t stream);
+// `cap`: columns `out` has room for -- the copy is skipped (the round kernel then indexes `y` by series) while more problems run
 void launch_gather_columns(const double *y, size_t ld, const int32_t *series_of, const int32_t *n_active, int n_series,
-                           int t_max, double *out, size_t ld_out, hipStream_t);
+                           int t_max, double *out, size_t ld_out, hipStream_t stream, int cap);
 
 // AutoARIMA (arima.hip): prep (D, d, differenced block), stepwise CSS search (advance / fit sweeps), forecast + integration
 struct ArimaArgs {

@@ -611,6 +611,21 @@ def test_device_resident_batch_and_stats(env):
     b.close()
 
 
+@pytest.mark.parametrize("cols", ["64", "192", "1024"])
+def test_partial_gather_blocks_give_the_same_results(env, monkeypatch, cols):
+    """A batch whose per-spec gather blocks cannot hold every column (1M series x 1,024: 25 blocks of 8.2 GB) gets blocks of fewer
+    columns: the rounds index y by series until that few problems still run, then switch to the dense copy -- decided on the device
+    from the running count, by the gather kernel and the round kernel alike.  Forced here on a small batch (ANOFOX_HIP_GATHER_COLS):
+    AutoETS, a fitted spec and Holt-Winters (the classic family borrows the first spec's block) agree with the oracle bit for bit."""
+    api, O, lib, synth = env
+    monkeypatch.setenv("ANOFOX_HIP_GATHER_COLS", cols)
+    Y = synth.gen_series(synth.SEED_M5, 9100, 300, 160, 7, positive=True)
+    series = [Y[s, : 160 - (s % 5) * 9] for s in range(300)]
+    _compare(api, O, lib, series, "AutoETS", 7, seasonal_period=7)
+    _compare(api, O, lib, series, "ETS", 7, ets_model="MAdM", seasonal_period=7)
+    _compare(api, O, lib, series, "HoltWinters", 7, seasonal_period=7)
+
+
 @pytest.mark.parametrize("T", [700, 9000])
 def test_period_detection_kernel_matches_oracle(env, T):
     """auto_detect_seasonality on a RESIDENT block: detect_period_kernel (one workgroup per series, the centred series in LDS, in an
