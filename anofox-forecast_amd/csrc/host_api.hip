@@ -595,6 +595,7 @@ struct AnofoxHipBatch {
     anofox::NmStateBuf classic_st{};
     int32_t *d_classic_status = nullptr, *classic_map[2] = {nullptr, nullptr}, *classic_cnt = nullptr;
     double *d_classic_ybuf = nullptr;
+    size_t classic_ybuf_cols = 0;
     std::vector<void *> retired;  // blocks a run outgrew while kernels may still read them: handed back when the batch is destroyed
                                   // (freeing them on the spot needs a device-wide synchronisation, which couples every host thread's batch)
     int merged_m_max = 0;         // ... and its largest period (sizes)
@@ -1045,9 +1046,15 @@ void run_classic(AnofoxHipBatch *b, int kind, const int32_t *d_len, int m, int o
         // dense re-gather between rounds: the spec lanes' block when there is one (free by now), else the family's own
         double *ybuf = (b->n_slots_cap > 0 && b->use_gather) ? b->lanes[0].ybuf : nullptr;
         size_t ybuf_cols = ybuf ? b->gather_cols : ld;
-        if (!ybuf && (double)std::max<size_t>(b->t_max, 1) * (double)ld * 8.0 <= 8.0 * 1073741824.0) {
-            if (!b->d_classic_ybuf) b->d_classic_ybuf = dalloc<double>(std::max<size_t>(b->t_max, 1) * ld);
-            ybuf = b->d_classic_ybuf;
+        if (!ybuf) {
+            // the family's own block: up to 32 GiB of columns (the 1M x 1,024 block is 8.2 GB), fewer if the batch is larger still
+            const double per_col = (double)std::max<size_t>(b->t_max, 1) * 8.0;
+            const size_t cols = (size_t)std::min((double)ld, 32.0 * 1073741824.0 / per_col) / 64 * 64;
+            if (cols >= 1024 || cols >= ld) {
+                if (!b->d_classic_ybuf) { b->d_classic_ybuf = dalloc<double>(std::max<size_t>(b->t_max, 1) * cols); b->classic_ybuf_cols = cols; }
+                ybuf = b->d_classic_ybuf;
+                ybuf_cols = b->classic_ybuf_cols;
+            }
         }
         const bool seasonal = kind == CK_HW || kind == CK_SEASONAL_ES;
         FitArgs f{};
