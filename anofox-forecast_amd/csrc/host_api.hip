@@ -577,7 +577,8 @@ struct AnofoxHipBatch {
     hipEvent_t ev_join[N_AUX_STREAMS] = {};
     // per aux stream: gathered block of the running problems, ping-pong column maps + counts, parked NM state
     struct Lane {
-        double *ybuf = nullptr;
+        double *ybuf = nullptr;          // allocated when a run first needs it (launch_fit_slots: only the specs that have anything to fit)
+        size_t ybuf_cols = 0;            // columns it holds (<= ld)
         int32_t *map[2] = {nullptr, nullptr};
         int32_t *cnt = nullptr;          // [2]
         anofox::NmStateBuf st{};
@@ -605,8 +606,9 @@ struct AnofoxHipBatch {
     int spec2_below = 1024;    // same, other specs (single-spec ETS(A,A,A) fit: 22.5 -> 18.2 ms; all specs at 2048 / 4096: 588 / 673 ms)
     int spec_below = 8192;   // per spec: switch to the speculative driver once this few problems are still running
     bool use_gather = false; // rebuild a dense block of the running problems between rounds (else index y by series)
-    size_t gather_cols = 0;  // columns of every spec's gather block: ld, or fewer when a block per spec would not fit (the gather then
-                             // starts once that few problems still run; until then the rounds index y by series)
+    double gather_budget = 0.0;  // bytes the gather blocks of one run may take together (55 % of the device): a block holds ld columns, or
+                                 // fewer when the live specs' blocks would not fit (the gather then starts once that few problems still
+                                 // run; until then the rounds index y by series)
     double *d_ring = nullptr;        // seasonal rings of periods above the LDS limit: one area per (candidate spec, workgroup)
     size_t ring_elems = 0;
     double *d_prep_scratch = nullptr;   // prep kernel's window ring + per-phase accumulators for such periods
@@ -759,7 +761,7 @@ void free_batch_buffers(AnofoxHipBatch *b)
     F(b->ar_order); F(b->ar_status); F(b->ar_evals); F(b->ar_passes); F(b->ar_models);
     batch_detach_streams(b);
     for (auto &l : b->lanes) {
-        F(l.ybuf); F(l.map[0]); F(l.map[1]); F(l.cnt);
+        F(l.ybuf); l.ybuf_cols = 0; F(l.map[0]); F(l.map[1]); F(l.cnt);
         F(l.st.sim); F(l.st.fs); F(l.st.phase); F(l.st.evals); F(l.st.iters); F(l.st.passes); F(l.st.done);
     }
 }
@@ -820,19 +822,6 @@ void alloc_common(AnofoxHipBatch *b)
         b->d_passes_slots = dalloc<int32_t>(S * ld);
         b->d_slot_spec = dalloc<int32_t>(S);
         const int n_lanes = std::min<int>(N_AUX_STREAMS, b->n_slots_cap);
-        const size_t T = std::max<size_t>(b->t_max, 1);
-        while (b->use_gather) {
-            try {
-                for (int q = 0; q < n_lanes; q++) b->lanes[q].ybuf = dalloc<double>(T * b->gather_cols);
-                break;
-            } catch (const HipFail &f) {
-                if (!f.oom) throw;
-                // no room for blocks of this size (a co-resident allocator holds memory): half the columns, or none at all
-                for (int q = 0; q < n_lanes; q++) { dev_free(b->lanes[q].ybuf, true); b->lanes[q].ybuf = nullptr; }
-                b->gather_cols = b->gather_cols / 2 / 64 * 64;
-                if (b->gather_cols < 1024) { b->use_gather = false; b->gather_cols = 0; }
-            }
-        }
         for (int q = 0; q < n_lanes; q++) {
             auto &l = b->lanes[q];
             l.map[0] = dalloc<int32_t>(ld);
@@ -1045,7 +1034,7 @@ void run_classic(AnofoxHipBatch *b, int kind, const int32_t *d_len, int m, int o
         }
         // dense re-gather between rounds: the spec lanes' block when there is one (free by now), else the family's own
         double *ybuf = (b->n_slots_cap > 0 && b->use_gather) ? b->lanes[0].ybuf : nullptr;
-        size_t ybuf_cols = ybuf ? b->gather_cols : ld;
+        size_t ybuf_cols = ybuf ? b->lanes[0].ybuf_cols : ld;
         if (!ybuf) {
             // the family's own block: up to 32 GiB of columns (the 1M x 1,024 block is 8.2 GB), fewer if the batch is larger still
             const double per_col = (double)std::max<size_t>(b->t_max, 1) * 8.0;
@@ -1325,6 +1314,41 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
                 hipLaunchKernelGGL(retire_nonpositive_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, b->aux[stream_of[oi]], (int)n, d_len,
                                    b->d_notpos, a.status, a.st.done, a.st.passes, a.st.evals, a.st.iters, a.aicc, a.passes, a.evals, a.iters);
             }
+    if (b->use_gather && !b->fixed_params) {
+        // gather blocks of the specs that have something to fit: as many columns as the spec can ever have running (the strictly
+        // positive series for a spec with a multiplicative component), scaled down together if that exceeds the budget
+        const size_t T = std::max<size_t>(b->t_max, 1);
+        std::vector<size_t> need(order.size(), 0);
+        double total = 0.0;
+        for (size_t oi = 0; oi < order.size(); oi++) {
+            if (dead[oi]) continue;
+            size_t c = (b->use_pos && args[oi].need_positive && b->live_pos >= 0) ? (size_t)b->live_pos : n;
+            need[oi] = std::min(ld, (c + 63) / 64 * 64);
+            total += (double)need[oi] * (double)T * 8.0;
+        }
+        const double scale = total > b->gather_budget ? b->gather_budget / total : 1.0;
+        for (size_t oi = 0; oi < order.size(); oi++) {
+            if (dead[oi]) continue;
+            auto &lane = b->lanes[oi % (size_t)n_lanes];
+            size_t cols = scale < 1.0 ? (size_t)((double)need[oi] * scale) / 64 * 64 : need[oi];
+            if (b->tun.gather_cols > 0) cols = std::min<size_t>(need[oi], (size_t)b->tun.gather_cols / 64 * 64);
+            if (cols < need[oi] && cols < 1024 && b->tun.gather_cols <= 0) cols = 0;      // (a block for a few hundred stragglers is not worth its launches)
+            if (lane.ybuf && lane.ybuf_cols >= cols) continue;                            // (a larger block from an earlier run serves as well)
+            if (lane.ybuf) {
+                HIPCHECK(hipDeviceSynchronize());                                          // an earlier run of this batch may still read the old block
+                dev_free(lane.ybuf, true);
+                lane.ybuf = nullptr; lane.ybuf_cols = 0;
+            }
+            while (cols >= 64) {
+                try { lane.ybuf = dalloc<double>(T * cols); lane.ybuf_cols = cols; break; }
+                catch (const HipFail &f) {
+                    if (!f.oom) throw;
+                    cols = cols / 2 / 64 * 64;                 // a co-resident allocator holds memory: half the columns, in the end none
+                    if (cols < 1024) cols = 0;
+                }
+            }
+        }
+    }
     if (b->fixed_params) {
         // given smoothing parameters: no rounds at all -- admissibility + parameters, then the final pass below
         for (size_t oi = 0; oi < order.size(); oi++) {
@@ -1371,9 +1395,9 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
                 launch_compact(prev_map, prev_cnt, (int)n, lane.st.done, lane.map[r & 1], lane.cnt + (r % 3), sq, lane.cnt + ((r + 1) % 3));
                 a.series_of = lane.map[r & 1]; a.n_active = lane.cnt + (r % 3);
                 if (b->use_gather && lane.ybuf) {
-                    launch_gather_columns(b->d_y, ld, lane.map[r & 1], lane.cnt + (r % 3), (int)n, (int)b->t_max, lane.ybuf, b->gather_cols, sq,
-                                          (int)b->gather_cols);
-                    a.y_round = lane.ybuf; a.ld_round = b->gather_cols; a.gathered = 1; a.gather_cap = (int)b->gather_cols;
+                    launch_gather_columns(b->d_y, ld, lane.map[r & 1], lane.cnt + (r % 3), (int)n, (int)b->t_max, lane.ybuf, lane.ybuf_cols, sq,
+                                          (int)lane.ybuf_cols);
+                    a.y_round = lane.ybuf; a.ld_round = lane.ybuf_cols; a.gathered = 1; a.gather_cap = (int)lane.ybuf_cols;
                 } else {
                     a.y_round = b->d_y; a.ld_round = ld;
                 }
@@ -1849,18 +1873,15 @@ bool anofox_hip_batch_create(size_t n_series, size_t t_max, const ForecastOption
         // dense re-gather of the running problems between rounds (up to 2x on a large batch) costs one block copy per
         // candidate spec (sized below)
         {
-            // one block per candidate spec: as many columns as fit 55 % of the device (158 GB of the MI355X's 288: the 1M x 1,024 stress
-            // configuration on ONE GPU gets 772k of its 1M columns -- 1.30 s per step against 1.64 s with 96 GiB of blocks and 2.75 s
-            // without any); halved below if the allocator refuses
+            // one block per candidate spec THAT HAS ANYTHING TO FIT, allocated by the first run that needs it (launch_fit_slots): together
+            // at most 55 % of the device (158 GB of the MI355X's 288).  The 1M x 1,024 stress configuration on ONE GPU: 6 admissible specs
+            // on intermittent counts -> six full blocks of 8.2 GB; with all 25 specs live, blocks of 772k of the 1M columns (1.34 s per
+            // step against 2.75 s without any gather, which is what the old all-or-nothing 96 GiB rule gave)
             size_t free_b = 0, total_b = 0;
-            const double budget = hipMemGetInfo(&free_b, &total_b) == hipSuccess ? std::max(96.0 * 1073741824.0, 0.55 * (double)total_b) : 96.0 * 1073741824.0;
-            const double per_col = (double)std::max(max_slots_for(plan), 1) * (double)std::max<size_t>(t_max, 1) * 8.0;
-            size_t cols = (size_t)std::min((double)b->ld, budget / per_col) / 64 * 64;
-            if (b->tun.gather_cols > 0) cols = std::min<size_t>(b->ld, (size_t)b->tun.gather_cols / 64 * 64);
-            b->gather_cols = cols;
-            b->use_gather = cols >= 1024 || cols >= b->ld;           // (a block for a few hundred stragglers is not worth its launches)
+            b->gather_budget = hipMemGetInfo(&free_b, &total_b) == hipSuccess ? std::max(96.0 * 1073741824.0, 0.55 * (double)total_b) : 96.0 * 1073741824.0;
+            b->use_gather = true;
         }
-        if (b->tun.gather >= 0) b->use_gather = b->tun.gather != 0 && b->gather_cols >= 64;
+        if (b->tun.gather >= 0) b->use_gather = b->tun.gather != 0;
         b->spec_below = b->tun.spec_below; b->spec_below_md = b->tun.spec_below_md;
         b->spec2_below = b->tun.spec2_below; b->spec2_below_md = b->tun.spec2_below_md;
         b->arima_method = g_default_arima_method.load();
