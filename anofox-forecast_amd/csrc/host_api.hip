@@ -2179,17 +2179,25 @@ bool anofox_hip_batch_fetch(AnofoxHipBatch *b, ForecastResult *out_results, Anof
     const size_t n = b->n, h = (size_t)std::max(b->h, 0);
     if (hipStreamSynchronize(b->last_stream) != hipSuccess) return false;
     b->quiesced = true;
-    std::vector<double> yhat(n * h), lo(n * h), hi(n * h);
-    std::vector<int32_t> status(n), code(n), detail(n);
+    // results come back through ONE pinned block (a copy into pageable memory is staged by the runtime at a fraction of the link
+    // speed: 672 MB of forecasts for 1M series), on the stream of the run
+    const size_t nh = n * h;
+    struct PinBlock { void *p = nullptr; ~PinBlock() { pin_free(p); } } pin;
+    try { pin.p = pin_alloc_bytes(std::max<size_t>(3 * nh * sizeof(double) + 3 * n * sizeof(int32_t), 64)); }
+    catch (...) { return false; }
+    double *const yhat = (double *)pin.p, *const lo = yhat + nh, *const hi = lo + nh;
+    int32_t *const status = (int32_t *)(hi + nh), *const code = status + n, *const detail = code + n;
     bool ok = true;
-    if (h) {
-        ok &= hipMemcpy(yhat.data(), b->d_yhat, n * h * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess;
-        ok &= hipMemcpy(lo.data(), b->d_lo, n * h * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess;
-        ok &= hipMemcpy(hi.data(), b->d_hi, n * h * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess;
+    hipStream_t cs = b->last_stream;
+    if (nh) {
+        ok &= hipMemcpyAsync(yhat, b->d_yhat, nh * sizeof(double), hipMemcpyDeviceToHost, cs) == hipSuccess;
+        ok &= hipMemcpyAsync(lo, b->d_lo, nh * sizeof(double), hipMemcpyDeviceToHost, cs) == hipSuccess;
+        ok &= hipMemcpyAsync(hi, b->d_hi, nh * sizeof(double), hipMemcpyDeviceToHost, cs) == hipSuccess;
     }
-    ok &= hipMemcpy(status.data(), b->d_status, n * sizeof(int32_t), hipMemcpyDeviceToHost) == hipSuccess;
-    ok &= hipMemcpy(code.data(), b->d_model_code, n * sizeof(int32_t), hipMemcpyDeviceToHost) == hipSuccess;
-    ok &= hipMemcpy(detail.data(), b->d_detail, n * sizeof(int32_t), hipMemcpyDeviceToHost) == hipSuccess;
+    ok &= hipMemcpyAsync(status, b->d_status, n * sizeof(int32_t), hipMemcpyDeviceToHost, cs) == hipSuccess;
+    ok &= hipMemcpyAsync(code, b->d_model_code, n * sizeof(int32_t), hipMemcpyDeviceToHost, cs) == hipSuccess;
+    ok &= hipMemcpyAsync(detail, b->d_detail, n * sizeof(int32_t), hipMemcpyDeviceToHost, cs) == hipSuccess;
+    ok &= hipStreamSynchronize(cs) == hipSuccess;
     if (!ok) return false;
     // the per-series result records (three allocations each, the reference's ownership contract): on several host threads for a large
     // batch -- 1M series spent 0.47 s here on one
