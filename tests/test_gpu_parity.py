@@ -787,6 +787,34 @@ def test_stress_shape_properties(env):
         assert _rel(sub["yhat"][j], ref["point"]) <= REL_TOL and sub_names[j] == ref["model_name"]
 
 
+def test_host_entry_uploads_large_blocks_in_chunks(env):
+    """A block above 512 MB goes to the device in column chunks through two pinned staging buffers (pitched copies while the packer
+    threads fill the other buffer): 36,000 ragged series x 2,000 observations = 576 MB = two chunks (33,536 + 2,496 columns).
+    SeasonalNaive makes every column checkable without the oracle: the forecast is the series' own last season, so a column that
+    landed in the wrong place, or a row of the wrong chunk, shows up in exactly that series."""
+    api, O, lib, synth = env
+    n, T, m, h = 36000, 2000, 7, 14
+    rng = np.random.default_rng(77)
+    Y = rng.normal(0.0, 1.0, (n, T)) + np.arange(n)[:, None] * 1.0e-3
+    lens = np.where(np.arange(n) % 9 == 0, rng.integers(20, T, n), T)
+    series = [Y[s, : lens[s]] for s in range(n)]
+    got, berr = api.forecast_batch(series, lib.make_options("SeasonalNaive", h, seasonal_period=m))
+    assert berr["ok"], berr
+    bad = 0
+    for s in range(n):
+        y = series[s]
+        want = np.array([y[len(y) - m + (i % m)] for i in range(h)])
+        if not (got[s]["ok"] and np.array_equal(got[s]["point"], want)):
+            bad += 1
+    assert bad == 0, bad
+    # ... and the fitted path through the same upload: a sample against the oracle
+    got2, berr2 = api.forecast_batch(series, lib.make_options("SES", h))
+    assert berr2["ok"], berr2
+    for s in (0, 9, 33535, 33536, 33537, n - 1):
+        ref = O.forecast(series[s], O.make_options("SES", h))
+        assert got2[s]["ok"] and np.array_equal(got2[s]["point"], ref["point"]), s
+
+
 @pytest.mark.parametrize("scaling", ["strong", "weak"])
 def test_bench_two_ranks_on_one_gpu(env, scaling):
     """bench.py's N > 1 path end to end -- two processes, torch.distributed rendezvous, sharded batches on the device, gather
