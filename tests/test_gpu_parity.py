@@ -795,7 +795,8 @@ def test_host_entry_uploads_large_blocks_in_chunks(env):
     api, O, lib, synth = env
     n, T, m, h = 36000, 2000, 7, 14
     rng = np.random.default_rng(77)
-    Y = rng.normal(0.0, 1.0, (n, T)) + np.arange(n)[:, None] * 1.0e-3
+    per = 5 + np.arange(n) % 40
+    Y = rng.normal(0.0, 1.0, (n, T)) + np.arange(n)[:, None] * 1.0e-3 + 3.0 * np.sin(2.0 * np.pi * np.arange(T)[None, :] / per[:, None])
     lens = np.where(np.arange(n) % 9 == 0, rng.integers(20, T, n), T)
     series = [Y[s, : lens[s]] for s in range(n)]
     got, berr = api.forecast_batch(series, lib.make_options("SeasonalNaive", h, seasonal_period=m))
@@ -813,6 +814,20 @@ def test_host_entry_uploads_large_blocks_in_chunks(env):
     for s in (0, 9, 33535, 33536, 33537, n - 1):
         ref = O.forecast(series[s], O.make_options("SES", h))
         assert got2[s]["ok"] and np.array_equal(got2[s]["point"], ref["point"]), s
+    # ... and the period detection, which packs the same series in chunks of its own (~128 MB, five here): SeasonalNaive without
+    # a period repeats the last DETECTED season
+    got3, berr3 = api.forecast_batch(series, lib.make_options("SeasonalNaive", h))
+    assert berr3["ok"], berr3
+    L = O.lib()
+    seen = set()
+    for s in list(range(0, n, 97)) + [8191, 8192, 16383, 16384, 33535, 33536, n - 1]:
+        y = np.ascontiguousarray(series[s])
+        p = L.oracle_detect_seasonality_first(y.ctypes.data, len(y)) if len(y) >= 3 else 0
+        p = p if p > 0 else 1
+        seen.add(p)
+        want = np.array([y[len(y) - p + (i % p)] for i in range(h)])
+        assert got3[s]["ok"] and np.array_equal(got3[s]["point"], want), (s, p)
+    assert len(seen) > 20
 
 
 @pytest.mark.parametrize("scaling", ["strong", "weak"])
