@@ -787,6 +787,37 @@ def test_stress_shape_properties(env):
         assert _rel(sub["yhat"][j], ref["point"]) <= REL_TOL and sub_names[j] == ref["model_name"]
 
 
+@pytest.mark.parametrize("model", ["HoltWinters", "AutoETS"])
+def test_auto_detected_big_parts_run_beside_the_small_ones(env, model):
+    """params := MAP{} on a batch where one detected period has >= 2,048 series (it runs as its own batch with the compile-time kernels,
+    on its own host thread) beside merged batches of the rare periods and a non-seasonal rest: every series equals the oracle."""
+    api, O, lib, synth = env
+    rng = np.random.default_rng(23)
+    series = []
+    for k in range(2300):
+        p = 7 if k < 2100 else (5, 12, 20, 33, 70)[k % 5]
+        T = int(6 * p + 30 + rng.integers(0, 12))
+        t = np.arange(T)
+        series.append(40.0 + 0.05 * t + 6.0 * np.sin(2 * np.pi * t / p) + 2.0 * np.cos(4 * np.pi * t / p) + rng.normal(0, 0.4, T))
+    series += [rng.normal(10, 1, 40) for _ in range(60)] + [np.full(30, 2.0), np.array([1.0, 2.0])]
+    _compare(api, O, lib, series, model, 5)
+
+
+@pytest.mark.parametrize("m,T", [(700, 5200)])
+def test_long_period_figures_through_the_scratch_variant(env, m, T):
+    """season_figures_kernel keeps the series and its trend in LDS up to 2 T + 2 m = 12,288 doubles; above that the workgroup
+    works in an HBM scratch (T = 5,200, m = 700: 11,800 + ... > 12,288).  ETS(A,A,A) and AutoETS with that period equal the oracle."""
+    api, O, lib, synth = env
+    rng = np.random.default_rng(m)
+    series = []
+    for k in range(6):
+        L = T - 37 * k
+        t = np.arange(L)
+        series.append(100.0 + 0.01 * t + (8.0 + k) * np.sin(2 * np.pi * t / m) + rng.normal(0, 0.5, L))
+    _compare(api, O, lib, series, "ETS", 9, ets_model="AAA", seasonal_period=m)
+    _compare(api, O, lib, series[:3], "AutoETS", 9, seasonal_period=m)
+
+
 def test_host_entry_uploads_large_blocks_in_chunks(env):
     """A block above 512 MB goes to the device in column chunks through two pinned staging buffers (pitched copies while the packer
     threads fill the other buffer): 36,000 ragged series x 2,000 observations = 576 MB = two chunks (33,536 + 2,496 columns).
