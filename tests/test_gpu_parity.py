@@ -803,10 +803,10 @@ def test_auto_detected_big_parts_run_beside_the_small_ones(env, model):
     _compare(api, O, lib, series, model, 5)
 
 
-@pytest.mark.parametrize("m,T", [(700, 5200)])
+@pytest.mark.parametrize("m,T", [(700, 5800)])
 def test_long_period_figures_through_the_scratch_variant(env, m, T):
     """season_figures_kernel keeps the series and its trend in LDS up to 2 T + 2 m = 12,288 doubles; above that the workgroup
-    works in an HBM scratch (T = 5,200, m = 700: 11,800 + ... > 12,288).  ETS(A,A,A) and AutoETS with that period equal the oracle."""
+    works in an HBM scratch (T = 5,800, m = 700: 13,000 doubles).  ETS(A,A,A) and AutoETS with that period equal the oracle."""
     api, O, lib, synth = env
     rng = np.random.default_rng(m)
     series = []
