@@ -531,7 +531,6 @@ struct AnofoxHipBatch {
     bool quiesced = true;              // nothing of this batch is in flight (set by the fetch's wait, cleared by a run): destroy need not wait
     std::vector<int32_t> h_period;     // per-series period
     std::vector<int32_t> h_base_status;
-    std::vector<int32_t> h_seed_status;  // what d_status is seeded with: base status, usable series = STATUS_NOT_COMPUTED
     std::vector<int32_t> h_slot_spec;
     double *h_stage = nullptr;         // pinned staging copy of the time-major block (packer output, H2D source)
     size_t h_stage_elems = 0;
@@ -1100,6 +1099,19 @@ void run_classic(AnofoxHipBatch *b, int kind, const int32_t *d_len, int m, int o
     launch_classic(kind, a, st);
 }
 
+// Start of a run, ONE launch (it was a status upload plus six fills: a fifth of the device time of the fixed-parameter step):
+// usable series start as "not computed" and only a kernel turns that into success, the forecasts start as NaN (all bits set, as
+// the 0xff fill wrote them), the per-series totals and the model codes as zero.
+__global__ void seed_outputs_kernel(int n, int ld, size_t nh, const int32_t *len, int32_t *status, double *yhat, double *lo, double *hi,
+                                    int32_t *passes_total, int32_t *evals_total, int32_t *model_code)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const double nanv = __longlong_as_double(-1LL);
+    if (i < nh) { yhat[i] = nanv; lo[i] = nanv; hi[i] = nanv; }
+    if (i < (size_t)ld) { passes_total[i] = 0; evals_total[i] = 0; model_code[i] = 0; }
+    if (i < (size_t)n) status[i] = len[i] > 0 ? (int32_t)STATUS_NOT_COMPUTED : (int32_t)INSUFFICIENT_DATA;      // (finalize_lengths: a series too short to forecast reads as empty)
+}
+
 __global__ void fill_i32_kernel(int n, int32_t *dst, int32_t v)
 {
     int s = blockIdx.x * 256 + threadIdx.x;
@@ -1225,7 +1237,12 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
     // the final pass sweeps the original blocks (one period each)
     const bool merged = b->d_m_col != nullptr;
     const int lds_limit = merged ? ETS_MERGED_LDS_PERIOD : ETS_LDS_PERIOD;      // largest period whose seasonal ring stays in LDS
-    const int n_fork = n_lanes;                          // streams that carry work: one per spec
+    // ONE spec (ETS with an explicit model, fitted or with given parameters): its launches go on the run's own stream -- no fork, no
+    // join.  A cross-stream event wait is cheap when the host has just synchronised and expensive inside a pipeline of runs: twenty
+    // fixed-parameter steps enqueued back to back took 1.4 ms each with the fork / join against 0.5 ms with a host wait in between.
+    const bool inline_stream = specs.size() == 1;
+    const int n_fork = inline_stream ? 0 : n_lanes;      // streams that carry work: one per spec
+    auto spec_stream = [&](int idx) -> hipStream_t { return inline_stream ? st : b->aux[idx]; };
     for (int i = 0; i < n_fork; i++) HIPCHECK(hipStreamWaitEvent(b->aux[i], b->ev_fit0, 0));
     // enqueue order: most expensive specs first, dealt round-robin over the streams, so the long
     // multiplicative / damped / seasonal fits start together instead of queueing behind each other
@@ -1311,7 +1328,7 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
             if (args[oi].need_positive) {
                 dead[oi] = 1;
                 const FitArgs &a = args[oi];
-                hipLaunchKernelGGL(retire_nonpositive_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, b->aux[stream_of[oi]], (int)n, d_len,
+                hipLaunchKernelGGL(retire_nonpositive_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, spec_stream(stream_of[oi]), (int)n, d_len,
                                    b->d_notpos, a.status, a.st.done, a.st.passes, a.st.evals, a.st.iters, a.aicc, a.passes, a.evals, a.iters);
             }
     if (b->use_gather && !b->fixed_params) {
@@ -1361,7 +1378,7 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
             if (spec_trend_idx(id) != 0) x[d++] = b->fixed_x[1];
             if (spec_season(id) != 0) x[d++] = b->fixed_x[2];
             if (spec_trend_idx(id) == 2 || spec_trend_idx(id) == 4) x[d++] = b->fixed_x[3];
-            hipLaunchKernelGGL(ets_fixed_setup_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, b->aux[stream_of[oi]], (int)n, ld, d_len,
+            hipLaunchKernelGGL(ets_fixed_setup_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, spec_stream(stream_of[oi]), (int)n, ld, d_len,
                                b->d_flags, spec_season(id) != 0 ? 1 : 0, a.m, a.n_param, a.need_positive, d, x[0], x[1], x[2], x[3], a.status,
                                a.st.sim, a.st.evals, a.st.iters, a.st.passes, a.st.done);
         }
@@ -1372,7 +1389,7 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
             if (dead[oi]) continue;
             const int q = (int)(oi % (size_t)n_lanes);
             auto &lane = b->lanes[q];
-            hipStream_t sq = b->aux[stream_of[oi]];
+            hipStream_t sq = spec_stream(stream_of[oi]);
             FitArgs &a = args[oi];
             const bool spec_mode = r >= b->seq_rounds;
             a.first_round = (r == 0);
@@ -1428,9 +1445,9 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
         LAUNCHCHECK("ETS fit round");
     }
     // fixed parameters: the one streamed pass IS the workload -- the fit events bracket exactly that launch, on its stream
-    if (b->fixed_params && order.size() == 1) HIPCHECK(hipEventRecord(b->ev_fit0, b->aux[stream_of[0]]));
-    for (size_t oi = 0; oi < order.size(); oi++) if (!dead[oi]) fns[oi].final(args[oi], b->aux[stream_of[oi]]);
-    if (b->fixed_params && order.size() == 1) HIPCHECK(hipEventRecord(b->ev_fit1, b->aux[stream_of[0]]));
+    if (b->fixed_params && order.size() == 1) HIPCHECK(hipEventRecord(b->ev_fit0, spec_stream(stream_of[0])));
+    for (size_t oi = 0; oi < order.size(); oi++) if (!dead[oi]) fns[oi].final(args[oi], spec_stream(stream_of[oi]));
+    if (b->fixed_params && order.size() == 1) HIPCHECK(hipEventRecord(b->ev_fit1, spec_stream(stream_of[0])));
     LAUNCHCHECK("ETS final pass");
     for (int i = 0; i < n_fork; i++) {
         HIPCHECK(hipEventRecord(b->ev_join[i], b->aux[i]));
@@ -1643,19 +1660,13 @@ void run_batch(AnofoxHipBatch *b, hipStream_t st)
     b->quiesced = false;         // (from here on, also when a launch below fails)
     b->last_stream = st;
     HIPCHECK(hipEventRecord(b->ev_start, st));
-    // usable series start as "not computed" and only a kernel turns that into success; the forecasts start as NaN
-    b->h_seed_status.resize(n);
-    for (size_t s = 0; s < n; s++) b->h_seed_status[s] = b->h_base_status[s] == 0 ? STATUS_NOT_COMPUTED : b->h_base_status[s];
-    HIPCHECK(hipMemcpyAsync(b->d_status, b->h_seed_status.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    if (b->h > 0) {
-        const size_t bytes = n * (size_t)b->h * sizeof(double);
-        HIPCHECK(hipMemsetAsync(b->d_yhat, 0xff, bytes, st));
-        HIPCHECK(hipMemsetAsync(b->d_lo, 0xff, bytes, st));
-        HIPCHECK(hipMemsetAsync(b->d_hi, 0xff, bytes, st));
+    {
+        const size_t nh = n * (size_t)std::max(b->h, 0);
+        const size_t cover = std::max<size_t>(std::max(nh, ld), 1);
+        hipLaunchKernelGGL(seed_outputs_kernel, dim3((unsigned)((cover + 255) / 256)), dim3(256), 0, st, (int)n, (int)ld, nh, (const int32_t *)b->d_len, b->d_status,
+                           b->d_yhat, b->d_lo, b->d_hi, b->d_passes_total, b->d_evals_total, b->d_model_code);
+        LAUNCHCHECK("output seeding");
     }
-    HIPCHECK(hipMemsetAsync(b->d_passes_total, 0, ld * sizeof(int32_t), st));
-    HIPCHECK(hipMemsetAsync(b->d_evals_total, 0, ld * sizeof(int32_t), st));
-    HIPCHECK(hipMemsetAsync(b->d_model_code, 0, ld * sizeof(int32_t), st));
     // group series by seasonal period (all equal unless auto-detection ran).  Detection gives ~140 distinct periods per
     // thousand M5-like series and every group is one run of the whole pipeline, so series are grouped by the period the
     // model actually USES: none for the non-seasonal models, 1 for every AutoARIMA period outside 2..24 (no seasonal terms).
