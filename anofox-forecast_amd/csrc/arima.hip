@@ -437,8 +437,11 @@ struct ArWs {
     double *best_aicc;    // [n]
     int32_t *state;       // [n x 8] stage, idx, base key, best key, have, improved, n_models, fin
     int32_t *q_series, *q_key;   // [7 x cap] problem queues by dimension
-    int32_t *counts;      // [32] 0..6 queue lengths, 8 fetch cursor, 9..13 refit class cursors, 16..20 refit class sizes
+    int32_t *counts;      // [32] 0..6 queue lengths, 8 fetch cursor, 9..13 refit class cursors, 16..20 refit class sizes,
+                          //      21..25 class cursors of the refit's second (speculative) launch, 26 series parked for it
     double *ml_sim;       // [waves x 42 x 64] simplex scratch of the exact-likelihood refit
+    double *ml_park;      // [n x 64] Nelder-Mead state of the series the first refit launch parks for the second
+    int32_t *ml_park_list;   // [n] those series
     size_t tw, cap;
     static size_t align(size_t x) { return (x + 255) & ~(size_t)255; }
     size_t carve(char *p, int n, int t_max)
@@ -459,6 +462,8 @@ struct ArWs {
         q_key = (int32_t *)take(sizeof(int32_t) * 7 * cap);
         counts = (int32_t *)take(sizeof(int32_t) * 32);
         ml_sim = (double *)take(sizeof(double) * (size_t)ar_ml_sim_waves(n) * 64 * NM_BLOCK);   // AR_ML_CTX <= 64 slots per lane
+        ml_park = (double *)take(sizeof(double) * (size_t)n * 64);
+        ml_park_list = (int32_t *)take(sizeof(int32_t) * (size_t)n);
         return off;
     }
 };
@@ -1484,8 +1489,11 @@ struct ArSimG {
 // Series whose state dimension r lies in (r_lo, RM] are refitted by the RM instantiation (the unrolled loops cost RM whatever
 // the lane's own r, so the common small models -- r = 9 for (0,1,1)(1,0,1)[7] -- run in a narrower kernel); `cursor` is the
 // queue cursor of this launch in ws.counts.
+// `budget` > 0: a series that has used this many evaluations when an iteration starts is PARKED -- its simplex, function values and
+// counters go to ws.ml_park, its index to ws.ml_park_list -- and the second launch (ar_refit_body_spec) finishes it with four
+// trial points per pass.
 template <int RM>
-__device__ __noinline__ int ar_refit_body(const ArimaArgs &a, const ArWs &ws, const int r_lo, const int cursor, double *lds)
+__device__ __noinline__ int ar_refit_body(const ArimaArgs &a, const ArWs &ws, const int r_lo, const int cursor, double *lds, const int budget)
 {
     const int lane = threadIdx.x;
     const bool even = (lane & 1) == 0;                     // the pair's lanes run the same Nelder-Mead on the same values; the even one talks to memory
@@ -1550,6 +1558,14 @@ __device__ __noinline__ int ar_refit_body(const ArimaArgs &a, const ArWs &ws, co
                     if (even && fabs(fb) <= 1.7976931348623157e308 && fb <= L.f0())
                         for (int i = 0; i < D; i++) a.xbest[(size_t)i * ld + s] = L.sim(0, i);
                     ph = RP_DONE;
+                } else if (budget > 0 && nm_evals >= budget) {
+                    if (even) {
+                        double *pk = ws.ml_park + (size_t)s * 64;
+                        for (int c = 0; c < AR_ML_CTX; c++) pk[c] = L.base[(size_t)c * NM_BLOCK + L.col];
+                        pk[60] = (double)nm_evals; pk[61] = (double)nm_iters;
+                        ws.ml_park_list[atomicAdd(&ws.counts[26], 1)] = s;
+                    }
+                    ph = RP_DONE;
                 }
             }
             if (ph == RP_F0) { for (int i = 0; i < D; i++) x[i] = a.xbest[(size_t)i * ld + s]; }      // the CSS optimum
@@ -1611,6 +1627,109 @@ __device__ __noinline__ int ar_refit_body(const ArimaArgs &a, const ArWs &ws, co
     return loops;
 }
 
+// Second launch of the refit: the series the first one parked (those still running after its evaluation budget -- the few that
+// decide how long the refit takes) continue with FOUR trial points per filter pass: reflection, expansion, outside and inside
+// contraction by four lane pairs (eight lanes per series) instead of the sequential driver's ~1.7 passes per iteration, the four
+// vertices of a shrink likewise.  Every pair keeps its own copy of the simplex and applies the same decisions to it (the function
+// values cross the octet through wave shuffles) and the evaluation counts advance as in the sequential driver: same estimates, bit for bit.
+template <int RM>
+__device__ __noinline__ int ar_refit_body_spec(const ArimaArgs &a, const ArWs &ws, const int r_lo, const int cursor, double *lds)
+{
+    const int lane = threadIdx.x;
+    const int g = (lane >> 1) & 3, lead = lane & ~7;       // pair g of the octet evaluates trial point g
+    const int m = a.m;
+    const size_t ld = a.ld;
+    const ArSimG L{ws.ml_sim + (size_t)blockIdx.x * (size_t)64 * NM_BLOCK, lane};
+    const ArSimG &F = L;
+    ArMlLds Q{lds, RM, ar_ml_l1(m > AR_LDS_PERIOD ? 1 : m)};
+    const int n_parked = ws.counts[26];
+    int s = 0, len = 0, D = 0;
+    ArOrd o{0, 0, 0, 0, 0};
+    const double *w = ws.W;
+    bool fin = false;
+    int ph = RP_DONE, vi = 0, nm_evals = 0, nm_iters = 1, evals = 0, passes = 0;
+
+    int loops = 0;
+    for (;; loops++) {
+        for (int attempt = 0; attempt < 4 && !fin && ph == RP_DONE; attempt++) {
+            if (passes > 0) { if (lane == lead) { a.passes[s] += passes; a.evals[s] += evals; } evals = 0; passes = 0; }
+            int item = 0;
+            if (lane == lead) item = atomicAdd(&ws.counts[cursor], 1);
+            item = __shfl(item, lead);
+            if (item >= n_parked) { fin = true; break; }
+            s = ws.ml_park_list[item];
+            len = a.wlen[s];
+            o.p = a.order[(size_t)0 * ld + s]; o.q = a.order[(size_t)1 * ld + s]; o.P = a.order[(size_t)2 * ld + s];
+            o.Q = a.order[(size_t)3 * ld + s]; o.c = a.order[(size_t)4 * ld + s];
+            D = o.p + o.q + o.P + o.Q + o.c;
+            {
+                const int la = o.p + m * o.P, lb1 = o.q + m * o.Q + 1;
+                const int rr = la > lb1 ? la : lb1;
+                if (rr <= r_lo || rr > RM) continue;              // another instantiation's series
+            }
+            w = ws.W + (size_t)s * ws.tw;
+            const double *pk = ws.ml_park + (size_t)s * 64;
+            for (int c = 0; c < AR_ML_CTX; c++) L.base[(size_t)c * NM_BLOCK + L.col] = pk[c];
+            nm_evals = (int)pk[60]; nm_iters = (int)pk[61];
+            vi = 0;
+            ph = RP_ITER;
+        }
+        if (__all(fin && ph == RP_DONE)) break;
+        double x[AR_MAXDIM] = {0, 0, 0, 0, 0, 0};
+        bool mine = false;                                   // this pair's evaluation is a real one
+        if (ph != RP_DONE) {
+            if (ph == RP_ITER) {
+                bool stop = !(nm_evals < AR_ML_NM_CAP * D && nm_iters < AR_ML_NM_CAP * D);
+                if (!stop) {
+                    bool small = true;
+                    for (int k = 1; k <= D; k++) {
+                        for (int i = 0; i < D; i++)
+                            if (!(fabs(L.sim(k, i) - L.sim(0, i)) <= 1.0e-4)) small = false;
+                        if (!(fabs(F.get(0) - F.get(k)) <= 1.0e-8)) small = false;
+                    }
+                    stop = small;
+                }
+                if (stop) {
+                    const double fb = F.get(0);
+                    if (lane == lead && fabs(fb) <= 1.7976931348623157e308 && fb <= L.f0())
+                        for (int i = 0; i < D; i++) a.xbest[(size_t)i * ld + s] = L.sim(0, i);
+                    ph = RP_DONE;
+                }
+            }
+            if (ph == RP_ITER) { mine = true; for (int i = 0; i < D; i++) x[i] = ar_trial(L, D, g, i); }
+            else if (ph == RP_SHRINK) { mine = 1 + vi + g <= D; if (mine) for (int i = 0; i < D; i++) x[i] = L.sim(1 + vi + g, i); }
+        }
+        int La = 0, Lb = 0;
+        double mu = 0.0;
+        if (ph != RP_DONE) { ar_build_poly_ml(o, m, x, Q, La, Lb, mu); passes++; }
+        const double f = ar_ml_eval<RM>(ph != RP_DONE && mine, La, Lb, mu, w, len, Q);     // the whole wave: wave-uniform filter loop
+        double fj[4];
+        for (int j = 0; j < 4; j++) fj[j] = __shfl(f, lead + 2 * j);
+        if (ph == RP_ITER) {
+            const double fr = fj[0], fe = fj[1], foc = fj[2], fic = fj[3];
+            nm_evals++; evals++;
+            bool shrink = false;
+            if (fr < F.get(0)) { nm_evals++; evals++; if (fe < fr) ar_accept(L, F, D, 1, fe); else ar_accept(L, F, D, 0, fr); }
+            else if (fr < F.get(D - 1)) ar_accept(L, F, D, 0, fr);
+            else if (fr < F.get(D)) { nm_evals++; evals++; if (foc <= fr) ar_accept(L, F, D, 2, foc); else shrink = true; }
+            else { nm_evals++; evals++; if (fic < F.get(D)) ar_accept(L, F, D, 3, fic); else shrink = true; }
+            if (!shrink) nm_iters++;
+            else {
+                for (int k = 1; k <= D; k++)
+                    for (int i = 0; i < D; i++) L.sim(k, i) = L.sim(0, i) + 0.5 * (L.sim(k, i) - L.sim(0, i));
+                vi = 0; ph = RP_SHRINK;
+            }
+        } else if (ph == RP_SHRINK) {
+            for (int j = 0; j < 4; j++) if (1 + vi + j <= D) F.set(1 + vi + j, fj[j]);
+            const int cnt = (D - vi) < 4 ? (D - vi) : 4;
+            vi += cnt; nm_evals += cnt; evals += cnt;
+            if (vi == D) { nm_iters++; ar_sort(L, F, D); ph = RP_ITER; }
+        }
+    }
+    if (passes > 0 && lane == lead) { a.passes[s] += passes; a.evals[s] += evals; }
+    return loops;
+}
+
 // class of a series' state dimension: 0..4 = r <= 8 / 12 / 16 / 20 / 32, -1 = nothing to refit
 __device__ __forceinline__ int ar_ml_class(const ArimaArgs &a, int s)
 {
@@ -1637,9 +1756,11 @@ __global__ void arima_refit_count_kernel(const ArimaArgs a, const ArWs ws)
 // cursors it mostly finds exhausted): the classes run side by side and the kernel ends with the slowest class, not with the
 // sum of their critical paths.  256 registers (two waves per SIMD): with 512 allowed the scheduler spread the r-vectors over
 // VGPRs, AGPRs and scratch -- 15 scratch reloads per filter step at r = 20, 2,500 cycles per step, measured.
-__global__ __launch_bounds__(NM_BLOCK, 2) void arima_refit_kernel(const ArimaArgs a, const ArWs ws)
+template <bool SPEC>
+__global__ __launch_bounds__(NM_BLOCK, 2) void arima_refit_kernel(const ArimaArgs a, const ArWs ws, const int budget)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    if (SPEC && ws.counts[26] == 0) return;                  // nothing was parked
     int first = 0;
     {
         long tot = 0;
@@ -1655,11 +1776,11 @@ __global__ __launch_bounds__(NM_BLOCK, 2) void arima_refit_kernel(const ArimaArg
     for (int k = 0; k < 5; k++) {
         const int c = (first + k) % 5;
         if (ws.counts[16 + c] == 0) { tc[k + 1] = tc[k]; continue; }
-        if (c == 0) it[0] += ar_refit_body<8>(a, ws, 0, 9, lds);
-        else if (c == 1) it[1] += ar_refit_body<12>(a, ws, 8, 10, lds);
-        else if (c == 2) it[2] += ar_refit_body<16>(a, ws, 12, 11, lds);
-        else if (c == 3) it[3] += ar_refit_body<20>(a, ws, 16, 12, lds);
-        else it[4] += ar_refit_body<AR_ML_MAX_R>(a, ws, 20, 13, lds);
+        if (c == 0) it[0] += SPEC ? ar_refit_body_spec<8>(a, ws, 0, 21, lds) : ar_refit_body<8>(a, ws, 0, 9, lds, budget);
+        else if (c == 1) it[1] += SPEC ? ar_refit_body_spec<12>(a, ws, 8, 22, lds) : ar_refit_body<12>(a, ws, 8, 10, lds, budget);
+        else if (c == 2) it[2] += SPEC ? ar_refit_body_spec<16>(a, ws, 12, 23, lds) : ar_refit_body<16>(a, ws, 12, 11, lds, budget);
+        else if (c == 3) it[3] += SPEC ? ar_refit_body_spec<20>(a, ws, 16, 24, lds) : ar_refit_body<20>(a, ws, 16, 12, lds, budget);
+        else it[4] += SPEC ? ar_refit_body_spec<AR_ML_MAX_R>(a, ws, 20, 25, lds) : ar_refit_body<AR_ML_MAX_R>(a, ws, 20, 13, lds, budget);
         tc[k + 1] = wall_clock64();
     }
     if (a.trace && threadIdx.x == 0 && (blockIdx.x % 32) == 0)      // 100 MHz wall clock: 1e5 ticks per ms
@@ -1773,17 +1894,25 @@ int launch_arima(const ArimaArgs &a, hipStream_t stream)
     // on request (ANOFOX_ARIMA_CSS_ML): final estimates of the selected models on the exact Gaussian likelihood
     if (a.ml_refit) {
         const size_t lds_b = sizeof(double) * ar_ml_lds_doubles(long_m ? 1 : a.m) * NM_BLOCK;
-        if (lds_b > 48 * 1024) AR_HIPCHECK(hipFuncSetAttribute((const void *)arima_refit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
+        if (lds_b > 48 * 1024) {
+            AR_HIPCHECK(hipFuncSetAttribute((const void *)arima_refit_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
+            AR_HIPCHECK(hipFuncSetAttribute((const void *)arima_refit_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
+        }
         int per = (int)((160 * 1024) / lds_b);
         per = per < 1 ? 1 : (per > 8 ? 8 : per);                            // 256 registers: two waves per SIMD at most
         // persistent lane pairs, no more waves than fit the chip; two lanes per series and some slack, so that (nearly) every
         // series finds a pair among the waves that start with its class
         const int want = (2 * a.n_series + NM_BLOCK - 1) / NM_BLOCK + 8;
         const int g = std::min(std::min(cus * per, ar_ml_sim_waves(a.n_series)), want);
-        AR_HIPCHECK(hipMemsetAsync(ws.counts + 9, 0, 12 * sizeof(int32_t), stream));
+        AR_HIPCHECK(hipMemsetAsync(ws.counts + 9, 0, 18 * sizeof(int32_t), stream));
         hipLaunchKernelGGL(arima_refit_count_kernel, dim3(grid256), dim3(256), 0, stream, a, ws);
-        hipLaunchKernelGGL(arima_refit_kernel, dim3(g), dim3(NM_BLOCK), lds_b, stream, a, ws);
-        launches += 2;
+        // two launches: the sequential driver up to `budget` evaluations per series (most series are done by then), then the
+        // speculative one -- four trial points per pass, eight lanes per series -- for the ones that are not: the refit lasts as
+        // long as its slowest series, and those need one pass per iteration instead of ~1.7 once the chip has room for them
+        const int budget = a.refit_budget;
+        hipLaunchKernelGGL(arima_refit_kernel<false>, dim3(g), dim3(NM_BLOCK), lds_b, stream, a, ws, budget);
+        if (budget > 0) hipLaunchKernelGGL(arima_refit_kernel<true>, dim3(g), dim3(NM_BLOCK), lds_b, stream, a, ws, 0);
+        launches += 3;
     }
     hipLaunchKernelGGL(arima_forecast_kernel, dim3(grid), dim3(NM_BLOCK), fc_lds, stream, a, ws);
     return launches + 1;

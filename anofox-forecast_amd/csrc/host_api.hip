@@ -77,6 +77,7 @@ struct Tunables {
     double arima_lookahead = 12.0;   // ANOFOX_HIP_ARIMA_LOOKAHEAD, _LOOKAHEAD_DEPTH, _SPEC_FACTOR: see arima.hip launch_arima
     int arima_lookahead_depth = 2;
     double arima_spec_factor = 8.0;
+    int arima_refit_budget = 100;   // ANOFOX_HIP_ARIMA_REFIT_BUDGET: evaluations per series before the exact-likelihood refit's speculative launch takes over (0: off)
     static Tunables from_env()
     {
         Tunables t;
@@ -106,6 +107,7 @@ struct Tunables {
         if (const char *e = std::getenv("ANOFOX_HIP_ARIMA_LOOKAHEAD")) t.arima_lookahead = std::atof(e);
         geti("ANOFOX_HIP_ARIMA_LOOKAHEAD_DEPTH", t.arima_lookahead_depth);
         if (const char *e = std::getenv("ANOFOX_HIP_ARIMA_SPEC_FACTOR")) t.arima_spec_factor = std::atof(e);
+        geti("ANOFOX_HIP_ARIMA_REFIT_BUDGET", t.arima_refit_budget);
         return t;
     }
 };
@@ -1634,7 +1636,7 @@ void run_group(AnofoxHipBatch *b, int period, const int32_t *d_len, hipStream_t 
         aa.yhat = b->d_yhat; aa.model_code = b->d_model_code;
         aa.ml_refit = b->arima_method == ANOFOX_ARIMA_CSS_ML ? 1 : 0;
         aa.trace = b->tun.arima_trace ? 1 : 0;
-        aa.lookahead = b->tun.arima_lookahead; aa.lookahead_depth = b->tun.arima_lookahead_depth; aa.spec_factor = b->tun.arima_spec_factor;
+        aa.lookahead = b->tun.arima_lookahead; aa.lookahead_depth = b->tun.arima_lookahead_depth; aa.spec_factor = b->tun.arima_spec_factor; aa.refit_budget = b->tun.arima_refit_budget;
         HIPCHECK(hipEventRecord(b->ev_fit0, st));
         try { b->fit_launches += launch_arima(aa, st); }
         catch (const std::exception &e) { throw HipFail{e.what()}; }

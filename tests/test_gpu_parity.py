@@ -896,6 +896,46 @@ def test_auto_arima_matches_oracle(env):
     assert r["ok"] and r["model_name"].startswith("AutoARIMA(") and abs(r["point"][0] - 18.014537) / 18.014537 < 2e-3
 
 
+@pytest.mark.parametrize("budget", ["0", "3", "25", "100"])
+def test_exact_likelihood_refit_in_two_launches(env, monkeypatch, budget):
+    """The exact-likelihood refit runs its sequential Nelder-Mead up to a budget of evaluations per series, parks the series that are
+    still running (simplex, function values, counters) and finishes them in a second launch with four trial points per filter pass
+    (eight lanes per series).  The trajectory is the sequential one whatever the budget -- 0 (one launch), 3 (everything is parked
+    after the first iteration), 25, 100 (the default): every forecast equals the oracle's refit, seasonal and non-seasonal, ragged."""
+    import ctypes as C
+    api, O, lib, synth = env
+    L = lib.load()
+    flag = C.c_int.in_dll(O.lib(), "oracle_arima_ml_refit")
+    monkeypatch.setenv("ANOFOX_HIP_ARIMA_REFIT_BUDGET", budget)
+    rng = np.random.default_rng(41)
+    Y = synth.gen_series(synth.SEED_M5, 9300, 90, 220, 7)
+    series = [Y[s, : 220 - (s % 6) * 11] for s in range(90)]
+    for k in range(30):                                         # richer dynamics: higher orders get selected, long Nelder-Mead runs
+        T = 180 + 7 * (k % 5)
+        e = rng.normal(0, 1, T + 20)
+        x = np.zeros(T + 20)
+        for t in range(14, T + 20):
+            x[t] = 0.6 * x[t - 1] - 0.3 * x[t - 2] + 0.4 * x[t - 7] + e[t] + 0.5 * e[t - 1] + 0.3 * e[t - 7]
+        series.append(50.0 + 0.05 * np.arange(T) + 3.0 * x[20:])
+    try:
+        assert L.anofox_hip_set_default_arima_method(lib.ARIMA_CSS_ML)
+        flag.value = 1
+        for kw in (dict(seasonal_period=7), dict(seasonal_period=1)):
+            got, berr = api.forecast_batch(series, lib.make_options("AutoARIMA", 8, **kw))
+            assert berr["ok"], berr
+            names = set()
+            for s, y in enumerate(series):
+                ref = O.forecast(y, O.make_options("AutoARIMA", 8, **kw))
+                assert got[s]["ok"] == ref["ok"], s
+                if ref["ok"]:
+                    assert got[s]["model_name"] == ref["model_name"] and np.array_equal(got[s]["point"], ref["point"]), (s, got[s]["model_name"])
+                    names.add(ref["model_name"])
+            assert len(names) >= 6, names
+    finally:
+        flag.value = 0
+        L.anofox_hip_set_default_arima_method(lib.ARIMA_CSS)
+
+
 def test_auto_arima_estimation_method_is_a_caller_choice(env):
     """ANOFOX_ARIMA_CSS (default) keeps the selected model's CSS estimates, ANOFOX_ARIMA_CSS_ML refits it on the exact Gaussian
     likelihood (the Kalman / Chandrasekhar kernel): per batch (anofox_hip_batch_set_arima_method) and as the process default
