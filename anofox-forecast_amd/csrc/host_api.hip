@@ -31,6 +31,7 @@ using namespace anofox;
 
 namespace {
 
+constexpr int TINY_BATCH_PROBLEMS = 1024;   // (series x specs) up to which every problem runs on a wave of its own in one launch
 constexpr int N_AUX_STREAMS = 32;   // one stream per candidate ETS spec (the hardware multiplexes them onto GPU_MAX_HW_QUEUES queues)
 
 struct HipFail { std::string msg; bool oom = false; };      // oom: the device or pinned-host allocator refused (reported as ALLOCATION_ERROR)
@@ -1062,13 +1063,20 @@ void run_classic(AnofoxHipBatch *b, int kind, const int32_t *d_len, int m, int o
             f.ring_scratch = ensure_ring(b, wg * (size_t)f.m * 64u);
         }
         static const int BUDGET[] = {24, 24, 24, 24, 48, 48, 96, 192, 1024};
-        const int n_rounds = merged ? (n > 4096 ? 4 : 3) : (int)(sizeof BUDGET / sizeof BUDGET[0]);
+        // a handful of series (one call per group from the scalar binding, the coalesced calls of a few workers): every problem
+        // gets a WAVE from the start -- two iterations per pass -- and runs to completion in ONE launch instead of nine rounds of
+        // compaction + gather + fit (one series through Holt-Winters: 8.6 ms of launches)
+        const bool tiny = n <= TINY_BATCH_PROBLEMS;
+        const int n_rounds = tiny ? 1 : (merged ? (n > 4096 ? 4 : 3) : (int)(sizeof BUDGET / sizeof BUDGET[0]));
         for (int r = 0; r < n_rounds; r++) {
             f.first_round = (r == 0);
             f.spec_below = -1; f.spec2_below = -1;
             f.gathered = 0;
             f.y_round = b->d_y; f.ld_round = ld; f.series_of = nullptr; f.n_active = nullptr;
-            if (merged) {
+            if (tiny) {
+                f.budget = 1 << 30; f.budget_seq = f.budget;
+                fns.round_spec2(f, st);
+            } else if (merged) {
                 // several periods in one block: every launch sweeps all columns in place (see launch_fit_slots)
                 f.budget = r == 0 ? 64 : (r == 1 ? 128 : 256); f.budget_seq = f.budget;
                 (r < n_rounds - 1 ? fns.round_spec : fns.round_spec2)(f, st);
@@ -1386,7 +1394,10 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
         }
         LAUNCHCHECK("ETS fixed-parameter setup");
     }
-    for (int r = 0; r < (b->fixed_params ? 0 : n_rounds); r++) {
+    // a handful of series: one launch per spec, every problem on a wave of its own (two iterations per pass) to completion -- one
+    // series through AutoETS was 12 rounds x 3 launches x 25 specs
+    const bool tiny = (uint64_t)n * order.size() <= (uint64_t)TINY_BATCH_PROBLEMS;
+    for (int r = 0; r < (b->fixed_params ? 0 : (tiny ? 1 : n_rounds)); r++) {
         for (size_t oi = 0; oi < order.size(); oi++) {
             if (dead[oi]) continue;
             const int q = (int)(oi % (size_t)n_lanes);
@@ -1397,6 +1408,13 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
             a.first_round = (r == 0);
             a.spec_below = -1; a.spec2_below = -1;
             a.gathered = 0;
+            if (tiny) {
+                a.y_round = b->d_y; a.ld_round = ld; a.series_of = nullptr; a.n_active = nullptr;
+                a.budget = 1 << 30; a.budget_seq = a.budget;
+                fns[oi].round_spec2(a, sq);
+                b->fit_launches++;
+                continue;
+            }
             if (r == 0 && b->use_pos && a.need_positive) {
                 // mixed batch: this spec is admissible for the strictly positive series only -- its first round runs on
                 // their dense list (built once per group) instead of sweeping every wave for a few live lanes
