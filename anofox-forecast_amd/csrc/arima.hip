@@ -4,8 +4,10 @@
 // Reference call site: crates/anofox-fcst-core/src/forecast.rs:1435-1521 (AutoARIMAConfig::default()
 // [.with_seasonal_period(m)]); the arithmetic is in the un-vendored anofox-forecast 0.15.3 crate, so this
 // follows the published Hyndman-Khandakar procedure exactly as restated by the CPU checker (oracle/arima.c):
-// D by seasonal strength > 0.64, d by KPSS (lag trunc(3 sqrt(n)/13), 0.463), CSS over tanh-PACF coefficients
-// minimised by Nelder-Mead (absolute initial steps), stepwise neighbourhood search on AICc.
+// D by seasonal strength > 0.64, d by KPSS (lag trunc(3 sqrt(n)/13), 0.463), CSS over the coefficients themselves, boxed to
+// [-0.99, 0.99] by clipping, minimised by Nelder-Mead (absolute initial steps), stepwise neighbourhood search on AICc with the
+// lineage's root check (a candidate with an AR or MA root inside radius 1.001 is inadmissible).  Round 4: box + root check replace
+// the tanh-PACF transform -- this is the procedure that reproduces the reference's known answer (oracle/arima.h).
 //
 // Organisation (problem-parallel): the fit of one candidate order depends on nothing but the series (fixed start,
 // fixed steps), so the stepwise search is split into
@@ -39,7 +41,9 @@ constexpr int AR_LDS_PERIOD = 24, AR_MAX_PERIOD = 2048;
 // Nelder-Mead budgets (evaluations / iterations), oracle/arima.h: every candidate of the stepwise search gets a bounded run
 // (ARIMA_SEARCH_EVALS: an approximate criterion, which keeps the whole search inside the reference's measured cost), the
 // selected model's CSS estimates then run to convergence (ARIMA_POLISH_NM_CAP x dim)
-__host__ __device__ inline int ar_search_cap(int dim) { return 20 + 10 * dim; }
+__host__ __device__ inline int ar_search_cap(int dim) { return 30 + 15 * dim; }
+constexpr double AR_COEF_BOX = 0.99;                  // oracle/arima.h ARIMA_COEF_BOX
+constexpr double AR_ROOT_MIN = 1.001;                 // oracle/arima.h ARIMA_ROOT_MIN
 __host__ __device__ inline int ar_polish_cap(int dim) { return 100 * dim; }
 constexpr int AR_KEYS = 6 * 6 * 3 * 3 * 2;            // order keys (p, q, P, Q, constant)
 constexpr int AR_KEYWORDS = (AR_KEYS + 31) / 32;      // bitmap words
@@ -54,28 +58,45 @@ __device__ __forceinline__ int ar_wave_max(int v)
     return v;
 }
 
-__device__ __forceinline__ double ar_tanh(double u)
-{
-    if (u > 20.0) return 1.0;
-    if (u < -20.0) return -1.0;
-    double e2 = dm_exp(2.0 * u);
-    return (e2 - 1.0) / (e2 + 1.0);
-}
-
 struct ArOrd { int p, q, P, Q, c; };
 __device__ __forceinline__ int ar_dim(const ArOrd &o) { return o.p + o.q + o.P + o.Q + o.c; }
 __device__ __forceinline__ int ar_key(const ArOrd &o) { return (((o.p * 6 + o.q) * 3 + o.P) * 3 + o.Q) * 2 + o.c; }
 
-// partial autocorrelations -> AR coefficients (Durbin-Levinson), k <= 5
+// the optimiser's coordinates are the coefficients, read through the box (oracle/arima.c box_coef), k <= 5
 __device__ __forceinline__ void ar_pacf(const double *u, int k, double *phi)
 {
-    double work[AR_MAXP];
     for (int j = 0; j < k; j++) {
-        double a = ar_tanh(u[j]);
-        for (int i = 0; i < j; i++) work[i] = phi[i] - a * phi[j - 1 - i];
-        for (int i = 0; i < j; i++) phi[i] = work[i];
+        double a = u[j];
+        if (a < -AR_COEF_BOX) a = -AR_COEF_BOX;
+        if (a > AR_COEF_BOX) a = AR_COEF_BOX;
         phi[j] = a;
     }
+}
+
+// All roots of 1 - sum_i c_i z^i outside the circle of radius r1 (oracle/arima.c roots_outside): coefficients scaled by r1^i, then
+// the step-down recursion -- every reflection coefficient inside (-1, 1).  Compile-time indices only (the arrays stay in registers);
+// entries beyond k are never read by an active step, so the active arithmetic is the oracle's operation for operation.
+template <int N>
+__device__ __forceinline__ bool ar_roots_outside(const double (&c)[N], int k, double r1)
+{
+    double al[N], tmp[N];
+    double sc = 1.0;
+#pragma unroll
+    for (int i = 0; i < N; i++) { sc = sc * r1; al[i] = i < k ? c[i] * sc : 0.0; tmp[i] = 0.0; }
+    bool ok = true;
+#pragma unroll
+    for (int j = N; j >= 1; j--) {
+        if (j <= k) {
+            const double kj = al[j - 1];
+            if (!(fabs(kj) < 1.0)) ok = false;
+            const double den = 1.0 - kj * kj;
+#pragma unroll
+            for (int i = 1; i <= j - 1; i++) tmp[i - 1] = fma(kj, al[j - i - 1], al[i - 1]) / den;
+#pragma unroll
+            for (int i = 1; i <= j - 1; i++) al[i - 1] = tmp[i - 1];
+        }
+    }
+    return ok;
 }
 
 // LDS layout per wave (lane-minor): [ring: R slots x 64 lanes x {e, v}][simplex 42 + values 7][acoef L1][bcoef L1][tried 11 words]
@@ -152,6 +173,28 @@ __device__ __forceinline__ void ar_factors(const ArOrd &o, int m, const double *
     ar_pacf(x + k, o.Q, f.Th); k += o.Q;
     f.mu = o.c ? x[k] : 0.0;
     f.nc = o.p + m * o.P;
+}
+
+// the lineage's admissibility rule on the factors of a point (oracle/arima.c model_roots_ok): the seasonal factors are polynomials
+// in z^m, so their radius is AR_ROOT_MIN^m (built by m multiplications, like the oracle)
+__device__ __forceinline__ bool ar_model_roots_ok(const ArOrd &o, int m, const ArFac &f)
+{
+    double rm = 1.0;
+    for (int i = 0; i < m; i++) rm = rm * AR_ROOT_MIN;
+    const bool a1 = ar_roots_outside<AR_MAXP>(f.phi, o.p, AR_ROOT_MIN), a2 = ar_roots_outside<AR_MAXP>(f.th, o.q, AR_ROOT_MIN);
+    const bool a3 = ar_roots_outside<AR_MAXSP>(f.Phi, o.P, rm), a4 = ar_roots_outside<AR_MAXSP>(f.Th, o.Q, rm);
+    return a1 && a2 && a3 && a4;
+}
+
+// the refit's estimates replace the CSS ones only where they are admissible (oracle refit_ml: fb <= f0 && model_roots_ok)
+template <class LDS>
+__device__ __forceinline__ bool ar_simplex_best_roots_ok(const ArOrd &o, int m, int D, const LDS &L)
+{
+    double xb[AR_MAXDIM] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < D; i++) xb[i] = L.sim(0, i);
+    ArFac fb;
+    ar_factors(o, m, xb, fb);
+    return ar_model_roots_ok(o, m, fb);
 }
 
 // expanded lag polynomials of the fitted model (forecast only), in LDS after the ring
@@ -954,10 +997,16 @@ __global__ __launch_bounds__(NM_BLOCK, ar_fit_waves(MODE)) void arima_fit_kernel
                 aicc = dn * dm_log(v) + 2.0 * dk + 2.0 * dk * (dk + 1.0) / (dn - dk - 1.0);
                 if (!(fabs(aicc) <= 1.7976931348623157e308)) aicc = __builtin_huge_val();
             }
+            // admissibility (root check): an inadmissible candidate has an infinite criterion; an inadmissible POLISHED point leaves
+            // the search's own estimates (and their criterion) in place
+            const bool roots_ok = ar_model_roots_ok(cur, m, fac);
+            if (!roots_ok) aicc = __builtin_huge_val();
             if (polish) {
-                a.aicc[s] = aicc;
                 a.evals[s] += nm_evals;
-                for (int i = 0; i < D; i++) a.xbest[(size_t)i * a.ld + s] = L.sim(0, i);
+                if (roots_ok) {
+                    a.aicc[s] = aicc;
+                    for (int i = 0; i < D; i++) a.xbest[(size_t)i * a.ld + s] = L.sim(0, i);
+                }
             } else {
                 const size_t ci = (size_t)s * AR_KEYS + key;
                 ws.cache_aicc[ci] = aicc;
@@ -1098,11 +1147,15 @@ __global__ __launch_bounds__(NM_BLOCK, ar_fit_waves(MODE)) void arima_fit_spec_k
                 aicc = dn * dm_log(v) + 2.0 * dk + 2.0 * dk * (dk + 1.0) / (dn - dk - 1.0);
                 if (!(fabs(aicc) <= 1.7976931348623157e308)) aicc = __builtin_huge_val();
             }
+            const bool roots_ok = ar_model_roots_ok(cur, m, fac);
+            if (!roots_ok) aicc = __builtin_huge_val();
             if (g == 0) {
                 if (polish) {
-                    a.aicc[s] = aicc;
                     a.evals[s] += nm_evals;
-                    for (int i = 0; i < D; i++) a.xbest[(size_t)i * a.ld + s] = L.sim(0, i);
+                    if (roots_ok) {
+                        a.aicc[s] = aicc;
+                        for (int i = 0; i < D; i++) a.xbest[(size_t)i * a.ld + s] = L.sim(0, i);
+                    }
                 } else {
                     const size_t ci = (size_t)s * AR_KEYS + key;
                     ws.cache_aicc[ci] = aicc;
@@ -1555,7 +1608,7 @@ __device__ __noinline__ int ar_refit_body(const ArimaArgs &a, const ArWs &ws, co
                 if (stop) {
                     // the exact-likelihood estimates replace the CSS ones when they are at least as good as the start
                     const double fb = F.get(0);
-                    if (even && fabs(fb) <= 1.7976931348623157e308 && fb <= L.f0())
+                    if (even && fabs(fb) <= 1.7976931348623157e308 && fb <= L.f0() && ar_simplex_best_roots_ok(o, m, D, L))
                         for (int i = 0; i < D; i++) a.xbest[(size_t)i * ld + s] = L.sim(0, i);
                     ph = RP_DONE;
                 } else if (budget > 0 && nm_evals >= budget) {
@@ -1691,7 +1744,7 @@ __device__ __noinline__ int ar_refit_body_spec(const ArimaArgs &a, const ArWs &w
                 }
                 if (stop) {
                     const double fb = F.get(0);
-                    if (lane == lead && fabs(fb) <= 1.7976931348623157e308 && fb <= L.f0())
+                    if (lane == lead && fabs(fb) <= 1.7976931348623157e308 && fb <= L.f0() && ar_simplex_best_roots_ok(o, m, D, L))
                         for (int i = 0; i < D; i++) a.xbest[(size_t)i * ld + s] = L.sim(0, i);
                     ph = RP_DONE;
                 }

@@ -20,6 +20,22 @@
 #endif
 namespace anofox {
 
+// Per-class residency policy of the round kernels (round 4).  PARK: the Nelder-Mead simplex of every lane rests in a global scratch
+// of the workgroup between passes instead of LDS (nm.hpp), so LDS holds only the b^phi tables and the kernel may be resident four
+// times per SIMD; WAVES: the residency the register allocation is asked to allow (caps VGPRs at 512 / WAVES).
+// -DANOFOX_PARK_CLASS: 0 none (round-3 behaviour), 1 damped multiplicative trend (default), 2 + every general-class spec, 3 all ETS specs.
+#ifndef ANOFOX_PARK_CLASS
+#define ANOFOX_PARK_CLASS 0
+#endif
+#ifndef ANOFOX_PARK_WAVES
+#define ANOFOX_PARK_WAVES 4
+#endif
+template <class Cfg> struct RoundTraits {
+    static constexpr bool DAMPED_MUL = !Cfg::CLASSIC && Cfg::T == C_MUL && Cfg::D;
+    static constexpr bool PARK = !Cfg::CLASSIC && (ANOFOX_PARK_CLASS >= 3 || (ANOFOX_PARK_CLASS == 2 && !Cfg::ADDITIVE) || (ANOFOX_PARK_CLASS == 1 && DAMPED_MUL));
+    static constexpr int WAVES = PARK ? ANOFOX_PARK_WAVES : ANOFOX_ROUND_WAVES;
+};
+
 // the model behind a Cfg: an ETS spec, or one of the SES / Holt / Holt-Winters / SeasonalES family (SSE objective, own start values)
 template <class Cfg, int MS, bool CLASSIC = Cfg::CLASSIC> struct RoundModelOf { using type = EtsModel<Cfg, MS, 1>; };
 template <class Cfg, int MS> struct RoundModelOf<Cfg, MS, true> { using type = ClassicRoundModel<Cfg::KIND, MS>; };
@@ -31,11 +47,15 @@ template <class Cfg, int MS> struct RoundModelOf<Cfg, MS, true> { using type = C
 //           a launch whose workgroups only find out that another driver owns the round still has to be dispatched, and on a
 //           saturated chip that stalls the spec's chain for milliseconds (6 ms measured for 1,024 empty workgroups)
 template <class Cfg, int MS, int SPEC>
-__global__ __launch_bounds__(NM_BLOCK, ANOFOX_ROUND_WAVES) void ets_round_kernel(const FitArgs a)
+__global__ __launch_bounds__(NM_BLOCK, RoundTraits<Cfg>::WAVES) void ets_round_kernel(const FitArgs a)
 {
     extern __shared__ double lds[];
     constexpr int D = Cfg::DIM;
+    constexpr bool PARK = RoundTraits<Cfg>::PARK;
     const int lane = threadIdx.x;
+    // the wave's simplex store: LDS, or its own slice of the launch's global scratch (then LDS starts with the seasonal ring)
+    double *const nmst = PARK ? a.nm_scratch + (size_t)blockIdx.x * (size_t)nm_lds_doubles<D>() : lds;
+    double *const lds_ring = PARK ? lds : lds + nm_lds_doubles<D>();
     const int n_act = a.n_active ? *a.n_active : a.n_series;
     int mode = SPEC;
     if constexpr (SPEC == 3) mode = n_act > a.spec_below ? 0 : ((a.spec2_below > 0 && n_act <= a.spec2_below && n_act <= (int)gridDim.x) ? 2 : 1);
@@ -102,17 +122,17 @@ __global__ __launch_bounds__(NM_BLOCK, ANOFOX_ROUND_WAVES) void ets_round_kernel
     mdl.in.fig = a.fig ? a.fig + s : nullptr;
     mdl.in.fig_ld = a.fig_ld;
     mdl.in.m = m;
-    mdl.ring = (MS == -2 || MS == -4) ? a.ring_scratch + (size_t)blockIdx.x * (size_t)a.m * NM_BLOCK : lds + nm_lds_doubles<D>();
+    mdl.ring = (MS == -2 || MS == -4) ? a.ring_scratch + (size_t)blockIdx.x * (size_t)a.m * NM_BLOCK : lds_ring;
 
     NmRun r;
-    if (a.first_round) nm_init_simplex(mdl, lds, r, active);
+    if (a.first_round) nm_init_simplex(mdl, nmst, r, active);
     else {
         // resume: simplex and counters were parked in HBM, indexed by series
 #pragma unroll
         for (int k = 0; k <= D; k++) {
 #pragma unroll
-            for (int i = 0; i < D; i++) ANOFOX_SIM(k, i) = active ? a.st.sim[(size_t)(k * D + i) * a.ld + s] : 0.0;
-            ANOFOX_FS(k) = active ? a.st.fs[(size_t)k * a.ld + s] : 0.0;
+            for (int i = 0; i < D; i++) nmst[(k * D + i) * NM_BLOCK + lane] = active ? a.st.sim[(size_t)(k * D + i) * a.ld + s] : 0.0;
+            nmst[((D + 1) * D + k) * NM_BLOCK + lane] = active ? a.st.fs[(size_t)k * a.ld + s] : 0.0;
         }
         r.phase = active ? a.st.phase[s] : NM_ITER;
         r.evals = active ? a.st.evals[s] : 0;
@@ -124,19 +144,20 @@ __global__ __launch_bounds__(NM_BLOCK, ANOFOX_ROUND_WAVES) void ets_round_kernel
     // one problem per wave (the last problems of a spec) runs to completion
     const int budget = mode == 2 ? (1 << 30) : ((SPEC == 3 && mode == 0) ? a.budget_seq : a.budget);
     if constexpr (SPEC == 3) {
-        if (mode == 2) nm_advance_spec2(mdl, lds, r, budget);
-        else if (mode == 1) nm_advance_spec(mdl, lds, r, budget);
-        else nm_advance_seq(mdl, lds, r, budget);
-    } else if constexpr (SPEC == 2) nm_advance_spec2(mdl, lds, r, budget);
-    else if constexpr (SPEC == 1) nm_advance_spec(mdl, lds, r, budget);
-    else nm_advance_seq(mdl, lds, r, budget);
+        if (mode == 2) nm_advance_spec2(mdl, nmst, r, budget);
+        else if (mode == 1) nm_advance_spec(mdl, nmst, r, budget);
+        else nm_advance_seq(mdl, nmst, r, budget);
+    } else if constexpr (SPEC == 2) nm_advance_spec2(mdl, nmst, r, budget);
+    else if constexpr (SPEC == 1) nm_advance_spec(mdl, nmst, r, budget);
+    else nm_advance_seq(mdl, nmst, r, budget);
+    nm_fence();
 
     if (active && (lane % LPP) == 0) {
 #pragma unroll
         for (int k = 0; k <= D; k++) {
 #pragma unroll
-            for (int i = 0; i < D; i++) a.st.sim[(size_t)(k * D + i) * a.ld + s] = ANOFOX_SIM(k, i);
-            a.st.fs[(size_t)k * a.ld + s] = ANOFOX_FS(k);
+            for (int i = 0; i < D; i++) a.st.sim[(size_t)(k * D + i) * a.ld + s] = nmst[(k * D + i) * NM_BLOCK + lane];
+            a.st.fs[(size_t)k * a.ld + s] = nmst[((D + 1) * D + k) * NM_BLOCK + lane];
         }
         a.st.phase[s] = r.phase;
         a.st.evals[s] = r.evals;
@@ -252,7 +273,9 @@ void ets_round_launch(const FitArgs &a, hipStream_t stream)
         grid = (n_max + PPB - 1) / PPB;
     }
     if (grid <= 0) return;
-    size_t lds_bytes = sizeof(double) * (size_t)nm_lds_doubles<Cfg::DIM>();
+    if (RoundTraits<Cfg>::PARK && (a.nm_scratch == nullptr || (size_t)grid * (size_t)nm_lds_doubles<Cfg::DIM>() > a.nm_scratch_doubles))
+        throw std::runtime_error("ets_round_launch: the simplex scratch does not cover the launch");
+    size_t lds_bytes = RoundTraits<Cfg>::PARK ? 0 : sizeof(double) * (size_t)nm_lds_doubles<Cfg::DIM>();
     if (MS == -1 || MS == -3) lds_bytes += sizeof(double) * (size_t)a.m * NM_BLOCK;
     if (lds_bytes > 48 * 1024)
         anofox_check_attr(hipFuncSetAttribute((const void *)ets_round_kernel<Cfg, MS, SPEC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));

@@ -22,7 +22,8 @@ template <int ID, int MS> FitLaunchers launchers_of()
     constexpr int MSF = MS == -3 ? -1 : (MS == -4 ? -2 : MS);
     return FitLaunchers{&ets_round_launch<typename SpecOf<ID>::Cfg, MS, 0>, &ets_round_launch<typename SpecOf<ID>::Cfg, MS, 1>,
                         &ets_round_launch<typename SpecOf<ID>::Cfg, MS, 2>, &ets_round_launch<typename SpecOf<ID>::Cfg, MS, 3>,
-                        &ets_final_launch<typename SpecOf<ID>::Cfg, MSF>};
+                        &ets_final_launch<typename SpecOf<ID>::Cfg, MSF>,
+                        RoundTraits<typename SpecOf<ID>::Cfg>::PARK ? (size_t)nm_lds_doubles<SpecOf<ID>::Cfg::DIM>() : 0};
 }
 
 FitLaunchers fit_unit_nonseasonal(int spec_id, int m);

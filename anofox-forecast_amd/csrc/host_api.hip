@@ -168,20 +168,35 @@ struct DevCache {
     uint64_t next_age = 0;
     int defer = 0;                                                     // > 0: evicted blocks wait in `deferred` (EvictionDeferral below)
     std::vector<void *> deferred;
+    std::unordered_map<void *, size_t> dropped_size;                   // bytes of the blocks on their way out (evicted / not cacheable)
+    size_t deferred_bytes = 0;                                         // ... parked in `deferred`: never more than a device's cache cap
 };
 DevCache &dev_cache() { static DevCache *c = new DevCache; return *c; }     // never destroyed: no HIP calls at process exit
 
 // hipFree waits for the whole device.  A call that keeps several batches running from several host threads (auto-detected periods:
 // the merged batches beside the per-period ones) would stall a finishing thread in its evictions for as long as the other threads'
 // kernels run -- 0.5-1.1 s per destroy measured -- so inside such a call evicted blocks are parked and freed when the call ends
-// (nothing is running then), or when an allocation needs the memory.
+// (nothing is running then), or when an allocation needs the memory.  The counter is process wide, so with steadily overlapping
+// callers it may never reach zero: parked memory is therefore BOUNDED by the cache cap (ANOFOX_HIP_CACHE_GB) -- a block that would
+// take the parked set over it is freed on the spot together with everything parked (the price is one stalled destroy, not an
+// unbounded hold on HBM that no co-resident allocator could reclaim).
 void dev_cache_free_blocks(std::vector<void *> &drop)
 {
     if (drop.empty()) return;
     DevCache &c = dev_cache();
     {
         std::lock_guard<std::mutex> lock(c.mu);
-        if (c.defer > 0) { c.deferred.insert(c.deferred.end(), drop.begin(), drop.end()); drop.clear(); return; }
+        size_t bytes = 0, cap = 0;
+        for (void *q : drop) { auto it = c.dropped_size.find(q); if (it != c.dropped_size.end()) bytes += it->second; }
+        for (auto &kv : c.cap) cap = std::max(cap, kv.second);
+        if (c.defer > 0 && c.deferred_bytes + bytes <= cap) {
+            c.deferred.insert(c.deferred.end(), drop.begin(), drop.end());
+            c.deferred_bytes += bytes;
+            drop.clear();
+            return;
+        }
+        if (c.defer > 0) { drop.insert(drop.end(), c.deferred.begin(), c.deferred.end()); c.deferred.clear(); c.deferred_bytes = 0; }
+        for (void *q : drop) c.dropped_size.erase(q);
     }
     for (void *q : drop) (void)hipFree(q);
     drop.clear();
@@ -193,6 +208,8 @@ void dev_cache_flush_deferred()
     {
         std::lock_guard<std::mutex> lock(c.mu);
         drop.swap(c.deferred);
+        c.deferred_bytes = 0;
+        for (void *q : drop) c.dropped_size.erase(q);
     }
     for (void *q : drop) (void)hipFree(q);
 }
@@ -228,6 +245,7 @@ void dev_cache_evict_locked(DevCache &c, int dev, size_t need, std::vector<void 
         c.idle_ptr.erase(b.ptr);
         c.idle_bytes[dev] -= b.size;
         drop.push_back(b.ptr);
+        c.dropped_size[b.ptr] = b.size;
         it = c.by_age.erase(it);
     }
 }
@@ -269,6 +287,7 @@ void *dev_alloc_bytes(size_t bytes)
         {
             std::lock_guard<std::mutex> lock(c.mu);
             dev_cache_evict_locked(c, dev, SIZE_MAX, drop);
+            for (void *q : drop) c.dropped_size.erase(q);
         }
         for (void *q : drop) (void)hipFree(q);
         dev_cache_flush_deferred();
@@ -311,7 +330,7 @@ void dev_free(void *p, bool quiesced = false)
             c.idle_ptr[p] = age;
             c.idle_bytes[dev] += sz;
             cached = true;
-        }
+        } else c.dropped_size[p] = sz;
     }
     if (!cached) drop.push_back(p);
     dev_cache_free_blocks(drop);
@@ -515,6 +534,16 @@ struct Plan {
 
 thread_local unsigned tl_host_thread_share = 1;   // > 1 while this thread runs one of several device shards of a batch call (the packer takes its share of the host threads)
 std::atomic<int> g_default_arima_method{0};      // ANOFOX_ARIMA_CSS (anofox_hip_set_default_arima_method)
+// The estimation method a CALL runs under is fixed when the call enters the library and handed to every host thread that works for
+// it (shard, part and merged-batch workers; the leader of a coalesced group runs under the method its members were matched on) --
+// a concurrent anofox_hip_set_default_arima_method never changes a call half way.  -1: no call in force, the process default.
+thread_local int tl_arima_method = -1;
+static int arima_method_in_force() { return tl_arima_method >= 0 ? tl_arima_method : g_default_arima_method.load(); }
+struct ArimaMethodScope {
+    int saved;
+    explicit ArimaMethodScope(int m) : saved(tl_arima_method) { tl_arima_method = m; }
+    ~ArimaMethodScope() { tl_arima_method = saved; }
+};
 
 } // namespace
 
@@ -584,6 +613,8 @@ struct AnofoxHipBatch {
         int32_t *map[2] = {nullptr, nullptr};
         int32_t *cnt = nullptr;          // [2]
         anofox::NmStateBuf st{};
+        double *nm_scratch = nullptr;    // where the lanes' simplices rest between passes (kernels that keep them out of LDS: RoundTraits::PARK)
+        size_t nm_scratch_doubles = 0;
     } lanes[N_AUX_STREAMS];
     hipStream_t last_stream = nullptr;
     bool ran = false, timed_fit = false;
@@ -765,6 +796,7 @@ void free_batch_buffers(AnofoxHipBatch *b)
     for (auto &l : b->lanes) {
         F(l.ybuf); l.ybuf_cols = 0; F(l.map[0]); F(l.map[1]); F(l.cnt);
         F(l.st.sim); F(l.st.fs); F(l.st.phase); F(l.st.evals); F(l.st.iters); F(l.st.passes); F(l.st.done);
+        F(l.nm_scratch); l.nm_scratch_doubles = 0;
     }
 }
 
@@ -1325,6 +1357,24 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
             for (size_t oi = 0; oi < order.size(); oi++) if (args[oi].m > lds_limit) args[oi].ring_scratch = base + (k++) * per_spec;
         }
     }
+    // Specs whose round kernels keep the Nelder-Mead simplex out of LDS: a global scratch per stream, one slice per workgroup of the
+    // widest launch (four lanes per problem for every series, or one wave per problem for the last spec2_below / a tiny batch)
+    {
+        const bool tiny_batch = (uint64_t)n * order.size() <= (uint64_t)TINY_BATCH_PROBLEMS;
+        const size_t wg = std::max<size_t>((n + 15) / 16, std::min<size_t>(n, tiny_batch ? n : (size_t)std::max(b->spec2_below, b->spec2_below_md)));
+        for (size_t oi = 0; oi < order.size(); oi++) {
+            if (!fns[oi].nm_scratch_per_wg) continue;
+            auto &lane = b->lanes[oi % (size_t)n_lanes];
+            const size_t need = wg * fns[oi].nm_scratch_per_wg;
+            if (lane.nm_scratch_doubles < need) {
+                if (lane.nm_scratch) b->retired.push_back(lane.nm_scratch);
+                lane.nm_scratch = nullptr; lane.nm_scratch_doubles = 0;
+                lane.nm_scratch = dalloc<double>(need);
+                lane.nm_scratch_doubles = need;
+            }
+            args[oi].nm_scratch = lane.nm_scratch; args[oi].nm_scratch_doubles = lane.nm_scratch_doubles;
+        }
+    }
     // Round-major submission: round r of every spec is enqueued before round r+1 of any, each spec on its
     // own stream, so that all specs advance together and the hardware queues never hold a long spec behind
     // another one.  Early rounds run the sequential driver (least arithmetic while problems outnumber
@@ -1689,17 +1739,16 @@ void run_batch(AnofoxHipBatch *b, hipStream_t st)
     }
     // group series by seasonal period (all equal unless auto-detection ran).  Detection gives ~140 distinct periods per
     // thousand M5-like series and every group is one run of the whole pipeline, so series are grouped by the period the
-    // model actually USES: none for the non-seasonal models, 1 for every AutoARIMA period outside 2..24 (no seasonal terms).
+    // model actually USES: none for the non-seasonal models.
     auto used_period = [&](int period) {
         switch (b->plan.model) {
         case M_Naive: case M_RandomWalkDrift: case M_ARIMA: case M_SES: case M_SESOptimized: case M_Holt: return 1;
-        case M_AutoARIMA: {
-            // a DETECTED period above 24 falls back to the non-seasonal search (the reference's documentation: AutoARIMA without
-            // seasonal_period is non-seasonal); an EXPLICIT one is used up to 2,048 (rings in HBM scratch) and fails loudly beyond
-            const bool detected = b->opt.auto_detect_seasonality && b->opt.seasonal_period == 0;
-            if (period > 24 && detected) return 1;
+        case M_AutoARIMA:
+            // a DETECTED period goes to the seasonal search exactly like an explicit one (forecast.rs:528-537 hands it to
+            // forecast_auto_arima, :1448-1452 passes any period > 1 to with_seasonal_period): used up to 2,048 (rings in LDS up to
+            // 24, in HBM scratch above), failing loudly beyond.  Rounds 2-3 made detected periods above 24 non-seasonal -- a
+            // product limit the oracle had been written to share; both are gone.
             return period > ETS_MAX_PERIOD ? ETS_MAX_PERIOD + 1 : (period > 1 ? period : 1);
-        }
         default: return period;
         }
     };
@@ -1915,7 +1964,7 @@ bool anofox_hip_batch_create(size_t n_series, size_t t_max, const ForecastOption
         if (b->tun.gather >= 0) b->use_gather = b->tun.gather != 0;
         b->spec_below = b->tun.spec_below; b->spec_below_md = b->tun.spec_below_md;
         b->spec2_below = b->tun.spec2_below; b->spec2_below_md = b->tun.spec2_below_md;
-        b->arima_method = g_default_arima_method.load();
+        b->arima_method = arima_method_in_force();
         alloc_common(b);
     } catch (const HipFail &f) {
         report_hip_failure(out_error, f);
@@ -2177,6 +2226,20 @@ bool anofox_hip_batch_stats(AnofoxHipBatch *b, AnofoxHipStats *out)
         out->total_evals += (uint64_t)std::max(evals[s], 0);
         out->algorithmic_bytes += 8ull * (uint64_t)b->h_len[s] * p + 24ull * (uint64_t)std::max(b->h, 0);
     }
+    // the one-pass-per-iteration count of the same run (the spec slots of the last fit: iterations per problem, + 1 final pass each)
+    if (b->insp_ok && b->d_iters_slots && b->d_status_slots && !b->fixed_params) {
+        const size_t n_used = b->insp_spec.size(), ld = b->ld;
+        std::vector<int32_t> it(n_used * ld), stt(n_used * ld);
+        if (hipMemcpy(it.data(), b->d_iters_slots, it.size() * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) return false;
+        if (hipMemcpy(stt.data(), b->d_status_slots, stt.size() * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) return false;
+        for (size_t s = 0; s < b->n; s++) {
+            uint64_t q = 0;
+            for (size_t k = 0; k < n_used; k++)
+                if (stt[k * ld + s] == anofox::FIT_OK) q += (uint64_t)std::max(it[k * ld + s], 0) + 1;
+            out->total_iters += q;
+            out->min_pass_bytes += 8ull * (uint64_t)b->h_len[s] * q + 24ull * (uint64_t)std::max(b->h, 0);
+        }
+    }
     return true;
 }
 
@@ -2202,6 +2265,19 @@ void anofox_hip_model_name(const ForecastOptions *options, int32_t model_code, c
     if (options && make_plan(options, p, &e)) {
         std::snprintf(out_name, 64, "%s", p.static_name.c_str());
     }
+}
+
+void anofox_hip_batch_model_name(const AnofoxHipBatch *b, size_t series, int32_t model_code, char out_name[64])
+{
+    out_name[0] = 0;
+    if (!b) return;
+    // the period the series was fitted with (given, or detected on the resident block): what anofox_hip_batch_fetch names it with
+    if (model_code >= 1000000) {
+        const int period = (series < b->h_period.size()) ? b->h_period[series] : (b->opt.seasonal_period > 0 ? b->opt.seasonal_period : 1);
+        auto_arima_name(model_code, period, out_name);
+        return;
+    }
+    anofox_hip_model_name(&b->opt, model_code, out_name);
 }
 
 bool anofox_hip_batch_fetch(AnofoxHipBatch *b, ForecastResult *out_results, AnofoxError *out_errors)
@@ -2456,6 +2532,7 @@ static bool forecast_batch_one_device(const double *const *values, const uint64_
     // its period -- forecast() sees the same period either way (forecast.rs:527-539), so the results are unchanged.
     Plan plan;
     AnofoxError pe;
+    const int method_in_force = arima_method_in_force();       // ... for the worker threads below
     const bool detect = options->auto_detect_seasonality && options->seasonal_period == 0 && n_series >= 2;
     if (!detect || !make_plan(options, plan, &pe))
         return forecast_batch_uniform(values, validity, lengths, n_series, options, horizons, out_results, out_errors, out_batch_error);
@@ -2464,7 +2541,7 @@ static bool forecast_batch_one_device(const double *const *values, const uint64_
         auto used_period = [&](int period) {
             switch (plan.model) {
             case M_Naive: case M_RandomWalkDrift: case M_ARIMA: case M_SES: case M_SESOptimized: case M_Holt: return 1;
-            case M_AutoARIMA: return period > 24 ? 1 : (period > 1 ? period : 1);      // detection is on in this branch: see run_batch
+            case M_AutoARIMA: return period > ETS_MAX_PERIOD ? ETS_MAX_PERIOD + 1 : (period > 1 ? period : 1);      // (forecast.rs:528-537, 1448-1452: any detected period is seasonal)
             default: return period;
             }
         };
@@ -2650,6 +2727,7 @@ static bool forecast_batch_one_device(const double *const *values, const uint64_
             (void)hipGetDevice(&cur_dev_m);
             // one host thread per LDS-ring batch, one for the HBM-ring batches (one after the other: they share the ring scratch)
             auto run_cls = [&](std::vector<std::vector<Part> *> group) {
+                ArimaMethodScope method_scope(method_in_force);
                 try {
                     (void)hipSetDevice(cur_dev_m);
                     for (auto *cls : group) if (!run_merged(*cls)) merged_ok = false;
@@ -2746,6 +2824,7 @@ static bool forecast_batch_one_device(const double *const *values, const uint64_
             if (wb) anofox_hip_batch_destroy(wb);
         };
         auto work = [&]() {
+            ArimaMethodScope method_scope(method_in_force);
             try { work_body(); }
             catch (const std::exception &e) {           // nothing may leave a worker thread
                 std::lock_guard<std::mutex> lock(err_mu);
@@ -2767,6 +2846,7 @@ static bool forecast_batch_one_device(const double *const *values, const uint64_
             // critical path of the call), each on its own thread, largest first
             std::atomic<size_t> next_big{0};
             auto big_work = [&]() {
+                ArimaMethodScope method_scope(method_in_force);
                 (void)hipSetDevice(cur_dev);
                 try {
                     for (size_t g = next_big.fetch_add(1); g < first_small; g = next_big.fetch_add(1)) run_part(parts[g]);
@@ -2908,7 +2988,9 @@ bool anofox_ts_forecast_batch(const double *const *values, const uint64_t *const
     std::vector<std::thread> threads;
     const bool timing = std::getenv("ANOFOX_HIP_TIMING") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
+    const int method_in_force = arima_method_in_force();
     auto shard = [&](size_t g) {
+        ArimaMethodScope method_scope(method_in_force);
         berr[g].code = SUCCESS; berr[g].message[0] = 0;
         try {
             size_t lo = 0, hi = 0;
@@ -2986,7 +3068,7 @@ static bool forecast_one_pooled(const double *values, const uint64_t *validity, 
     if (b) {
         try { batch_attach_streams(b); }
         catch (const HipFail &f) { report_hip_failure(out_error, f); anofox_hip_batch_destroy(b); return false; }
-        b->arima_method = g_default_arima_method.load();      // a parked batch predates the process default of this call
+        b->arima_method = arima_method_in_force();      // a parked batch predates the method of this call
         b->tun = Tunables::from_env();
     }
     if (!b) {
@@ -3111,40 +3193,64 @@ bool anofox_ts_forecast(const double *values, const uint64_t *validity, size_t l
         return true;
     }
     // ---- the leader runs the group (its members are blocked on the group; their request records live on their stacks) ----
+    // Whatever happens below -- a refused allocation of the argument vectors included -- every member gets an answer and is woken:
+    // the guard fills the requests nobody answered with INTERNAL_ERROR, marks the group done and gives the in-flight count back.
     const size_t k = grp->reqs.size();
-    bool my_ok = false;
-    if (k == 1) {
-        my_ok = forecast_one_pooled(values, validity, length, options, key, &req.res, &req.err);
-        req.ok = my_ok;
-    } else {
-        std::vector<const double *> v(k);
-        std::vector<const uint64_t *> m(k);
-        std::vector<size_t> len(k);
-        bool any_mask = false;
-        for (size_t j = 0; j < k; j++) { v[j] = grp->reqs[j]->values; m[j] = grp->reqs[j]->validity; len[j] = grp->reqs[j]->length; any_mask |= m[j] != nullptr; }
-        std::vector<ForecastResult> res(k);
-        std::vector<AnofoxError> errs(k);
-        for (size_t j = 0; j < k; j++) { std::memset(&res[j], 0, sizeof(ForecastResult)); errs[j].code = SUCCESS; errs[j].message[0] = 0; }
-        AnofoxError be;
-        be.code = SUCCESS; be.message[0] = 0;
-        bool ok = false;
-        try {
-            ok = forecast_batch_one_device(v.data(), any_mask ? m.data() : nullptr, len.data(), k, options, nullptr, res.data(), errs.data(), &be);
-        } catch (...) { ok = false; }
-        if (!ok && be.code == SUCCESS) set_error(&be, INTERNAL_ERROR, "Internal error: device batch failed");
-        for (size_t j = 0; j < k; j++) {
-            CoalesceReq *q = grp->reqs[j];
-            if (!ok) { anofox_free_forecast_result(&res[j]); q->ok = false; q->err = be; }
-            else if (errs[j].code != SUCCESS) { anofox_free_forecast_result(&res[j]); q->ok = false; q->err = errs[j]; }
-            else { q->ok = true; q->res = res[j]; }
+    char answered[COALESCE_MAX] = {0};          // (no allocation outside the try block; k <= COALESCE_MAX)
+    struct LeaderGuard {
+        std::shared_ptr<CoalesceGroup> &grp;
+        char *answered;
+        ~LeaderGuard()
+        {
+            for (size_t j = 0; j < grp->reqs.size() && j < COALESCE_MAX; j++)
+                if (!answered[j]) {
+                    CoalesceReq *q = grp->reqs[j];
+                    q->ok = false;
+                    set_error(&q->err, INTERNAL_ERROR, "Internal error: coalesced batch failed");
+                }
+            std::lock_guard<std::mutex> lock(g_co_mu);
+            grp->done = true;
+            g_co_inflight--;
+            grp->cv.notify_all();
         }
-        my_ok = req.ok;
-    }
-    {
-        std::lock_guard<std::mutex> lock(g_co_mu);
-        grp->done = true;
-        g_co_inflight--;
-        grp->cv.notify_all();
+    };
+    bool my_ok = false;
+    try {
+        LeaderGuard guard{grp, answered};
+        ArimaMethodScope method_scope(grp->method);        // the method the members were matched on, not a re-read of the process default
+        if (k == 1) {
+            my_ok = forecast_one_pooled(values, validity, length, options, key, &req.res, &req.err);
+            req.ok = my_ok;
+            answered[0] = 1;
+        } else {
+            std::vector<const double *> v(k);
+            std::vector<const uint64_t *> m(k);
+            std::vector<size_t> len(k);
+            bool any_mask = false;
+            for (size_t j = 0; j < k; j++) { v[j] = grp->reqs[j]->values; m[j] = grp->reqs[j]->validity; len[j] = grp->reqs[j]->length; any_mask |= m[j] != nullptr; }
+            std::vector<ForecastResult> res(k);
+            std::vector<AnofoxError> errs(k);
+            for (size_t j = 0; j < k; j++) { std::memset(&res[j], 0, sizeof(ForecastResult)); errs[j].code = SUCCESS; errs[j].message[0] = 0; }
+            AnofoxError be;
+            be.code = SUCCESS; be.message[0] = 0;
+            bool ok = false;
+            try {
+                ok = forecast_batch_one_device(v.data(), any_mask ? m.data() : nullptr, len.data(), k, options, nullptr, res.data(), errs.data(), &be);
+            } catch (...) { ok = false; }
+            if (!ok && be.code == SUCCESS) set_error(&be, INTERNAL_ERROR, "Internal error: device batch failed");
+            for (size_t j = 0; j < k; j++) {
+                CoalesceReq *q = grp->reqs[j];
+                if (!ok) { anofox_free_forecast_result(&res[j]); q->ok = false; q->err = be; }
+                else if (errs[j].code != SUCCESS) { anofox_free_forecast_result(&res[j]); q->ok = false; q->err = errs[j]; }
+                else { q->ok = true; q->res = res[j]; }
+                answered[j] = 1;
+            }
+            my_ok = req.ok;
+        }
+    } catch (...) {
+        // (the guard has answered and woken everyone; nothing leaves the C ABI)
+        my_ok = false;
+        if (req.err.code == SUCCESS) set_error(&req.err, INTERNAL_ERROR, "Internal error: coalesced batch failed (out of host memory)");
     }
     if (!my_ok) { if (out_error) *out_error = req.err; return false; }
     *out_result = req.res;

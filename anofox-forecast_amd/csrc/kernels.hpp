@@ -70,6 +70,8 @@ struct FitArgs {
     int gather_cap;              // columns y_round has room for: the gather (and this flag) only apply while n_active <= gather_cap
     NmStateBuf st;
     double *ring_scratch;        // periods above ETS_LDS_PERIOD: m * 64 doubles per workgroup of the launch (seasonal ring in HBM)
+    double *nm_scratch;          // PARK kernels (ets_fit_kernel.hpp RoundTraits): nm_lds_doubles<DIM>() doubles per workgroup of the launch,
+    size_t nm_scratch_doubles;   //   where the lanes' simplices rest between passes (else they rest in LDS); doubles it holds
     int m, h;
     const double *l0, *b0;       // [ld] for this spec's (season, trend) class
     const double *fig; size_t fig_ld;
@@ -142,7 +144,7 @@ struct IntervalArgs {
 // ETS fit kernels, one per (spec id, ring variant).  ring: 0 = none / VGPR ring for the
 // compile-time period given, -1 = LDS ring.  Returns NULL when not instantiated.
 typedef void (*FitLaunchFn)(const FitArgs &, hipStream_t);
-struct FitLaunchers { FitLaunchFn round_seq, round_spec, round_spec2, round_auto, final; };   // sequential / speculative / two-level speculative rounds, all three behind a device-side choice, final pass
+struct FitLaunchers { FitLaunchFn round_seq, round_spec, round_spec2, round_auto, final; size_t nm_scratch_per_wg; };   // sequential / speculative / two-level speculative rounds, all three behind a device-side choice, final pass; doubles of global simplex scratch per workgroup (0: the simplex rests in LDS)
 // `m`: the period (7 and 12 have compile-time variants), or ETS_PERLANE_LDS / ETS_PERLANE_HBM for the round kernels of a merged
 // batch of several periods (per-lane period, ring in LDS / in HBM scratch sized by the batch's largest period)
 constexpr int ETS_PERLANE_LDS = -3, ETS_PERLANE_HBM = -4;

@@ -106,9 +106,14 @@ class DeviceBatch:
             "status": view(ptrs[4], (self.n,), torch.int32, 4),
         }
 
-    def model_name(self, code: int) -> str:
+    def model_name(self, code: int, series: int | None = None) -> str:
+        """Name of a model code; with `series`, the name anofox_hip_batch_fetch gives that series (an AutoARIMA code carries the
+        period the series was fitted with -- detected periods included)."""
         buf = (C.c_char * 64)()
-        self.L.anofox_hip_model_name(C.byref(self.opts), int(code), buf)
+        if series is None:
+            self.L.anofox_hip_model_name(C.byref(self.opts), int(code), buf)
+        else:
+            self.L.anofox_hip_batch_model_name(self.handle, int(series), int(code), buf)
         return buf.value.decode()
 
     def close(self):

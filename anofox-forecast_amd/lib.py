@@ -71,6 +71,8 @@ class AnofoxHipStats(C.Structure):
         ("total_device_ms", C.c_double),
         ("fit_kernel_launches", C.c_uint32),
         ("reserved", C.c_uint32),
+        ("total_iters", C.c_uint64),
+        ("min_pass_bytes", C.c_uint64),
     ]
 
 
@@ -88,7 +90,7 @@ EXPORTED_SYMBOLS = [
     "anofox_ts_forecast", "anofox_free_forecast_result", "anofox_fcst_version", "anofox_ts_forecast_batch",
     "anofox_hip_device_count", "anofox_hip_set_device", "anofox_hip_batch_create", "anofox_hip_batch_destroy",
     "anofox_hip_batch_ld", "anofox_hip_batch_pack_host", "anofox_hip_batch_set_device_block", "anofox_hip_batch_run",
-    "anofox_hip_batch_stats", "anofox_hip_batch_device_results", "anofox_hip_batch_fetch", "anofox_hip_model_name",
+    "anofox_hip_batch_stats", "anofox_hip_batch_device_results", "anofox_hip_batch_fetch", "anofox_hip_model_name", "anofox_hip_batch_model_name",
     "anofox_hip_ingest_create", "anofox_hip_ingest_destroy", "anofox_hip_ingest_append", "anofox_hip_ingest_finish",
     "anofox_hip_ingest_group_keys", "anofox_hip_ingest_last_dates", "anofox_hip_ingest_lengths", "anofox_hip_ingest_values",
     "anofox_hip_ingest_validity", "anofox_hip_batch_pack_ingest", "anofox_hip_batch_inspect",
@@ -153,6 +155,8 @@ def load():
     L.anofox_hip_batch_fetch.restype = C.c_bool
     L.anofox_hip_batch_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.anofox_hip_model_name.argtypes = [P(ForecastOptions), C.c_int32, C.c_char * 64]
+    L.anofox_hip_batch_model_name.argtypes = [C.c_void_p, C.c_size_t, C.c_int32, C.c_char * 64]
+    L.anofox_hip_batch_model_name.restype = None
     L.anofox_hip_batch_inspect.restype = C.c_bool
     L.anofox_hip_batch_inspect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, P(AnofoxError)]
     L.anofox_hip_set_devices.restype = C.c_bool

@@ -11,9 +11,11 @@ chunks to rank 0, inside the timed region.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
---scaling weak   (default) every rank owns a full batch of the workload's size: value = N x series / time
---scaling strong the workload's series are split over the ranks (BASELINE config 3: "M5 30,490 series,
-                 series-sharded 1->8 GPUs"): rank r owns dist.shard_range(n, r, N)
+--scaling strong (default) the workload's series are split over the ranks (BASELINE config 3: "M5 30,490 series,
+                 series-sharded 1->8 GPUs"): rank r owns dist.shard_range(n, r, N); value = series_total / max-rank time
+--scaling weak   every rank owns a full batch of the workload's size: value = N x series / time
+(at N = 1 the two are the same run).  The 1M x 1,024 configuration (BASELINE config 5) is
+`--workload autoets_stress --n-series 1000000` (strong: 125,000 series per GPU at N = 8).
 
 Workloads (--workload):
     autoets_m5_positive   (default) 30,490 x 1,913, h=28, m=7, strictly positive counts: all 25
@@ -56,7 +58,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="autoets_m5_positive")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="strong")
     ap.add_argument("--n-series", type=int, default=0, help="series per GPU (weak) / in total (strong); 0 = workload default")
     ap.add_argument("--t", type=int, default=0, help="observations per series (0 = workload default)")
     ap.add_argument("--horizon", type=int, default=28)
@@ -232,6 +234,11 @@ def main():
             # config 2: the timed unit is the STEP (HIP events around everything the run enqueues), not the final pass alone
             final_pass_ms, fit_ms_avg = fit_ms_avg, float(np.mean(dev_ms))
         achieved = float(np.mean(alg_bytes)) / (fit_ms_avg * 1e-3) / 1e9 if fit_ms_avg > 0 else 0.0
+        # the same time against the bytes of a one-pass-per-iteration schedule (Nelder-Mead iterations + one final pass per problem):
+        # `frac` counts the passes the drivers actually executed (the sequential one runs ~1.7 per iteration), this one does not
+        # depend on which driver ran which round
+        min_bytes = int(st.get("min_pass_bytes", 0))
+        achieved_min = min_bytes / (fit_ms_avg * 1e-3) / 1e9 if (fit_ms_avg > 0 and min_bytes > 0) else None
         if model == "AutoARIMA":
             kernel = ("arima_fit_kernel + arima_fit_spec_kernel (all sweeps of one step + the selected models' polish)" +
                       (" + arima_refit_kernel (exact-likelihood refit)" if wl["arima_method"] else ""))
@@ -261,7 +268,10 @@ def main():
                        "device_ms_per_step": round(float(np.mean(dev_ms)), 3), "datagen_s": round(gen_s, 1)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": kernel, "kernel_ms": round(fit_ms_avg, 3), "algorithmic_bytes": int(np.mean(alg_bytes))},
+                         "kernel": kernel, "kernel_ms": round(fit_ms_avg, 3), "algorithmic_bytes": int(np.mean(alg_bytes)),
+                         "frac_min_passes": round(achieved_min / HBM_PEAK_GBS, 4) if achieved_min else None,
+                         "min_pass_bytes": min_bytes or None,
+                         "mean_iterations_per_series": round(st.get("total_iters", 0) / max(n, 1), 1) if min_bytes else None},
         }
         if final_pass_ms:
             out["roofline"]["final_pass"] = {"kernel": "ets_final_kernel<spec,period> alone", "kernel_ms": round(final_pass_ms, 4),

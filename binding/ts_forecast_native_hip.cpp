@@ -113,6 +113,13 @@ unique_ptr<FunctionData> HipForecastBindFn(ClientContext &, TableFunctionBindInp
         }
         try { return std::stod(it->second); } catch (...) { return fallback; }
     };
+    auto integer = [&](const char *key, int64_t fallback) {
+        auto it = params.find(key);
+        if (it == params.end()) {
+            return fallback;
+        }
+        try { return (int64_t)std::stoll(it->second); } catch (...) { return fallback; }
+    };
     const string model_spec = text("model");
     const int64_t seasonal_period = (int64_t)number("seasonal_period", 0);
     const double confidence = number("confidence_level", 0.90);
@@ -156,7 +163,9 @@ unique_ptr<FunctionData> HipForecastBindFn(ClientContext &, TableFunctionBindInp
     CopyText(o.seasonal_periods_str, sizeof o.seasonal_periods_str, seasonal_periods);
     CopyText(o.model_pool, sizeof o.model_pool, text("model_pool"));
     CopyText(o.laplace_variant, sizeof o.laplace_variant, text("laplace_variant"));
-    o.laplace_seasonal_batch_init = StringUtil::Lower(text("laplace_seasonal_batch_init")) == "true";
+    // an integer, non-zero = on, anything unparsable = the default 0 -- ParseInt64FromParams(...) != 0, ts_forecast_native.cpp:182-200, 353-354
+    // ('1' enables it, 'true' does not: the reference's answer for both spellings)
+    o.laplace_seasonal_batch_init = integer("laplace_seasonal_batch_init", 0) != 0;
 
     bind->group_type = input.input_table_types[0];
     bind->date_type = input.input_table_types[1];
@@ -180,6 +189,7 @@ unique_ptr<FunctionData> HipForecastBindFn(ClientContext &, TableFunctionBindInp
 // ------------------------------------------------------------------------------------------------ state
 struct HipForecastLocal : public LocalTableFunctionState {
     bool collecting = false, done_collecting = false;
+    bool owns_finalize = false;      // this operator instance claimed the emission (the reference's lstate.owns_finalize, ts_forecast_native.cpp:575-586)
 };
 
 struct HipForecastGlobal : public GlobalTableFunctionState {
@@ -322,13 +332,15 @@ OperatorFinalizeResultType HipForecastFinalize(ExecutionContext &, TableFunction
     }
     // one thread emits everything: after source exhaustion all threads share one batch index, so rows from several threads would
     // collide in PhysicalBatchInsert (docs/table-in-out-parallel-execution.md:58-77)
-    static thread_local const HipForecastGlobal *owned = nullptr;
-    if (owned != &g) {
+    // Ownership lives in the LOCAL state, as in the reference (ts_forecast_native.cpp:575-586): HAVE_MORE_OUTPUT re-entries come
+    // back with the same local state, and a later statement whose global state happens to be allocated at a freed one's address
+    // can never inherit a claim (a thread_local keyed by the global state's address could).
+    if (!l.owns_finalize) {
         bool expected = false;
         if (!g.claimed.compare_exchange_strong(expected, true)) {
             return OperatorFinalizeResultType::FINISHED;
         }
-        owned = &g;
+        l.owns_finalize = true;
         while (g.collectors_done.load() < g.collectors.load()) {
             std::this_thread::yield();
         }

@@ -187,6 +187,11 @@ typedef struct AnofoxHipStats {
     double   total_device_ms;   /* HIP-event time of the whole run on its stream  */
     uint32_t fit_kernel_launches;
     uint32_t reserved;
+    uint64_t total_iters;       /* Nelder-Mead iterations summed over the ETS problems (each problem counts from 1: the initial
+                                   simplex) -- the passes a one-pass-per-iteration schedule needs; 0 for models without spec slots */
+    uint64_t min_pass_bytes;    /* sum over problems of 8*T_s*(iterations + 1 final pass) + 24*h per series: the algorithmic bytes
+                                   of that schedule ("if the kernel evaluates k simplex vertices in one pass, that
+                                   is one pass"), independent of which driver ran which round                                  */
 } AnofoxHipStats;
 
 /* Device selection; returns number of visible devices or -1. */
@@ -302,6 +307,13 @@ bool anofox_hip_batch_inspect(AnofoxHipBatch *batch, AnofoxHipInspection *out,
 /* Render a device model_code to the reference's model_name text (<= 63 chars). */
 void anofox_hip_model_name(const struct ForecastOptions *options, int32_t model_code,
                            char out_name[64]);
+/*
+ * The same for a series of a batch: an AutoARIMA code is rendered with the period THAT SERIES was fitted with -- the given one,
+ * or the one detect_period_kernel found on a resident block (anofox_hip_batch_periods) -- i.e. exactly the name
+ * anofox_hip_batch_fetch writes ("AutoARIMA(p,d,q)(P,D,Q)[m]", forecast.rs:1469-1493).  anofox_hip_model_name only has the option
+ * block, whose seasonal_period is 0 when periods are detected.
+ */
+void anofox_hip_batch_model_name(const AnofoxHipBatch *batch, size_t series, int32_t model_code, char out_name[64]);
 
 /* ------------------------------------------------------------------------- */
 /* Block 4: columnar ingest for the table-in-out caller (route B)              */

@@ -618,10 +618,10 @@ static int run_forecast(const double *y, size_t n, const ForecastOptions *o, Mod
         FAIL(err, COMPUTATION_ERROR, "Computation error: %s fit failed: unsupported seasonal period (periods above %d are not supported)",
              MODEL_NAMES[model], ETS_MAX_PERIOD);
 
-    /* AutoARIMA: an EXPLICIT period above the cap fails loudly; a DETECTED one (the ACF heuristic of seasonality.rs:323-377 on a
-     * call without seasonal_period) falls back to the non-seasonal search -- the reference's own documentation says AutoARIMA
-     * without seasonal_period selects a non-seasonal model (docs/reference/models/state-space/auto_arima.md) */
-    if (model == M_AutoARIMA && period > ARIMA_DETECT_MAX_PERIOD && o->auto_detect_seasonality && o->seasonal_period == 0) period = 1;
+    /* AutoARIMA: a DETECTED period (the ACF heuristic of seasonality.rs:323-377 on a call without seasonal_period) goes to the
+     * seasonal search exactly like an explicit one -- forecast.rs:528-537 hands it to forecast_auto_arima, :1448-1452 passes any
+     * period > 1 to with_seasonal_period.  (Rounds 2-3 made detected periods above 24 non-seasonal: a product limit, not the
+     * reference's behaviour.)  Above the cap it fails loudly either way. */
     if (model == M_AutoARIMA && period > ARIMA_MAX_PERIOD)
         FAIL(err, COMPUTATION_ERROR, "Computation error: AutoARIMA fit failed: unsupported seasonal period (periods above %d are not supported)",
              ARIMA_MAX_PERIOD);

