@@ -130,29 +130,57 @@ __device__ __forceinline__ double dm_exp(double x)
 static __device__ const double dm_pow_inv_c_src[ANOFOX_POW_INV_C_N] = { ANOFOX_POW_INV_C_VALUES };
 static __device__ const double dm_pow_log_c_src[ANOFOX_POW_LOG_C_N] = { ANOFOX_POW_LOG_C_VALUES };
 static __device__ const double dm_pow_exp2_t_src[ANOFOX_POW_EXP2_T_N] = { ANOFOX_POW_EXP2_T_VALUES };
-constexpr int DM_POW_TAB_DOUBLES = 2 * ANOFOX_POW_INV_C_N + ANOFOX_POW_EXP2_T_N;
+// Round 4 experiment, kept as a build switch: the workgroup's copy of the tables can be REPLICATED (-DANOFOX_POW_R128 / _R64: entry j
+// stored R times side by side, a lane reads copy (its position in its LDS lane group) mod R -- with 16 / 32 copies no two lanes of a
+// ds_read_b128 / ds_read_b64 lane group can meet on a bank, MI355X_MICROARCH.md "LDS").  Measured: NO gain (profiles/r04_README.md:
+// 8 / 8 and 2 / 4 copies run the damped multiplicative-trend fit in 137.9 / 137.3 ms against 137.1 ms) -- the two lookups cost their
+// LATENCY on the step's critical path (taking them out altogether, with wrong values: 113 ms), not bank-conflict cycles.  Default 1 / 1.
+#ifndef ANOFOX_POW_R128
+#define ANOFOX_POW_R128 1
+#endif
+#ifndef ANOFOX_POW_R64
+#define ANOFOX_POW_R64 1
+#endif
+constexpr int DM_POW_R128 = ANOFOX_POW_R128, DM_POW_R64 = ANOFOX_POW_R64;
+constexpr int DM_POW_EXP_BASE = 2 * ANOFOX_POW_INV_C_N * DM_POW_R128;
+constexpr int DM_POW_TAB_DOUBLES = DM_POW_EXP_BASE + ANOFOX_POW_EXP2_T_N * DM_POW_R64;
 
-// the workgroup's copy: {INV_C[j], LOG_C[j]} side by side (one 128-bit LDS read), then EXP2_T
+// the workgroup's copy: pair (j, copy c) = {INV_C[j], LOG_C[j]} at doubles 2 (j R128 + c) (one 128-bit LDS read), then EXP2_T[n] copy c
+// at DM_POW_EXP_BASE + n R64 + c
 __device__ __forceinline__ double *dm_pow_tab()
 {
     __shared__ __attribute__((aligned(16))) double tab[DM_POW_TAB_DOUBLES];
     return tab;
 }
 
-// once per kernel, by a 64-lane workgroup, before the first dm_pow_step
+// once per kernel, by ALL threads of the workgroup (any size), before the first dm_pow_step and before any thread leaves
 __device__ __forceinline__ void dm_pow_tab_init()
 {
     double *tab = dm_pow_tab();
-    const int l = threadIdx.x & 63;
-    tab[2 * l] = dm_pow_inv_c_src[l];
-    tab[2 * l + 1] = dm_pow_log_c_src[l];
-    tab[2 * (l + 64)] = dm_pow_inv_c_src[l + 64];
-    tab[2 * (l + 64) + 1] = dm_pow_log_c_src[l + 64];
-    tab[2 * ANOFOX_POW_INV_C_N + l] = dm_pow_exp2_t_src[l];
+    const int nt = blockDim.x;
+    for (int idx = threadIdx.x; idx < ANOFOX_POW_INV_C_N * DM_POW_R128; idx += nt) {
+        const int j = idx / DM_POW_R128;
+        tab[2 * idx] = dm_pow_inv_c_src[j];
+        tab[2 * idx + 1] = dm_pow_log_c_src[j];
+    }
+    for (int idx = threadIdx.x; idx < ANOFOX_POW_EXP2_T_N * DM_POW_R64; idx += nt) tab[DM_POW_EXP_BASE + idx] = dm_pow_exp2_t_src[idx / DM_POW_R64];
     __syncthreads();
 }
 
-__device__ __forceinline__ double dm_pow_step(double x, double y)
+// this lane's copies (offsets in doubles): its position inside its ds_read_b128 lane group -- {0-3, 12-15, 20-27} and
+// {4-11, 16-19, 28-31} of each 32-lane half -- and inside its ds_read_b64 group (the 32-lane half)
+struct DmPowLane { int o128, o64; };
+__device__ __forceinline__ DmPowLane dm_pow_lane()
+{
+    const int l = threadIdx.x & 31;
+    const int gp = l < 4 ? l : (l < 12 ? l - 4 : (l < 20 ? l - 8 : (l < 28 ? l - 12 : l - 16)));
+    DmPowLane r;
+    r.o128 = 2 * (gp % DM_POW_R128);
+    r.o64 = DM_POW_EXP_BASE + (l % DM_POW_R64);
+    return r;
+}
+
+__device__ __forceinline__ double dm_pow_step(double x, double y, const DmPowLane &cp)
 {
     const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
     const double n_per_ln2 = 0x1.71547652b82fep+6;                           // 64 / ln2
@@ -164,7 +192,7 @@ __device__ __forceinline__ double dm_pow_step(double x, double y)
     const int j = (int)(hx >> 13) & 127;
     const double m = dm_from_bits((u & 0x000fffffffffffffull) | 0x3ff0000000000000ull);
     typedef double d2_t __attribute__((ext_vector_type(2)));
-    const d2_t ic = *reinterpret_cast<const d2_t *>(tab + 2 * j);            // {INV_C[j], LOG_C[j]}
+    const d2_t ic = *reinterpret_cast<const d2_t *>(tab + 2 * DM_POW_R128 * j + cp.o128);      // {INV_C[j], LOG_C[j]}, this lane's copy
     const double r = fma(m, ic.x, -1.0);
     const double r2 = r * r;
     const double pa = fma(r, 1.0 / 3.0, -0.5);
@@ -182,7 +210,7 @@ __device__ __forceinline__ double dm_pow_step(double x, double y)
     const double q = fma(s2, fma(s2, 1.0 / 720.0, qb), qa);
     const double p = fma(s2, q, s);
     const int n = (int)dn;
-    const double tv = tab[2 * ANOFOX_POW_INV_C_N + (n & 63)];
+    const double tv = tab[DM_POW_R64 * (n & 63) + cp.o64];
     const double ev = fma(tv, p, tv);
     // ev 2^(n >> 6): |n >> 6| <= 1000 and ev in [1/2, 2], so the scaling is exact -- v_ldexp_f64, one instruction instead of the three
     // integer operations + multiply that build and apply the power of two (same value: the oracle multiplies by the constructed double)

@@ -66,7 +66,7 @@ struct EtsCfg {
     static constexpr bool CLASSIC = false;      // (classic_device.hpp: the SES / Holt / Holt-Winters / SeasonalES family on the same round kernels)
 };
 
-struct EtsPar { double alpha, bstar, phi, beta, gamma; };
+struct EtsPar { double alpha, bstar, phi, beta, gamma; DmPowLane pl; };      // pl: this lane's copies of the b^phi tables (damped multiplicative trend only)
 struct EtsState { double l, b, sse, mant; int eacc; int bad; double f; };   // f: last one-step forecast (inspection only)
 
 template <class Cfg>
@@ -113,7 +113,7 @@ __device__ __forceinline__ void ets_step(const EtsPar &p, EtsState &st, double y
                 // growth rates outside [2^-1000, 2^1000] reject the trial point (oracle/ets.c does the same), so the
                 // power below never meets a special case and runs without a branch
                 if (!(st.b >= 0x1p-1000 && st.b <= 0x1p+1000)) st.bad = 1;
-                phib = dm_pow_step(st.b, p.phi);
+                phib = dm_pow_step(st.b, p.phi, p.pl);
             } else phib = st.b;
             q = st.l * phib;
         }
@@ -198,12 +198,13 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
                                          double *ring, const EtsFinalOut *fin)
 {
     static_assert((Cfg::S == C_NONE) == (MS == 0), "MS == 0 iff no seasonal component");
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & (NM_BLOCK - 1);       // (round kernels may run several waves per workgroup)
     EtsPar par[K];
     EtsState st[K];
 #pragma unroll
     for (int k = 0; k < K; k++) {
         ets_unpack<Cfg>(cand[k], par[k]);
+        if constexpr (Cfg::T == C_MUL && Cfg::D) par[k].pl = dm_pow_lane();
         st[k].l = in.l0; st[k].b = in.b0; st[k].sse = 0.0; st[k].mant = 1.0; st[k].eacc = 0; st[k].bad = 0;
     }
     const double *yp = v.yb;            // wave-uniform base; the lane's column is added as a 32-bit offset
@@ -454,13 +455,13 @@ struct EtsModel {
         if constexpr (CPL == NM_K) {
             ets_pass<Cfg, MS, NM_K, false>(v, in, cand, f, ring, nullptr);
         } else {
-            const int sub = threadIdx.x & 3;
+            const int sub = threadIdx.x & 3;                 // (lane & 3: a wave is 64 consecutive threads)
             double mine[1][DIM], f1[1];
 #pragma unroll
             for (int i = 0; i < DIM; i++)
                 mine[0][i] = sub == 0 ? cand[0][i] : (sub == 1 ? cand[1][i] : (sub == 2 ? cand[2][i] : cand[3][i]));
             ets_pass<Cfg, MS, 1, false>(v, in, mine, f1, ring, nullptr);
-            const int base = threadIdx.x & ~3;
+            const int base = (threadIdx.x & (NM_BLOCK - 1)) & ~3;
 #pragma unroll
             for (int k = 0; k < NM_K; k++) f[k] = __shfl(f1[0], base + k);
         }

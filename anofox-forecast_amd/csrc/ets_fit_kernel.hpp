@@ -30,10 +30,20 @@ namespace anofox {
 #ifndef ANOFOX_PARK_WAVES
 #define ANOFOX_PARK_WAVES 4
 #endif
+// WPB: waves per workgroup of the damped multiplicative-trend kernels (-DANOFOX_DM_WPB; default 1).  Several independent waves may
+// share one copy of the b^phi tables: nothing else is shared -- a wave owns its 64 lanes' problems, its slice of the dynamic LDS
+// and its slices of the scratch areas (indexed by its VIRTUAL block number blockIdx.x * WPB + wave); the only barrier is the one
+// behind the table fill.  Measured (profiles/r04_README.md): four waves per workgroup run a lone damped-M fit 6.5 % faster
+// (128.2 against 137.1 ms) and the 25-spec batch 12 % SLOWER (614-626 against 548-551 ms: a 71 KB workgroup waits for a CU with
+// that much LDS free while the other specs' 15 KB workgroups keep taking it).
+#ifndef ANOFOX_DM_WPB
+#define ANOFOX_DM_WPB 1
+#endif
 template <class Cfg> struct RoundTraits {
     static constexpr bool DAMPED_MUL = !Cfg::CLASSIC && Cfg::T == C_MUL && Cfg::D;
     static constexpr bool PARK = !Cfg::CLASSIC && (ANOFOX_PARK_CLASS >= 3 || (ANOFOX_PARK_CLASS == 2 && !Cfg::ADDITIVE) || (ANOFOX_PARK_CLASS == 1 && DAMPED_MUL));
     static constexpr int WAVES = PARK ? ANOFOX_PARK_WAVES : ANOFOX_ROUND_WAVES;
+    static constexpr int WPB = DAMPED_MUL ? ANOFOX_DM_WPB : 1;
 };
 
 // the model behind a Cfg: an ETS spec, or one of the SES / Holt / Holt-Winters / SeasonalES family (SSE objective, own start values)
@@ -47,26 +57,32 @@ template <class Cfg, int MS> struct RoundModelOf<Cfg, MS, true> { using type = C
 //           a launch whose workgroups only find out that another driver owns the round still has to be dispatched, and on a
 //           saturated chip that stalls the spec's chain for milliseconds (6 ms measured for 1,024 empty workgroups)
 template <class Cfg, int MS, int SPEC>
-__global__ __launch_bounds__(NM_BLOCK, RoundTraits<Cfg>::WAVES) void ets_round_kernel(const FitArgs a)
+__global__ __launch_bounds__(NM_BLOCK * RoundTraits<Cfg>::WPB, (RoundTraits<Cfg>::WAVES + RoundTraits<Cfg>::WPB - 1) / RoundTraits<Cfg>::WPB) void ets_round_kernel(const FitArgs a)
 {
-    extern __shared__ double lds[];
+    extern __shared__ double lds_all[];
     constexpr int D = Cfg::DIM;
     constexpr bool PARK = RoundTraits<Cfg>::PARK;
-    const int lane = threadIdx.x;
-    // the wave's simplex store: LDS, or its own slice of the launch's global scratch (then LDS starts with the seasonal ring)
-    double *const nmst = PARK ? a.nm_scratch + (size_t)blockIdx.x * (size_t)nm_lds_doubles<D>() : lds;
+    constexpr int WPB = RoundTraits<Cfg>::WPB;
+    if constexpr (Cfg::T == C_MUL && Cfg::D) dm_pow_tab_init();     // b^phi tables -> LDS, by every thread of the workgroup, before any wave leaves
+    const int lane = threadIdx.x & (NM_BLOCK - 1);
+    const int wave = WPB > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+    const int vblock = (int)blockIdx.x * WPB + wave, vgrid = (int)gridDim.x * WPB;      // the wave's virtual one-wave workgroup
+    // this wave's slice of the dynamic LDS: [simplex store unless it rests in global scratch][seasonal ring of a run-time period]
+    const int lds_per_wave = (PARK ? 0 : nm_lds_doubles<D>()) + ((MS == -1 || MS == -3) ? a.m * NM_BLOCK : 0);
+    double *const lds = lds_all + (size_t)wave * (size_t)lds_per_wave;
+    double *const nmst = PARK ? a.nm_scratch + (size_t)vblock * (size_t)nm_lds_doubles<D>() : lds;
     double *const lds_ring = PARK ? lds : lds + nm_lds_doubles<D>();
     const int n_act = a.n_active ? *a.n_active : a.n_series;
     int mode = SPEC;
-    if constexpr (SPEC == 3) mode = n_act > a.spec_below ? 0 : ((a.spec2_below > 0 && n_act <= a.spec2_below && n_act <= (int)gridDim.x) ? 2 : 1);
+    if constexpr (SPEC == 3) mode = n_act > a.spec_below ? 0 : ((a.spec2_below > 0 && n_act <= a.spec2_below && n_act <= vgrid) ? 2 : 1);
     else if (a.spec_below >= 0) {                                           // another driver may own this round
         const int owner = n_act > a.spec_below ? 0 : (n_act > a.spec2_below ? 1 : 2);
         if (owner != SPEC) return;
     }
     const int LPP = mode == 0 ? 1 : (mode == 1 ? NM_K : NM_BLOCK);         // lanes per problem (a constant unless SPEC == 3)
     const int PPB = NM_BLOCK / LPP;                                         // problems per workgroup
-    if ((int)blockIdx.x * PPB >= n_act) return;
-    const int p = blockIdx.x * PPB + lane / LPP;
+    if (vblock * PPB >= n_act) return;
+    const int p = vblock * PPB + lane / LPP;
     const bool valid = p < n_act;
     const int s = valid ? (a.series_of ? a.series_of[p] : p) : 0;
     const int len = valid ? a.len[s] : 0;
@@ -113,7 +129,6 @@ __global__ __launch_bounds__(NM_BLOCK, RoundTraits<Cfg>::WAVES) void ets_round_k
     v.wave_min_len = wave_min_i32(active ? len : 0x7fffffff);
     v.rows = a.t_rows;
     if (v.wave_len == 0) return;
-    if constexpr (Cfg::T == C_MUL && Cfg::D) dm_pow_tab_init();     // b^phi tables -> LDS (wave-uniform point: no lane has left)
 
     typename RoundModelOf<Cfg, MS>::type mdl;
     mdl.v = v;
@@ -122,7 +137,7 @@ __global__ __launch_bounds__(NM_BLOCK, RoundTraits<Cfg>::WAVES) void ets_round_k
     mdl.in.fig = a.fig ? a.fig + s : nullptr;
     mdl.in.fig_ld = a.fig_ld;
     mdl.in.m = m;
-    mdl.ring = (MS == -2 || MS == -4) ? a.ring_scratch + (size_t)blockIdx.x * (size_t)a.m * NM_BLOCK : lds_ring;
+    mdl.ring = (MS == -2 || MS == -4) ? a.ring_scratch + (size_t)vblock * (size_t)a.m * NM_BLOCK : lds_ring;
 
     NmRun r;
     if (a.first_round) nm_init_simplex(mdl, nmst, r, active);
@@ -273,13 +288,16 @@ void ets_round_launch(const FitArgs &a, hipStream_t stream)
         grid = (n_max + PPB - 1) / PPB;
     }
     if (grid <= 0) return;
-    if (RoundTraits<Cfg>::PARK && (a.nm_scratch == nullptr || (size_t)grid * (size_t)nm_lds_doubles<Cfg::DIM>() > a.nm_scratch_doubles))
+    constexpr int WPB = RoundTraits<Cfg>::WPB;
+    const int blocks = (grid + WPB - 1) / WPB;                  // `grid` counts one-wave workgroups; WPB of them share a real one
+    if (RoundTraits<Cfg>::PARK && (a.nm_scratch == nullptr || (size_t)blocks * WPB * (size_t)nm_lds_doubles<Cfg::DIM>() > a.nm_scratch_doubles))
         throw std::runtime_error("ets_round_launch: the simplex scratch does not cover the launch");
     size_t lds_bytes = RoundTraits<Cfg>::PARK ? 0 : sizeof(double) * (size_t)nm_lds_doubles<Cfg::DIM>();
     if (MS == -1 || MS == -3) lds_bytes += sizeof(double) * (size_t)a.m * NM_BLOCK;
+    lds_bytes *= WPB;
     if (lds_bytes > 48 * 1024)
         anofox_check_attr(hipFuncSetAttribute((const void *)ets_round_kernel<Cfg, MS, SPEC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    hipLaunchKernelGGL((ets_round_kernel<Cfg, MS, SPEC>), dim3(grid), dim3(NM_BLOCK), lds_bytes, stream, a);
+    hipLaunchKernelGGL((ets_round_kernel<Cfg, MS, SPEC>), dim3(blocks), dim3(NM_BLOCK * WPB), lds_bytes, stream, a);
 }
 
 template <class Cfg, int MS>

@@ -1365,7 +1365,7 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
         for (size_t oi = 0; oi < order.size(); oi++) {
             if (!fns[oi].nm_scratch_per_wg) continue;
             auto &lane = b->lanes[oi % (size_t)n_lanes];
-            const size_t need = wg * fns[oi].nm_scratch_per_wg;
+            const size_t need = (wg + 8) * fns[oi].nm_scratch_per_wg;         // (+ the waves that round a launch up to whole workgroups)
             if (lane.nm_scratch_doubles < need) {
                 if (lane.nm_scratch) b->retired.push_back(lane.nm_scratch);
                 lane.nm_scratch = nullptr; lane.nm_scratch_doubles = 0;

@@ -174,7 +174,7 @@ template <class Model>
 __device__ void nm_init_simplex(Model &mdl, double *st, NmRun &r, bool active)
 {
     constexpr int D = Model::DIM;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & (NM_BLOCK - 1);
     double lo[D], hi[D], x0[D];
     mdl.bounds(lo, hi, x0);
     NmSimplex<D> S;
@@ -203,7 +203,7 @@ template <class Model>
 __device__ void nm_advance_spec(Model &mdl, double *st, NmRun &r, int budget)
 {
     constexpr int D = Model::DIM;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & (NM_BLOCK - 1);
     double lo[D], hi[D], x0[D];
     mdl.bounds(lo, hi, x0);
     const int maxiter = 200 * D, maxfun = 200 * D;
@@ -374,7 +374,7 @@ __device__ void nm_advance_spec2(Model &mdl, double *st, NmRun &r, int budget)
 {
     constexpr int D = Model::DIM;
     constexpr int NH = 3 * D + 3;                 // hypotheses about the first iteration
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & (NM_BLOCK - 1);
     double lo[D], hi[D], x0[D];
     mdl.bounds(lo, hi, x0);
     const int maxiter = 200 * D, maxfun = 200 * D;
@@ -487,7 +487,7 @@ template <class Model>
 __device__ void nm_advance_seq(Model &mdl, double *st, NmRun &r, int budget)
 {
     constexpr int D = Model::DIM;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & (NM_BLOCK - 1);
     double lo[D], hi[D], x0[D];
     mdl.bounds(lo, hi, x0);
     const int maxiter = 200 * D, maxfun = 200 * D;
@@ -582,7 +582,7 @@ template <class Model>
 __device__ void nm_minimize(Model &mdl, bool active, double *st, double (&xbest)[Model::DIM], double &fbest, NmStats &stats)
 {
     constexpr int D = Model::DIM;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & (NM_BLOCK - 1);
     NmRun r;
     nm_init_simplex(mdl, st, r, active);
     nm_advance_spec(mdl, st, r, 0x7fffffff);
