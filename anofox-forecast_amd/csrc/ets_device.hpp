@@ -57,6 +57,9 @@ __device__ __forceinline__ int wave_min_i32(int v)
     return v;
 }
 
+#ifndef ANOFOX_K4_S_SEAS
+#define ANOFOX_K4_S_SEAS 8      // block length of the four-candidates-per-lane pass with a seasonal ring in registers (4 x m more doubles of state)
+#endif
 template <int ERR, int TREND, bool DAMPED, int SEAS>
 struct EtsCfg {
     static constexpr int E = ERR, T = TREND, S = SEAS;
@@ -223,7 +226,8 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
     // a step holds a reciprocal, a quarter when it holds a pow (damped multiplicative trend) -- those are long enough to
     // cover the latency with fewer rows in flight, and their own register needs leave less room for the buffers
     // (ring in HBM: the ring values stream through two more buffers of S -- half the block length, or the four buffers spill)
-    constexpr int S_FULL = Cfg::ADDITIVE ? 32 : ((Cfg::T == C_MUL && Cfg::D) ? 8 : 16);
+    //  (four candidates per lane, K = 4: half the block, the four recursions' states take the registers)
+    constexpr int S_FULL = Cfg::ADDITIVE ? (K == 4 ? (MS > 0 ? ANOFOX_K4_S_SEAS : 16) : 32) : ((Cfg::T == C_MUL && Cfg::D) ? 8 : 16);
     //  and at most 8 -- the ring prefetch needs periods of two blocks, a merged batch keeps periods from 17 up in HBM)
     constexpr int S_TARGET = ((MS == -2 || MS == -4) && K == 1 && S_FULL > 8) ? 8 : S_FULL;
     constexpr int S = (MS > 0) ? ((S_TARGET / MS > 0 ? S_TARGET / MS : 1) * MS) : S_TARGET;

@@ -56,7 +56,13 @@ template <class Cfg, int MS> struct RoundModelOf<Cfg, MS, true> { using type = C
 // SPEC = 3: all three in one kernel, picked from the device-side count of running problems -- ONE launch per round and spec:
 //           a launch whose workgroups only find out that another driver owns the round still has to be dispatched, and on a
 //           saturated chip that stalls the spec's chain for milliseconds (6 ms measured for 1,024 empty workgroups)
-template <class Cfg, int MS, int SPEC>
+// K4 (round 4; SPEC 0 / 3, additive class, no run-time ring): the one-lane-per-problem driver is the SPECULATIVE one with all four
+//           trial points of an iteration evaluated by the SAME lane in one pass (ets_pass<.., K = 4>: one y load feeds four
+//           recursions) -- one pass per iteration instead of ~1.7.  The additive-class pass is 6-10 instructions per 8-byte load:
+//           memory bound, so on a batch whose live specs are all additive (intermittent counts: the real M5 shape) the passes
+//           ARE the cost and four times the arithmetic is free; in a mix with the general-class specs (VALU bound) it is not,
+//           and the sequential driver stays.  Same iterates, same evaluation counts (the speculative driver's bookkeeping).
+template <class Cfg, int MS, int SPEC, bool K4 = false>
 __global__ __launch_bounds__(NM_BLOCK * RoundTraits<Cfg>::WPB, (RoundTraits<Cfg>::WAVES + RoundTraits<Cfg>::WPB - 1) / RoundTraits<Cfg>::WPB) void ets_round_kernel(const FitArgs a)
 {
     extern __shared__ double lds_all[];
@@ -157,14 +163,25 @@ __global__ __launch_bounds__(NM_BLOCK * RoundTraits<Cfg>::WPB, (RoundTraits<Cfg>
     }
 
     // one problem per wave (the last problems of a spec) runs to completion
-    const int budget = mode == 2 ? (1 << 30) : ((SPEC == 3 && mode == 0) ? a.budget_seq : a.budget);
+    const int budget = mode == 2 ? (1 << 30) : ((SPEC == 3 && mode == 0 && !K4) ? a.budget_seq : a.budget);
+    // mode 0, one lane per problem: the sequential driver, or (K4) the speculative one on a model that evaluates four points per lane
+    // (written out per branch: a lambda capturing the model by reference kept it, and the run state, in scratch memory)
+#define ANOFOX_ADVANCE_LANE()                                                                          \
+    do {                                                                                               \
+        if constexpr (K4) {                                                                            \
+            EtsModel<Cfg, MS, NM_K> mdl4;                                                              \
+            mdl4.v = mdl.v; mdl4.in = mdl.in; mdl4.ring = mdl.ring;                                    \
+            nm_advance_spec(mdl4, nmst, r, budget);                                                    \
+        } else nm_advance_seq(mdl, nmst, r, budget);                                                   \
+    } while (0)
     if constexpr (SPEC == 3) {
         if (mode == 2) nm_advance_spec2(mdl, nmst, r, budget);
         else if (mode == 1) nm_advance_spec(mdl, nmst, r, budget);
-        else nm_advance_seq(mdl, nmst, r, budget);
+        else ANOFOX_ADVANCE_LANE();
     } else if constexpr (SPEC == 2) nm_advance_spec2(mdl, nmst, r, budget);
     else if constexpr (SPEC == 1) nm_advance_spec(mdl, nmst, r, budget);
-    else nm_advance_seq(mdl, nmst, r, budget);
+    else ANOFOX_ADVANCE_LANE();
+#undef ANOFOX_ADVANCE_LANE
     nm_fence();
 
     if (active && (lane % LPP) == 0) {
@@ -269,9 +286,10 @@ __global__ __launch_bounds__(NM_BLOCK) void ets_final_kernel(const FitArgs a)
     }
 }
 
-template <class Cfg, int MS, int SPEC>
+template <class Cfg, int MS, int SPEC, bool K4 = false>
 void ets_round_launch(const FitArgs &a, hipStream_t stream)
 {
+    static_assert(!K4 || ((SPEC == 0 || SPEC == 3) && MS >= 0 && !Cfg::CLASSIC), "K4: the one-lane-per-problem driver of an ETS spec without a run-time ring");
     constexpr int PPB = SPEC == 0 ? NM_BLOCK : (SPEC == 1 ? NM_BLOCK / NM_K : 1);
     int grid;
     if (SPEC == 3) {
@@ -296,8 +314,8 @@ void ets_round_launch(const FitArgs &a, hipStream_t stream)
     if (MS == -1 || MS == -3) lds_bytes += sizeof(double) * (size_t)a.m * NM_BLOCK;
     lds_bytes *= WPB;
     if (lds_bytes > 48 * 1024)
-        anofox_check_attr(hipFuncSetAttribute((const void *)ets_round_kernel<Cfg, MS, SPEC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    hipLaunchKernelGGL((ets_round_kernel<Cfg, MS, SPEC>), dim3(blocks), dim3(NM_BLOCK * WPB), lds_bytes, stream, a);
+        anofox_check_attr(hipFuncSetAttribute((const void *)ets_round_kernel<Cfg, MS, SPEC, K4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    hipLaunchKernelGGL((ets_round_kernel<Cfg, MS, SPEC, K4>), dim3(blocks), dim3(NM_BLOCK * WPB), lds_bytes, stream, a);
 }
 
 template <class Cfg, int MS>

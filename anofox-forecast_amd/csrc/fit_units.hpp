@@ -15,6 +15,12 @@ template <int ID> struct SpecOf {
     static constexpr int s = ID % 3;
     using Cfg = EtsCfg<e, t, d, s>;
 };
+// the K4 forms exist for the additive class without a period or with the weekly one in registers (m = 12: four rings of 12 spill): ets_fit_kernel.hpp
+template <int ID, int MS, int SPEC> FitLaunchFn k4_launcher()
+{
+    if constexpr (SpecOf<ID>::Cfg::ADDITIVE && (MS == 0 || MS == 7)) return &ets_round_launch<typename SpecOf<ID>::Cfg, MS, SPEC, true>;
+    else return nullptr;
+}
 template <int ID, int MS> FitLaunchers launchers_of()
 {
     // the final pass sweeps the columns in their original blocks of one period each: the per-lane period variants (-3 / -4) exist for
@@ -23,7 +29,8 @@ template <int ID, int MS> FitLaunchers launchers_of()
     return FitLaunchers{&ets_round_launch<typename SpecOf<ID>::Cfg, MS, 0>, &ets_round_launch<typename SpecOf<ID>::Cfg, MS, 1>,
                         &ets_round_launch<typename SpecOf<ID>::Cfg, MS, 2>, &ets_round_launch<typename SpecOf<ID>::Cfg, MS, 3>,
                         &ets_final_launch<typename SpecOf<ID>::Cfg, MSF>,
-                        RoundTraits<typename SpecOf<ID>::Cfg>::PARK ? (size_t)nm_lds_doubles<SpecOf<ID>::Cfg::DIM>() : 0};
+                        RoundTraits<typename SpecOf<ID>::Cfg>::PARK ? (size_t)nm_lds_doubles<SpecOf<ID>::Cfg::DIM>() : 0,
+                        k4_launcher<ID, MS, 0>(), k4_launcher<ID, MS, 3>()};
 }
 
 FitLaunchers fit_unit_nonseasonal(int spec_id, int m);

@@ -71,6 +71,10 @@ struct Tunables {
     int spec_below_md = 8192;   //   (_MD: the damped multiplicative-trend specs, whose pass is ~10x longer)
     int spec2_below = 1024;     // ANOFOX_HIP_SPEC2_BELOW[_MD]: one wave per problem, two iterations per pass, for the last problems
     int spec2_below_md = 2048;  //   (tools/spec2_sweep.sh: 0 / 256 / 1024 / 2048 / 4096 / 8192 -> 579 / 575 / 565 / 562 / 594 / 736 ms on the 30-spec M5 batch)
+    int k4 = 1;                 // ANOFOX_HIP_K4: additive-class specs run one lane per problem with all four trial points of an iteration in ONE
+                                //   pass (ets_fit_kernel.hpp K4) wherever one or four LANES per problem would run: 1 always (default: measured
+                                //   -18 % on the intermittent M5 batch, -24 % on the 125k x 1,024 one, neutral beside the 19 general-class specs
+                                //   of the strictly positive batch), 0 never, -1 only when the general-class specs see under half of the series
     bool merge_periods = true;  // ANOFOX_HIP_MERGE_PERIODS: auto-detected periods run as merged batches (0: one batch per period)
     int pack_threads = 0;       // ANOFOX_HIP_PACK_THREADS: host threads of the packer (0: all, at most 32)
     bool timing = false;        // ANOFOX_HIP_TIMING: phase times of the batch entry on stderr
@@ -99,6 +103,7 @@ struct Tunables {
         if (const char *e = std::getenv("ANOFOX_HIP_SPEC_BELOW")) t.spec_below = t.spec_below_md = std::atoi(e);
         geti("ANOFOX_HIP_SPEC_BELOW_MD", t.spec_below_md);
         geti("ANOFOX_HIP_GATHER_COLS", t.gather_cols);
+        geti("ANOFOX_HIP_K4", t.k4);
         if (const char *e = std::getenv("ANOFOX_HIP_SPEC2_BELOW")) t.spec2_below = t.spec2_below_md = std::atoi(e);
         geti("ANOFOX_HIP_SPEC2_BELOW_MD", t.spec2_below_md);
         if (const char *e = std::getenv("ANOFOX_HIP_MERGE_PERIODS")) t.merge_periods = std::atoi(e) != 0;
@@ -1391,6 +1396,19 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
                 hipLaunchKernelGGL(retire_nonpositive_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, spec_stream(stream_of[oi]), (int)n, d_len,
                                    b->d_notpos, a.status, a.st.done, a.st.passes, a.st.evals, a.st.iters, a.aicc, a.passes, a.evals, a.iters);
             }
+    // additive-class specs, one lane per problem: four trial points per pass (K4).  Their pass is memory bound (6-10 instructions per
+    // 8-byte load): against the sequential driver K4 is one pass per iteration instead of ~1.7, against four lanes per problem it is
+    // the same bytes through a quarter of the load instructions (512 instead of 128 bytes each)
+    std::vector<char> k4(order.size(), 0);
+    {
+        bool all_additive = true;           // (-1: only when the general-class specs see under half of the series)
+        for (size_t oi = 0; oi < order.size(); oi++)
+            if (!dead[oi] && spec_has_mult(specs[order[oi]]) && !(b->live_all > 0 && b->live_pos >= 0 && 2 * (int64_t)b->live_pos < (int64_t)b->live_all))
+                all_additive = false;
+        const bool on = b->tun.k4 > 0 || (b->tun.k4 < 0 && all_additive);
+        for (size_t oi = 0; oi < order.size(); oi++)
+            k4[oi] = on && !dead[oi] && !b->fixed_params && !spec_has_mult(specs[order[oi]]) && fns[oi].round_k4 && fns[oi].round_auto_k4;
+    }
     if (b->use_gather && !b->fixed_params) {
         // gather blocks of the specs that have something to fit: as many columns as the spec can ever have running (the strictly
         // positive series for a spec with a multiplicative component), scaled down together if that exceeds the budget
@@ -1490,7 +1508,20 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
                 }
             }
             const int s2 = (spec_trend_idx(specs[order[oi]]) == 4) ? b->spec2_below_md : b->spec2_below;
-            if (r == 0 || b->seq_rounds_env >= 0 || b->seq_rounds == 0) {
+            if (k4[oi]) {
+                // additive spec of a memory-bound run: one lane per problem with four trial points per pass wherever four LANES per
+                // problem would otherwise run -- the same bytes per iteration through a quarter of the load instructions (a wave of
+                // four-lane groups moves 128 bytes per load, and it is the CU's address pipeline that such a run saturates) -- as
+                // long as the spec still has more problems than `spec_below`; fewer are a latency problem again: four lanes, then
+                // one wave per problem
+                a.budget = BUDGET[r]; a.budget_seq = BUDGET[r];
+                const int64_t live = b->live_all >= 0 ? b->live_all : (int64_t)n;
+                if (r == 0) (live > b->spec_below ? fns[oi].round_k4 : fns[oi].round_spec)(a, sq);
+                else {
+                    a.spec_below = b->spec_below; a.spec2_below = s2 > 0 ? s2 : -1;
+                    fns[oi].round_auto_k4(a, sq);
+                }
+            } else if (r == 0 || b->seq_rounds_env >= 0 || b->seq_rounds == 0) {
                 // first round (no device count yet) or a forced schedule: the host picks the driver
                 a.budget = spec_mode ? BUDGET[r] : (BUDGET[r] * 7) / 4;     // ~1.7 passes per iteration when sequential
                 if (spec_mode && r > 0 && s2 > 0) {

@@ -144,7 +144,7 @@ struct IntervalArgs {
 // ETS fit kernels, one per (spec id, ring variant).  ring: 0 = none / VGPR ring for the
 // compile-time period given, -1 = LDS ring.  Returns NULL when not instantiated.
 typedef void (*FitLaunchFn)(const FitArgs &, hipStream_t);
-struct FitLaunchers { FitLaunchFn round_seq, round_spec, round_spec2, round_auto, final; size_t nm_scratch_per_wg; };   // sequential / speculative / two-level speculative rounds, all three behind a device-side choice, final pass; doubles of global simplex scratch per workgroup (0: the simplex rests in LDS)
+struct FitLaunchers { FitLaunchFn round_seq, round_spec, round_spec2, round_auto, final; size_t nm_scratch_per_wg; FitLaunchFn round_k4, round_auto_k4; };   // sequential / speculative / two-level speculative rounds, all three behind a device-side choice, final pass; doubles of global simplex scratch per workgroup (0: the simplex rests in LDS); the K4 forms of round_seq / round_auto (additive class, NULL otherwise: ets_fit_kernel.hpp)
 // `m`: the period (7 and 12 have compile-time variants), or ETS_PERLANE_LDS / ETS_PERLANE_HBM for the round kernels of a merged
 // batch of several periods (per-lane period, ring in LDS / in HBM scratch sized by the batch's largest period)
 constexpr int ETS_PERLANE_LDS = -3, ETS_PERLANE_HBM = -4;

@@ -429,6 +429,27 @@ def test_schedule_variants_are_bit_identical(env, monkeypatch, seq_rounds, gathe
     _compare(api, O, lib, series, "ETS", 12, ets_model="MAdM", seasonal_period=7)
 
 
+@pytest.mark.parametrize("k4", ["-1", "0", "1"])
+def test_four_candidates_per_lane_is_bit_identical(env, monkeypatch, k4):
+    """ANOFOX_HIP_K4: the additive-class specs run one lane per problem with all four trial points of an iteration evaluated by
+    that lane in ONE pass (one y load feeds four recursions: the memory-bound form) instead of the sequential driver.  Same
+    iterates, same forecasts as the oracle: on intermittent counts (only the additive specs are admissible: the automatic
+    choice), on strictly positive data beside the general-class specs (forced), non-seasonal, ragged, and with enough series
+    that the sequential-class rounds really run (SEQ_ROUNDS forced as well)."""
+    api, O, lib, synth = env
+    monkeypatch.setenv("ANOFOX_HIP_K4", k4)
+    Yi = synth.gen_series(synth.SEED_M5, 5800, 200, 170, 7)
+    series = [Yi[s, : 170 - (s % 6) * 8] for s in range(200)]
+    _compare(api, O, lib, series, "AutoETS", 9, seasonal_period=7)
+    _compare(api, O, lib, series, "AutoETS", 9, seasonal_period=1)
+    _compare(api, O, lib, series, "ETS", 9, ets_model="AAdA", seasonal_period=7)
+    Yp = synth.gen_series(synth.SEED_M5, 5900, 90, 150, 7, positive=True)
+    _compare(api, O, lib, list(Yp), "AutoETS", 9, seasonal_period=7)
+    monkeypatch.setenv("ANOFOX_HIP_SEQ_ROUNDS", "3")
+    _compare(api, O, lib, series, "AutoETS", 9, seasonal_period=7)
+    _compare(api, O, lib, series[:50], "AutoETS", 9, seasonal_period=12)        # (no K4 kernels for m = 12: the sequential driver)
+
+
 @pytest.mark.parametrize("below", ["20", "100000"])
 def test_two_level_speculation_is_bit_identical(env, monkeypatch, below):
     """ANOFOX_HIP_SPEC2_BELOW: the last problems of a spec run one per wave, lanes 4..63 evaluating the next iteration's
