@@ -152,3 +152,21 @@ def test_ingest_under_address_and_ub_sanitizers():
                                "-x", "c++", os.path.join(ROOT, "tests", "c_abi", "ingest_san.cpp"), "-o", exe])
         r = subprocess.run([exe, "150"], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0 and r.stdout.startswith("OK 150 rounds"), (r.stdout, r.stderr[-2000:])
+
+
+@pytest.mark.parametrize("sanitizer", ["thread", "address,undefined"])
+def test_device_keyed_caches_on_four_fake_devices(sanitizer):
+    """csrc/host_resources.hpp -- DeviceGuard, the caching device allocator, the pinned cache, the stream sets, the device list --
+    compiled against tests/c_abi/fake_hip.h (a host-only stand-in for the ~20 HIP calls it makes: four "devices" with 64 MB
+    each) and driven by eight host threads under ThreadSanitizer, then under ASan + UBSan (tests/c_abi/resources_mt.cpp): a cached
+    block only goes back to its own device, caps / LRU eviction / the bounded deferral hold per device, a second free never
+    reaches hipFree, out-of-memory empties the cache and retries, one priority stream set per device, nothing leaks.  The real
+    runtime only ever showed this code ONE device.  Test infrastructure: the product never sees the fake."""
+    with tempfile.TemporaryDirectory() as d:
+        exe = os.path.join(d, "resources_mt")
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", f"-fsanitize={sanitizer}", "-fno-sanitize-recover=all", "-pthread",
+                               os.path.join(ROOT, "tests", "c_abi", "resources_mt.cpp"), "-o", exe])
+        env = dict(os.environ, FAKE_HIP_DEVICES="4", FAKE_HIP_DEVICE_MB="64", TSAN_OPTIONS="halt_on_error=1")
+        env.pop("ANOFOX_HIP_CACHE_GB", None)
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0 and r.stdout.startswith("resources_mt: ok"), (r.stdout, r.stderr[-3000:])
