@@ -2374,7 +2374,10 @@ static bool forecast_batch_one_device(const double *const *values, const uint64_
                 all_ok = false;
             }
         };
-        const unsigned n_thr = (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)std::thread::hardware_concurrency(), 16, parts.size() - first_small}));
+        // (a small part is a chain of latency-bound launches with host round trips in between -- AutoARIMA: ~13 sweeps of advance /
+        //  read-back / fit, ~0.2 s whatever its size -- so the number of parts in flight is what the call's duration divides by)
+        const size_t part_threads = (size_t)std::max(1, tun.part_threads);
+        const unsigned n_thr = (unsigned)std::max<size_t>(1, std::min<size_t>({(size_t)std::thread::hardware_concurrency(), part_threads, parts.size() - first_small}));
         std::vector<std::thread> pool;
         struct PoolJoiner { std::vector<std::thread> &t; ~PoolJoiner() { for (auto &x : t) if (x.joinable()) x.join(); } } pool_joiner{pool};
         const bool have_big = first_small > 0;

@@ -53,6 +53,7 @@ struct Tunables {
                                 //   -18 % on the intermittent M5 batch, -24 % on the 125k x 1,024 one, neutral beside the 19 general-class specs
                                 //   of the strictly positive batch), 0 never, -1 only when the general-class specs see under half of the series
     bool merge_periods = true;  // ANOFOX_HIP_MERGE_PERIODS: auto-detected periods run as merged batches (0: one batch per period)
+    int part_threads = 16;      // ANOFOX_HIP_PART_THREADS: host threads that run the small per-period parts of an auto-detected batch side by side
     int pack_threads = 0;       // ANOFOX_HIP_PACK_THREADS: host threads of the packer (0: all, at most 32)
     bool timing = false;        // ANOFOX_HIP_TIMING: phase times of the batch entry on stderr
     bool arima_trace = false;   // ANOFOX_HIP_ARIMA_TRACE: per-sweep queue lengths / per-wave refit timings on stderr
@@ -85,6 +86,7 @@ struct Tunables {
         geti("ANOFOX_HIP_SPEC2_BELOW_MD", t.spec2_below_md);
         if (const char *e = std::getenv("ANOFOX_HIP_MERGE_PERIODS")) t.merge_periods = std::atoi(e) != 0;
         if (const char *e = std::getenv("ANOFOX_HIP_PACK_THREADS")) t.pack_threads = std::max(1, std::atoi(e));
+        geti("ANOFOX_HIP_PART_THREADS", t.part_threads);
         t.timing = std::getenv("ANOFOX_HIP_TIMING") != nullptr;
         t.arima_trace = std::getenv("ANOFOX_HIP_ARIMA_TRACE") != nullptr;
         if (const char *e = std::getenv("ANOFOX_HIP_ARIMA_LOOKAHEAD")) t.arima_lookahead = std::atof(e);
