@@ -1895,7 +1895,7 @@ int launch_arima(const ArimaArgs &a, hipStream_t stream)
     int launches = 2;
     long prev_total = -1;
     auto launch_fit = [&](long total, int polish) {
-        const double spec_factor = a.spec_factor;   // (ANOFOX_HIP_ARIMA_SPEC_FACTOR, default 8)
+        const double spec_factor = a.spec_factor;   // (tune arima_spec_factor, default 8)
         if ((double)total <= spec_factor * (double)sched_waves * (NM_BLOCK / 4)) {
             // short queue (up to a few problems per resident 4-lane group): four lanes per problem, one pass per Nelder-Mead
             // iteration -- such a launch is bound by its slowest fit, not by throughput
@@ -1912,11 +1912,11 @@ int launch_arima(const ArimaArgs &a, hipStream_t stream)
         AR_HIPCHECK(hipMemsetAsync(ws.counts, 0, 16 * sizeof(int32_t), stream));
         // look one sweep ahead once the previous sweep's queue times the fan-out (~18 candidates per series) fits the
         // resident lanes `la_factor` times over: the extra fits cost idle lanes, the saved sweeps cost ~0.1-0.2 s each
-        const double la_factor = a.lookahead;   // (ANOFOX_HIP_ARIMA_LOOKAHEAD, default 12) measured 0 / 0.25 / 1 / 4 / 16: 2.16 / 2.03 / 1.93 / 1.92 / 1.90 s on the M5 batch (round 1); with the refit 4 / 8 / 12 / 16 / 24 / 32 / 64: 2.23 / 2.23 / 2.14 / 2.14 / 2.17 / 2.17 / 2.92 s
+        const double la_factor = a.lookahead;   // (tune arima_lookahead, default 12) measured 0 / 0.25 / 1 / 4 / 16: 2.16 / 2.03 / 1.93 / 1.92 / 1.90 s on the M5 batch (round 1); with the refit 4 / 8 / 12 / 16 / 24 / 32 / 64: 2.23 / 2.23 / 2.14 / 2.14 / 2.17 / 2.17 / 2.92 s
         int lookahead = (prev_total >= 0 && (double)prev_total * (AR_SWEEP + 1) <= la_factor * (double)sched_waves * NM_BLOCK) ? 1 : 0;
         // ... and two sweeps ahead once even that fan-out squared fits the resident lanes (the late sweeps of a few hundred series are
         // each bound by their slowest fit, ~0.1 s: 5 of them on the M5 batch)
-        const int la_depth = a.lookahead_depth;   // (ANOFOX_HIP_ARIMA_LOOKAHEAD_DEPTH, default 2)
+        const int la_depth = a.lookahead_depth;   // (tune arima_lookahead_depth, default 2)
         if (lookahead && la_depth >= 2 && (double)prev_total * (AR_SWEEP + 1) * (AR_SWEEP + 1) <= la_factor * (double)sched_waves * NM_BLOCK) lookahead = 2;
         hipLaunchKernelGGL(arima_advance_kernel, dim3(grid256), dim3(256), 0, stream, a, ws, lookahead);
         int32_t counts[8];

@@ -134,7 +134,7 @@ struct AnofoxHipBatch {
     uint64_t n_problems = 0;
     Tunables tun;            // the environment knobs, read when the batch was created
     int seq_rounds = 3;      // rounds run by the sequential Nelder-Mead driver before switching to the speculative one
-    int seq_rounds_env = -1; // ANOFOX_HIP_SEQ_ROUNDS override (-1 = decide from the number of live problems)
+    int seq_rounds_env = -1; // tune seq_rounds override (-1 = decide from the number of live problems)
     int spec_below_md = 8192; // same, for the damped multiplicative-trend specs (their pass is ~10x longer: the stragglers matter more)
     // the SES / Holt / Holt-Winters / SeasonalES family on the round kernels: its own Nelder-Mead state, status and compaction lists
     // (the spec lanes keep the optima an inspection call re-reads)
@@ -780,7 +780,7 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
     const size_t n = b->n, ld = b->ld;
     // Round budgets (streamed passes per launch).  Geometric, so every round retires roughly half of the
     // still-running problems and the compaction + gather in between stays a few percent of the passes.
-    // iteration budgets of the rounds (the last one runs everything left to completion); ANOFOX_HIP_BUDGETS overrides
+    // iteration budgets of the rounds (the last one runs everything left to completion); ANOFOX_HIP_TUNE budgets=... overrides
     const std::vector<int> &BUDGET = b->tun.budgets;
     const int n_rounds = (int)BUDGET.size();
     const int n_lanes = std::min<int>(N_AUX_STREAMS, b->n_slots_cap);

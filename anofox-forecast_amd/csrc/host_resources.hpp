@@ -40,34 +40,60 @@ constexpr int32_t STATUS_NOT_COMPUTED = -1;
 // the process-wide ones (caches, devices, priority streams) once.  None of them changes a result: every schedule walks the same
 // Nelder-Mead iterates (tests/test_gpu_parity.py::test_schedule_variants_are_bit_identical).
 struct Tunables {
-    std::vector<int> budgets{24, 24, 24, 24, 24, 24, 48, 48, 96, 96, 192, 1024};   // ANOFOX_HIP_BUDGETS: Nelder-Mead iterations per round (last = to completion)
-    int seq_rounds = -1;        // ANOFOX_HIP_SEQ_ROUNDS: rounds run by the sequential driver (-1: decided from the live problems)
-    int gather_cols = 0;        // ANOFOX_HIP_GATHER_COLS (tests): columns of the per-spec gather blocks (0: as many as fit 55 % of the device, at most ld)
-    int gather = -1;            // ANOFOX_HIP_GATHER: dense re-gather of the running problems between rounds (-1: on, block size by memory)
-    int spec_below = 8192;      // ANOFOX_HIP_SPEC_BELOW[_MD]: four lanes per problem once this few problems of a spec still run
+    std::vector<int> budgets{24, 24, 24, 24, 24, 24, 48, 48, 96, 96, 192, 1024};   // tune budgets: Nelder-Mead iterations per round (last = to completion)
+    int seq_rounds = -1;        // tune seq_rounds: rounds run by the sequential driver (-1: decided from the live problems)
+    int gather_cols = 0;        // tune gather_cols (tests): columns of the per-spec gather blocks (0: as many as fit 55 % of the device, at most ld)
+    int gather = -1;            // tune gather: dense re-gather of the running problems between rounds (-1: on, block size by memory)
+    int spec_below = 8192;      // tune spec_below[_md]: four lanes per problem once this few problems of a spec still run
     int spec_below_md = 8192;   //   (_MD: the damped multiplicative-trend specs, whose pass is ~10x longer)
-    int spec2_below = 1024;     // ANOFOX_HIP_SPEC2_BELOW[_MD]: one wave per problem, two iterations per pass, for the last problems
+    int spec2_below = 1024;     // tune spec2_below[_md]: one wave per problem, two iterations per pass, for the last problems
     int spec2_below_md = 2048;  //   (tools/spec2_sweep.sh: 0 / 256 / 1024 / 2048 / 4096 / 8192 -> 579 / 575 / 565 / 562 / 594 / 736 ms on the 30-spec M5 batch)
-    int k4 = 1;                 // ANOFOX_HIP_K4: additive-class specs run one lane per problem with all four trial points of an iteration in ONE
+    int k4 = 1;                 // tune k4: additive-class specs run one lane per problem with all four trial points of an iteration in ONE
                                 //   pass (ets_fit_kernel.hpp K4) wherever one or four LANES per problem would run: 1 always (default: measured
                                 //   -18 % on the intermittent M5 batch, -24 % on the 125k x 1,024 one, neutral beside the 19 general-class specs
                                 //   of the strictly positive batch), 0 never, -1 only when the general-class specs see under half of the series
-    bool merge_periods = true;  // ANOFOX_HIP_MERGE_PERIODS: auto-detected periods run as merged batches (0: one batch per period)
-    int part_threads = 16;      // ANOFOX_HIP_PART_THREADS: host threads that run the small per-period parts of an auto-detected batch side by side
+    bool merge_periods = true;  // tune merge_periods: auto-detected periods run as merged batches (0: one batch per period)
+    int part_threads = 16;      // tune part_threads: host threads that run the small per-period parts of an auto-detected batch side by side
     int pack_threads = 0;       // ANOFOX_HIP_PACK_THREADS: host threads of the packer (0: all, at most 32)
     bool timing = false;        // ANOFOX_HIP_TIMING: phase times of the batch entry on stderr
-    bool arima_trace = false;   // ANOFOX_HIP_ARIMA_TRACE: per-sweep queue lengths / per-wave refit timings on stderr
-    double arima_lookahead = 12.0;   // ANOFOX_HIP_ARIMA_LOOKAHEAD, _LOOKAHEAD_DEPTH, _SPEC_FACTOR: see arima.hip launch_arima
+    bool arima_trace = false;   // tune arima_trace: per-sweep queue lengths / per-wave refit timings on stderr
+    double arima_lookahead = 12.0;   // tune arima_lookahead, _lookahead_depth, _spec_factor: see arima.hip launch_arima
     int arima_lookahead_depth = 2;
     double arima_spec_factor = 8.0;
-    int arima_refit_budget = 100;   // ANOFOX_HIP_ARIMA_REFIT_BUDGET: evaluations per series before the exact-likelihood refit's speculative launch takes over (0: off)
+    int arima_refit_budget = 100;   // tune arima_refit_budget: evaluations per series before the exact-likelihood refit's speculative launch takes over (0: off)
+    // ANOFOX_HIP_TUNE="key=value;key=value": the ONE developer / test variable behind every schedule knob above (keys: the field names;
+    // budgets is a comma list) -- the sweep scripts under tools/ and the schedule-variant tests use it; a deployment never sets it.
+    // The variables a deployment may set are ANOFOX_HIP_DEVICES, _COALESCE_US, _CACHE_GB, _PINNED_CACHE_GB, _PACK_THREADS and _TIMING.
+    static std::map<std::string, std::string> tune_map()
+    {
+        std::map<std::string, std::string> kv;
+        const char *e = std::getenv("ANOFOX_HIP_TUNE");
+        if (!e) return kv;
+        std::string all(e);
+        for (size_t pos = 0; pos < all.size();) {
+            size_t end = all.find(';', pos);
+            if (end == std::string::npos) end = all.size();
+            const std::string item = all.substr(pos, end - pos);
+            const size_t eq = item.find('=');
+            if (eq != std::string::npos) {
+                std::string k = item.substr(0, eq), v = item.substr(eq + 1);
+                while (!k.empty() && k.front() == ' ') k.erase(k.begin());
+                while (!k.empty() && k.back() == ' ') k.pop_back();
+                kv[k] = v;
+            }
+            pos = end + 1;
+        }
+        return kv;
+    }
     static Tunables from_env()
     {
         Tunables t;
-        auto geti = [](const char *k, int &v) { if (const char *e = std::getenv(k)) v = std::atoi(e); };
-        if (const char *e = std::getenv("ANOFOX_HIP_BUDGETS")) {
+        const std::map<std::string, std::string> kv = tune_map();
+        auto geti = [&](const char *k, int &v) { auto it = kv.find(k); if (it != kv.end()) v = std::atoi(it->second.c_str()); };
+        auto getd = [&](const char *k, double &v) { auto it = kv.find(k); if (it != kv.end()) v = std::atof(it->second.c_str()); };
+        if (kv.count("budgets")) {
             std::vector<int> v;
-            for (const char *q = e; *q;) {
+            for (const char *q = kv.at("budgets").c_str(); *q;) {
                 char *end = nullptr;
                 long x = std::strtol(q, &end, 10);
                 if (end == q) break;
@@ -76,28 +102,28 @@ struct Tunables {
             }
             if (!v.empty()) t.budgets = v;
         }
-        geti("ANOFOX_HIP_SEQ_ROUNDS", t.seq_rounds);
-        geti("ANOFOX_HIP_GATHER", t.gather);
-        if (const char *e = std::getenv("ANOFOX_HIP_SPEC_BELOW")) t.spec_below = t.spec_below_md = std::atoi(e);
-        geti("ANOFOX_HIP_SPEC_BELOW_MD", t.spec_below_md);
-        geti("ANOFOX_HIP_GATHER_COLS", t.gather_cols);
-        geti("ANOFOX_HIP_K4", t.k4);
-        if (const char *e = std::getenv("ANOFOX_HIP_SPEC2_BELOW")) t.spec2_below = t.spec2_below_md = std::atoi(e);
-        geti("ANOFOX_HIP_SPEC2_BELOW_MD", t.spec2_below_md);
-        if (const char *e = std::getenv("ANOFOX_HIP_MERGE_PERIODS")) t.merge_periods = std::atoi(e) != 0;
+        geti("seq_rounds", t.seq_rounds);
+        geti("gather", t.gather);
+        if (kv.count("spec_below")) t.spec_below = t.spec_below_md = std::atoi(kv.at("spec_below").c_str());
+        geti("spec_below_md", t.spec_below_md);
+        geti("gather_cols", t.gather_cols);
+        geti("k4", t.k4);
+        if (kv.count("spec2_below")) t.spec2_below = t.spec2_below_md = std::atoi(kv.at("spec2_below").c_str());
+        geti("spec2_below_md", t.spec2_below_md);
+        if (kv.count("merge_periods")) t.merge_periods = std::atoi(kv.at("merge_periods").c_str()) != 0;
+        geti("part_threads", t.part_threads);
+        if (kv.count("arima_trace")) t.arima_trace = std::atoi(kv.at("arima_trace").c_str()) != 0;
+        getd("arima_lookahead", t.arima_lookahead);
+        geti("arima_lookahead_depth", t.arima_lookahead_depth);
+        getd("arima_spec_factor", t.arima_spec_factor);
+        geti("arima_refit_budget", t.arima_refit_budget);
         if (const char *e = std::getenv("ANOFOX_HIP_PACK_THREADS")) t.pack_threads = std::max(1, std::atoi(e));
-        geti("ANOFOX_HIP_PART_THREADS", t.part_threads);
         t.timing = std::getenv("ANOFOX_HIP_TIMING") != nullptr;
-        t.arima_trace = std::getenv("ANOFOX_HIP_ARIMA_TRACE") != nullptr;
-        if (const char *e = std::getenv("ANOFOX_HIP_ARIMA_LOOKAHEAD")) t.arima_lookahead = std::atof(e);
-        geti("ANOFOX_HIP_ARIMA_LOOKAHEAD_DEPTH", t.arima_lookahead_depth);
-        if (const char *e = std::getenv("ANOFOX_HIP_ARIMA_SPEC_FACTOR")) t.arima_spec_factor = std::atof(e);
-        geti("ANOFOX_HIP_ARIMA_REFIT_BUDGET", t.arima_refit_budget);
         return t;
     }
 };
 // process-wide settings, read once: ANOFOX_HIP_CACHE_GB (idle device blocks kept, default 1/4 of the device), ANOFOX_HIP_PINNED_CACHE_GB
-// (idle pinned staging blocks, default 2), ANOFOX_HIP_PRIO_STREAMS (high-priority streams of the first stream set, default from
+// (idle pinned staging blocks, default 2), tune prio_streams (high-priority streams of the first stream set, default from
 // GPU_MAX_HW_QUEUES), ANOFOX_HIP_DEVICES (devices the batch entry shards over, default: the caller's current device only)
 struct ProcessTunables {
     double cache_gb = -1.0, pinned_cache_gb = 2.0;
@@ -113,7 +139,7 @@ struct ProcessTunables {
             ProcessTunables p;
             if (const char *e = std::getenv("ANOFOX_HIP_CACHE_GB")) p.cache_gb = std::atof(e);
             if (const char *e = std::getenv("ANOFOX_HIP_PINNED_CACHE_GB")) p.pinned_cache_gb = std::atof(e);
-            if (const char *e = std::getenv("ANOFOX_HIP_PRIO_STREAMS")) p.prio_streams = std::atoi(e);
+            { const auto kv = Tunables::tune_map(); auto it = kv.find("prio_streams"); if (it != kv.end()) p.prio_streams = std::atoi(it->second.c_str()); }
             if (const char *e = std::getenv("ANOFOX_HIP_COALESCE_US")) p.coalesce_us = std::atof(e);
             if (const char *e = std::getenv("ANOFOX_HIP_DEVICES")) p.devices = e;
             return p;
@@ -447,7 +473,7 @@ StreamSet *stream_set_take()
     // priority level has its own hardware queues and the chip multiplexes well only up to ~23 of them in total (16 normal + 7
     // high: 541 ms, + 8: 747 ms; 13 + 10, 14 + 9, 15 + 8: 544 ms; 20 + 7: 785 ms), so the count follows GPU_MAX_HW_QUEUES (none
     // when the host has not set it: the runtime's default of 4 queues leaves no room) and later sets (concurrent batches of other
-    // host threads) stay at normal priority.  ANOFOX_HIP_PRIO_STREAMS overrides the count.  The priority set is RESERVED under
+    // host threads) stay at normal priority.  ANOFOX_HIP_TUNE prio_streams=N overrides the count.  The priority set is RESERVED under
     // the lock before any stream exists, so two threads creating their first sets at once cannot both take it.
     bool want_prio = false;
     {

@@ -421,8 +421,7 @@ def test_schedule_variants_are_bit_identical(env, monkeypatch, seq_rounds, gathe
     """The sequential and the speculative Nelder-Mead drivers, with or without the column gather between
     rounds, must walk the same trajectory: every schedule reproduces the oracle bit for bit."""
     api, O, lib, synth = env
-    monkeypatch.setenv("ANOFOX_HIP_SEQ_ROUNDS", seq_rounds)
-    monkeypatch.setenv("ANOFOX_HIP_GATHER", gather)
+    monkeypatch.setenv("ANOFOX_HIP_TUNE", f"seq_rounds={seq_rounds};gather={gather}")
     Y = synth.gen_series(synth.SEED_M5, 5000, 130, 160, 7, positive=True)
     series = [Y[s, : 160 - (s % 5) * 9] for s in range(130)]          # ragged lengths
     _compare(api, O, lib, series, "AutoETS", 12, seasonal_period=7)
@@ -431,13 +430,13 @@ def test_schedule_variants_are_bit_identical(env, monkeypatch, seq_rounds, gathe
 
 @pytest.mark.parametrize("k4", ["-1", "0", "1"])
 def test_four_candidates_per_lane_is_bit_identical(env, monkeypatch, k4):
-    """ANOFOX_HIP_K4: the additive-class specs run one lane per problem with all four trial points of an iteration evaluated by
+    """ANOFOX_HIP_TUNE k4: the additive-class specs run one lane per problem with all four trial points of an iteration evaluated by
     that lane in ONE pass (one y load feeds four recursions: the memory-bound form) instead of the sequential driver.  Same
     iterates, same forecasts as the oracle: on intermittent counts (only the additive specs are admissible: the automatic
     choice), on strictly positive data beside the general-class specs (forced), non-seasonal, ragged, and with enough series
     that the sequential-class rounds really run (SEQ_ROUNDS forced as well)."""
     api, O, lib, synth = env
-    monkeypatch.setenv("ANOFOX_HIP_K4", k4)
+    monkeypatch.setenv("ANOFOX_HIP_TUNE", f"k4={k4}")
     Yi = synth.gen_series(synth.SEED_M5, 5800, 200, 170, 7)
     series = [Yi[s, : 170 - (s % 6) * 8] for s in range(200)]
     _compare(api, O, lib, series, "AutoETS", 9, seasonal_period=7)
@@ -445,19 +444,19 @@ def test_four_candidates_per_lane_is_bit_identical(env, monkeypatch, k4):
     _compare(api, O, lib, series, "ETS", 9, ets_model="AAdA", seasonal_period=7)
     Yp = synth.gen_series(synth.SEED_M5, 5900, 90, 150, 7, positive=True)
     _compare(api, O, lib, list(Yp), "AutoETS", 9, seasonal_period=7)
-    monkeypatch.setenv("ANOFOX_HIP_SEQ_ROUNDS", "3")
+    monkeypatch.setenv("ANOFOX_HIP_TUNE", f"k4={k4};seq_rounds=3")
     _compare(api, O, lib, series, "AutoETS", 9, seasonal_period=7)
     _compare(api, O, lib, series[:50], "AutoETS", 9, seasonal_period=12)        # (no K4 kernels for m = 12: the sequential driver)
 
 
 @pytest.mark.parametrize("below", ["20", "100000"])
 def test_two_level_speculation_is_bit_identical(env, monkeypatch, below):
-    """ANOFOX_HIP_SPEC2_BELOW: the last problems of a spec run one per wave, lanes 4..63 evaluating the next iteration's
+    """ANOFOX_HIP_TUNE spec2_below: the last problems of a spec run one per wave, lanes 4..63 evaluating the next iteration's
     trial points under all 3 D + 3 outcomes of the current one (two Nelder-Mead iterations per pass).  Same iterates, same
     evaluation counts, same forecasts as the oracle -- for every parameter dimension (1..4: the AutoETS grid), ragged
     lengths, a mixed batch, a run-time period (ring in LDS) and a long one (ring in HBM scratch)."""
     api, O, lib, synth = env
-    monkeypatch.setenv("ANOFOX_HIP_SPEC2_BELOW", below)
+    monkeypatch.setenv("ANOFOX_HIP_TUNE", f"spec2_below={below}")
     Y = synth.gen_series(synth.SEED_M5, 5000, 130, 160, 7, positive=True)
     series = [Y[s, : 160 - (s % 5) * 9] for s in range(130)]          # ragged lengths
     _compare(api, O, lib, series, "AutoETS", 12, seasonal_period=7)
@@ -481,7 +480,7 @@ def test_two_level_speculation_counts(env, monkeypatch):
     opts = lib.make_options("AutoETS", h, seasonal_period=7)
     runs = []
     for below in ("0", "100000"):                              # off / every problem after the first round
-        monkeypatch.setenv("ANOFOX_HIP_SPEC2_BELOW", below)
+        monkeypatch.setenv("ANOFOX_HIP_TUNE", f"spec2_below={below}")
         b = DeviceBatch(n, T, opts, "cuda:0")
         y = torch.from_numpy(pack_time_major(Y, b.ld)).cuda()
         ln = torch.full((b.ld,), T, dtype=torch.int32, device="cuda")
@@ -504,7 +503,7 @@ def test_auto_detected_periods_merge_into_one_batch(env, monkeypatch, model):
     """params := MAP{} (no seasonal_period): every series gets its own detected period.  The batch entry runs the series of all
     periods of a ring class as ONE batch whose 64-column blocks each have their own period (prep, fit, final pass and the
     fallback chain read the period per block) instead of one tiny batch per period -- same forecasts as the oracle, which
-    detects and fits series by series; the split path (ANOFOX_HIP_MERGE_PERIODS=0) gives the same results."""
+    detects and fits series by series; the split path (ANOFOX_HIP_TUNE merge_periods=0) gives the same results."""
     api, O, lib, synth = env
     rng = np.random.default_rng(17)
     series = []
@@ -518,12 +517,12 @@ def test_auto_detected_periods_merge_into_one_batch(env, monkeypatch, model):
     kw = {}
     if ":" in model: model, kw = model.split(":")[0], {"ets_model": model.split(":")[1]}
     _compare(api, O, lib, series, model, 9, **kw)
-    monkeypatch.setenv("ANOFOX_HIP_MERGE_PERIODS", "0")
+    monkeypatch.setenv("ANOFOX_HIP_TUNE", "merge_periods=0")
     _compare(api, O, lib, series, model, 9, **kw)
 
 
-@pytest.mark.parametrize("envset", [{"ANOFOX_HIP_CACHE_GB": "0", "ANOFOX_HIP_PINNED_CACHE_GB": "0"}, {"ANOFOX_HIP_PRIO_STREAMS": "0", "ANOFOX_HIP_BUDGETS": "32,32,64,128,256,1024"},
-                                    {"ANOFOX_HIP_PRIO_STREAMS": "3", "GPU_MAX_HW_QUEUES": "8"}])
+@pytest.mark.parametrize("envset", [{"ANOFOX_HIP_CACHE_GB": "0", "ANOFOX_HIP_PINNED_CACHE_GB": "0"}, {"ANOFOX_HIP_TUNE": "prio_streams=0;budgets=32,32,64,128,256,1024"},
+                                    {"ANOFOX_HIP_TUNE": "prio_streams=3", "GPU_MAX_HW_QUEUES": "8"}])
 def test_process_wide_switches(envset):
     """The allocation caches and the stream priorities are decided once per process (a round schedule rides along): a fresh process
     with each of them switched off (or sized differently) reproduces the oracle like the defaults do -- three batches in a
@@ -636,10 +635,10 @@ def test_device_resident_batch_and_stats(env):
 def test_partial_gather_blocks_give_the_same_results(env, monkeypatch, cols):
     """A batch whose per-spec gather blocks cannot hold every column (1M series x 1,024: 25 blocks of 8.2 GB) gets blocks of fewer
     columns: the rounds index y by series until that few problems still run, then switch to the dense copy -- decided on the device
-    from the running count, by the gather kernel and the round kernel alike.  Forced here on a small batch (ANOFOX_HIP_GATHER_COLS):
+    from the running count, by the gather kernel and the round kernel alike.  Forced here on a small batch (ANOFOX_HIP_TUNE gather_cols):
     AutoETS, a fitted spec and Holt-Winters (the classic family borrows the first spec's block) agree with the oracle bit for bit."""
     api, O, lib, synth = env
-    monkeypatch.setenv("ANOFOX_HIP_GATHER_COLS", cols)
+    monkeypatch.setenv("ANOFOX_HIP_TUNE", f"gather_cols={cols}")
     Y = synth.gen_series(synth.SEED_M5, 9100, 300, 160, 7, positive=True)
     series = [Y[s, : 160 - (s % 5) * 9] for s in range(300)]
     _compare(api, O, lib, series, "AutoETS", 7, seasonal_period=7)
@@ -953,7 +952,7 @@ def test_exact_likelihood_refit_in_two_launches(env, monkeypatch, budget):
     api, O, lib, synth = env
     L = lib.load()
     flag = C.c_int.in_dll(O.lib(), "oracle_arima_ml_refit")
-    monkeypatch.setenv("ANOFOX_HIP_ARIMA_REFIT_BUDGET", budget)
+    monkeypatch.setenv("ANOFOX_HIP_TUNE", f"arima_refit_budget={budget}")
     rng = np.random.default_rng(41)
     Y = synth.gen_series(synth.SEED_M5, 9300, 90, 220, 7)
     series = [Y[s, : 220 - (s % 6) * 11] for s in range(90)]

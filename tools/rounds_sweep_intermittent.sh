@@ -9,11 +9,11 @@ run() { # label, workload, env...
 }
 for wl in autoets_m5 ets_aaa_m5; do
 run base $wl X=1
-run "48,48,96,192,1024" $wl ANOFOX_HIP_BUDGETS=48,48,96,192,1024
-run "32,32,64,128,256,1024" $wl ANOFOX_HIP_BUDGETS=32,32,64,128,256,1024
-run "32,64,128,1024" $wl ANOFOX_HIP_BUDGETS=32,64,128,1024
-run "64,128,1024" $wl ANOFOX_HIP_BUDGETS=64,128,1024
-run "24,24,48,96,192,1024" $wl ANOFOX_HIP_BUDGETS=24,24,48,96,192,1024
-run "16,16,32,64,128,256,1024" $wl ANOFOX_HIP_BUDGETS=16,16,32,64,128,256,1024
+run "48,48,96,192,1024" $wl ANOFOX_HIP_TUNE=budgets=48,48,96,192,1024
+run "32,32,64,128,256,1024" $wl ANOFOX_HIP_TUNE=budgets=32,32,64,128,256,1024
+run "32,64,128,1024" $wl ANOFOX_HIP_TUNE=budgets=32,64,128,1024
+run "64,128,1024" $wl ANOFOX_HIP_TUNE=budgets=64,128,1024
+run "24,24,48,96,192,1024" $wl ANOFOX_HIP_TUNE=budgets=24,24,48,96,192,1024
+run "16,16,32,64,128,256,1024" $wl ANOFOX_HIP_TUNE=budgets=16,16,32,64,128,256,1024
 done
 cat $OUT

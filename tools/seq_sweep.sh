@@ -11,6 +11,6 @@ run() { # label, workload, env...
 }
 for wl in autoets_m5 ets_aaa_m5 autoets_stress; do
   run default $wl X=1
-  for v in 1 2 3 4 6; do run "seq_rounds=$v" $wl ANOFOX_HIP_SEQ_ROUNDS=$v; done
+  for v in 1 2 3 4 6; do run "seq_rounds=$v" $wl ANOFOX_HIP_TUNE=seq_rounds=$v; done
 done
 cat $OUT
