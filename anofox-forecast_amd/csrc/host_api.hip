@@ -912,7 +912,11 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
         for (size_t oi = 0; oi < order.size(); oi++)
             if (!dead[oi] && spec_has_mult(specs[order[oi]]) && !(b->live_all > 0 && b->live_pos >= 0 && 2 * (int64_t)b->live_pos < (int64_t)b->live_all))
                 all_additive = false;
-        const bool on = b->tun.k4 > 0 || (b->tun.k4 < 0 && all_additive);
+        // ... and enough of them to fill the chip one lane per problem: two K4 waves per SIMD
+        int64_t additive_live = 0;
+        for (size_t oi = 0; oi < order.size(); oi++)
+            if (!dead[oi] && !spec_has_mult(specs[order[oi]])) additive_live += b->live_all >= 0 ? (int64_t)b->live_all : (int64_t)n;
+        const bool on = b->tun.k4 > 0 || (b->tun.k4 < 0 && all_additive && additive_live >= 131072);
         for (size_t oi = 0; oi < order.size(); oi++)
             k4[oi] = on && !dead[oi] && !b->fixed_params && !spec_has_mult(specs[order[oi]]) && fns[oi].round_k4 && fns[oi].round_auto_k4;
     }

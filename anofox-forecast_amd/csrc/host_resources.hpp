@@ -48,10 +48,13 @@ struct Tunables {
     int spec_below_md = 8192;   //   (_MD: the damped multiplicative-trend specs, whose pass is ~10x longer)
     int spec2_below = 1024;     // tune spec2_below[_md]: one wave per problem, two iterations per pass, for the last problems
     int spec2_below_md = 2048;  //   (tools/spec2_sweep.sh: 0 / 256 / 1024 / 2048 / 4096 / 8192 -> 579 / 575 / 565 / 562 / 594 / 736 ms on the 30-spec M5 batch)
-    int k4 = 1;                 // tune k4: additive-class specs run one lane per problem with all four trial points of an iteration in ONE
-                                //   pass (ets_fit_kernel.hpp K4) wherever one or four LANES per problem would run: 1 always (default: measured
-                                //   -18 % on the intermittent M5 batch, -24 % on the 125k x 1,024 one, neutral beside the 19 general-class specs
-                                //   of the strictly positive batch), 0 never, -1 only when the general-class specs see under half of the series
+    int k4 = -1;                // tune k4: additive-class specs run one lane per problem with all four trial points of an iteration in ONE
+                                //   pass (ets_fit_kernel.hpp K4) wherever one or four LANES per problem would run.  -1 (default): when the run is
+                                //   memory bound and fills the chip that way -- the general-class specs see under half of the series AND the
+                                //   additive specs have >= 131,072 live problems together (two K4 waves per SIMD); 0 never; 1 always.
+                                //   Measured: intermittent M5 batch 86.3 -> 70.4 ms, 125k x 1,024 batch 181 -> 136-140 ms, 1M x 1,024 1,200 -> 853 ms;
+                                //   beside the 19 general-class specs of the strictly positive batch it is time-neutral (fewer passes, the step is
+                                //   bound by fp64 issue), and ONE additive spec on 30,490 series is slower with it (20.5 against 17.9 ms: 477 waves)
     bool merge_periods = true;  // tune merge_periods: auto-detected periods run as merged batches (0: one batch per period)
     int part_threads = 16;      // tune part_threads: host threads that run the small per-period parts of an auto-detected batch side by side
     int pack_threads = 0;       // ANOFOX_HIP_PACK_THREADS: host threads of the packer (0: all, at most 32)
