@@ -114,6 +114,8 @@ struct ArLds {
     int col;              // lane column holding this lane's simplex (its own, or its group leader's in the speculative fit)
     double *gring;        // the ring of R slots in HBM scratch (long periods), else NULL: the ring is the first 2 R x 64 doubles of `base`
     double *tile;         // fit kernels with the cooperative row loader: LDS tile behind the simplex (ArCoop), else NULL
+    bool lane_m = false;  // merged batch of several long periods: R and the period are PER-LANE quantities (pass variant 6: the ring is
+                          // still slot k of lane l at gring[k * 64 + l], sized by the batch's largest period; only the slot arithmetic is per lane)
     __device__ double *smp() const { return gring ? base : base + (size_t)2 * R * NM_BLOCK; }
     __device__ double &sim(int k, int i) const { return smp()[(k * AR_MAXDIM + i) * NM_BLOCK + col]; }
     __device__ double e_at(int t) const { return (gring ? gring : base)[((size_t)(t % R) * NM_BLOCK + threadIdx.x) * 2]; }
@@ -288,17 +290,20 @@ __device__ __noinline__ double ar_css_pass_impl(const double *wrow, int len, int
     // wave-uniform quantities in scalar registers
     const int wave_len = __builtin_amdgcn_readfirstlane(wave_len_v);
     constexpr bool CT = M > 0;
-    const int m = CT ? M : __builtin_amdgcn_readfirstlane(m_v);
-    const int R = CT ? ArBlockLen<M>::R : __builtin_amdgcn_readfirstlane(L.R);
+    // MODE 6 (round 4): MODE 5 with the period -- hence the ring length and every slot index -- a PER-LANE quantity: the series of all
+    // detected long periods of a call run as ONE batch (each used to be a latency-bound batch of its own: ~400 of them on the M5 shape)
+    constexpr bool LANE_M = MODE == 6, HB = MODE == 5 || MODE == 6;
+    const int m = CT ? M : (LANE_M ? m_v : __builtin_amdgcn_readfirstlane(m_v));
+    const int R = CT ? ArBlockLen<M>::R : (LANE_M ? L.R : __builtin_amdgcn_readfirstlane(L.R));
     const int lim = live ? len : 0;
     const int nc_max = __builtin_amdgcn_readfirstlane(ar_wave_max(live ? nc : 0));
     const int len_min = -__builtin_amdgcn_readfirstlane(ar_wave_max(live ? -len : -0x3fffffff));
     // explicit address spaces: through the call boundary the pointers are generic, and generic (flat) loads would make
     // every LDS wait also wait for the row prefetch in flight
     typedef const __attribute__((address_space(1))) ar_ev_t *gptr_t;
-    typedef typename std::conditional<MODE == 5, __attribute__((address_space(1))) ar_ev_t *, __attribute__((address_space(3))) ar_ev_t *>::type lptr_t;
+    typedef typename std::conditional<HB, __attribute__((address_space(1))) ar_ev_t *, __attribute__((address_space(3))) ar_ev_t *>::type lptr_t;
     gptr_t wp_next = (gptr_t)wrow;
-    const lptr_t ring = (lptr_t)(MODE == 5 ? L.gring : L.base) + threadIdx.x;        // slot k of this lane: ring[k * NM_BLOCK]
+    const lptr_t ring = (lptr_t)(HB ? L.gring : L.base) + threadIdx.x;        // slot k of this lane: ring[k * NM_BLOCK]
     double css = 0.0;
     double wl[AR_MAXP] = {0, 0, 0, 0, 0}, ul[AR_MAXP] = {0, 0, 0, 0, 0};
     if (MODE != 3)
@@ -365,7 +370,7 @@ __device__ __noinline__ double ar_css_pass_impl(const double *wrow, int len, int
             const int t0 = base + sb;
             ar_ev_t l1[4], l2[4];                 // slots t - m and t - 2m: {e, v}
             double vnew[4], enew[4];
-            if (MODE == 1 || MODE == 5) {
+            if (MODE == 1 || HB) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     if (sb + j >= S) continue;
@@ -425,7 +430,7 @@ __device__ __noinline__ double ar_css_pass_impl(const double *wrow, int len, int
                 const double ec = (!GATED || t < lim) ? et : 0.0;
                 css = fma(ec, ec, css);
             }
-            if (MODE == 1 || MODE == 2 || MODE == 5) {
+            if (MODE == 1 || MODE == 2 || HB) {
 #pragma unroll
                 for (int j = 0; j < 4; j++)
                     if (sb + j < S && (!GATED || t0 + j < lim)) ring[slot0(sb + j, j) * NM_BLOCK] = ar_ev_t{enew[j], vnew[j]};
@@ -454,7 +459,8 @@ __device__ __noinline__ double ar_css_pass_impl(const double *wrow, int len, int
 
 __device__ __forceinline__ double ar_css_pass(const double *wrow, int len, int wave_len, bool live, const ArFac &f, int m, const ArLds &L)
 {
-    if (L.gring) return ar_css_pass_impl<5, 0>(wrow, len, wave_len, live, f, m, L);      // long period: ring in HBM scratch
+    if (L.gring) return L.lane_m ? ar_css_pass_impl<6, 0>(wrow, len, wave_len, live, f, m, L)       // long periods, one per lane
+                                 : ar_css_pass_impl<5, 0>(wrow, len, wave_len, live, f, m, L);      // long period: ring in HBM scratch
     if (L.R == 2 * m + 4) {      // fit kernels: common periods compiled in
         if (m == 7) return ar_css_pass_impl<3, 7>(wrow, len, wave_len, live, f, m, L);
         if (m == 12) return ar_css_pass_impl<1, 12>(wrow, len, wave_len, live, f, m, L);
@@ -621,9 +627,9 @@ __global__ __launch_bounds__(NM_BLOCK) void arima_prep_kernel(const ArimaArgs a,
     const double *y = a.y + s;
     double *w = ws.W + (size_t)s * ws.tw;
     const size_t ld = a.ld;
-    const int m = a.m;
+    const int m = a.m_col ? a.m_col[s] : a.m;          // (merged batch of long periods: the series' own; a.m is the largest and sizes the scratch)
     int len = n, D = 0, d = 0;
-    double *const fig = a.long_scratch ? a.long_scratch + (size_t)blockIdx.x * ar_fc_scratch_doubles(m) + threadIdx.x : lds + threadIdx.x;
+    double *const fig = a.long_scratch ? a.long_scratch + (size_t)blockIdx.x * ar_fc_scratch_doubles(a.m) + threadIdx.x : lds + threadIdx.x;
     if (m > 1 && ar_seasonal_strength(y, ld, n, m, fig) > 0.64 && n > m + 2) {
         D = 1;
         for (int t = m; t < n; t++) w[t - m] = y[(size_t)t * ld] - y[(size_t)(t - m) * ld];
@@ -687,7 +693,7 @@ __global__ __launch_bounds__(256) void arima_advance_kernel(const ArimaArgs a, c
     int32_t *st = ws.state + (size_t)s * 8;
     if (st[AS_FIN]) return;
     const int len = a.wlen[s];
-    const int m = a.m;
+    const int m = a.m_col ? a.m_col[s] : a.m;
     const int allow_c = (a.d[s] + a.D[s] <= 1) ? 1 : 0;
     const int maxP = m > 1 ? AR_MAXSP : 0;
     uint32_t *tried = ws.tried + (size_t)s * AR_KEYWORDS;
@@ -867,7 +873,7 @@ __device__ __forceinline__ void ar_sort(const LT &L, FT &F, int D)
 // the registers of ITS pass only (see AR_MODE3_REVS for the two-waves-per-SIMD experiment).
 // the cooperative row loader needs an LDS tile (15-17 KB per wave): on where the ring is not in LDS -- the weekly period (registers),
 // no period (8 slots) and the long periods (HBM scratch); the LDS-ring periods keep per-lane row loads (the tile would halve their waves per CU)
-constexpr bool ar_fit_coop(int mode) { return mode == 3 || mode == 2 || mode == 5; }
+constexpr bool ar_fit_coop(int mode) { return mode == 3 || mode == 2 || mode == 5 || mode == 6; }
 constexpr int ar_fit_waves(int mode) { return (mode == 3 && AR_MODE3_REVS == 1) ? 2 : 1; }
 template <int MODE, int M>
 __global__ __launch_bounds__(NM_BLOCK, ar_fit_waves(MODE)) void arima_fit_kernel(const ArimaArgs a, const ArWs ws, const int total, const int polish)
@@ -876,7 +882,9 @@ __global__ __launch_bounds__(NM_BLOCK, ar_fit_waves(MODE)) void arima_fit_kernel
     const int m = a.m;
     // MODE 3: both seasonal lags live in registers, MODE 5: in the wave's HBM scratch ring -- LDS holds the simplex only
     ArLds L{lds, MODE == 3 ? 0 : ar_fit_ring_slots(m), (int)threadIdx.x,
-            MODE == 5 ? a.long_scratch + (size_t)blockIdx.x * 2 * ar_fit_ring_slots(m) * NM_BLOCK : nullptr, nullptr};
+            (MODE == 5 || MODE == 6) ? a.long_scratch + (size_t)blockIdx.x * 2 * ar_fit_ring_slots(m) * NM_BLOCK : nullptr, nullptr};
+    L.lane_m = MODE == 6;
+    int pm = m;                 // the period of this lane's problem (MODE 6: its series' own; a.m is the batch's largest, the ring's size)
     if (ar_fit_coop(MODE)) L.tile = L.smp() + (size_t)(AR_MAXDIM + 1) * AR_MAXDIM * NM_BLOCK;
     ArFs F;
     for (int k = 0; k <= AR_MAXDIM; k++) F.v[k] = 0.0;
@@ -908,6 +916,7 @@ __global__ __launch_bounds__(NM_BLOCK, ar_fit_waves(MODE)) void arima_fit_kernel
                 cur = ar_unkey(key);
                 D = dmn;
                 len = a.wlen[s];
+                if (MODE == 6) { pm = a.m_col[s]; L.R = ar_fit_ring_slots(pm); }
                 wrow = ws.W + (size_t)s * ws.tw;
                 const double wmean = a.wmean[s], wsd = a.wsd[s];
                 for (int i = 0; i < D; i++) L.sim(0, i) = polish ? a.xbest[(size_t)i * a.ld + s] : 0.0;
@@ -948,12 +957,12 @@ __global__ __launch_bounds__(NM_BLOCK, ar_fit_waves(MODE)) void arima_fit_kernel
             else { for (int i = 0; i < D; i++) x[i] = L.sim(0, i); }      // PH_FINAL
         }
         ArFac fac;
-        ar_factors(cur, m, x, fac);
+        ar_factors(cur, pm, x, fac);
         if (__all(fin)) break;
 
         // ---- 3. one streamed pass -------------------------------------------------------------------
         const int wave_len = ar_wave_max(fin ? 0 : len);
-        const double css = ar_css_pass_impl<MODE, M, ar_fit_coop(MODE)>(wrow, len, wave_len, !fin, fac, m, L);
+        const double css = ar_css_pass_impl<MODE, M, ar_fit_coop(MODE)>(wrow, len, wave_len, !fin, fac, pm, L);
         if (fin) continue;
         passes++;
         const int nu = len - fac.nc;
@@ -999,7 +1008,7 @@ __global__ __launch_bounds__(NM_BLOCK, ar_fit_waves(MODE)) void arima_fit_kernel
             }
             // admissibility (root check): an inadmissible candidate has an infinite criterion; an inadmissible POLISHED point leaves
             // the search's own estimates (and their criterion) in place
-            const bool roots_ok = ar_model_roots_ok(cur, m, fac);
+            const bool roots_ok = ar_model_roots_ok(cur, pm, fac);
             if (!roots_ok) aicc = __builtin_huge_val();
             if (polish) {
                 a.evals[s] += nm_evals;
@@ -1032,7 +1041,9 @@ __global__ __launch_bounds__(NM_BLOCK, ar_fit_waves(MODE)) void arima_fit_spec_k
     const int m = a.m;
     const int lane = threadIdx.x, g = lane & 3, leader = lane & ~3;
     ArLds L{lds, MODE == 3 ? 0 : ar_fit_ring_slots(m), leader,
-            MODE == 5 ? a.long_scratch + (size_t)blockIdx.x * 2 * ar_fit_ring_slots(m) * NM_BLOCK : nullptr, nullptr};
+            (MODE == 5 || MODE == 6) ? a.long_scratch + (size_t)blockIdx.x * 2 * ar_fit_ring_slots(m) * NM_BLOCK : nullptr, nullptr};
+    L.lane_m = MODE == 6;
+    int pm = m;
     // (per-lane row loads here: the four lanes of a problem read the same row, 16 distinct rows per wave -- measured 173 ms with them
     //  against 183 ms with the cooperative loader over the nine four-lane launches of the M5 batch; the sequential kernel 163 -> 132 ms)
     ArFs F;
@@ -1063,6 +1074,7 @@ __global__ __launch_bounds__(NM_BLOCK, ar_fit_waves(MODE)) void arima_fit_spec_k
                 cur = ar_unkey(key);
                 D = dmn;
                 len = a.wlen[s];
+                if (MODE == 6) { pm = a.m_col[s]; L.R = ar_fit_ring_slots(pm); }
                 wrow = ws.W + (size_t)s * ws.tw;
                 const double wmean = a.wmean[s], wsd = a.wsd[s];
                 for (int i = 0; i < D; i++) L.sim(0, i) = polish ? a.xbest[(size_t)i * a.ld + s] : 0.0;
@@ -1101,11 +1113,11 @@ __global__ __launch_bounds__(NM_BLOCK, ar_fit_waves(MODE)) void arima_fit_spec_k
             else { mine = true; for (int i = 0; i < D; i++) x[i] = L.sim(0, i); }      // PH_FINAL
         }
         ArFac fac;
-        ar_factors(cur, m, x, fac);
+        ar_factors(cur, pm, x, fac);
         if (__all(fin)) break;
 
         const int wave_len = ar_wave_max(fin ? 0 : len);
-        const double css = ar_css_pass_impl<MODE, M, false>(wrow, len, wave_len, !fin, fac, m, L);
+        const double css = ar_css_pass_impl<MODE, M, false>(wrow, len, wave_len, !fin, fac, pm, L);
         if (fin) continue;
         passes++;
         const int nu = len - fac.nc;
@@ -1147,7 +1159,7 @@ __global__ __launch_bounds__(NM_BLOCK, ar_fit_waves(MODE)) void arima_fit_spec_k
                 aicc = dn * dm_log(v) + 2.0 * dk + 2.0 * dk * (dk + 1.0) / (dn - dk - 1.0);
                 if (!(fabs(aicc) <= 1.7976931348623157e308)) aicc = __builtin_huge_val();
             }
-            const bool roots_ok = ar_model_roots_ok(cur, m, fac);
+            const bool roots_ok = ar_model_roots_ok(cur, pm, fac);
             if (!roots_ok) aicc = __builtin_huge_val();
             if (g == 0) {
                 if (polish) {
@@ -1180,11 +1192,13 @@ __global__ __launch_bounds__(NM_BLOCK) void arima_forecast_kernel(const ArimaArg
     const bool valid = s < a.n_series;
     const int len = valid ? a.wlen[s] : 0;
     const bool live = valid && len >= 3 && a.status[s] == FIT_OK;
-    const int m = a.m;
+    // (merged batch of long periods: the lane's own period for every index, the batch's largest, a.m, for every region size)
+    const int m = (a.m_col && valid) ? a.m_col[s] : a.m;
     // long period: ring and polynomials in the workgroup's HBM scratch
-    double *const wg_scratch = a.long_scratch ? a.long_scratch + (size_t)blockIdx.x * ar_fc_scratch_doubles(m) : nullptr;
+    double *const wg_scratch = a.long_scratch ? a.long_scratch + (size_t)blockIdx.x * ar_fc_scratch_doubles(a.m) : nullptr;
     ArLds L{lds, ar_ring_slots(m), (int)threadIdx.x, wg_scratch, nullptr};
-    ArPolyLds PL{(wg_scratch ? wg_scratch : lds) + (size_t)2 * L.R * NM_BLOCK, AR_MAXP + AR_MAXSP * m + 1};
+    L.lane_m = a.m_col != nullptr;
+    ArPolyLds PL{(wg_scratch ? wg_scratch : lds) + (size_t)2 * ar_ring_slots(a.m) * NM_BLOCK, AR_MAXP + AR_MAXSP * a.m + 1};
     const double *w = ws.W + (size_t)(valid ? s : 0) * ws.tw;
     const size_t ld = a.ld;
     const int wave_len = ar_wave_max(live ? len : 0);
@@ -1860,6 +1874,7 @@ int launch_arima(const ArimaArgs &a, hipStream_t stream)
     const size_t fit_lds = ar_lds_bytes(a.m);
     const bool long_m = a.m > AR_LDS_PERIOD;
     if (a.m > AR_MAX_PERIOD) throw std::runtime_error("AutoARIMA: seasonal period above the cap");
+    if (a.m_col && !long_m) throw std::runtime_error("AutoARIMA: a batch of several periods needs all of them above the LDS limit");
     if (long_m && !a.long_scratch) throw std::runtime_error("AutoARIMA: a period above the LDS limit needs the scratch area");
     const size_t fc_lds = long_m ? 0 : sizeof(double) * ar_fc_scratch_doubles(a.m);
     // the pass variant of the period (ar_css_pass: the fit kernels' ring has 2 m + 4 slots)
@@ -1869,6 +1884,7 @@ int launch_arima(const ArimaArgs &a, hipStream_t stream)
     if (a.m == 7) { fit_seq = arima_fit_kernel<3, 7>; fit_spec = arima_fit_spec_kernel<3, 7>; fit_waves = ar_fit_waves(3); }
     else if (a.m == 12) { fit_seq = arima_fit_kernel<1, 12>; fit_spec = arima_fit_spec_kernel<1, 12>; }
     else if (a.m == 4) { fit_seq = arima_fit_kernel<1, 4>; fit_spec = arima_fit_spec_kernel<1, 4>; }
+    else if (a.m > AR_LDS_PERIOD && a.m_col) { fit_seq = arima_fit_kernel<6, 0>; fit_spec = arima_fit_spec_kernel<6, 0>; }      // long periods, one per series
     else if (a.m > AR_LDS_PERIOD) { fit_seq = arima_fit_kernel<5, 0>; fit_spec = arima_fit_spec_kernel<5, 0>; }
     else if (a.m >= 4) { fit_seq = arima_fit_kernel<1, 0>; fit_spec = arima_fit_spec_kernel<1, 0>; }
     else if (a.m <= 1) { fit_seq = arima_fit_kernel<2, 0>; fit_spec = arima_fit_spec_kernel<2, 0>; }

@@ -1238,6 +1238,7 @@ void run_group(AnofoxHipBatch *b, int period, const int32_t *d_len, hipStream_t 
         aa.y = b->d_y; aa.ld = ld; aa.len = d_len; aa.n_series = (int)n;
         aa.m = period > 1 ? period : 1;                        // <= 2,048 here: longer periods failed loudly above
         aa.long_scratch = nullptr;
+        aa.m_col = (b->d_m_col && aa.m > 24) ? b->d_m_col : nullptr;      // merged batch of long periods: `period` is the largest
         if (aa.m > 24) aa.long_scratch = ensure_ring(b, arima_long_scratch_doubles((int)n, aa.m, arima_max_fit_waves()));
         aa.h = b->h;
         aa.ws = b->ar_w; aa.ws_bytes = b->ar_ws_bytes; aa.t_max = (int)std::max<size_t>(b->t_max, 1); aa.wlen = b->ar_wlen; aa.d = b->ar_d; aa.D = b->ar_D; aa.wmean = b->ar_wmean; aa.wsd = b->ar_wsd;
@@ -2137,8 +2138,13 @@ static bool forecast_batch_one_device(const double *const *values, const uint64_
         // AutoETS: the small parts with periods 2..48 run as ONE batch whose columns are grouped by period in blocks of 64 (the
         // kernels read the period per block): 138 tiny batches x 25 spec chains on 16 hardware queues were latency bound end to end
         const Tunables tun = Tunables::from_env();
-        const bool do_merge = tun.merge_periods && (plan.model == M_AutoETS || plan.model == M_HoltWinters || plan.model == M_SeasonalES || plan.model == M_SeasonalESOptimized ||
-                                                (plan.model == M_ETS && plan.ets_spec_id >= 0 && spec_season(plan.ets_spec_id) != 0));
+        // AutoARIMA (round 4): every detected period is seasonal now (forecast.rs:528-537, 1448-1452) -- ~400 distinct ones on the M5
+        // shape, each a latency-bound batch of its own (13 sweeps with a host round trip apiece: 8.2 s for the 30,490 series).  The
+        // periods above 24 (ring of seasonal lags in the HBM scratch) run as ONE batch with the period per series (arima.hip pass
+        // variant 6); the periods up to 24 keep their compile-time / LDS-ring kernels, one batch each.
+        const bool arima_merge = tun.merge_periods && plan.model == M_AutoARIMA;
+        const bool do_merge = arima_merge || (tun.merge_periods && (plan.model == M_AutoETS || plan.model == M_HoltWinters || plan.model == M_SeasonalES || plan.model == M_SeasonalESOptimized ||
+                                                (plan.model == M_ETS && plan.ets_spec_id >= 0 && spec_season(plan.ets_spec_id) != 0)));
             // one merged batch per ring class (seasonal ring in LDS up to 64, in an HBM scratch above; the scratch is sized by the
             // class's largest period, hence a few classes)
             using Part = std::pair<int, std::vector<size_t>>;
@@ -2230,7 +2236,8 @@ static bool forecast_batch_one_device(const double *const *values, const uint64_
             std::vector<std::vector<Part>> take(sizeof CLASS_HI / sizeof CLASS_HI[0]);
             for (auto &part : parts) {
                 int c = -1;
-                if (do_merge && part.first >= 2 && part.second.size() < 2048)
+                if (arima_merge) { if (part.first > 24 && part.first <= ETS_MAX_PERIOD && part.second.size() < 2048) c = 1; }
+                else if (do_merge && part.first >= 2 && part.second.size() < 2048)
                     for (size_t k = 0; k < take.size(); k++) if (part.first <= CLASS_HI[k]) { c = (int)k; break; }
                 (c >= 0 ? take[(size_t)c] : keep).push_back(std::move(part));
             }

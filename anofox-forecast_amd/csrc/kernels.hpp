@@ -189,6 +189,8 @@ struct ArimaArgs {
     int refit_budget;                   // exact-likelihood refit: evaluations per series in the sequential launch before the speculative one takes over (0: one launch)
     double *long_scratch;               // seasonal period above 24: HBM scratch of arima_long_scratch_doubles() doubles (rings, polynomials), else NULL
     int ml_refit;                       // exact-likelihood (Kalman / Chandrasekhar) refit of the selected models; 0 keeps the CSS estimates
+    const int32_t *m_col;               // [ld] merged batch of several LONG periods (all above 24): the period of every series; `m` is then the
+                                        // largest (scratch sizes); NULL = one period `m` for the whole batch
 };
 size_t arima_workspace_bytes(int n_series, int t_max);
 size_t arima_long_scratch_doubles(int n_series, int m, int max_fit_waves);   // 0 for periods whose rings live in LDS (m <= 24)
