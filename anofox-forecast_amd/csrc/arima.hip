@@ -363,6 +363,20 @@ __device__ __noinline__ double ar_css_pass_impl(const double *wrow, int len, int
     auto slot1 = [&](int sbj, int j) __attribute__((always_inline)) { return CT ? (sbj + 4 * (CT ? ArBlockLen<M>::R : 1) - M) % (CT ? ArBlockLen<M>::R : 1) : wrap(s1 + j); };
     auto slot2 = [&](int sbj, int j) __attribute__((always_inline)) { return CT ? (sbj + 4 * (CT ? ArBlockLen<M>::R : 1) - 2 * M) % (CT ? ArBlockLen<M>::R : 1) : wrap(s2 + j); };
 
+    // Ring in HBM (MODE 5 / 6): the two seasonal lags of a sub-block are requested TWO sub-blocks ahead.  Loaded where they are used,
+    // every group of four steps waited out a memory round trip (the long-period fits ran at a third of the weekly kernels' rate);
+    // the values exist long before -- the period is above 24, so the lags of steps t0 + 8 .. t0 + 11 were stored at least three
+    // sub-blocks ago, and their slots are not written again before step t0 + 12 (R = 2 m + 4 slots) -- so the loads of sub-block
+    // k + 2 are issued at the start of sub-block k and arrive behind eight steps of arithmetic.  Same values, same arithmetic.
+    static_assert(!HB || S % 4 == 0, "the lag prefetch walks whole sub-blocks");
+    ar_ev_t l1p[HB ? 4 : 1], l2p[HB ? 4 : 1], l1q[HB ? 4 : 1], l2q[HB ? 4 : 1];
+    if (HB) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {       // the lags of the first two sub-blocks lie before the series: the ring was cleared above
+            l1p[j] = ar_ev_t{0.0, 0.0}; l2p[j] = ar_ev_t{0.0, 0.0};
+            l1q[j] = ring[wrap(wrap(s1 + 4) + j) * NM_BLOCK]; l2q[j] = ring[wrap(wrap(s2 + 4) + j) * NM_BLOCK];
+        }
+    }
     auto block = [&](const int base, auto gated_tag) __attribute__((always_inline)) {
         constexpr bool GATED = decltype(gated_tag)::value;
 #pragma unroll
@@ -370,7 +384,17 @@ __device__ __noinline__ double ar_css_pass_impl(const double *wrow, int len, int
             const int t0 = base + sb;
             ar_ev_t l1[4], l2[4];                 // slots t - m and t - 2m: {e, v}
             double vnew[4], enew[4];
-            if (MODE == 1 || HB) {
+            if (HB) {
+                const int n1 = wrap(wrap(s1 + 4) + 4), n2 = wrap(wrap(s2 + 4) + 4);      // slots of sub-block k + 2
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    l1[j] = l1p[j]; l2[j] = l2p[j];
+                    l1p[j] = l1q[j]; l2p[j] = l2q[j];
+                    l1q[j] = ring[wrap(n1 + j) * NM_BLOCK];
+                    l2q[j] = ring[wrap(n2 + j) * NM_BLOCK];
+                }
+            }
+            if (MODE == 1) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     if (sb + j >= S) continue;
