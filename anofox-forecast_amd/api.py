@@ -16,9 +16,10 @@ and error behaviour:
 All numeric work goes through the C-ABI of libanofox_fcst_hip.so (one batch call replacing the
 reference's serial per-group loop); nothing here computes a forecast.
 
-Parity status of the models: every model reproduces the known answers the reference's SQL tests hold, except
-model = 'AutoARIMA' (UNPINNED: 18.000000 against the reference's 18.014537 on ts_model_distinctness.test:164;
-DESIGN.md section 3 explains why no consistent estimator reproduces that figure).
+Parity status of the models: every model reproduces the known answers the reference's SQL tests hold -- since round 4
+also model = 'AutoARIMA' (ARIMA(2,1,1) + constant, 18.0145125 against the reference's 18.014537 on
+ts_model_distinctness.test:164: 1.3e-6 relative).  Nothing with a seasonal period is pinned in the
+reference tree.
 """
 from __future__ import annotations
 

@@ -538,6 +538,9 @@ static int refit_ml(ArimaFit *fit, const double *w, int n, double wsd)
     return evals + 1;
 }
 
+/* test hook: the admissibility rule on its own (tests/test_oracle_golden.py compares it with numpy's roots) */
+int oracle_arima_roots_ok(const ArimaOrder *ord, const double *x) { return model_roots_ok(ord, x, ARIMA_ROOT_MIN); }
+
 /* AICc of the conditional sum of squares at fit->x (k = estimated coefficients + innovation variance) */
 static int css_criterion(const ArimaOrder *o, const double *w, int n, double *e, double *v, ArimaFit *fit)
 {

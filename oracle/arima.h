@@ -68,6 +68,7 @@ double oracle_arima_seasonal_strength(const double *y, int n, int m);
 double oracle_arima_ml(const ArimaOrder *ord, const double *x, const double *w, int n);   /* 0.5 (log(ssq/n) + sumlog/n) */
 extern int oracle_arima_ml_refit;
 double oracle_arima_css(const ArimaOrder *ord, const double *x, const double *w, int n, double *css_out, int *nu_out);
+int oracle_arima_roots_ok(const ArimaOrder *ord, const double *x);                         /* every AR / MA root outside radius ARIMA_ROOT_MIN */
 int oracle_auto_arima_detail(const double *y, int n, int period, int h, double *out, ArimaFit *fit, int *models_tried, int *total_evals);
 
 #ifdef __cplusplus

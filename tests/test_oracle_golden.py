@@ -280,6 +280,51 @@ def test_exact_likelihood_equals_the_kalman_filter(oracle):
     assert checked > 100 and rejected > 3 and worst < 1e-9, (checked, rejected, worst)
 
 
+def test_root_check_is_the_smallest_root_modulus(oracle):
+    """The admissibility rule of the AutoARIMA search -- every root of the AR and of the MA polynomial (seasonal factors expanded:
+    a root of 1 - Phi z^m has modulus |1/Phi|^(1/m)) outside radius 1.001 -- is decided by a step-down recursion on coefficients
+    scaled by 1.001^i (no root finder: the kernels state the same arithmetic).  Against numpy's roots of the expanded polynomials,
+    on random boxed coefficients, away from the threshold itself."""
+    import ctypes as C
+    L = oracle.lib()
+
+    class Ord(C.Structure):
+        _fields_ = [(k, C.c_int) for k in ("p", "d", "q", "P", "D", "Q", "s", "with_constant")]
+    L.oracle_arima_roots_ok.restype = C.c_int
+    L.oracle_arima_roots_ok.argtypes = [C.POINTER(Ord), C.c_void_p]
+
+    def minroot(c):                       # 1 - sum c_i z^i
+        c = np.trim_zeros(np.asarray(c, dtype=float), "b")
+        if len(c) == 0:
+            return np.inf
+        return float(np.min(np.abs(np.roots(np.concatenate([(-c)[::-1], [1.0]])))))
+    rng = np.random.default_rng(7)
+    checked = {True: 0, False: 0}
+    for _ in range(4000):
+        m = int(rng.choice([1, 4, 7, 12, 30]))
+        while True:                       # the search's own limit: p + q + P + Q <= 5
+            p, q = int(rng.integers(0, 4)), int(rng.integers(0, 4))
+            P, Q = (int(rng.integers(0, 3)), int(rng.integers(0, 3))) if m > 1 else (0, 0)
+            if p + q + P + Q <= 5:
+                break
+        x = np.clip(rng.normal(0, 0.6, 6), -1.2, 1.2)
+        x[p + q + P + Q:] = 0.0
+        k = 0
+        fac = []
+        for n_c in (p, q, P, Q):
+            fac.append(np.clip(x[k:k + n_c], -0.99, 0.99)); k += n_c
+        r = min(minroot(fac[0]), minroot(fac[1]), minroot(fac[2]) ** (1.0 / m), minroot(fac[3]) ** (1.0 / m))
+        if abs(r - 1.001) < 1e-6:
+            continue
+        got = bool(L.oracle_arima_roots_ok(C.byref(Ord(p, 0, q, P, 0, Q, m, 0)), x.ctypes.data))
+        assert got == (r > 1.001), (p, q, P, Q, m, x, r)
+        checked[got] += 1
+    assert checked[True] > 500 and checked[False] > 500, checked
+    # the box corner of the known-answer model passes (roots at 1.00504), the exact fit of the periodic series does not (on the circle)
+    assert L.oracle_arima_roots_ok(C.byref(Ord(2, 1, 1, 0, 0, 0, 1, 1)), np.array([-0.99, -0.99, -0.8888, 0.33, 0, 0]).ctypes.data)
+    assert not L.oracle_arima_roots_ok(C.byref(Ord(3, 1, 0, 0, 0, 0, 1, 1)), np.array([-0.3372, -0.3372, 0.6628, 0.33, 0, 0]).ctypes.data)
+
+
 def _period30_series():
     rng = np.random.default_rng(30)
     t = np.arange(360)
