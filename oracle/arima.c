@@ -584,6 +584,9 @@ static int fit_model(const ArimaOrder *o, const double *w, int n, double wmean, 
     CssCtx ctx = { o, w, n, e, v, css_obj_fn, ARIMA_SEARCH_EVALS(dim) };
     double f;
     nm_steps(&ctx, dim, x0, step, fit->x, &f, &fit->iters, &fit->evals);
+#ifdef ARIMA_TRACE
+    fprintf(stderr, "F %d %d %d %d %d %d\n", o->p, o->q, o->P, o->Q, o->with_constant, fit->evals);
+#endif
     return css_criterion(o, w, n, e, v, fit);
 }
 
@@ -601,6 +604,9 @@ static int polish_css(ArimaFit *fit, const double *w, int n, double wsd, double 
     CssCtx ctx = { o, w, n, e, v, css_obj_fn, ARIMA_POLISH_NM_CAP * dim };
     int iters = 0, evals = 0;
     nm_steps(&ctx, dim, fit->x, step, xb, &fb, &iters, &evals);
+#ifdef ARIMA_TRACE
+    fprintf(stderr, "P %d %d %d %d %d %d\n", o->p, o->q, o->P, o->Q, o->with_constant, evals);
+#endif
     /* the polished point replaces the search's only if it is still admissible (the search's own point was: it has a finite criterion) */
     if (model_roots_ok(o, xb, ARIMA_ROOT_MIN)) for (int i = 0; i < dim; i++) fit->x[i] = xb[i];
     css_criterion(o, w, n, e, v, fit);
