@@ -61,6 +61,35 @@ __device__ __forceinline__ int ar_wave_max(int v)
 struct ArOrd { int p, q, P, Q, c; };
 __device__ __forceinline__ int ar_dim(const ArOrd &o) { return o.p + o.q + o.P + o.Q + o.c; }
 __device__ __forceinline__ int ar_key(const ArOrd &o) { return (((o.p * 6 + o.q) * 3 + o.P) * 3 + o.Q) * 2 + o.c; }
+// Shape classes of the CSS pass (ar_css_pass_impl NP, NQ, NSP, NSQ): class c runs the variant whose bounds are row c -- every class is
+// covered by the rows after it.  Chosen on the candidates the stepwise search of M5-like series fits (oracle built with -DARIMA_TRACE, 300
+// series, 498k evaluations): fused multiply-adds per step 15 -> 6.7 on average with these four, 8.4 with two, 4.05 if every order had its own.
+constexpr int AR_NCLS = 4;
+__host__ __device__ inline int ar_shape_class(int p, int q, int P, int Q)
+{
+    if (p <= 1 && q <= 1 && P <= 1 && Q <= 1) return 0;         // pass <1, 1, 1, 1>:  5 per step
+    if (p <= 1 && q <= 2 && P <= 1 && Q <= 2) return 1;         // pass <1, 2, 1, 2>:  7
+    if (p <= 2 && q <= 3) return 2;                             // pass <2, 3, 2, 2>: 10
+    return 3;                                                   // pass <5, 5, 2, 2>: 15
+}
+// problem queues: one per (dimension, shape class), so that the 64 (or 16) problems a wave starts with share a pass variant; fetched
+// longest first (dimension, then class, descending: the tail of a launch is made of the cheap problems)
+constexpr int AR_NBUCKETS = (AR_MAXDIM + 1) * AR_NCLS;
+constexpr int AR_QC = 32;                                       // ws.counts[AR_QC + bucket]: queue lengths
+// Queue order (ArimaArgs::queue_sort).  The candidates of one series read the same row of W, and the big sweeps are bound by exactly
+// that traffic (round 4, once the pass stopped paying for absent terms: 6 TB/s of algorithmic row bytes on the two largest launches), so
+// the queue of a sweep is sorted by series within each bucket: neighbouring lanes then hold candidates of the same series, their row
+// loads carry the same addresses and the memory pipeline fetches the row once.
+//   0  as emitted (atomic order), buckets (dimension, shape class)
+//   1  buckets (dimension, shape class), by series within a bucket
+//   2  buckets by dimension only (shape classes mix in a wave: a wider pass variant, more lanes per row)
+//   3  one bucket: by series only
+__device__ __forceinline__ int ar_bucket(const ArOrd &o, int sort_mode)
+{
+    if (sort_mode == 3) return 0;
+    if (sort_mode == 2) return ar_dim(o) * AR_NCLS;
+    return ar_dim(o) * AR_NCLS + ar_shape_class(o.p, o.q, o.P, o.Q);
+}
 
 // the optimiser's coordinates are the coefficients, read through the box (oracle/arima.c box_coef), k <= 5
 __device__ __forceinline__ void ar_pacf(const double *u, int k, double *phi)
@@ -116,6 +145,8 @@ struct ArLds {
     double *tile;         // fit kernels with the cooperative row loader: LDS tile behind the simplex (ArCoop), else NULL
     bool lane_m = false;  // merged batch of several long periods: R and the period are PER-LANE quantities (pass variant 6: the ring is
                           // still slot k of lane l at gring[k * 64 + l], sized by the batch's largest period; only the slot arithmetic is per lane)
+    // (round 4, measured: the simplex in an HBM scratch area instead -- it is only touched between passes -- costs 25 % per pass on a
+    //  lone wave, 258 -> 340 ms on the M5 batch: the few dozen dependent accesses of a Nelder-Mead update are L2 round trips then)
     __device__ double *smp() const { return gring ? base : base + (size_t)2 * R * NM_BLOCK; }
     __device__ double &sim(int k, int i) const { return smp()[(k * AR_MAXDIM + i) * NM_BLOCK + col]; }
     __device__ double e_at(int t) const { return (gring ? gring : base)[((size_t)(t % R) * NM_BLOCK + threadIdx.x) * 2]; }
@@ -274,10 +305,18 @@ template <int S_> struct ArCoop {
     static constexpr int TS = (U % 2) ? U : U + 1;         // tile row stride in units
     static constexpr int TILE_DOUBLES = 2 * NM_BLOCK * TS;
 };
-template <int MODE, int M, bool COOP = false>
+// NP, NQ, NSP, NSQ (round 4): the SHAPE of the pass -- upper bounds on the orders of every live lane of the wave.  The fixed 5 + 2 + 5 + 2
+// form pays 15 fused multiply-adds per step for candidates that have 4 on average (M5-like batch: (0,1)(1,1), (0,1)(0,1), (1,0)(1,0) ...
+// carry most of the evaluations); the terms beyond a lane's orders multiply exact zeros, the oracle does not compute them at all, so a pass
+// that leaves out the terms NO lane of the wave has is the same arithmetic.  The fit kernels queue their problems by shape class
+// (ar_shape_class) so that the lanes of a wave agree, and pick the variant per pass from the wave's live lanes (ar_css_pass_shaped).
+template <int MODE, int M, bool COOP = false, int NP = AR_MAXP, int NQ = AR_MAXP, int NSP = AR_MAXSP, int NSQ = AR_MAXSP, bool KEEP_E = true>
 __device__ __noinline__ double ar_css_pass_impl(const double *wrow, int len, int wave_len_v, bool live, const ArFac &fin, int m_v,
                                                 const ArLds &L)
 {
+    constexpr bool SEAS = MODE != 2 && (NSP > 0 || NSQ > 0);      // some lane may have a seasonal factor: the ring of lags is kept
+    constexpr bool LAG2 = MODE != 2 && (NSP > 1 || NSQ > 1);      // ... and its second lag is read
+    constexpr bool RING = SEAS || (KEEP_E && MODE != 3);           // KEEP_E: the caller reads the last residuals from the ring (forecast)
     // out of line on purpose: the pass gets its own register allocation (the fit kernel around it is a large state
     // machine), and the coefficients are copied out of the caller's (scratch-resident) block once per pass
     double phi[AR_MAXP], th[AR_MAXP], Phi[AR_MAXSP], Th[AR_MAXSP];
@@ -306,18 +345,21 @@ __device__ __noinline__ double ar_css_pass_impl(const double *wrow, int len, int
     const lptr_t ring = (lptr_t)(HB ? L.gring : L.base) + threadIdx.x;        // slot k of this lane: ring[k * NM_BLOCK]
     double css = 0.0;
     double wl[AR_MAXP] = {0, 0, 0, 0, 0}, ul[AR_MAXP] = {0, 0, 0, 0, 0};
-    if (MODE != 3)
+    if (MODE != 3 && RING)
         for (int k = 0; k < R; k++) ring[k * NM_BLOCK] = ar_ev_t{0.0, 0.0};
     // MODE 3: compile-time period with BOTH seasonal lags in registers (shift rings of 2 M values of e and of v, block =
     // two revolutions so every ring index is a constant): no LDS traffic in the pass at all
     constexpr int S = (MODE == 3) ? AR_MODE3_REVS * 2 * M : ArBlockLen<M>::value;
     constexpr int RR = (MODE == 3) ? 2 * M : 1;
-    static_assert(S % 2 == 0 && 2 * S <= AR_SPARE, "block length");
+    static_assert(S % 2 == 0 && 3 * S <= AR_SPARE, "block length (the row prefetch runs two blocks ahead)");
     double er[RR], vr[RR];
 #pragma unroll
     for (int k = 0; k < RR; k++) { er[k] = 0.0; vr[k] = 0.0; }
     typedef ArCoop<S> CO;
-    ar_ev_t cur[S / 2], nxt[COOP ? CO::NI : S / 2];
+    // two blocks in flight (round 4): with one block the loads of block k + 1 had the ~28 steps of block k to arrive -- a few hundred
+    // cycles once the pass carries 5-10 multiply-adds per step instead of 15, against a memory round trip of a microsecond and more;
+    // a launch of few problems (the late sweeps, the polish) ran at the pace of that round trip
+    ar_ev_t cur[S / 2], nxa[COOP ? CO::NI : S / 2], nxb[COOP ? CO::NI : S / 2];
     // COOP: this lane loads unit `cu` of the segments of rows i * RPI + cr (i = 0 .. NI - 1); lanes past RPI * U and rows past 63
     // repeat an in-range address and drop the value
     typedef __attribute__((address_space(3))) ar_ev_t *tile_t;
@@ -336,11 +378,11 @@ __device__ __noinline__ double ar_css_pass_impl(const double *wrow, int len, int
             rowp[i] = (gptr_t)(((unsigned long long)hi << 32) | lo) + cu;
         }
     }
-    auto coop_issue = [&](const int unit0) __attribute__((always_inline)) {
+    auto coop_issue = [&](ar_ev_t (&nxt)[COOP ? CO::NI : S / 2], const int unit0) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < CO::NI; i++) nxt[i] = rowp[i][unit0];
     };
-    auto coop_commit = [&]() __attribute__((always_inline)) {
+    auto coop_commit = [&](const ar_ev_t (&nxt)[COOP ? CO::NI : S / 2]) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < CO::NI; i++)
             if (cr < CO::RPI && i * CO::RPI + cr < NM_BLOCK) tile[(i * CO::RPI + cr) * CO::TS + cu] = nxt[i];
@@ -349,12 +391,27 @@ __device__ __noinline__ double ar_css_pass_impl(const double *wrow, int len, int
         for (int j = 0; j < S / 2; j++) cur[j] = tile[(int)threadIdx.x * CO::TS + j];
         __builtin_amdgcn_wave_barrier();
     };
-    if (COOP) { coop_issue(0); coop_commit(); }
-    else {
+    // issue the loads of the block that starts at 16-byte unit `unit0` of the rows into one of the two buffers / make a buffer current
+    auto issue = [&](ar_ev_t (&nxt)[COOP ? CO::NI : S / 2], const int unit0) __attribute__((always_inline)) {
+        if (COOP) coop_issue(nxt, unit0);
+        else {
 #pragma unroll
-        for (int j = 0; j < S / 2; j++) cur[j] = wp_next[j];
-    }
-    wp_next += S / 2;
+            for (int j = 0; j < S / 2; j++) nxt[j] = wp_next[unit0 + j];
+        }
+    };
+    auto commit = [&](const ar_ev_t (&nxt)[COOP ? CO::NI : S / 2]) __attribute__((always_inline)) {
+        if (COOP) coop_commit(nxt);
+        else {
+#pragma unroll
+            for (int j = 0; j < S / 2; j++) cur[j] = nxt[j];
+        }
+    };
+    // (not where the registers are spoken for: the HBM-ring variants already hold two sub-blocks of lags in flight and would spill
+    //  400 bytes more; the four-lane kernel without a period keeps its two waves per SIMD)
+    constexpr bool DEEP = !HB && !(MODE == 2 && !COOP);
+    issue(nxa, 0);
+    commit(nxa);
+    if (DEEP) issue(nxa, S / 2);
     // ring slots of t0, t0 - m, t0 - 2m (scalar, advanced by 4 per sub-block)
     int s0 = 0, s1 = (R - m % R) % R, s2 = (R - (2 * m) % R) % R;
     auto wrap = [&](int x) __attribute__((always_inline)) { return x >= R ? x - R : x; };
@@ -374,7 +431,9 @@ __device__ __noinline__ double ar_css_pass_impl(const double *wrow, int len, int
 #pragma unroll
         for (int j = 0; j < 4; j++) {       // the lags of the first two sub-blocks lie before the series: the ring was cleared above
             l1p[j] = ar_ev_t{0.0, 0.0}; l2p[j] = ar_ev_t{0.0, 0.0};
-            l1q[j] = ring[wrap(wrap(s1 + 4) + j) * NM_BLOCK]; l2q[j] = ring[wrap(wrap(s2 + 4) + j) * NM_BLOCK];
+            l1q[j] = ar_ev_t{0.0, 0.0}; l2q[j] = ar_ev_t{0.0, 0.0};
+            if (SEAS) l1q[j] = ring[wrap(wrap(s1 + 4) + j) * NM_BLOCK];
+            if (LAG2) l2q[j] = ring[wrap(wrap(s2 + 4) + j) * NM_BLOCK];
         }
     }
     auto block = [&](const int base, auto gated_tag) __attribute__((always_inline)) {
@@ -390,18 +449,92 @@ __device__ __noinline__ double ar_css_pass_impl(const double *wrow, int len, int
                 for (int j = 0; j < 4; j++) {
                     l1[j] = l1p[j]; l2[j] = l2p[j];
                     l1p[j] = l1q[j]; l2p[j] = l2q[j];
-                    l1q[j] = ring[wrap(n1 + j) * NM_BLOCK];
-                    l2q[j] = ring[wrap(n2 + j) * NM_BLOCK];
+                    if (SEAS) l1q[j] = ring[wrap(n1 + j) * NM_BLOCK];
+                    if (LAG2) l2q[j] = ring[wrap(n2 + j) * NM_BLOCK];
                 }
             }
             if (MODE == 1) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     if (sb + j >= S) continue;
-                    l1[j] = ring[slot1(sb + j, j) * NM_BLOCK];
-                    l2[j] = ring[slot2(sb + j, j) * NM_BLOCK];
+                    if (SEAS) l1[j] = ring[slot1(sb + j, j) * NM_BLOCK];
+                    if (LAG2) l2[j] = ring[slot2(sb + j, j) * NM_BLOCK];
                 }
             }
+            // STAGED (round 4): the four steps of a sub-block stage by stage instead of step by step.  A wave issues in order, and a step is
+            // a chain -- w' -> v -> z -> u -> e -> e^2: written step by step every instruction waited for the one before it (~50 cycles per
+            // step for 6 instructions on a wave alone on its SIMD).  Only u (one multiply-add on u_{t-1}) and the sum of squares are
+            // recursions; v, z and e are feed-forward once the lags of the sub-block are in hand (they are: m >= 4), so the four v's, the four
+            // z's, the four e's are independent instructions next to each other.  Same operations on the same operands.
+            constexpr bool STAGED = MODE != 0;
+            if constexpr (STAGED) {
+                double vtj[4], uj[4];
+                bool onj[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (sb + j >= S) continue;
+                    const double wv = ((sb + j) & 1) ? cur[(sb + j) / 2].y : cur[(sb + j) / 2].x;
+                    const double wp = wv - mu;
+                    double vt = wp;
+#pragma unroll
+                    for (int q = 0; q < NP; q++) vt = fma(phi[q], wl[q], vt);
+#pragma unroll
+                    for (int q = NP - 1; q > 0; q--) wl[q] = wl[q - 1];
+                    if (NP > 0) wl[0] = wp;
+                    vtj[j] = vt;
+                    if (MODE == 3) {
+                        l2[j] = ar_ev_t{er[(sb + j) % RR], vr[(sb + j) % RR]};
+                        l1[j] = ar_ev_t{er[(sb + j + M) % RR], vr[(sb + j + M) % RR]};
+                    }
+                }
+                double zj[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (sb + j >= S) continue;
+                    double z = vtj[j];
+                    if (MODE != 2) {
+                        if (NSP > 0) z = fma(Phi[0], l1[j].y, z);
+                        if (NSP > 1) z = fma(Phi[1], l2[j].y, z);
+                    }
+                    zj[j] = z;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (sb + j >= S) continue;
+                    double u = zj[j];
+#pragma unroll
+                    for (int q = NQ - 1; q >= 0; q--) u = fma(th[q], ul[q], u);
+                    onj[j] = t0 + j >= nc;
+                    if (GATED) u = onj[j] ? u : 0.0;
+#pragma unroll
+                    for (int q = NQ - 1; q > 0; q--) ul[q] = ul[q - 1];
+                    if (NQ > 0) ul[0] = u;
+                    uj[j] = u;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (sb + j >= S) continue;
+                    const int t = t0 + j;
+                    double et = uj[j];
+                    if (MODE != 2) {
+                        if (NSQ > 0) et = fma(Th[0], l1[j].x, et);
+                        if (NSQ > 1) et = fma(Th[1], l2[j].x, et);
+                        if (GATED) et = onj[j] ? et : 0.0;
+                    }
+                    if (MODE == 3 && SEAS) {
+                        const bool keep = GATED && !(t < lim);
+                        er[(sb + j) % RR] = keep ? er[(sb + j) % RR] : et;
+                        vr[(sb + j) % RR] = keep ? vr[(sb + j) % RR] : vtj[j];
+                    }
+                    vnew[j] = vtj[j]; enew[j] = et;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (sb + j >= S) continue;
+                    const double ec = (!GATED || t0 + j < lim) ? enew[j] : 0.0;
+                    css = fma(ec, ec, css);
+                }
+            } else {
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 if (sb + j >= S) continue;              // (a block length that is not a multiple of four: the last sub-block is short)
@@ -410,42 +543,42 @@ __device__ __noinline__ double ar_css_pass_impl(const double *wrow, int len, int
                 const double wp = wv - mu;
                 double vt = wp;
 #pragma unroll
-                for (int q = 0; q < AR_MAXP; q++) vt = fma(phi[q], wl[q], vt);
+                for (int q = 0; q < NP; q++) vt = fma(phi[q], wl[q], vt);
 #pragma unroll
-                for (int q = AR_MAXP - 1; q > 0; q--) wl[q] = wl[q - 1];
-                wl[0] = wp;
+                for (int q = NP - 1; q > 0; q--) wl[q] = wl[q - 1];
+                if (NP > 0) wl[0] = wp;
                 double z = vt;
                 if (MODE == 0) {
-                    l1[j] = ring[slot1(sb + j, j) * NM_BLOCK];
-                    l2[j] = ring[slot2(sb + j, j) * NM_BLOCK];
+                    if (SEAS) l1[j] = ring[slot1(sb + j, j) * NM_BLOCK];
+                    if (LAG2) l2[j] = ring[slot2(sb + j, j) * NM_BLOCK];
                 }
                 if (MODE == 3) {
                     l2[j] = ar_ev_t{er[(sb + j) % RR], vr[(sb + j) % RR]};
                     l1[j] = ar_ev_t{er[(sb + j + M) % RR], vr[(sb + j + M) % RR]};
                 }
                 if (MODE != 2) {
-                    z = fma(Phi[0], l1[j].y, z);
-                    z = fma(Phi[1], l2[j].y, z);
+                    if (NSP > 0) z = fma(Phi[0], l1[j].y, z);
+                    if (NSP > 1) z = fma(Phi[1], l2[j].y, z);
                 }
                 // the newest lag enters last, so consecutive steps are one fused multiply-add apart
                 double u = z;
 #pragma unroll
-                for (int q = AR_MAXP - 1; q >= 0; q--) u = fma(th[q], ul[q], u);
+                for (int q = NQ - 1; q >= 0; q--) u = fma(th[q], ul[q], u);
                 const bool on = t >= nc;
                 if (GATED) u = on ? u : 0.0;
 #pragma unroll
-                for (int q = AR_MAXP - 1; q > 0; q--) ul[q] = ul[q - 1];
-                ul[0] = u;
+                for (int q = NQ - 1; q > 0; q--) ul[q] = ul[q - 1];
+                if (NQ > 0) ul[0] = u;
                 double et = u;
                 if (MODE != 2) {
-                    et = fma(Th[0], l1[j].x, et);
-                    et = fma(Th[1], l2[j].x, et);
+                    if (NSQ > 0) et = fma(Th[0], l1[j].x, et);
+                    if (NSQ > 1) et = fma(Th[1], l2[j].x, et);
                     if (GATED) et = on ? et : 0.0;
                 }
                 if (MODE == 0) {
-                    if (!GATED || t < lim) ring[slot0(sb + j, j) * NM_BLOCK] = ar_ev_t{et, vt};
+                    if (RING && (!GATED || t < lim)) ring[slot0(sb + j, j) * NM_BLOCK] = ar_ev_t{et, vt};
                 }
-                if (MODE == 3) {
+                if (MODE == 3 && SEAS) {
                     const bool keep = GATED && !(t < lim);
                     er[(sb + j) % RR] = keep ? er[(sb + j) % RR] : et;
                     vr[(sb + j) % RR] = keep ? vr[(sb + j) % RR] : vt;
@@ -454,7 +587,8 @@ __device__ __noinline__ double ar_css_pass_impl(const double *wrow, int len, int
                 const double ec = (!GATED || t < lim) ? et : 0.0;
                 css = fma(ec, ec, css);
             }
-            if (MODE == 1 || MODE == 2 || HB) {
+            }
+            if ((MODE == 1 || MODE == 2 || HB) && RING) {
 #pragma unroll
                 for (int j = 0; j < 4; j++)
                     if (sb + j < S && (!GATED || t0 + j < lim)) ring[slot0(sb + j, j) * NM_BLOCK] = ar_ev_t{enew[j], vnew[j]};
@@ -463,19 +597,25 @@ __device__ __noinline__ double ar_css_pass_impl(const double *wrow, int len, int
         }
     };
 
-    for (int base = 0; base < wave_len; base += S) {
-        if (COOP) coop_issue((base + S) / 2);
-        else {
-#pragma unroll
-            for (int j = 0; j < S / 2; j++) nxt[j] = wp_next[j];
-        }
-        wp_next += S / 2;
+    auto run_block = [&](const int base) __attribute__((always_inline)) {
         if (base >= nc_max && base + S <= len_min) block(base, std::false_type{});
         else block(base, std::true_type{});
-        if (COOP) coop_commit();
-        else {
-#pragma unroll
-            for (int j = 0; j < S / 2; j++) cur[j] = nxt[j];
+    };
+    if (DEEP) {
+        for (int base = 0; base < wave_len; base += 2 * S) {
+            issue(nxb, (base + 2 * S) / 2);
+            run_block(base);
+            commit(nxa);
+            if (base + S >= wave_len) break;
+            issue(nxa, (base + 3 * S) / 2);
+            run_block(base + S);
+            commit(nxb);
+        }
+    } else {
+        for (int base = 0; base < wave_len; base += S) {
+            issue(nxa, (base + S) / 2);
+            run_block(base);
+            commit(nxa);
         }
     }
     return css;
@@ -509,9 +649,13 @@ struct ArWs {
     uint32_t *tried;      // [n x AR_KEYWORDS] candidate has been tried by the (replayed) sequential search
     double *best_aicc;    // [n]
     int32_t *state;       // [n x 8] stage, idx, base key, best key, have, improved, n_models, fin
-    int32_t *q_series, *q_key;   // [7 x cap] problem queues by dimension
-    int32_t *counts;      // [32] 0..6 queue lengths, 8 fetch cursor, 9..13 refit class cursors, 16..20 refit class sizes,
+    int32_t *q_series, *q_key;   // [AR_NBUCKETS x cap] problem queues by (dimension, shape class)
+    int32_t *counts;      // [64] AR_QC + bucket: queue lengths, 8 fetch cursor, 9..13 refit class cursors, 16..20 refit class sizes,
                           //      21..25 class cursors of the refit's second (speculative) launch, 26 series parked for it
+    int32_t *q_rank;      // [AR_NBUCKETS x cap] rank of a queued problem among its series' problems of the same bucket (emission order)
+    int32_t *q2_series, *q2_key;   // the queues sorted by series within a bucket (arima_queue_scan / _scatter_kernel)
+    int32_t *hist;        // [AR_NBUCKETS x n] problems per (bucket, series) of the sweep, then their exclusive prefix over the series
+    int nser;
     double *ml_sim;       // [waves x 42 x 64] simplex scratch of the exact-likelihood refit
     double *ml_park;      // [n x 64] Nelder-Mead state of the series the first refit launch parks for the second
     int32_t *ml_park_list;   // [n] those series
@@ -531,9 +675,14 @@ struct ArWs {
         tried = (uint32_t *)take(sizeof(uint32_t) * (size_t)n * AR_KEYWORDS);
         best_aicc = (double *)take(sizeof(double) * (size_t)n);
         state = (int32_t *)take(sizeof(int32_t) * (size_t)n * 8);
-        q_series = (int32_t *)take(sizeof(int32_t) * 7 * cap);
-        q_key = (int32_t *)take(sizeof(int32_t) * 7 * cap);
-        counts = (int32_t *)take(sizeof(int32_t) * 32);
+        q_series = (int32_t *)take(sizeof(int32_t) * AR_NBUCKETS * cap);
+        q_key = (int32_t *)take(sizeof(int32_t) * AR_NBUCKETS * cap);
+        counts = (int32_t *)take(sizeof(int32_t) * 96);
+        q_rank = (int32_t *)take(sizeof(int32_t) * AR_NBUCKETS * cap);
+        q2_series = (int32_t *)take(sizeof(int32_t) * AR_NBUCKETS * cap);
+        q2_key = (int32_t *)take(sizeof(int32_t) * AR_NBUCKETS * cap);
+        hist = (int32_t *)take(sizeof(int32_t) * (size_t)AR_NBUCKETS * n);
+        nser = n;
         ml_sim = (double *)take(sizeof(double) * (size_t)ar_ml_sim_waves(n) * 64 * NM_BLOCK);   // AR_ML_CTX <= 64 slots per lane
         ml_park = (double *)take(sizeof(double) * (size_t)n * 64);
         ml_park_list = (int32_t *)take(sizeof(int32_t) * (size_t)n);
@@ -561,10 +710,13 @@ __device__ __forceinline__ ArOrd ar_unkey(int key)
 __device__ bool ar_kpss_reject(const double *x, size_t ld, int n)
 {
     if (n < 4) return false;
+    // (unrolled sweeps: the loads of eight steps are in flight together; the sums stay sequential)
     double s = 0.0;
+#pragma unroll 8
     for (int i = 0; i < n; i++) s = s + x[(size_t)i * ld];
     const double mean = s / (double)n;
     double cum = 0.0, eta = 0.0, s2 = 0.0;
+#pragma unroll 8
     for (int i = 0; i < n; i++) {
         double e = x[(size_t)i * ld] - mean;
         cum = cum + e;
@@ -575,34 +727,82 @@ __device__ bool ar_kpss_reject(const double *x, size_t ld, int n)
     eta = eta / (dn * dn);
     s2 = s2 / dn;
     const int lag = (int)(3.0 * sqrt(dn) / 13.0);
-    for (int k = 1; k <= lag; k++) {
-        double acc = 0.0;
-        for (int t = k; t < n; t++) acc = fma(x[(size_t)t * ld] - mean, x[(size_t)(t - k) * ld] - mean, acc);
-        double wgt = 1.0 - (double)k / ((double)lag + 1.0);
-        s2 = s2 + 2.0 * wgt * (acc / dn);
+    // autocovariances of lags 1 .. lag, eight lags per sweep of the series (round 4; it was one sweep per lag: two loads and one
+    // dependent multiply-add per term, 2 x lag x n loads -- most of the prep kernel's time).  Every lag keeps its own accumulator and
+    // receives its terms in the order t = k .. n - 1, so each sum is the oracle's sum; the window holds the centred values the eight
+    // lags of the sweep pair with the current one.
+    constexpr int KW = 8;
+    for (int k0 = 0; k0 < lag; k0 += KW) {
+        double acc[KW], win[KW];                       // win[j] = x[t - (k0 + 1 + j)] - mean
+#pragma unroll
+        for (int j = 0; j < KW; j++) { acc[j] = 0.0; win[j] = 0.0; }
+#pragma unroll 4
+        for (int t = k0 + 1; t < n; t++) {
+#pragma unroll
+            for (int j = KW - 1; j > 0; j--) win[j] = win[j - 1];
+            win[0] = x[(size_t)(t - k0 - 1) * ld] - mean;
+            const double ct = x[(size_t)t * ld] - mean;
+#pragma unroll
+            for (int j = 0; j < KW; j++)
+                if (k0 + 1 + j <= lag && t >= k0 + 1 + j) acc[j] = fma(ct, win[j], acc[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < KW; j++) {
+            const int k = k0 + 1 + j;
+            if (k <= lag) {
+                double wgt = 1.0 - (double)k / ((double)lag + 1.0);
+                s2 = s2 + 2.0 * wgt * (acc[j] / dn);
+            }
+        }
     }
     if (!(s2 > 0.0)) return false;
     return (eta / s2) > 0.463;
 }
 
-__device__ double ar_seasonal_strength(const double *y, size_t ld, int n, int m, double *fig /* [m] lane-private scratch, stride NM_BLOCK */)
+// Seasonal strength of the classical decomposition (oracle/arima.c oracle_arima_seasonal_strength).  Round 4: the detrended value
+// d_i = y_i - (centred moving average at i) is computed ONCE per i, in one sweep with the window of the last L values in a lane-private
+// ring (fig + m entries: LDS, or the HBM scratch of a long period), and parked in the series' row of W (free until the copy below); the
+// per-phase sums of the first stage are accumulated in that same sweep (each phase still receives its terms in ascending i), the second
+// and third stage read the parked d_i.  It used to be three sweeps, each re-reading L values of y per i through a loop of dependent
+// loads: 9.5 of the prep kernel's 14 ms on the M5 batch.  Same operations on the same operands, in the same order per accumulator.
+__device__ double ar_seasonal_strength(const double *y, size_t ld, int n, int m, double *fig /* [m + L] lane-private scratch, stride NM_BLOCK */,
+                                       double *dpark /* [n] lane-private: the series' row of W */)
 {
     if (m < 2 || n < 3 * m) return 0.0;
     const int half = m / 2;
     const int L = (m % 2 == 0) ? m + 1 : m;
     const double w = 1.0 / (double)m;
     const double wend = (m % 2 == 0) ? 0.5 / (double)m : w;
+    double *const ring = fig + (size_t)m * NM_BLOCK;           // slot t mod L holds y_t for the L values around the current centre
+    for (int j = 0; j < m; j++) fig[j * NM_BLOCK] = 0.0;
+    for (int t = 0; t < L - 1; t++) ring[t * NM_BLOCK] = y[(size_t)t * ld];
+    {
+        int start = 0, fresh = L - 1, centre = half, ph = half % m;
+        double ynext = y[(size_t)(2 * half) * ld];              // the value that enters the window at the next centre, requested a step ahead
+        for (int i = half; i < n - half; i++) {
+            ring[fresh * NM_BLOCK] = ynext;
+            if (i + 1 < n - half) ynext = y[(size_t)(i + 1 + half) * ld];
+            double acc = 0.0;
+            int sl = start;
+#pragma unroll 4
+            for (int k = 0; k < L; k++) {
+                acc = acc + ((k == 0 || k == L - 1) ? wend : w) * ring[sl * NM_BLOCK];
+                sl = (sl + 1 == L) ? 0 : sl + 1;
+            }
+            const double d = ring[centre * NM_BLOCK] - acc;
+            dpark[i] = d;
+            fig[ph * NM_BLOCK] = fig[ph * NM_BLOCK] + d;
+            start = (start + 1 == L) ? 0 : start + 1;
+            fresh = (fresh + 1 == L) ? 0 : fresh + 1;
+            centre = (centre + 1 == L) ? 0 : centre + 1;
+            ph = (ph + 1 == m) ? 0 : ph + 1;
+        }
+    }
     double tot = 0.0;
     for (int j = 0; j < m; j++) {
-        double sj = 0.0;
-        int cnt = 0;
-        for (int i = (j >= half ? j : j + m); i < n - half; i += m) {
-            double acc = 0.0;
-            for (int k = 0; k < L; k++) acc = acc + ((k == 0 || k == L - 1) ? wend : w) * y[(size_t)(i - half + k) * ld];
-            sj = sj + (y[(size_t)i * ld] - acc);
-            cnt++;
-        }
-        fig[j * NM_BLOCK] = sj / (double)cnt;
+        const int first = j >= half ? j : j + m;
+        const int cnt = (n - half - 1 - first) / m + 1;        // centres i = first, first + m, ... below n - half (n >= 3 m: at least one)
+        fig[j * NM_BLOCK] = fig[j * NM_BLOCK] / (double)cnt;
         tot = tot + fig[j * NM_BLOCK];
     }
     const double fmean = tot / (double)m;
@@ -610,10 +810,9 @@ __device__ double ar_seasonal_strength(const double *y, size_t ld, int n, int m,
     const int nv = n - 2 * half;
     double sd = 0.0, sr = 0.0;
     int ph = half % m;
+#pragma unroll 8
     for (int i = half; i < n - half; i++) {
-        double acc = 0.0;
-        for (int k = 0; k < L; k++) acc = acc + ((k == 0 || k == L - 1) ? wend : w) * y[(size_t)(i - half + k) * ld];
-        double d = y[(size_t)i * ld] - acc;
+        const double d = dpark[i];
         sd = sd + d;
         sr = sr + (d - fig[ph * NM_BLOCK]);
         ph = (ph + 1 == m) ? 0 : ph + 1;
@@ -621,11 +820,10 @@ __device__ double ar_seasonal_strength(const double *y, size_t ld, int n, int m,
     const double md = sd / (double)nv, mr = sr / (double)nv;
     double vd = 0.0, vr = 0.0;
     ph = half % m;
+#pragma unroll 8
     for (int i = half; i < n - half; i++) {
-        double acc = 0.0;
-        for (int k = 0; k < L; k++) acc = acc + ((k == 0 || k == L - 1) ? wend : w) * y[(size_t)(i - half + k) * ld];
-        double d = y[(size_t)i * ld] - acc;
-        double r = d - fig[ph * NM_BLOCK];
+        const double d = dpark[i];
+        const double r = d - fig[ph * NM_BLOCK];
         vd = fma(d - md, d - md, vd);
         vr = fma(r - mr, r - mr, vr);
         ph = (ph + 1 == m) ? 0 : ph + 1;
@@ -640,7 +838,7 @@ __device__ double ar_seasonal_strength(const double *y, size_t ld, int n, int m,
 __global__ __launch_bounds__(NM_BLOCK) void arima_prep_kernel(const ArimaArgs a, const ArWs ws)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int s = blockIdx.x * NM_BLOCK + threadIdx.x;
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;      // (blockDim.x: 64, or fewer series per wave where that fills the chip -- launch_arima)
     if (s >= a.n_series) return;
     // search state of this series (a series outside this period group keeps wlen = 0 and is skipped everywhere)
     for (int i = 0; i < 8; i++) ws.state[(size_t)s * 8 + i] = 0;
@@ -653,19 +851,27 @@ __global__ __launch_bounds__(NM_BLOCK) void arima_prep_kernel(const ArimaArgs a,
     const size_t ld = a.ld;
     const int m = a.m_col ? a.m_col[s] : a.m;          // (merged batch of long periods: the series' own; a.m is the largest and sizes the scratch)
     int len = n, D = 0, d = 0;
+    long long tk[6] = {0, 0, 0, 0, 0, 0};
+    tk[0] = wall_clock64();
     double *const fig = a.long_scratch ? a.long_scratch + (size_t)blockIdx.x * ar_fc_scratch_doubles(a.m) + threadIdx.x : lds + threadIdx.x;
-    if (m > 1 && ar_seasonal_strength(y, ld, n, m, fig) > 0.64 && n > m + 2) {
+    const double strength = m > 1 ? ar_seasonal_strength(y, ld, n, m, fig, w) : 0.0;
+    tk[1] = wall_clock64();
+    if (m > 1 && strength > 0.64 && n > m + 2) {
         D = 1;
+#pragma unroll 8
         for (int t = m; t < n; t++) w[t - m] = y[(size_t)t * ld] - y[(size_t)(t - m) * ld];
         len = n - m;
     } else {
+#pragma unroll 8
         for (int t = 0; t < n; t++) w[t] = y[(size_t)t * ld];
     }
     // integration constants of the seasonally differenced series (before the ordinary differences)
     a.last_d0[s] = w[len - 1];
     a.last_d1[s] = len >= 2 ? w[len - 1] - w[len - 2] : 0.0;
+    tk[2] = wall_clock64();
     while (d < 2 && len > 3 && ar_kpss_reject(w, 1, len)) {
         double prev = w[0];
+#pragma unroll 8
         for (int t = 1; t < len; t++) {
             double cur = w[t];
             w[t - 1] = cur - prev;
@@ -674,11 +880,14 @@ __global__ __launch_bounds__(NM_BLOCK) void arima_prep_kernel(const ArimaArgs a,
         len -= 1;
         d++;
     }
+    tk[3] = wall_clock64();
     for (int t = len; t < (int)ws.tw; t++) w[t] = 0.0;       // padding read by the streamed blocks (never used)
     double sum = 0.0;
+#pragma unroll 8
     for (int i = 0; i < len; i++) sum = sum + w[i];
     const double wmean = sum / (double)len;
     double v = 0.0;
+#pragma unroll 8
     for (int i = 0; i < len; i++) { double dd = w[i] - wmean; v = fma(dd, dd, v); }
     a.wlen[s] = len;
     a.d[s] = d;
@@ -686,6 +895,10 @@ __global__ __launch_bounds__(NM_BLOCK) void arima_prep_kernel(const ArimaArgs a,
     a.wmean[s] = wmean;
     a.wsd[s] = sqrt(v / (double)len);
     if (len < 3) ws.state[(size_t)s * 8 + AS_FIN] = 1;
+    tk[4] = wall_clock64();
+    if (a.trace >= 3 && threadIdx.x == 0 && (blockIdx.x % 97) == 0)      // 100 MHz wall clock: 100 ticks per microsecond
+        printf("prep wave %d: seasonal strength %lld us, copy %lld us, KPSS + differences %lld us (d = %d), moments + padding %lld us\n", (int)blockIdx.x,
+               (tk[1] - tk[0]) / 100, (tk[2] - tk[1]) / 100, (tk[3] - tk[2]) / 100, d, (tk[4] - tk[3]) / 100);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -754,11 +967,16 @@ __global__ __launch_bounds__(256) void arima_advance_kernel(const ArimaArgs a, c
                 if ((tried[ck >> 5] | computed[ck >> 5]) & (1u << (ck & 31))) return;
                 if (impossible(c)) return;
                 computed[ck >> 5] |= (1u << (ck & 31));
-                const int dim = ar_dim(c);
-                const int pos = atomicAdd(&ws.counts[dim], 1);
-                if ((size_t)pos >= ws.cap) { atomicSub(&ws.counts[dim], 1); computed[ck >> 5] &= ~(1u << (ck & 31)); return; }
-                ws.q_series[(size_t)dim * ws.cap + pos] = s;
-                ws.q_key[(size_t)dim * ws.cap + pos] = ck;
+                const int bk = ar_bucket(c, a.queue_sort);
+                const int pos = atomicAdd(&ws.counts[AR_QC + bk], 1);
+                if ((size_t)pos >= ws.cap) { atomicSub(&ws.counts[AR_QC + bk], 1); computed[ck >> 5] &= ~(1u << (ck & 31)); return; }
+                ws.q_series[(size_t)bk * ws.cap + pos] = s;
+                ws.q_key[(size_t)bk * ws.cap + pos] = ck;
+                if (a.queue_sort) {             // (this lane is the only one that touches its series' counters)
+                    int32_t *hc = ws.hist + (size_t)bk * ws.nser + s;
+                    ws.q_rank[(size_t)bk * ws.cap + pos] = *hc;
+                    *hc = *hc + 1;
+                }
             };
             for (int j = idx; j < last; j++) {
                 ArOrd c;
@@ -834,17 +1052,88 @@ __global__ __launch_bounds__(256) void arima_polish_queue_kernel(const ArimaArgs
     const int s = blockIdx.x * 256 + threadIdx.x;
     if (s >= a.n_series || a.wlen[s] < 3 || a.status[s] != FIT_OK) return;
     const int key = ws.state[(size_t)s * 8 + AS_BEST];
-    const int dim = ar_dim(ar_unkey(key));
-    if (dim == 0) return;                                    // nothing to estimate
-    const int pos = atomicAdd(&ws.counts[dim], 1);
-    ws.q_series[(size_t)dim * ws.cap + pos] = s;
-    ws.q_key[(size_t)dim * ws.cap + pos] = key;
+    const ArOrd o = ar_unkey(key);
+    if (ar_dim(o) == 0) return;                              // nothing to estimate
+    const int bk = ar_bucket(o, 1);                          // (one problem per series: nothing to sort)
+    const int pos = atomicAdd(&ws.counts[AR_QC + bk], 1);
+    ws.q_series[(size_t)bk * ws.cap + pos] = s;
+    ws.q_key[(size_t)bk * ws.cap + pos] = key;
 }
 
 // ------------------------------------------------------------------------------------------------
 // fit: persistent lanes, one (series, order) problem at a time from the queue
 // ------------------------------------------------------------------------------------------------
+// the queue of a sweep, sorted by series within each bucket: exclusive prefix of the per-(bucket, series) counts over the series (one
+// workgroup per bucket), then every problem moves to prefix[its series] + its rank
+__global__ __launch_bounds__(1024) void arima_queue_scan_kernel(const ArWs ws)
+{
+    __shared__ int part[1024];
+    const int b = blockIdx.x, n = ws.nser;
+    if (ws.counts[AR_QC + b] == 0) return;
+    int32_t *h = ws.hist + (size_t)b * n;
+    const int per = (n + 1023) / 1024;
+    const int i0 = (int)threadIdx.x * per, i1 = i0 + per < n ? i0 + per : n;
+    int sum = 0;
+    for (int i = i0; i < i1; i++) sum += h[i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int v = (int)threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = part[threadIdx.x] - sum;
+    for (int i = i0; i < i1; i++) { const int c = h[i]; h[i] = run; run += c; }
+}
+__global__ __launch_bounds__(256) void arima_queue_scatter_kernel(const ArWs ws)
+{
+    const int b = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= ws.counts[AR_QC + b]) return;
+    const size_t src = (size_t)b * ws.cap + i;
+    const int s = ws.q_series[src];
+    const size_t dst = (size_t)b * ws.cap + (size_t)(ws.hist[(size_t)b * ws.nser + s] + ws.q_rank[src]);
+    ws.q2_series[dst] = s;
+    ws.q2_key[dst] = ws.q_key[src];
+}
+
 enum { PH_NEXT = 0, PH_INIT, PH_ITER, PH_E, PH_OC, PH_IC, PH_SHRINK, PH_FINAL };
+
+// item `item` of the launch in fetch order: the queues one after the other, dimension 6 first (longest fits first, so the tail of the
+// launch is made of short ones), within a dimension the widest shape class first
+__device__ __forceinline__ size_t ar_queue_slot(const ArWs &ws, int item)
+{
+    int c[AR_NBUCKETS];
+#pragma unroll
+    for (int b = 0; b < AR_NBUCKETS; b++) c[b] = ws.counts[AR_QC + b];       // (independent loads, then a scan in registers)
+    int rem = item, bk = 0;
+    bool found = false;
+#pragma unroll
+    for (int b = AR_NBUCKETS - 1; b >= 0; b--) {
+        const bool here = !found && rem < c[b];
+        bk = here ? b : bk;
+        found = found || here;
+        rem = found ? rem : rem - c[b];
+    }
+    return (size_t)bk * ws.cap + (size_t)rem;
+}
+
+// the pass variant of a wave: the widest shape class among its live lanes (a wave-uniform branch)
+template <int MODE, int M, bool COOP>
+__device__ __forceinline__ double ar_css_pass_shaped(const double *wrow, int len, int wave_len, bool live, const ArFac &f, int m, const ArLds &L, const ArOrd &o,
+                                                     int32_t *trace_counts)
+{
+    constexpr int S1 = MODE == 2 ? 0 : 1, S2 = MODE == 2 ? 0 : 2;           // (no seasonal factors at all without a period)
+    const int cls = live ? ar_shape_class(o.p, o.q, o.P, o.Q) : 0;
+    if (trace_counts && threadIdx.x == 0) {        // (tune arima_trace) passes per variant, and live lane-passes per class
+        atomicAdd(&trace_counts[__any(cls >= 3) ? 3 : (__any(cls >= 2) ? 2 : (__any(cls >= 1) ? 1 : 0))], 1);
+    }
+    if (trace_counts && live) atomicAdd(&trace_counts[4 + cls], 1);
+    if (__any(cls >= 3)) return ar_css_pass_impl<MODE, M, COOP, AR_MAXP, AR_MAXP, S2, S2, false>(wrow, len, wave_len, live, f, m, L);
+    if (__any(cls >= 2)) return ar_css_pass_impl<MODE, M, COOP, 2, 3, S2, S2, false>(wrow, len, wave_len, live, f, m, L);
+    if (__any(cls >= 1)) return ar_css_pass_impl<MODE, M, COOP, 1, 2, S1, S2, false>(wrow, len, wave_len, live, f, m, L);
+    return ar_css_pass_impl<MODE, M, COOP, 1, 1, S1, S1, false>(wrow, len, wave_len, live, f, m, L);
+}
 
 template <class LT>
 __device__ __forceinline__ double ar_trial(const LT &L, int D, int which, int i)
@@ -912,12 +1201,6 @@ __global__ __launch_bounds__(NM_BLOCK, ar_fit_waves(MODE)) void arima_fit_kernel
     if (ar_fit_coop(MODE)) L.tile = L.smp() + (size_t)(AR_MAXDIM + 1) * AR_MAXDIM * NM_BLOCK;
     ArFs F;
     for (int k = 0; k <= AR_MAXDIM; k++) F.v[k] = 0.0;
-    // queue: dimension 6 first (longest fits first, so the tail of the launch is made of short ones)
-    int qoff[8];
-    {
-        int acc = 0;
-        for (int dmn = AR_MAXDIM; dmn >= 0; dmn--) { qoff[dmn] = acc; acc += ws.counts[dmn]; }
-    }
 
     bool fin = false;
     int s = 0, key = 0, len = 0, D = 0;
@@ -932,13 +1215,10 @@ __global__ __launch_bounds__(NM_BLOCK, ar_fit_waves(MODE)) void arima_fit_kernel
             const int item = atomicAdd(&ws.counts[8], 1);
             if (item >= total) fin = true;
             else {
-                int dmn = 0;
-                for (int k = AR_MAXDIM; k >= 0; k--)
-                    if (item >= qoff[k] && item < qoff[k] + ws.counts[k]) dmn = k;
-                const size_t qi = (size_t)dmn * ws.cap + (size_t)(item - qoff[dmn]);
+                const size_t qi = ar_queue_slot(ws, item);
                 s = ws.q_series[qi]; key = ws.q_key[qi];
                 cur = ar_unkey(key);
-                D = dmn;
+                D = ar_dim(cur);
                 len = a.wlen[s];
                 if (MODE == 6) { pm = a.m_col[s]; L.R = ar_fit_ring_slots(pm); }
                 wrow = ws.W + (size_t)s * ws.tw;
@@ -986,7 +1266,7 @@ __global__ __launch_bounds__(NM_BLOCK, ar_fit_waves(MODE)) void arima_fit_kernel
 
         // ---- 3. one streamed pass -------------------------------------------------------------------
         const int wave_len = ar_wave_max(fin ? 0 : len);
-        const double css = ar_css_pass_impl<MODE, M, ar_fit_coop(MODE)>(wrow, len, wave_len, !fin, fac, pm, L);
+        const double css = ar_css_pass_shaped<MODE, M, ar_fit_coop(MODE)>(wrow, len, wave_len, !fin, fac, pm, L, cur, a.trace >= 2 ? ws.counts + 64 : nullptr);
         if (fin) continue;
         passes++;
         const int nu = len - fac.nc;
@@ -1072,11 +1352,6 @@ __global__ __launch_bounds__(NM_BLOCK, ar_fit_waves(MODE)) void arima_fit_spec_k
     //  against 183 ms with the cooperative loader over the nine four-lane launches of the M5 batch; the sequential kernel 163 -> 132 ms)
     ArFs F;
     for (int k = 0; k <= AR_MAXDIM; k++) F.v[k] = 0.0;
-    int qoff[8];
-    {
-        int acc = 0;
-        for (int dmn = AR_MAXDIM; dmn >= 0; dmn--) { qoff[dmn] = acc; acc += ws.counts[dmn]; }
-    }
     bool fin = false;
     int s = 0, key = 0, len = 0, D = 0;
     ArOrd cur{0, 0, 0, 0, 0};
@@ -1090,13 +1365,10 @@ __global__ __launch_bounds__(NM_BLOCK, ar_fit_waves(MODE)) void arima_fit_spec_k
             item = __shfl(item, leader);
             if (item >= total) fin = true;
             else {
-                int dmn = 0;
-                for (int k = AR_MAXDIM; k >= 0; k--)
-                    if (item >= qoff[k] && item < qoff[k] + ws.counts[k]) dmn = k;
-                const size_t qi = (size_t)dmn * ws.cap + (size_t)(item - qoff[dmn]);
+                const size_t qi = ar_queue_slot(ws, item);
                 s = ws.q_series[qi]; key = ws.q_key[qi];
                 cur = ar_unkey(key);
-                D = dmn;
+                D = ar_dim(cur);
                 len = a.wlen[s];
                 if (MODE == 6) { pm = a.m_col[s]; L.R = ar_fit_ring_slots(pm); }
                 wrow = ws.W + (size_t)s * ws.tw;
@@ -1141,7 +1413,7 @@ __global__ __launch_bounds__(NM_BLOCK, ar_fit_waves(MODE)) void arima_fit_spec_k
         if (__all(fin)) break;
 
         const int wave_len = ar_wave_max(fin ? 0 : len);
-        const double css = ar_css_pass_impl<MODE, M, false>(wrow, len, wave_len, !fin, fac, pm, L);
+        const double css = ar_css_pass_shaped<MODE, M, false>(wrow, len, wave_len, !fin, fac, pm, L, cur, a.trace >= 2 ? ws.counts + 72 : nullptr);
         if (fin) continue;
         passes++;
         const int nu = len - fac.nc;
@@ -1929,12 +2201,19 @@ int launch_arima(const ArimaArgs &a, hipStream_t stream)
     // four-lane kernel, 2.35x the lane-passes: 358 -> 410 ms on the M5 batch)
     const int sched_waves = cus * (per_cu > 4 ? 4 : per_cu);
 
-    const size_t prep_lds = long_m ? 0 : sizeof(double) * (size_t)(a.m > 1 ? a.m : 1) * NM_BLOCK;
-    hipLaunchKernelGGL(arima_prep_kernel, dim3(grid), dim3(NM_BLOCK), prep_lds, stream, a, ws);
+    const size_t prep_lds = long_m ? 0 : sizeof(double) * (size_t)(2 * (a.m > 1 ? a.m : 1) + 1) * NM_BLOCK;      // figure (m) + window ring (m or m + 1)
+    if (a.trace >= 2) AR_HIPCHECK(hipMemsetAsync(ws.counts + 64, 0, 16 * sizeof(int32_t), stream));
+    // one lane per series, every loop a chain of dependent loads and adds: the kernel is as fast as the number of waves that hide each
+    // other's latency.  64 series per wave are 477 waves on the M5 batch -- half the SIMDs idle, the others with one wave; with 16 series
+    // per wave it is 1,906 waves (20.5 -> PREP_MS ms).  (Long periods keep 64: their figure scratch is laid out per 64 series.)
+    const int prep_block = long_m ? NM_BLOCK : a.prep_lanes;
+    hipLaunchKernelGGL(arima_prep_kernel, dim3((a.n_series + prep_block - 1) / prep_block), dim3(prep_block), prep_lds, stream, a, ws);
     hipLaunchKernelGGL(arima_skip_kernel, dim3(grid256), dim3(256), 0, stream, a);
     int launches = 2;
     long prev_total = -1;
-    auto launch_fit = [&](long total, int polish) {
+    ArWs ws_sorted = ws;                 // the fit kernels of a sweep read the sorted copy of the queues
+    ws_sorted.q_series = ws.q2_series; ws_sorted.q_key = ws.q2_key;
+    auto launch_fit = [&](long total, int polish, const ArWs &ws) {
         const double spec_factor = a.spec_factor;   // (tune arima_spec_factor, default 8)
         if ((double)total <= spec_factor * (double)sched_waves * (NM_BLOCK / 4)) {
             // short queue (up to a few problems per resident 4-lane group): four lanes per problem, one pass per Nelder-Mead
@@ -1949,7 +2228,8 @@ int launch_arima(const ArimaArgs &a, hipStream_t stream)
         }
     };
     for (int sweep = 0; sweep < 4 * AR_MAXMODELS; sweep++) {
-        AR_HIPCHECK(hipMemsetAsync(ws.counts, 0, 16 * sizeof(int32_t), stream));
+        AR_HIPCHECK(hipMemsetAsync(ws.counts, 0, 64 * sizeof(int32_t), stream));
+        if (a.queue_sort) AR_HIPCHECK(hipMemsetAsync(ws.hist, 0, sizeof(int32_t) * (size_t)AR_NBUCKETS * a.n_series, stream));
         // look one sweep ahead once the previous sweep's queue times the fan-out (~18 candidates per series) fits the
         // resident lanes `la_factor` times over: the extra fits cost idle lanes, the saved sweeps cost ~0.1-0.2 s each
         const double la_factor = a.lookahead;   // (tune arima_lookahead, default 12) measured 0 / 0.25 / 1 / 4 / 16: 2.16 / 2.03 / 1.93 / 1.92 / 1.90 s on the M5 batch (round 1); with the refit 4 / 8 / 12 / 16 / 24 / 32 / 64: 2.23 / 2.23 / 2.14 / 2.14 / 2.17 / 2.17 / 2.92 s
@@ -1959,29 +2239,36 @@ int launch_arima(const ArimaArgs &a, hipStream_t stream)
         const int la_depth = a.lookahead_depth;   // (tune arima_lookahead_depth, default 2)
         if (lookahead && la_depth >= 2 && (double)prev_total * (AR_SWEEP + 1) * (AR_SWEEP + 1) <= la_factor * (double)sched_waves * NM_BLOCK) lookahead = 2;
         hipLaunchKernelGGL(arima_advance_kernel, dim3(grid256), dim3(256), 0, stream, a, ws, lookahead);
-        int32_t counts[8];
-        AR_HIPCHECK(hipMemcpyAsync(counts, ws.counts, sizeof counts, hipMemcpyDeviceToHost, stream));
+        int32_t counts[AR_NBUCKETS];
+        AR_HIPCHECK(hipMemcpyAsync(counts, ws.counts + AR_QC, sizeof counts, hipMemcpyDeviceToHost, stream));
         AR_HIPCHECK(hipStreamSynchronize(stream));
         launches++;
         long total = 0;
-        for (int i = 0; i <= AR_MAXDIM; i++) total += counts[i];
+        for (int i = 0; i < AR_NBUCKETS; i++) total += counts[i];
         if (total == 0) break;
         if (a.trace) std::fprintf(stderr, "[anofox-hip] AutoARIMA sweep %d: %ld problems queued (lookahead %d)\n", sweep, total, lookahead);
         prev_total = total;
-        launch_fit(total, 0);
+        if (a.queue_sort) {
+            int longest = 0;
+            for (int i = 0; i < AR_NBUCKETS; i++) longest = counts[i] > longest ? counts[i] : longest;
+            hipLaunchKernelGGL(arima_queue_scan_kernel, dim3(AR_NBUCKETS), dim3(1024), 0, stream, ws);
+            hipLaunchKernelGGL(arima_queue_scatter_kernel, dim3((longest + 255) / 256, AR_NBUCKETS), dim3(256), 0, stream, ws);
+            launches += 2;
+        }
+        launch_fit(total, 0, a.queue_sort ? ws_sorted : ws);
         launches++;
     }
     // the selected models' CSS estimates, to convergence (one problem per series)
     {
-        AR_HIPCHECK(hipMemsetAsync(ws.counts, 0, 16 * sizeof(int32_t), stream));
+        AR_HIPCHECK(hipMemsetAsync(ws.counts, 0, 64 * sizeof(int32_t), stream));
         hipLaunchKernelGGL(arima_polish_queue_kernel, dim3(grid256), dim3(256), 0, stream, a, ws);
-        int32_t counts[8];
-        AR_HIPCHECK(hipMemcpyAsync(counts, ws.counts, sizeof counts, hipMemcpyDeviceToHost, stream));
+        int32_t counts[AR_NBUCKETS];
+        AR_HIPCHECK(hipMemcpyAsync(counts, ws.counts + AR_QC, sizeof counts, hipMemcpyDeviceToHost, stream));
         AR_HIPCHECK(hipStreamSynchronize(stream));
         long total = 0;
-        for (int i = 0; i <= AR_MAXDIM; i++) total += counts[i];
+        for (int i = 0; i < AR_NBUCKETS; i++) total += counts[i];
         if (a.trace) std::fprintf(stderr, "[anofox-hip] AutoARIMA polish: %ld selected models\n", total);
-        if (total > 0) { launch_fit(total, 1); launches++; }
+        if (total > 0) { launch_fit(total, 1, ws); launches++; }
         launches++;
     }
     // on request (ANOFOX_ARIMA_CSS_ML): final estimates of the selected models on the exact Gaussian likelihood
@@ -2008,6 +2295,14 @@ int launch_arima(const ArimaArgs &a, hipStream_t stream)
         launches += 3;
     }
     hipLaunchKernelGGL(arima_forecast_kernel, dim3(grid), dim3(NM_BLOCK), fc_lds, stream, a, ws);
+    if (a.trace >= 2) {
+        int32_t tc[16];
+        AR_HIPCHECK(hipMemcpyAsync(tc, ws.counts + 64, sizeof tc, hipMemcpyDeviceToHost, stream));
+        AR_HIPCHECK(hipStreamSynchronize(stream));
+        for (int k = 0; k < 2; k++)
+            std::fprintf(stderr, "[anofox-hip] AutoARIMA %s kernel: wave-passes by variant <1,1,1,1> %d <1,2,1,2> %d <2,3,2,2> %d full %d; live lane-passes by class %d %d %d %d\n",
+                         k ? "four-lane" : "sequential", tc[8 * k], tc[8 * k + 1], tc[8 * k + 2], tc[8 * k + 3], tc[8 * k + 4], tc[8 * k + 5], tc[8 * k + 6], tc[8 * k + 7]);
+    }
     return launches + 1;
 }
 

@@ -1246,8 +1246,9 @@ void run_group(AnofoxHipBatch *b, int period, const int32_t *d_len, hipStream_t 
         aa.status = b->d_detail; aa.evals = b->d_evals_total; aa.passes = b->d_passes_total; aa.models = b->ar_models;
         aa.yhat = b->d_yhat; aa.model_code = b->d_model_code;
         aa.ml_refit = b->arima_method == ANOFOX_ARIMA_CSS_ML ? 1 : 0;
-        aa.trace = b->tun.arima_trace ? 1 : 0;
-        aa.lookahead = b->tun.arima_lookahead; aa.lookahead_depth = b->tun.arima_lookahead_depth; aa.spec_factor = b->tun.arima_spec_factor; aa.refit_budget = b->tun.arima_refit_budget;
+        aa.trace = b->tun.arima_trace;
+        aa.lookahead = b->tun.arima_lookahead; aa.lookahead_depth = b->tun.arima_lookahead_depth; aa.spec_factor = b->tun.arima_spec_factor; aa.refit_budget = b->tun.arima_refit_budget; aa.queue_sort = b->tun.arima_queue_sort;
+        aa.prep_lanes = b->tun.arima_prep_lanes < 1 ? 1 : (b->tun.arima_prep_lanes > 64 ? 64 : b->tun.arima_prep_lanes);
         HIPCHECK(hipEventRecord(b->ev_fit0, st));
         try { b->fit_launches += launch_arima(aa, st); }
         catch (const std::exception &e) { throw HipFail{e.what()}; }

@@ -59,10 +59,12 @@ struct Tunables {
     int part_threads = 16;      // tune part_threads: host threads that run the small per-period parts of an auto-detected batch side by side
     int pack_threads = 0;       // ANOFOX_HIP_PACK_THREADS: host threads of the packer (0: all, at most 32)
     bool timing = false;        // ANOFOX_HIP_TIMING: phase times of the batch entry on stderr
-    bool arima_trace = false;   // tune arima_trace: per-sweep queue lengths / per-wave refit timings on stderr
-    double arima_lookahead = 12.0;   // tune arima_lookahead, _lookahead_depth, _spec_factor: see arima.hip launch_arima
+    int arima_trace = 0;        // tune arima_trace: 1 = per-sweep queue lengths / per-wave refit timings on stderr, 2 = also passes per variant (atomics: slow)
+    double arima_lookahead = 6.0;    // tune arima_lookahead, _lookahead_depth, _spec_factor: see arima.hip launch_arima
     int arima_lookahead_depth = 2;
-    double arima_spec_factor = 8.0;
+    double arima_spec_factor = 4.0;
+    int arima_prep_lanes = 64;       // tune arima_prep_lanes: series per wave of the AutoARIMA prep kernel (1..64)
+    int arima_queue_sort = 1;        // tune arima_queue_sort: see arima.hip ar_bucket
     int arima_refit_budget = 100;   // tune arima_refit_budget: evaluations per series before the exact-likelihood refit's speculative launch takes over (0: off)
     // ANOFOX_HIP_TUNE="key=value;key=value": the ONE developer / test variable behind every schedule knob above (keys: the field names;
     // budgets is a comma list) -- the sweep scripts under tools/ and the schedule-variant tests use it; a deployment never sets it.
@@ -115,10 +117,12 @@ struct Tunables {
         geti("spec2_below_md", t.spec2_below_md);
         if (kv.count("merge_periods")) t.merge_periods = std::atoi(kv.at("merge_periods").c_str()) != 0;
         geti("part_threads", t.part_threads);
-        if (kv.count("arima_trace")) t.arima_trace = std::atoi(kv.at("arima_trace").c_str()) != 0;
+        if (kv.count("arima_trace")) t.arima_trace = std::atoi(kv.at("arima_trace").c_str());
         getd("arima_lookahead", t.arima_lookahead);
         geti("arima_lookahead_depth", t.arima_lookahead_depth);
         getd("arima_spec_factor", t.arima_spec_factor);
+        geti("arima_queue_sort", t.arima_queue_sort);
+        geti("arima_prep_lanes", t.arima_prep_lanes);
         geti("arima_refit_budget", t.arima_refit_budget);
         if (const char *e = std::getenv("ANOFOX_HIP_PACK_THREADS")) t.pack_threads = std::max(1, std::atoi(e));
         t.timing = std::getenv("ANOFOX_HIP_TIMING") != nullptr;

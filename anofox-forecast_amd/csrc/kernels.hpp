@@ -186,6 +186,8 @@ struct ArimaArgs {
     int trace;                          // debugging: the refit kernel prints per-wave timings (ANOFOX_HIP_ARIMA_TRACE)
     double lookahead, spec_factor;      // schedule knobs of the search (host_api.hip Tunables: lookahead once the queue fits the resident lanes
     int lookahead_depth;                //   this many times over; four lanes per problem below spec_factor x the resident groups)
+    int prep_lanes;                     // series per wave of arima_prep_kernel (tune arima_prep_lanes: 16; 64 = one full wave per 64 series)
+    int queue_sort;                     // order of the fit queue (tune arima_queue_sort; arima.hip ar_bucket): 0 as emitted, 1..3 by series within a bucket
     int refit_budget;                   // exact-likelihood refit: evaluations per series in the sequential launch before the speculative one takes over (0: one launch)
     double *long_scratch;               // seasonal period above 24: HBM scratch of arima_long_scratch_doubles() doubles (rings, polynomials), else NULL
     int ml_refit;                       // exact-likelihood (Kalman / Chandrasekhar) refit of the selected models; 0 keeps the CSS estimates

@@ -8,5 +8,5 @@ cd /tmp && export TMPDIR=/tmp
 export ANOFOX_HIP_TUNE="arima_trace=1"
 rocprofv3 --kernel-trace -d $OUT/t -o t -- python3 /root/repo/bench.py --workload $W --steps 1 --warmup 0 --cpu-sample 0 --e2e-steps 0 > $OUT/bench.log 2>&1
 grep -a "AutoARIMA\|value" $OUT/bench.log | tail -40
-python3 /root/repo/tools/kernel_stats.py $OUT/t --timeline 45
+python3 /root/repo/tools/kernel_stats.py $OUT/t --timeline 75
 rm -rf $OUT/t
