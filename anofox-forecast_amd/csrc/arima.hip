@@ -61,16 +61,23 @@ __device__ __forceinline__ int ar_wave_max(int v)
 struct ArOrd { int p, q, P, Q, c; };
 __device__ __forceinline__ int ar_dim(const ArOrd &o) { return o.p + o.q + o.P + o.Q + o.c; }
 __device__ __forceinline__ int ar_key(const ArOrd &o) { return (((o.p * 6 + o.q) * 3 + o.P) * 3 + o.Q) * 2 + o.c; }
-// Shape classes of the CSS pass (ar_css_pass_impl NP, NQ, NSP, NSQ): class c runs the variant whose bounds are row c -- every class is
-// covered by the rows after it.  Chosen on the candidates the stepwise search of M5-like series fits (oracle built with -DARIMA_TRACE, 300
-// series, 498k evaluations): fused multiply-adds per step 15 -> 6.7 on average with these four, 8.4 with two, 4.05 if every order had its own.
-constexpr int AR_NCLS = 4;
+// Shape classes of the CSS pass (ar_css_pass_impl NP, NQ, NSP, NSQ): a wave runs the cheapest variant that covers its live lanes
+// (ar_css_pass_shaped).  Chosen on the candidates the stepwise search of M5-like series fits (oracle built with -DARIMA_TRACE, 300
+// series, 498k evaluations): fused multiply-adds per step 15 -> 6.7 on average with the four seasonal rows, 4.05 if every order had its
+// own.  The two rows WITHOUT seasonal factors also drop the ring of seasonal lags -- in the HBM-ring variants of the long periods that is
+// 48 of the 56 bytes a step moves.
+constexpr int AR_NCLS = 6;
 __host__ __device__ inline int ar_shape_class(int p, int q, int P, int Q)
 {
-    if (p <= 1 && q <= 1 && P <= 1 && Q <= 1) return 0;         // pass <1, 1, 1, 1>:  5 per step
-    if (p <= 1 && q <= 2 && P <= 1 && Q <= 2) return 1;         // pass <1, 2, 1, 2>:  7
-    if (p <= 2 && q <= 3) return 2;                             // pass <2, 3, 2, 2>: 10
-    return 3;                                                   // pass <5, 5, 2, 2>: 15
+    if (P == 0 && Q == 0) {
+        if (p <= 1 && q <= 1) return 0;                         // pass <1, 1, 0, 0>:  3 per step, no ring
+        if (p <= 2 && q <= 3) return 1;                         // pass <2, 3, 0, 0>:  6, no ring
+        return 5;
+    }
+    if (p <= 1 && q <= 1 && P <= 1 && Q <= 1) return 2;         // pass <1, 1, 1, 1>:  5
+    if (p <= 1 && q <= 2 && P <= 1 && Q <= 2) return 3;         // pass <1, 2, 1, 2>:  7
+    if (p <= 2 && q <= 3) return 4;                             // pass <2, 3, 2, 2>: 10
+    return 5;                                                   // pass <5, 5, 2, 2>: 15
 }
 // problem queues: one per (dimension, shape class), so that the 64 (or 16) problems a wave starts with share a pass variant; fetched
 // longest first (dimension, then class, descending: the tail of a launch is made of the cheap problems)
@@ -289,6 +296,8 @@ struct ArBlockLen<0> { static constexpr int R = 0; static constexpr int value = 
 // the measured best: ONE revolution brings the weekly fit kernels down to 256 registers and two waves per SIMD (371 registers
 // before; 17 doubles of spill), and the M5 batch then takes 381 ms against 358 ms -- the pass issues fp64 operations 68 % of the time
 // already (tools/pmc_arima.sh), a second wave only adds its spill traffic.  ar_fit_waves / AR_MODE3_REVS = 2 / 1 rebuilds that variant.
+// Round 4, after the pass variants: tried again, with the simplex in an HBM scratch so that LDS would allow the second wave -- 258 -> 339 ms
+// (the Nelder-Mead bookkeeping between passes turns into L2 round trips, and the 14-step block adds loop overhead); reverted.
 constexpr int AR_MODE3_REVS = 2;
 // COOP (fit kernels, where LDS has room): the rows of a block are fetched COOPERATIVELY.  The lanes of a fit wave hold unrelated
 // series, so "every lane streams its own row" makes each 128-bit load instruction touch 64 different cache lines: rocprofv3 showed the
@@ -650,7 +659,7 @@ struct ArWs {
     double *best_aicc;    // [n]
     int32_t *state;       // [n x 8] stage, idx, base key, best key, have, improved, n_models, fin
     int32_t *q_series, *q_key;   // [AR_NBUCKETS x cap] problem queues by (dimension, shape class)
-    int32_t *counts;      // [64] AR_QC + bucket: queue lengths, 8 fetch cursor, 9..13 refit class cursors, 16..20 refit class sizes,
+    int32_t *counts;      // [128] AR_QC + bucket: queue lengths (42), 8 fetch cursor, 96.. trace counters, 9..13 refit class cursors, 16..20 refit class sizes,
                           //      21..25 class cursors of the refit's second (speculative) launch, 26 series parked for it
     int32_t *q_rank;      // [AR_NBUCKETS x cap] rank of a queued problem among its series' problems of the same bucket (emission order)
     int32_t *q2_series, *q2_key;   // the queues sorted by series within a bucket (arima_queue_scan / _scatter_kernel)
@@ -677,7 +686,7 @@ struct ArWs {
         state = (int32_t *)take(sizeof(int32_t) * (size_t)n * 8);
         q_series = (int32_t *)take(sizeof(int32_t) * AR_NBUCKETS * cap);
         q_key = (int32_t *)take(sizeof(int32_t) * AR_NBUCKETS * cap);
-        counts = (int32_t *)take(sizeof(int32_t) * 96);
+        counts = (int32_t *)take(sizeof(int32_t) * 128);
         q_rank = (int32_t *)take(sizeof(int32_t) * AR_NBUCKETS * cap);
         q2_series = (int32_t *)take(sizeof(int32_t) * AR_NBUCKETS * cap);
         q2_key = (int32_t *)take(sizeof(int32_t) * AR_NBUCKETS * cap);
@@ -1118,21 +1127,27 @@ __device__ __forceinline__ size_t ar_queue_slot(const ArWs &ws, int item)
     return (size_t)bk * ws.cap + (size_t)rem;
 }
 
-// the pass variant of a wave: the widest shape class among its live lanes (a wave-uniform branch)
+// the pass variant of a wave: the cheapest one that covers the orders of its live lanes (wave-uniform branches)
 template <int MODE, int M, bool COOP>
 __device__ __forceinline__ double ar_css_pass_shaped(const double *wrow, int len, int wave_len, bool live, const ArFac &f, int m, const ArLds &L, const ArOrd &o,
                                                      int32_t *trace_counts)
 {
     constexpr int S1 = MODE == 2 ? 0 : 1, S2 = MODE == 2 ? 0 : 2;           // (no seasonal factors at all without a period)
-    const int cls = live ? ar_shape_class(o.p, o.q, o.P, o.Q) : 0;
-    if (trace_counts && threadIdx.x == 0) {        // (tune arima_trace) passes per variant, and live lane-passes per class
-        atomicAdd(&trace_counts[__any(cls >= 3) ? 3 : (__any(cls >= 2) ? 2 : (__any(cls >= 1) ? 1 : 0))], 1);
-    }
-    if (trace_counts && live) atomicAdd(&trace_counts[4 + cls], 1);
-    if (__any(cls >= 3)) return ar_css_pass_impl<MODE, M, COOP, AR_MAXP, AR_MAXP, S2, S2, false>(wrow, len, wave_len, live, f, m, L);
-    if (__any(cls >= 2)) return ar_css_pass_impl<MODE, M, COOP, 2, 3, S2, S2, false>(wrow, len, wave_len, live, f, m, L);
-    if (__any(cls >= 1)) return ar_css_pass_impl<MODE, M, COOP, 1, 2, S1, S2, false>(wrow, len, wave_len, live, f, m, L);
-    return ar_css_pass_impl<MODE, M, COOP, 1, 1, S1, S1, false>(wrow, len, wave_len, live, f, m, L);
+    const int p = live ? o.p : 0, q = live ? o.q : 0, P = live ? o.P : 0, Q = live ? o.Q : 0;
+    const bool seas = MODE != 2 && __any(P + Q > 0);
+    const bool pq11 = !__any(p > 1 || q > 1), pq12 = !__any(p > 1 || q > 2), pq23 = !__any(p > 2 || q > 3);
+    const bool s11 = !__any(P > 1 || Q > 1), s12 = !__any(P > 1);
+    int v;                                                                   // 0..5: the rows of ar_shape_class
+    if (!seas) v = pq11 ? 0 : (pq23 ? 1 : 5);
+    else v = (pq11 && s11) ? 2 : ((pq12 && s12) ? 3 : (pq23 ? 4 : 5));
+    if (trace_counts && threadIdx.x == 0) atomicAdd(&trace_counts[v], 1);   // (tune arima_trace = 2) wave-passes per variant
+    if (trace_counts && live) atomicAdd(&trace_counts[8 + ar_shape_class(o.p, o.q, o.P, o.Q)], 1);      // ... and live lane-passes per class
+    if (v == 0) return ar_css_pass_impl<MODE, M, COOP, 1, 1, 0, 0, false>(wrow, len, wave_len, live, f, m, L);
+    if (v == 1) return ar_css_pass_impl<MODE, M, COOP, 2, 3, 0, 0, false>(wrow, len, wave_len, live, f, m, L);
+    if (v == 2) return ar_css_pass_impl<MODE, M, COOP, 1, 1, S1, S1, false>(wrow, len, wave_len, live, f, m, L);
+    if (v == 3) return ar_css_pass_impl<MODE, M, COOP, 1, 2, S1, S2, false>(wrow, len, wave_len, live, f, m, L);
+    if (v == 4) return ar_css_pass_impl<MODE, M, COOP, 2, 3, S2, S2, false>(wrow, len, wave_len, live, f, m, L);
+    return ar_css_pass_impl<MODE, M, COOP, AR_MAXP, AR_MAXP, S2, S2, false>(wrow, len, wave_len, live, f, m, L);
 }
 
 template <class LT>
@@ -1189,7 +1204,7 @@ __device__ __forceinline__ void ar_sort(const LT &L, FT &F, int D)
 constexpr bool ar_fit_coop(int mode) { return mode == 3 || mode == 2 || mode == 5 || mode == 6; }
 constexpr int ar_fit_waves(int mode) { return (mode == 3 && AR_MODE3_REVS == 1) ? 2 : 1; }
 template <int MODE, int M>
-__global__ __launch_bounds__(NM_BLOCK, ar_fit_waves(MODE)) void arima_fit_kernel(const ArimaArgs a, const ArWs ws, const int total, const int polish)
+__global__ __launch_bounds__(NM_BLOCK, ar_fit_waves(MODE)) void arima_fit_kernel(const ArimaArgs a, const ArWs ws, const int first, const int total, const int polish)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int m = a.m;
@@ -1212,7 +1227,7 @@ __global__ __launch_bounds__(NM_BLOCK, ar_fit_waves(MODE)) void arima_fit_kernel
     for (;;) {
         // ---- 1. next problem of this lane ------------------------------------------------------------
         if (!fin && ph == PH_NEXT) {
-            const int item = atomicAdd(&ws.counts[8], 1);
+            const int item = first + atomicAdd(&ws.counts[8], 1);           // (items first .. total - 1 of the queue are this launch's)
             if (item >= total) fin = true;
             else {
                 const size_t qi = ar_queue_slot(ws, item);
@@ -1266,7 +1281,7 @@ __global__ __launch_bounds__(NM_BLOCK, ar_fit_waves(MODE)) void arima_fit_kernel
 
         // ---- 3. one streamed pass -------------------------------------------------------------------
         const int wave_len = ar_wave_max(fin ? 0 : len);
-        const double css = ar_css_pass_shaped<MODE, M, ar_fit_coop(MODE)>(wrow, len, wave_len, !fin, fac, pm, L, cur, a.trace >= 2 ? ws.counts + 64 : nullptr);
+        const double css = ar_css_pass_shaped<MODE, M, ar_fit_coop(MODE)>(wrow, len, wave_len, !fin, fac, pm, L, cur, a.trace >= 2 ? ws.counts + 96 : nullptr);
         if (fin) continue;
         passes++;
         const int nu = len - fac.nc;
@@ -1339,7 +1354,7 @@ __global__ __launch_bounds__(NM_BLOCK, ar_fit_waves(MODE)) void arima_fit_kernel
 // fit.  An iteration costs one pass instead of ~1.7: the critical path of a sweep's slowest fit shortens accordingly.
 // The simplex lives in the group leader's LDS column; all four lanes run the same bookkeeping on it (identical values).
 template <int MODE, int M>
-__global__ __launch_bounds__(NM_BLOCK, ar_fit_waves(MODE)) void arima_fit_spec_kernel(const ArimaArgs a, const ArWs ws, const int total, const int polish)
+__global__ __launch_bounds__(NM_BLOCK, ar_fit_waves(MODE)) void arima_fit_spec_kernel(const ArimaArgs a, const ArWs ws, const int first, const int total, const int polish)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int m = a.m;
@@ -1361,7 +1376,7 @@ __global__ __launch_bounds__(NM_BLOCK, ar_fit_waves(MODE)) void arima_fit_spec_k
     for (;;) {
         if (!fin && ph == PH_NEXT) {
             int item = 0;
-            if (g == 0) item = atomicAdd(&ws.counts[8], 1);
+            if (g == 0) item = first + atomicAdd(&ws.counts[8], 1);
             item = __shfl(item, leader);
             if (item >= total) fin = true;
             else {
@@ -1413,7 +1428,7 @@ __global__ __launch_bounds__(NM_BLOCK, ar_fit_waves(MODE)) void arima_fit_spec_k
         if (__all(fin)) break;
 
         const int wave_len = ar_wave_max(fin ? 0 : len);
-        const double css = ar_css_pass_shaped<MODE, M, false>(wrow, len, wave_len, !fin, fac, pm, L, cur, a.trace >= 2 ? ws.counts + 72 : nullptr);
+        const double css = ar_css_pass_shaped<MODE, M, false>(wrow, len, wave_len, !fin, fac, pm, L, cur, a.trace >= 2 ? ws.counts + 112 : nullptr);
         if (fin) continue;
         passes++;
         const int nu = len - fac.nc;
@@ -2174,7 +2189,7 @@ int launch_arima(const ArimaArgs &a, hipStream_t stream)
     if (long_m && !a.long_scratch) throw std::runtime_error("AutoARIMA: a period above the LDS limit needs the scratch area");
     const size_t fc_lds = long_m ? 0 : sizeof(double) * ar_fc_scratch_doubles(a.m);
     // the pass variant of the period (ar_css_pass: the fit kernels' ring has 2 m + 4 slots)
-    typedef void (*fit_fn_t)(const ArimaArgs, const ArWs, const int, const int);
+    typedef void (*fit_fn_t)(const ArimaArgs, const ArWs, const int, const int, const int);
     fit_fn_t fit_seq, fit_spec;
     int fit_waves = 1;
     if (a.m == 7) { fit_seq = arima_fit_kernel<3, 7>; fit_spec = arima_fit_spec_kernel<3, 7>; fit_waves = ar_fit_waves(3); }
@@ -2202,7 +2217,7 @@ int launch_arima(const ArimaArgs &a, hipStream_t stream)
     const int sched_waves = cus * (per_cu > 4 ? 4 : per_cu);
 
     const size_t prep_lds = long_m ? 0 : sizeof(double) * (size_t)(2 * (a.m > 1 ? a.m : 1) + 1) * NM_BLOCK;      // figure (m) + window ring (m or m + 1)
-    if (a.trace >= 2) AR_HIPCHECK(hipMemsetAsync(ws.counts + 64, 0, 16 * sizeof(int32_t), stream));
+    if (a.trace >= 2) AR_HIPCHECK(hipMemsetAsync(ws.counts + 96, 0, 32 * sizeof(int32_t), stream));
     // one lane per series, every loop a chain of dependent loads and adds: the kernel is as fast as the number of waves that hide each
     // other's latency.  64 series per wave are 477 waves on the M5 batch -- half the SIMDs idle, the others with one wave; with 16 series
     // per wave it is 1,906 waves (20.5 -> PREP_MS ms).  (Long periods keep 64: their figure scratch is laid out per 64 series.)
@@ -2213,22 +2228,34 @@ int launch_arima(const ArimaArgs &a, hipStream_t stream)
     long prev_total = -1;
     ArWs ws_sorted = ws;                 // the fit kernels of a sweep read the sorted copy of the queues
     ws_sorted.q_series = ws.q2_series; ws_sorted.q_key = ws.q2_key;
+    // A launch runs persistent lanes over the whole queue -- and holds every SIMD's registers while it does.  Alone on the device that is
+    // what we want; next to other AutoARIMA runs (the parts of a call with detected periods, one per period, each a chain of ~40 short
+    // launches with host round trips between them) it is a convoy: the other chains' advance / sort / forecast kernels -- a few waves,
+    // microseconds of work -- waited 28 ms on average (163 ms at most) for a long launch of somebody else to END (kernel trace of the
+    // default call shape, round 4).  With company, a launch therefore takes `shared_chunk_rounds` rounds of the resident lanes at most
+    // and the queue goes out in several launches: waves retire every few milliseconds and the other streams get in.
     auto launch_fit = [&](long total, int polish, const ArWs &ws) {
-        const double spec_factor = a.spec_factor;   // (tune arima_spec_factor, default 8)
-        if ((double)total <= spec_factor * (double)sched_waves * (NM_BLOCK / 4)) {
-            // short queue (up to a few problems per resident 4-lane group): four lanes per problem, one pass per Nelder-Mead
-            // iteration -- such a launch is bound by its slowest fit, not by throughput
-            long waves = (total * 4 + NM_BLOCK - 1) / NM_BLOCK;
+        const double spec_factor = a.spec_factor;   // (tune arima_spec_factor, default 4)
+        const bool spec = (double)total <= spec_factor * (double)sched_waves * (NM_BLOCK / 4);
+        // short queue (up to a few problems per resident 4-lane group): four lanes per problem, one pass per Nelder-Mead
+        // iteration -- such a launch is bound by its slowest fit, not by throughput
+        const long per_wave = spec ? NM_BLOCK / 4 : NM_BLOCK;
+        const bool shared = a.shared_chunk_rounds > 0.0 && a.concurrent && a.concurrent->load() > 1;
+        long chunk = shared ? (long)(a.shared_chunk_rounds * (double)max_waves * (double)per_wave) : total;
+        if (chunk < per_wave) chunk = per_wave;
+        int n = 0;
+        for (long first = 0; first < total; first += chunk) {
+            const long end = first + chunk < total ? first + chunk : total;
+            if (first > 0) AR_HIPCHECK(hipMemsetAsync(ws.counts + 8, 0, sizeof(int32_t), stream));
+            long waves = (end - first + per_wave - 1) / per_wave;
             if (waves > max_waves) waves = max_waves;
-            hipLaunchKernelGGL(fit_spec, dim3((int)waves), dim3(NM_BLOCK), fit_lds, stream, a, ws, (int)total, polish);
-        } else {
-            const long waves = (total + NM_BLOCK - 1) / NM_BLOCK;
-            const int fit_grid = (int)(waves < max_waves ? waves : max_waves);
-            hipLaunchKernelGGL(fit_seq, dim3(fit_grid), dim3(NM_BLOCK), fit_lds, stream, a, ws, (int)total, polish);
+            hipLaunchKernelGGL(spec ? fit_spec : fit_seq, dim3((int)waves), dim3(NM_BLOCK), fit_lds, stream, a, ws, (int)first, (int)end, polish);
+            n++;
         }
+        return n;
     };
     for (int sweep = 0; sweep < 4 * AR_MAXMODELS; sweep++) {
-        AR_HIPCHECK(hipMemsetAsync(ws.counts, 0, 64 * sizeof(int32_t), stream));
+        AR_HIPCHECK(hipMemsetAsync(ws.counts, 0, 96 * sizeof(int32_t), stream));
         if (a.queue_sort) AR_HIPCHECK(hipMemsetAsync(ws.hist, 0, sizeof(int32_t) * (size_t)AR_NBUCKETS * a.n_series, stream));
         // look one sweep ahead once the previous sweep's queue times the fan-out (~18 candidates per series) fits the
         // resident lanes `la_factor` times over: the extra fits cost idle lanes, the saved sweeps cost ~0.1-0.2 s each
@@ -2255,12 +2282,11 @@ int launch_arima(const ArimaArgs &a, hipStream_t stream)
             hipLaunchKernelGGL(arima_queue_scatter_kernel, dim3((longest + 255) / 256, AR_NBUCKETS), dim3(256), 0, stream, ws);
             launches += 2;
         }
-        launch_fit(total, 0, a.queue_sort ? ws_sorted : ws);
-        launches++;
+        launches += launch_fit(total, 0, a.queue_sort ? ws_sorted : ws);
     }
     // the selected models' CSS estimates, to convergence (one problem per series)
     {
-        AR_HIPCHECK(hipMemsetAsync(ws.counts, 0, 64 * sizeof(int32_t), stream));
+        AR_HIPCHECK(hipMemsetAsync(ws.counts, 0, 96 * sizeof(int32_t), stream));
         hipLaunchKernelGGL(arima_polish_queue_kernel, dim3(grid256), dim3(256), 0, stream, a, ws);
         int32_t counts[AR_NBUCKETS];
         AR_HIPCHECK(hipMemcpyAsync(counts, ws.counts + AR_QC, sizeof counts, hipMemcpyDeviceToHost, stream));
@@ -2268,7 +2294,7 @@ int launch_arima(const ArimaArgs &a, hipStream_t stream)
         long total = 0;
         for (int i = 0; i < AR_NBUCKETS; i++) total += counts[i];
         if (a.trace) std::fprintf(stderr, "[anofox-hip] AutoARIMA polish: %ld selected models\n", total);
-        if (total > 0) { launch_fit(total, 1, ws); launches++; }
+        if (total > 0) launches += launch_fit(total, 1, ws);
         launches++;
     }
     // on request (ANOFOX_ARIMA_CSS_ML): final estimates of the selected models on the exact Gaussian likelihood
@@ -2296,12 +2322,14 @@ int launch_arima(const ArimaArgs &a, hipStream_t stream)
     }
     hipLaunchKernelGGL(arima_forecast_kernel, dim3(grid), dim3(NM_BLOCK), fc_lds, stream, a, ws);
     if (a.trace >= 2) {
-        int32_t tc[16];
-        AR_HIPCHECK(hipMemcpyAsync(tc, ws.counts + 64, sizeof tc, hipMemcpyDeviceToHost, stream));
+        int32_t tc[32];
+        AR_HIPCHECK(hipMemcpyAsync(tc, ws.counts + 96, sizeof tc, hipMemcpyDeviceToHost, stream));
         AR_HIPCHECK(hipStreamSynchronize(stream));
-        for (int k = 0; k < 2; k++)
-            std::fprintf(stderr, "[anofox-hip] AutoARIMA %s kernel: wave-passes by variant <1,1,1,1> %d <1,2,1,2> %d <2,3,2,2> %d full %d; live lane-passes by class %d %d %d %d\n",
-                         k ? "four-lane" : "sequential", tc[8 * k], tc[8 * k + 1], tc[8 * k + 2], tc[8 * k + 3], tc[8 * k + 4], tc[8 * k + 5], tc[8 * k + 6], tc[8 * k + 7]);
+        for (int k = 0; k < 2; k++) {
+            const int32_t *c = tc + 16 * k;
+            std::fprintf(stderr, "[anofox-hip] AutoARIMA %s kernel: wave-passes by variant <1,1,0,0> %d <2,3,0,0> %d <1,1,1,1> %d <1,2,1,2> %d <2,3,2,2> %d full %d; live lane-passes by class %d %d %d %d %d %d\n",
+                         k ? "four-lane" : "sequential", c[0], c[1], c[2], c[3], c[4], c[5], c[8], c[9], c[10], c[11], c[12], c[13]);
+        }
     }
     return launches + 1;
 }

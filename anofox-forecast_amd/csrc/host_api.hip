@@ -49,6 +49,7 @@ std::atomic<int> g_default_arima_method{0};      // ANOFOX_ARIMA_CSS (anofox_hip
 // The estimation method a CALL runs under is fixed when the call enters the library and handed to every host thread that works for
 // it (shard, part and merged-batch workers; the leader of a coalesced group runs under the method its members were matched on) --
 // a concurrent anofox_hip_set_default_arima_method never changes a call half way.  -1: no call in force, the process default.
+std::atomic<int> g_arima_runs{0};       // AutoARIMA searches in flight (launch_arima shortens its launches when it shares the device)
 thread_local int tl_arima_method = -1;
 static int arima_method_in_force() { return tl_arima_method >= 0 ? tl_arima_method : g_default_arima_method.load(); }
 struct ArimaMethodScope {
@@ -1249,7 +1250,9 @@ void run_group(AnofoxHipBatch *b, int period, const int32_t *d_len, hipStream_t 
         aa.trace = b->tun.arima_trace;
         aa.lookahead = b->tun.arima_lookahead; aa.lookahead_depth = b->tun.arima_lookahead_depth; aa.spec_factor = b->tun.arima_spec_factor; aa.refit_budget = b->tun.arima_refit_budget; aa.queue_sort = b->tun.arima_queue_sort;
         aa.prep_lanes = b->tun.arima_prep_lanes < 1 ? 1 : (b->tun.arima_prep_lanes > 64 ? 64 : b->tun.arima_prep_lanes);
+        aa.concurrent = &g_arima_runs; aa.shared_chunk_rounds = b->tun.arima_shared_chunk_rounds;
         HIPCHECK(hipEventRecord(b->ev_fit0, st));
+        struct RunCount { RunCount() { g_arima_runs.fetch_add(1); } ~RunCount() { g_arima_runs.fetch_sub(1); } } run_count;
         try { b->fit_launches += launch_arima(aa, st); }
         catch (const std::exception &e) { throw HipFail{e.what()}; }
         HIPCHECK(hipEventRecord(b->ev_fit1, st));

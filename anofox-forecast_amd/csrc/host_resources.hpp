@@ -63,6 +63,7 @@ struct Tunables {
     double arima_lookahead = 6.0;    // tune arima_lookahead, _lookahead_depth, _spec_factor: see arima.hip launch_arima
     int arima_lookahead_depth = 2;
     double arima_spec_factor = 4.0;
+    double arima_shared_chunk_rounds = 1.0;   // tune arima_shared_chunk_rounds: see arima.hip launch_arima
     int arima_prep_lanes = 64;       // tune arima_prep_lanes: series per wave of the AutoARIMA prep kernel (1..64)
     int arima_queue_sort = 1;        // tune arima_queue_sort: see arima.hip ar_bucket
     int arima_refit_budget = 100;   // tune arima_refit_budget: evaluations per series before the exact-likelihood refit's speculative launch takes over (0: off)
@@ -123,6 +124,7 @@ struct Tunables {
         getd("arima_spec_factor", t.arima_spec_factor);
         geti("arima_queue_sort", t.arima_queue_sort);
         geti("arima_prep_lanes", t.arima_prep_lanes);
+        getd("arima_shared_chunk_rounds", t.arima_shared_chunk_rounds);
         geti("arima_refit_budget", t.arima_refit_budget);
         if (const char *e = std::getenv("ANOFOX_HIP_PACK_THREADS")) t.pack_threads = std::max(1, std::atoi(e));
         t.timing = std::getenv("ANOFOX_HIP_TIMING") != nullptr;

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <atomic>
 
 #include <stdexcept>
 #include <string>
@@ -186,6 +187,9 @@ struct ArimaArgs {
     int trace;                          // debugging: the refit kernel prints per-wave timings (ANOFOX_HIP_ARIMA_TRACE)
     double lookahead, spec_factor;      // schedule knobs of the search (host_api.hip Tunables: lookahead once the queue fits the resident lanes
     int lookahead_depth;                //   this many times over; four lanes per problem below spec_factor x the resident groups)
+    const std::atomic<int> *concurrent; // host only: AutoARIMA runs in flight in this process (the parts of a call with detected periods run side by side)
+    double shared_chunk_rounds;         // ... with more than one, a fit launch takes at most this many rounds of the resident lanes (tune
+                                        // arima_shared_chunk_rounds; 0 = whole queue): see launch_arima
     int prep_lanes;                     // series per wave of arima_prep_kernel (tune arima_prep_lanes: 16; 64 = one full wave per 64 series)
     int queue_sort;                     // order of the fit queue (tune arima_queue_sort; arima.hip ar_bucket): 0 as emitted, 1..3 by series within a bucket
     int refit_budget;                   // exact-likelihood refit: evaluations per series in the sequential launch before the speculative one takes over (0: one launch)
