@@ -2240,8 +2240,10 @@ int launch_arima(const ArimaArgs &a, hipStream_t stream)
         // short queue (up to a few problems per resident 4-lane group): four lanes per problem, one pass per Nelder-Mead
         // iteration -- such a launch is bound by its slowest fit, not by throughput
         const long per_wave = spec ? NM_BLOCK / 4 : NM_BLOCK;
-        const bool shared = a.shared_chunk_rounds > 0.0 && a.concurrent && a.concurrent->load() > 1;
-        long chunk = shared ? (long)(a.shared_chunk_rounds * (double)max_waves * (double)per_wave) : total;
+        // (a negative value: always, |value| rounds per launch -- the parity test of the chunked form)
+        const double rounds = a.shared_chunk_rounds < 0.0 ? -a.shared_chunk_rounds : a.shared_chunk_rounds;
+        const bool shared = a.shared_chunk_rounds < 0.0 || (rounds > 0.0 && a.concurrent && a.concurrent->load() > 1);
+        long chunk = shared ? (long)(rounds * (double)max_waves * (double)per_wave) : total;
         if (chunk < per_wave) chunk = per_wave;
         int n = 0;
         for (long first = 0; first < total; first += chunk) {

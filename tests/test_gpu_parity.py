@@ -921,6 +921,25 @@ def test_auto_arima_matches_oracle(env):
     assert r["ok"] and r["model_name"] == "AutoARIMA(2,1,1)" and abs(r["point"][0] - 18.014537) / 18.014537 < 1e-5
 
 
+@pytest.mark.parametrize("tune", ["arima_queue_sort=0", "arima_queue_sort=2", "arima_queue_sort=3", "arima_spec_factor=0.01;arima_lookahead=0.01",
+                                  "arima_spec_factor=1000;arima_lookahead=1000", "arima_shared_chunk_rounds=-0.002", "arima_prep_lanes=16",
+                                  "arima_trace=2"])
+def test_auto_arima_schedule_variants_are_bit_identical(env, monkeypatch, tune):
+    """Round 4: the fit queues of a sweep are bucketed by (dimension, order shape) and sorted by series, the pass variant follows the
+    orders of a wave's live lanes, a queue may go out in several launches when searches share the device.  None of it may move a bit:
+    every queue order (as emitted / by shape / by dimension / one bucket), both drivers forced (sequential lanes only, four lanes
+    only, with and without lookahead), launches of a few dozen problems each, and 16 series per prep wave reproduce the oracle --
+    weekly period (register rings), no period, a period in the LDS ring class and one in the HBM-ring class."""
+    api, O, lib, synth = env
+    monkeypatch.setenv("ANOFOX_HIP_TUNE", tune)
+    Y = synth.gen_series(synth.SEED_M5, 9300, 150, 170, 7)
+    series = [Y[s, : 170 - (s % 7) * 9] for s in range(150)]
+    _compare(api, O, lib, series, "AutoARIMA", 8, seasonal_period=7)
+    _compare(api, O, lib, series[:60], "AutoARIMA", 8, seasonal_period=1)
+    _compare(api, O, lib, series[:40], "AutoARIMA", 8, seasonal_period=12)
+    _compare(api, O, lib, series[:24], "AutoARIMA", 8, seasonal_period=30)
+
+
 def test_detected_period_above_24_is_seasonal(env):
     """A DETECTED period is handed to the seasonal AutoARIMA search like an explicit one (forecast.rs:528-537, 1448-1452): a series
     of period 30 called without seasonal_period comes back named ...[30] -- through the one-series entry and inside a batch whose
