@@ -665,6 +665,8 @@ struct ArWs {
     int32_t *q2_series, *q2_key;   // the queues sorted by series within a bucket (arima_queue_scan / _scatter_kernel)
     int32_t *hist;        // [AR_NBUCKETS x n] problems per (bucket, series) of the sweep, then their exclusive prefix over the series
     int nser;
+    int32_t *qp_series, *qp_key;   // [n] polish queue: the selected model of every series whose search has ended, in the order they ended (append only)
+    int32_t *counts_p;    // [128] its `counts` (same layout: one bucket, AR_QC = number queued so far; 8 = fetch cursor of the running polish launch)
     double *ml_sim;       // [waves x 42 x 64] simplex scratch of the exact-likelihood refit
     double *ml_park;      // [n x 64] Nelder-Mead state of the series the first refit launch parks for the second
     int32_t *ml_park_list;   // [n] those series
@@ -691,6 +693,9 @@ struct ArWs {
         q2_series = (int32_t *)take(sizeof(int32_t) * AR_NBUCKETS * cap);
         q2_key = (int32_t *)take(sizeof(int32_t) * AR_NBUCKETS * cap);
         hist = (int32_t *)take(sizeof(int32_t) * (size_t)AR_NBUCKETS * n);
+        qp_series = (int32_t *)take(sizeof(int32_t) * (size_t)n);
+        qp_key = (int32_t *)take(sizeof(int32_t) * (size_t)n);
+        counts_p = (int32_t *)take(sizeof(int32_t) * 128);
         nser = n;
         ml_sim = (double *)take(sizeof(double) * (size_t)ar_ml_sim_waves(n) * 64 * NM_BLOCK);   // AR_ML_CTX <= 64 slots per lane
         ml_park = (double *)take(sizeof(double) * (size_t)n * 64);
@@ -1044,6 +1049,13 @@ __global__ __launch_bounds__(256) void arima_advance_kernel(const ArimaArgs a, c
         for (int i = 0; i < AR_MAXDIM; i++)
             a.xbest[(size_t)i * ld + s] = have ? ws.cache_x[((size_t)s * AR_KEYS + best_key) * AR_MAXDIM + i] : 0.0;
         a.models[s] = n_models;
+        // the selected model goes to the polish queue the moment the search ends (round 4: most series are done sweeps before the last
+        // one; their polish runs beside the late, latency-bound sweeps -- launch_arima)
+        if (have && ar_dim(best) > 0) {
+            const int pos = atomicAdd(&ws.counts_p[AR_QC], 1);
+            ws.qp_series[pos] = s;
+            ws.qp_key[pos] = best_key;
+        }
     }
 }
 
@@ -1055,23 +1067,6 @@ __global__ __launch_bounds__(256) void arima_skip_kernel(const ArimaArgs a)
     if (a.wlen[s] < 3) { a.status[s] = FIT_SHORT; a.models[s] = 0; }
 }
 
-// the selected model of every series whose search found one, queued by dimension for the polish run of the fit kernels
-__global__ __launch_bounds__(256) void arima_polish_queue_kernel(const ArimaArgs a, const ArWs ws)
-{
-    const int s = blockIdx.x * 256 + threadIdx.x;
-    if (s >= a.n_series || a.wlen[s] < 3 || a.status[s] != FIT_OK) return;
-    const int key = ws.state[(size_t)s * 8 + AS_BEST];
-    const ArOrd o = ar_unkey(key);
-    if (ar_dim(o) == 0) return;                              // nothing to estimate
-    const int bk = ar_bucket(o, 1);                          // (one problem per series: nothing to sort)
-    const int pos = atomicAdd(&ws.counts[AR_QC + bk], 1);
-    ws.q_series[(size_t)bk * ws.cap + pos] = s;
-    ws.q_key[(size_t)bk * ws.cap + pos] = key;
-}
-
-// ------------------------------------------------------------------------------------------------
-// fit: persistent lanes, one (series, order) problem at a time from the queue
-// ------------------------------------------------------------------------------------------------
 // the queue of a sweep, sorted by series within each bucket: exclusive prefix of the per-(bucket, series) counts over the series (one
 // workgroup per bucket), then every problem moves to prefix[its series] + its rank
 __global__ __launch_bounds__(1024) void arima_queue_scan_kernel(const ArWs ws)
@@ -2222,6 +2217,7 @@ int launch_arima(const ArimaArgs &a, hipStream_t stream)
     // other's latency.  64 series per wave are 477 waves on the M5 batch -- half the SIMDs idle, the others with one wave; with 16 series
     // per wave it is 1,906 waves (20.5 -> PREP_MS ms).  (Long periods keep 64: their figure scratch is laid out per 64 series.)
     const int prep_block = long_m ? NM_BLOCK : a.prep_lanes;
+    AR_HIPCHECK(hipMemsetAsync(ws.counts_p, 0, 128 * sizeof(int32_t), stream));
     hipLaunchKernelGGL(arima_prep_kernel, dim3((a.n_series + prep_block - 1) / prep_block), dim3(prep_block), prep_lds, stream, a, ws);
     hipLaunchKernelGGL(arima_skip_kernel, dim3(grid256), dim3(256), 0, stream, a);
     int launches = 2;
@@ -2234,19 +2230,19 @@ int launch_arima(const ArimaArgs &a, hipStream_t stream)
     // microseconds of work -- waited 28 ms on average (163 ms at most) for a long launch of somebody else to END (kernel trace of the
     // default call shape, round 4).  With company, a launch therefore takes `shared_chunk_rounds` rounds of the resident lanes at most
     // and the queue goes out in several launches: waves retire every few milliseconds and the other streams get in.
-    auto launch_fit = [&](long total, int polish, const ArWs &ws) {
+    auto launch_fit = [&](long from, long total, int polish, const ArWs &ws, hipStream_t stream) {      // items from .. total - 1 of the queue
         const double spec_factor = a.spec_factor;   // (tune arima_spec_factor, default 4)
-        const bool spec = (double)total <= spec_factor * (double)sched_waves * (NM_BLOCK / 4);
+        const bool spec = (double)(total - from) <= spec_factor * (double)sched_waves * (NM_BLOCK / 4);
         // short queue (up to a few problems per resident 4-lane group): four lanes per problem, one pass per Nelder-Mead
         // iteration -- such a launch is bound by its slowest fit, not by throughput
         const long per_wave = spec ? NM_BLOCK / 4 : NM_BLOCK;
         // (a negative value: always, |value| rounds per launch -- the parity test of the chunked form)
         const double rounds = a.shared_chunk_rounds < 0.0 ? -a.shared_chunk_rounds : a.shared_chunk_rounds;
         const bool shared = a.shared_chunk_rounds < 0.0 || (rounds > 0.0 && a.concurrent && a.concurrent->load() > 1);
-        long chunk = shared ? (long)(rounds * (double)max_waves * (double)per_wave) : total;
+        long chunk = shared ? (long)(rounds * (double)max_waves * (double)per_wave) : total - from;
         if (chunk < per_wave) chunk = per_wave;
         int n = 0;
-        for (long first = 0; first < total; first += chunk) {
+        for (long first = from; first < total; first += chunk) {
             const long end = first + chunk < total ? first + chunk : total;
             if (first > 0) AR_HIPCHECK(hipMemsetAsync(ws.counts + 8, 0, sizeof(int32_t), stream));
             long waves = (end - first + per_wave - 1) / per_wave;
@@ -2256,6 +2252,15 @@ int launch_arima(const ArimaArgs &a, hipStream_t stream)
         }
         return n;
     };
+    // The selected models' CSS estimates, to convergence (one problem per series: the polish): advance queues a series' polish when its
+    // search ends, so the queue is complete when the last sweep is -- no queue kernel, no extra host round trip.
+    // (Round 4, measured: polishing the early finishers on a second stream BESIDE the remaining sweeps -- 20,623 of the 30,490 series have
+    //  ended their search by the fourth sweep of the M5 batch -- loses: 230 -> 238-255 ms for every share of the chip and every trigger
+    //  tried.  The persistent polish waves hold their SIMDs for the whole launch and the sweeps, which are the critical path, queue
+    //  behind them; the polish's own critical path -- its slowest fits, 600 iterations -- does not get shorter by starting earlier.)
+    ArWs ws_pol = ws;
+    ws_pol.q_series = ws.qp_series; ws_pol.q_key = ws.qp_key; ws_pol.counts = ws.counts_p; ws_pol.cap = (size_t)a.n_series;
+    long np_now = 0;
     for (int sweep = 0; sweep < 4 * AR_MAXMODELS; sweep++) {
         AR_HIPCHECK(hipMemsetAsync(ws.counts, 0, 96 * sizeof(int32_t), stream));
         if (a.queue_sort) AR_HIPCHECK(hipMemsetAsync(ws.hist, 0, sizeof(int32_t) * (size_t)AR_NBUCKETS * a.n_series, stream));
@@ -2268,10 +2273,12 @@ int launch_arima(const ArimaArgs &a, hipStream_t stream)
         const int la_depth = a.lookahead_depth;   // (tune arima_lookahead_depth, default 2)
         if (lookahead && la_depth >= 2 && (double)prev_total * (AR_SWEEP + 1) * (AR_SWEEP + 1) <= la_factor * (double)sched_waves * NM_BLOCK) lookahead = 2;
         hipLaunchKernelGGL(arima_advance_kernel, dim3(grid256), dim3(256), 0, stream, a, ws, lookahead);
-        int32_t counts[AR_NBUCKETS];
+        int32_t counts[AR_NBUCKETS], queued_p = 0;
         AR_HIPCHECK(hipMemcpyAsync(counts, ws.counts + AR_QC, sizeof counts, hipMemcpyDeviceToHost, stream));
+        AR_HIPCHECK(hipMemcpyAsync(&queued_p, ws.counts_p + AR_QC, sizeof queued_p, hipMemcpyDeviceToHost, stream));
         AR_HIPCHECK(hipStreamSynchronize(stream));
         launches++;
+        np_now = queued_p;
         long total = 0;
         for (int i = 0; i < AR_NBUCKETS; i++) total += counts[i];
         if (total == 0) break;
@@ -2284,20 +2291,12 @@ int launch_arima(const ArimaArgs &a, hipStream_t stream)
             hipLaunchKernelGGL(arima_queue_scatter_kernel, dim3((longest + 255) / 256, AR_NBUCKETS), dim3(256), 0, stream, ws);
             launches += 2;
         }
-        launches += launch_fit(total, 0, a.queue_sort ? ws_sorted : ws);
+        launches += launch_fit(0, total, 0, a.queue_sort ? ws_sorted : ws, stream);
     }
-    // the selected models' CSS estimates, to convergence (one problem per series)
-    {
-        AR_HIPCHECK(hipMemsetAsync(ws.counts, 0, 96 * sizeof(int32_t), stream));
-        hipLaunchKernelGGL(arima_polish_queue_kernel, dim3(grid256), dim3(256), 0, stream, a, ws);
-        int32_t counts[AR_NBUCKETS];
-        AR_HIPCHECK(hipMemcpyAsync(counts, ws.counts + AR_QC, sizeof counts, hipMemcpyDeviceToHost, stream));
-        AR_HIPCHECK(hipStreamSynchronize(stream));
-        long total = 0;
-        for (int i = 0; i < AR_NBUCKETS; i++) total += counts[i];
-        if (a.trace) std::fprintf(stderr, "[anofox-hip] AutoARIMA polish: %ld selected models\n", total);
-        if (total > 0) launches += launch_fit(total, 1, ws);
-        launches++;
+    if (np_now > 0) {
+        if (a.trace) std::fprintf(stderr, "[anofox-hip] AutoARIMA polish: %ld selected models\n", np_now);
+        AR_HIPCHECK(hipMemsetAsync(ws.counts_p + 8, 0, sizeof(int32_t), stream));
+        launches += launch_fit(0, np_now, 1, ws_pol, stream);
     }
     // on request (ANOFOX_ARIMA_CSS_ML): final estimates of the selected models on the exact Gaussian likelihood
     if (a.ml_refit) {
