@@ -665,8 +665,8 @@ struct ArWs {
     int32_t *q2_series, *q2_key;   // the queues sorted by series within a bucket (arima_queue_scan / _scatter_kernel)
     int32_t *hist;        // [AR_NBUCKETS x n] problems per (bucket, series) of the sweep, then their exclusive prefix over the series
     int nser;
-    int32_t *qp_series, *qp_key;   // [n] polish queue: the selected model of every series whose search has ended, in the order they ended (append only)
-    int32_t *counts_p;    // [128] its `counts` (same layout: one bucket, AR_QC = number queued so far; 8 = fetch cursor of the running polish launch)
+    int32_t *qp_series, *qp_key;   // [AR_NBUCKETS x n] polish queues: the selected model of every series whose search has ended, by (dimension, shape class)
+    int32_t *counts_p;    // [128] their `counts` (same layout: AR_QC + bucket = queue lengths, 8 = fetch cursor of the polish launch)
     double *ml_sim;       // [waves x 42 x 64] simplex scratch of the exact-likelihood refit
     double *ml_park;      // [n x 64] Nelder-Mead state of the series the first refit launch parks for the second
     int32_t *ml_park_list;   // [n] those series
@@ -693,8 +693,8 @@ struct ArWs {
         q2_series = (int32_t *)take(sizeof(int32_t) * AR_NBUCKETS * cap);
         q2_key = (int32_t *)take(sizeof(int32_t) * AR_NBUCKETS * cap);
         hist = (int32_t *)take(sizeof(int32_t) * (size_t)AR_NBUCKETS * n);
-        qp_series = (int32_t *)take(sizeof(int32_t) * (size_t)n);
-        qp_key = (int32_t *)take(sizeof(int32_t) * (size_t)n);
+        qp_series = (int32_t *)take(sizeof(int32_t) * (size_t)AR_NBUCKETS * n);
+        qp_key = (int32_t *)take(sizeof(int32_t) * (size_t)AR_NBUCKETS * n);
         counts_p = (int32_t *)take(sizeof(int32_t) * 128);
         nser = n;
         ml_sim = (double *)take(sizeof(double) * (size_t)ar_ml_sim_waves(n) * 64 * NM_BLOCK);   // AR_ML_CTX <= 64 slots per lane
@@ -1052,9 +1052,10 @@ __global__ __launch_bounds__(256) void arima_advance_kernel(const ArimaArgs a, c
         // the selected model goes to the polish queue the moment the search ends (round 4: most series are done sweeps before the last
         // one; their polish runs beside the late, latency-bound sweeps -- launch_arima)
         if (have && ar_dim(best) > 0) {
-            const int pos = atomicAdd(&ws.counts_p[AR_QC], 1);
-            ws.qp_series[pos] = s;
-            ws.qp_key[pos] = best_key;
+            const int bk = ar_bucket(best, 1);
+            const int pos = atomicAdd(&ws.counts_p[AR_QC + bk], 1);
+            ws.qp_series[(size_t)bk * ws.nser + pos] = s;
+            ws.qp_key[(size_t)bk * ws.nser + pos] = best_key;
         }
     }
 }
@@ -2273,12 +2274,13 @@ int launch_arima(const ArimaArgs &a, hipStream_t stream)
         const int la_depth = a.lookahead_depth;   // (tune arima_lookahead_depth, default 2)
         if (lookahead && la_depth >= 2 && (double)prev_total * (AR_SWEEP + 1) * (AR_SWEEP + 1) <= la_factor * (double)sched_waves * NM_BLOCK) lookahead = 2;
         hipLaunchKernelGGL(arima_advance_kernel, dim3(grid256), dim3(256), 0, stream, a, ws, lookahead);
-        int32_t counts[AR_NBUCKETS], queued_p = 0;
+        int32_t counts[AR_NBUCKETS], queued_p[AR_NBUCKETS];
         AR_HIPCHECK(hipMemcpyAsync(counts, ws.counts + AR_QC, sizeof counts, hipMemcpyDeviceToHost, stream));
-        AR_HIPCHECK(hipMemcpyAsync(&queued_p, ws.counts_p + AR_QC, sizeof queued_p, hipMemcpyDeviceToHost, stream));
+        AR_HIPCHECK(hipMemcpyAsync(queued_p, ws.counts_p + AR_QC, sizeof queued_p, hipMemcpyDeviceToHost, stream));
         AR_HIPCHECK(hipStreamSynchronize(stream));
         launches++;
-        np_now = queued_p;
+        np_now = 0;
+        for (int i = 0; i < AR_NBUCKETS; i++) np_now += queued_p[i];
         long total = 0;
         for (int i = 0; i < AR_NBUCKETS; i++) total += counts[i];
         if (total == 0) break;
