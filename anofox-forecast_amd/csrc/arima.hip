@@ -417,10 +417,7 @@ __device__ __noinline__ double ar_css_pass_impl(const double *wrow, int len, int
     };
     // (not where the registers are spoken for: the HBM-ring variants already hold two sub-blocks of lags in flight and would spill
     //  400 bytes more; the four-lane kernel without a period keeps its two waves per SIMD)
-#ifndef ANOFOX_AR_DEEP_NONCOOP
-#define ANOFOX_AR_DEEP_NONCOOP 1
-#endif
-    constexpr bool DEEP = !HB && !(MODE == 2 && !COOP) && (COOP || ANOFOX_AR_DEEP_NONCOOP != 0);
+    constexpr bool DEEP = !HB && !(MODE == 2 && !COOP);      // (the four-lane kernel without it: +2 % on the M5 batch, same-box A/B)
     issue(nxa, 0);
     commit(nxa);
     if (DEEP) issue(nxa, S / 2);
