@@ -675,7 +675,10 @@ struct ArWs {
     size_t carve(char *p, int n, int t_max)
     {
         tw = (size_t)((t_max + AR_S - 1) / AR_S) * AR_S + AR_SPARE;
-        cap = (size_t)n * AR_SWEEP;
+        // per (dimension, shape class) queue: six problems per series.  A sweep emits up to 17 per series (more with lookahead) over
+        // 42 queues; a queue that is full drops the candidate (its `computed` bit is cleared) and the next sweep queues it again --
+        // same results, one more sweep -- which the single-bucket queue order (tune arima_queue_sort = 3) does run into
+        cap = (size_t)n * 6;
         size_t off = 0;
         auto take = [&](size_t bytes) { char *r = p ? p + off : nullptr; off += align(bytes); return r; };
         W = (double *)take(sizeof(double) * (size_t)n * tw);
