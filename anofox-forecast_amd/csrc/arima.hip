@@ -2270,7 +2270,7 @@ int launch_arima(const ArimaArgs &a, hipStream_t stream)
         if (a.queue_sort) AR_HIPCHECK(hipMemsetAsync(ws.hist, 0, sizeof(int32_t) * (size_t)AR_NBUCKETS * a.n_series, stream));
         // look one sweep ahead once the previous sweep's queue times the fan-out (~18 candidates per series) fits the
         // resident lanes `la_factor` times over: the extra fits cost idle lanes, the saved sweeps cost ~0.1-0.2 s each
-        const double la_factor = a.lookahead;   // (tune arima_lookahead, default 12) measured 0 / 0.25 / 1 / 4 / 16: 2.16 / 2.03 / 1.93 / 1.92 / 1.90 s on the M5 batch (round 1); with the refit 4 / 8 / 12 / 16 / 24 / 32 / 64: 2.23 / 2.23 / 2.14 / 2.14 / 2.17 / 2.17 / 2.92 s
+        const double la_factor = a.lookahead;   // (tune arima_lookahead, default 6: profiles/r04_arima_experiments.txt; earlier rounds, default 12:) measured 0 / 0.25 / 1 / 4 / 16: 2.16 / 2.03 / 1.93 / 1.92 / 1.90 s on the M5 batch (round 1); with the refit 4 / 8 / 12 / 16 / 24 / 32 / 64: 2.23 / 2.23 / 2.14 / 2.14 / 2.17 / 2.17 / 2.92 s
         int lookahead = (prev_total >= 0 && (double)prev_total * (AR_SWEEP + 1) <= la_factor * (double)sched_waves * NM_BLOCK) ? 1 : 0;
         // ... and two sweeps ahead once even that fan-out squared fits the resident lanes (the late sweeps of a few hundred series are
         // each bound by their slowest fit, ~0.1 s: 5 of them on the M5 batch)
