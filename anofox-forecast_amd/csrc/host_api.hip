@@ -1028,9 +1028,16 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
                 // one wave per problem
                 a.budget = BUDGET[r]; a.budget_seq = BUDGET[r];
                 const int64_t live = b->live_all >= 0 ? b->live_all : (int64_t)n;
-                if (r == 0) (live > b->spec_below ? fns[oi].round_k4 : fns[oi].round_spec)(a, sq);
+                // The most expensive spec (`k4_top` of them) switches to four lanes per problem EARLIER, at `k4_top_below` live problems
+                // (20,480; every other spec at spec_below = 8,192): its chain ends the step, alone on the chip for the last 10-25 ms of
+                // the intermittent M5 batch with 477 one-lane waves on 1,024 SIMDs -- four lanes per problem are the same arithmetic on
+                // four times the waves.  70.6-71.7 -> 66.1-68.1 ms on that batch (thresholds 14,336-24,576: the same; 12,288 and 32,768:
+                // no gain -- at 32,768 the first round already runs four lanes while all six chains still fill the chip), 125k x 1,024:
+                // 138-142 -> 132-139 ms, batches with general-class specs: unchanged (profiles/r04_ab_experiments.txt).
+                const int sb = ((int)oi < b->tun.k4_top && b->tun.k4_top_below > 0) ? b->tun.k4_top_below : b->spec_below;
+                if (r == 0) (live > sb ? fns[oi].round_k4 : fns[oi].round_spec)(a, sq);
                 else {
-                    a.spec_below = b->spec_below; a.spec2_below = s2 > 0 ? s2 : -1;
+                    a.spec_below = sb; a.spec2_below = s2 > 0 ? s2 : -1;
                     fns[oi].round_auto_k4(a, sq);
                 }
             } else if (r == 0 || b->seq_rounds_env >= 0 || b->seq_rounds == 0) {

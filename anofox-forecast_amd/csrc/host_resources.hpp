@@ -49,6 +49,7 @@ struct Tunables {
     int spec2_below = 1024;     // tune spec2_below[_md]: one wave per problem, two iterations per pass, for the last problems
     int spec2_below_md = 2048;  //   (tools/spec2_sweep.sh: 0 / 256 / 1024 / 2048 / 4096 / 8192 -> 579 / 575 / 565 / 562 / 594 / 736 ms on the 30-spec M5 batch)
     int k4 = -1;                // tune k4: additive-class specs run one lane per problem with all four trial points of an iteration in ONE
+    int k4_top = 1, k4_top_below = 20480;   // tune k4_top, k4_top_below: see host_api.hip run_fit (0 = like every other spec)
                                 //   pass (ets_fit_kernel.hpp K4) wherever one or four LANES per problem would run.  -1 (default): when the run is
                                 //   memory bound and fills the chip that way -- the general-class specs see under half of the series AND the
                                 //   additive specs have >= 131,072 live problems together (two K4 waves per SIMD); 0 never; 1 always.
@@ -113,7 +114,7 @@ struct Tunables {
         if (kv.count("spec_below")) t.spec_below = t.spec_below_md = std::atoi(kv.at("spec_below").c_str());
         geti("spec_below_md", t.spec_below_md);
         geti("gather_cols", t.gather_cols);
-        geti("k4", t.k4);
+        geti("k4", t.k4); geti("k4_top", t.k4_top); geti("k4_top_below", t.k4_top_below);
         if (kv.count("spec2_below")) t.spec2_below = t.spec2_below_md = std::atoi(kv.at("spec2_below").c_str());
         geti("spec2_below_md", t.spec2_below_md);
         if (kv.count("merge_periods")) t.merge_periods = std::atoi(kv.at("merge_periods").c_str()) != 0;

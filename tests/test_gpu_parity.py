@@ -449,6 +449,21 @@ def test_four_candidates_per_lane_is_bit_identical(env, monkeypatch, k4):
     _compare(api, O, lib, series[:50], "AutoETS", 9, seasonal_period=12)        # (no K4 kernels for m = 12: the sequential driver)
 
 
+@pytest.mark.parametrize("tune", ["k4=1;k4_top=1;k4_top_below=60", "k4=1;k4_top=2;k4_top_below=100000", "k4=1;k4_top=6;k4_top_below=150;spec_below=40",
+                                  "k4=1;k4_top_below=0"])
+def test_early_four_lane_switch_of_the_top_specs_is_bit_identical(env, monkeypatch, tune):
+    """ANOFOX_HIP_TUNE k4_top / k4_top_below: the most expensive additive-class spec(s) leave the four-points-per-lane driver for four
+    lanes per problem at a higher count of live problems than the others (the chain that ends the step gets its parallelism
+    earlier).  Whatever the threshold -- below the batch size (the switch happens between rounds, by the device-side count), above it
+    (four lanes from the first round), for one, two or all specs -- the iterates are the oracle's."""
+    api, O, lib, synth = env
+    monkeypatch.setenv("ANOFOX_HIP_TUNE", tune)
+    Yi = synth.gen_series(synth.SEED_M5, 6100, 220, 180, 7)
+    series = [Yi[s, : 180 - (s % 6) * 8] for s in range(220)]
+    _compare(api, O, lib, series, "AutoETS", 9, seasonal_period=7)
+    _compare(api, O, lib, series[:120], "AutoETS", 9, seasonal_period=1)
+
+
 @pytest.mark.parametrize("below", ["20", "100000"])
 def test_two_level_speculation_is_bit_identical(env, monkeypatch, below):
     """ANOFOX_HIP_TUNE spec2_below: the last problems of a spec run one per wave, lanes 4..63 evaluating the next iteration's
