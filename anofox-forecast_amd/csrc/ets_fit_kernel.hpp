@@ -161,6 +161,7 @@ __global__ __launch_bounds__(NM_BLOCK * RoundTraits<Cfg>::WPB, (RoundTraits<Cfg>
         r.passes = active ? a.st.passes[s] : 0;
         r.done = !active;
     }
+    const int passes_in = r.passes;
 
     // one problem per wave (the last problems of a spec) runs to completion
     const int budget = mode == 2 ? (1 << 30) : ((SPEC == 3 && mode == 0 && !K4) ? a.budget_seq : a.budget);
@@ -184,6 +185,18 @@ __global__ __launch_bounds__(NM_BLOCK * RoundTraits<Cfg>::WPB, (RoundTraits<Cfg>
 #undef ANOFOX_ADVANCE_LANE
     nm_fence();
 
+    if (a.lane_stats) {
+        // a lane's pass counter moves only while it evaluates (nm.hpp); the lane that parks last was live in every pass of the wave
+        const int mine = r.passes - passes_in;
+        int sum = mine;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
+        const int most = wave_max_i32(mine);
+        if (lane == 0 && most > 0) {
+            atomicAdd(a.lane_stats, (unsigned long long)most);
+            atomicAdd(a.lane_stats + 1, (unsigned long long)sum);
+        }
+    }
     if (active && (lane % LPP) == 0) {
 #pragma unroll
         for (int k = 0; k <= D; k++) {

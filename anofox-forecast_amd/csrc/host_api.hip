@@ -89,6 +89,7 @@ struct AnofoxHipBatch {
     int n_slots_cap = 0;
     double *d_aicc = nullptr, *d_yhat_slots = nullptr;
     int32_t *d_status_slots = nullptr, *d_evals_slots = nullptr, *d_iters_slots = nullptr, *d_passes_slots = nullptr, *d_slot_spec = nullptr;
+    unsigned long long *d_lane_stats = nullptr;    // [n_slots_cap x 2] wave passes / live lane passes of every spec's round kernels (zeroed per run)
     // outputs
     double *d_yhat = nullptr, *d_lo = nullptr, *d_hi = nullptr;
     int32_t *d_model_code = nullptr, *d_status = nullptr, *d_detail = nullptr, *d_passes_total = nullptr, *d_evals_total = nullptr;
@@ -368,6 +369,8 @@ void alloc_common(AnofoxHipBatch *b)
         b->d_iters_slots = dalloc<int32_t>(S * ld);
         b->d_passes_slots = dalloc<int32_t>(S * ld);
         b->d_slot_spec = dalloc<int32_t>(S);
+        b->d_lane_stats = dalloc<unsigned long long>(2 * S);
+        HIPCHECK(hipMemset(b->d_lane_stats, 0, 2 * S * sizeof(unsigned long long)));
         const int n_lanes = std::min<int>(N_AUX_STREAMS, b->n_slots_cap);
         for (int q = 0; q < n_lanes; q++) {
             auto &l = b->lanes[q];
@@ -852,6 +855,7 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
         a.st = lane.st;
         a.ring_scratch = nullptr;
         a.m_col = b->d_m_col;
+        a.lane_stats = b->d_lane_stats ? b->d_lane_stats + 2 * k : nullptr;
         fns[oi] = ets_fit_launcher(id, (merged && se != 0) ? (a.m > lds_limit ? ETS_PERLANE_HBM : ETS_PERLANE_LDS) : a.m);
         if (!fns[oi].round_seq || !fns[oi].round_spec || !fns[oi].round_auto || !fns[oi].final) throw HipFail{"no kernel for ETS spec id " + std::to_string(id)};
     }
@@ -1284,6 +1288,7 @@ void run_batch(AnofoxHipBatch *b, hipStream_t st)
     b->quiesced = false;         // (from here on, also when a launch below fails)
     b->last_stream = st;
     HIPCHECK(hipEventRecord(b->ev_start, st));
+    if (b->d_lane_stats) HIPCHECK(hipMemsetAsync(b->d_lane_stats, 0, 2 * (size_t)b->n_slots_cap * sizeof(unsigned long long), st));
     {
         const size_t nh = n * (size_t)std::max(b->h, 0);
         const size_t cover = std::max<size_t>(std::max(nh, ld), 1);
@@ -1794,6 +1799,34 @@ bool anofox_hip_batch_stats(AnofoxHipBatch *b, AnofoxHipStats *out)
             out->min_pass_bytes += 8ull * (uint64_t)b->h_len[s] * q + 24ull * (uint64_t)std::max(b->h, 0);
         }
     }
+    return true;
+}
+
+bool anofox_hip_batch_lane_stats(AnofoxHipBatch *b, AnofoxHipLaneStats *out, size_t struct_size)
+{
+    if (!b || !out || !b->ran || struct_size < sizeof(uint64_t)) return false;
+    DeviceGuard guard(b->dev);
+    AnofoxHipLaneStats r;
+    std::memset(&r, 0, sizeof r);
+    r.struct_size = sizeof r;
+    if (hipEventSynchronize(b->ev_stop) != hipSuccess) return false;
+    if (b->insp_ok && b->d_lane_stats && !b->fixed_params) {
+        std::vector<unsigned long long> c(2 * (size_t)b->n_slots_cap);
+        if (hipMemcpy(c.data(), b->d_lane_stats, c.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return false;
+        // insp_spec[oi] = spec id in launch order; the counters are indexed by the slot k the spec was given (order[oi] = k): rebuild k
+        // from h_slot_spec (slot -> spec id)
+        for (size_t k = 0; k < b->h_slot_spec.size() && k < (size_t)b->n_slots_cap; k++) {
+            const int id = b->h_slot_spec[k];
+            const int cls = !spec_has_mult(id) ? 0 : (spec_trend_idx(id) == 4 ? 2 : 1);
+            r.wave_passes[cls] += c[2 * k];
+            r.live_lane_passes[cls] += c[2 * k + 1];
+            if (k < 30) { r.slot_spec_id[k] = id; r.slot_wave_passes[k] = c[2 * k]; r.slot_live_lane_passes[k] = c[2 * k + 1]; r.n_slots = (uint32_t)(k + 1); }
+        }
+    }
+    // the caller's struct may be older (smaller) or newer (larger) than this library's: copy what both know, report what was written
+    const size_t nbytes = std::min(struct_size, sizeof r);
+    r.struct_size = nbytes;
+    std::memcpy(out, &r, nbytes);
     return true;
 }
 

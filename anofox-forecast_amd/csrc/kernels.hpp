@@ -90,6 +90,10 @@ struct FitArgs {
     double *insp_fitted;         // [t_rows x ld] one-step fitted values (time-major)
     double *insp_states;         // [(2 + m) x ld] final level, growth, seasonal states by phase
     double *insp_info;           // [8 x ld] alpha, beta, gamma, phi, aic, aicc, bic, sse
+    // lane-level efficiency of the round kernels (round 5; NULL = not counted): [0] += passes the wave streamed, [1] += lane-passes
+    // that evaluated a trial point of a running problem -- live_lane_passes / (64 wave_passes) is the share of the issued lanes that
+    // did work (a converged or parked lane idles until its wave leaves; a wave of the one-wave-per-problem driver counts 64 live lanes)
+    unsigned long long *lane_stats;
 };
 
 struct SelectArgs {

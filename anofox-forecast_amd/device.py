@@ -85,6 +85,29 @@ class DeviceBatch:
             raise RuntimeError("anofox_hip_batch_stats failed")
         return {f: getattr(s, f) for f, _ in s._fields_}
 
+    SPEC_CLASSES = ("additive", "general", "damped_mul_trend")
+
+    def lane_stats(self) -> dict:
+        """Lane-level efficiency of the round kernels of the last run (include/anofox_fcst_hip.h AnofoxHipLaneStats): per spec class and
+        per spec, live lane-passes / (64 x wave passes)."""
+        s = _lib.AnofoxHipLaneStats()
+        if not self.L.anofox_hip_batch_lane_stats(self.handle, C.byref(s), C.sizeof(s)):
+            raise RuntimeError("anofox_hip_batch_lane_stats failed")
+        eff = lambda live, waves: round(live / (64.0 * waves), 4) if waves else None
+        E, T, S = "AM", ("N", "A", "Ad", "M", "Md"), "NAM"
+        out = {"by_class": {}, "by_spec": {}}
+        tw = tl = 0
+        for c, name in enumerate(self.SPEC_CLASSES):
+            w, l = int(s.wave_passes[c]), int(s.live_lane_passes[c])
+            tw += w; tl += l
+            out["by_class"][name] = {"wave_passes": w, "live_lane_passes": l, "lane_efficiency": eff(l, w)}
+        out["wave_passes"], out["live_lane_passes"], out["lane_efficiency"] = tw, tl, eff(tl, tw)
+        for k in range(int(s.n_slots)):
+            sid = int(s.slot_spec_id[k])
+            name = E[sid // 15] + T[(sid % 15) // 3] + S[sid % 3]
+            out["by_spec"][name] = {"wave_passes": int(s.slot_wave_passes[k]), "lane_efficiency": eff(int(s.slot_live_lane_passes[k]), int(s.slot_wave_passes[k]))}
+        return out
+
     def results(self) -> dict:
         """Zero-copy torch views of the device result arrays."""
         ptrs = [C.c_void_p() for _ in range(5)]

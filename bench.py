@@ -64,6 +64,9 @@ def parse_args():
     ap.add_argument("--horizon", type=int, default=28)
     ap.add_argument("--cpu-sample", type=int, default=-1, help="series for the CPU baseline (-1 auto, 0 skip)")
     ap.add_argument("--e2e-steps", type=int, default=-1, help="timed passes of the host-buffer entry (-1 auto, 0 skip)")
+    ap.add_argument("--also", type=int, default=-1,
+                    help="timed steps of each of the other BASELINE configurations, reported under \"also\" (-1 auto: 3 on the default "
+                         "single-GPU invocation, 0 otherwise; 0 skip)")
     ap.add_argument("--simulate-world", type=int, default=0,
                     help="ONE process, ONE GPU: run rank 0's share of an N-GPU job (strong: shard 0 of N; weak: one full batch) and report the "
                          "per-GPU figure an N-GPU run would start from -- what can be known about 8 GPUs on a 1-GPU box (no collective runs)")
@@ -117,8 +120,88 @@ def e2e_pass(lib, Y, opts, steps):
     return times, n_ok
 
 
+ALSO_WORKLOADS = ("autoets_m5", "autoarima_m5", "autoarima_css_m5", "ets_aaa_fixed_m5", "autoets_stress")
+
+
+def also_pass(names, steps, h, dev, lib, synth, DeviceBatch, pack_time_major, torch):
+    """Short timed loops of the other BASELINE configurations (configs 2, 4, 5 and the raw-M5 variant of config 3), so the line the
+    driver keeps holds every configuration and not only the headline one.  Same shape of measurement as the headline: batch resident
+    in HBM, one untimed step, `steps` timed steps between two synchronisations, the library's own HIP events for the kernel time.
+    The reference's harness times one statement per model the same way (benchmark/src/common/anofox_runner.py:135-149)."""
+    out, cache = {}, {}
+    for name in names:
+        wl = WORKLOADS[name]
+        n, T, m = wl["n"], wl["T"], wl["m"]
+        key = (wl["seed"], n, T, m, wl["positive"])
+        if key not in cache:
+            cache.clear()                                   # one host copy at a time (the 125k x 1,024 batch is 1 GB)
+            cache[key] = synth.gen_series(wl["seed"], 0, n, T, m, wl["positive"])
+        Y = cache[key]
+        opts = lib.make_options(wl["model"], h, ets_model=wl["ets_model"], seasonal_period=m)
+        batch = DeviceBatch(n, T, opts, dev)
+        if wl["fixed"]:
+            batch.set_fixed_params(*wl["fixed"])
+        if wl["model"] == "AutoARIMA":
+            batch.set_arima_method(wl["arima_method"])
+        y_dev = torch.from_numpy(pack_time_major(Y, batch.ld)).to(dev)
+        len_dev = torch.full((batch.ld,), T, dtype=torch.int32, device=dev)
+        len_dev[n:] = 0
+        batch.set_block(y_dev, len_dev)
+        batch.run()
+        torch.cuda.synchronize()
+        k = steps * (200 if wl["fixed"] else 1)             # the one-pass step is a third of a millisecond: enqueue enough of them to time
+        fit_ms, dev_ms = [], []
+        t0 = time.perf_counter()
+        for _ in range(k):
+            batch.run()
+            if not wl["fixed"]:
+                st = batch.stats()
+                fit_ms.append(st["fit_kernel_ms"]); dev_ms.append(st["total_device_ms"])
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / k
+        st = batch.stats()
+        if wl["fixed"]:
+            fit_ms.append(st["total_device_ms"]); dev_ms.append(st["total_device_ms"])       # the unit is the whole one-pass step
+        kms = float(np.mean(fit_ms))
+        ach = st["algorithmic_bytes"] / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+        minb = int(st.get("min_pass_bytes", 0))
+        res = batch.results()
+        out[name] = {"value": round(n / dt, 1), "unit": "series/s", "ms_per_step": round(dt * 1e3, 4), "steps": k,
+                     "series": n, "T": T, "series_ok": int((res["status"] == 0).sum().item()),
+                     "roofline": {"frac": round(ach / HBM_PEAK_GBS, 4), "achieved": round(ach, 1), "kernel_ms": round(kms, 4),
+                                  "frac_min_passes": round(minb / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if (minb and kms > 0) else None}}
+        if wl["model"] == "AutoARIMA":
+            out[name]["arima_method"] = "CSS-ML (exact Gaussian likelihood refit: the Kalman kernel BASELINE config 4 names)" if wl["arima_method"] else "CSS (library default)"
+        batch.close()
+        del y_dev, len_dev, batch
+    return out
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` (N > 1) outside a launcher: start the N ranks ourselves.
+
+    The driver times the N = 1 line as `python bench.py --gpus 1 ...`; invoked the same way with --gpus 8 this file used to run
+    ONE rank and print "n_gpus": 1.  Now the un-wrapped invocation becomes the documented one -- `python -m torch.distributed.run
+    --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same arguments>` -- as a CHILD process (never an
+    exec: this process must not be replaced once anything could have touched the GPU; here nothing has -- torch is not imported yet).
+    The child's stdout / stderr are ours (inherited), and its exit code is returned."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // args.gpus)))
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     import torch
     import torch.distributed as dist
 
@@ -143,6 +226,16 @@ def main():
             dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend="nccl", device_id=dev)     # "nccl" is RCCL on ROCm
+
+        if world != args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but the launcher started {world} ranks; reporting the ranks that exist", file=sys.stderr)
+    # what the ranks of this job actually are (rank -> device), stated in config.parallelism so an "8-GPU" line can be checked
+    backend = (dist.get_backend() if world > 1 else "none")
+    seen = [(rank, dev_index)]
+    if world > 1:
+        seen = [None] * world
+        dist.all_gather_object(seen, (rank, dev_index))
+    ranks_seen = f"{'RCCL (nccl)' if backend == 'nccl' else backend} ranks seen: {len(seen)} on devices {sorted(set(d for _, d in seen))}"
 
     wl = WORKLOADS[args.workload]
     model, ets_model, m, positive, seed = wl["model"], wl["ets_model"], wl["m"], wl["positive"], wl["seed"]
@@ -260,7 +353,7 @@ def main():
             "config": {"workload": args.workload, "model": model + (f"({ets_model})" if ets_model else ""),
                        "fixed_params": list(wl["fixed"]) if wl["fixed"] else None,
                        "series_total": n_total, "series_per_gpu": n, "T": T, "horizon": h, "seasonal_period": m, "positive": positive,
-                       "parallelism": f"series-sharded x{world} ({args.scaling}), gather of yhat chunks to rank 0",
+                       "parallelism": f"series-sharded x{world} ({args.scaling}), gather of yhat chunks to rank 0; {ranks_seen}",
                        "simulated_world": sim or None,
                        "series_ok": n_ok, "mean_passes_per_series": round(st["total_passes"] / max(n, 1), 1),
                        "max_passes_per_series": st["max_passes"], "mean_evals_per_series": round(st["total_evals"] / max(n, 1), 1),
@@ -273,6 +366,18 @@ def main():
                          "min_pass_bytes": min_bytes or None,
                          "mean_iterations_per_series": round(st.get("total_iters", 0) / max(n, 1), 1) if min_bytes else None},
         }
+        if model != "AutoARIMA" and not wl["fixed"]:
+            # lane-level efficiency of the round kernels (device counters of the LAST timed step): the share of issued lanes that
+            # evaluated a trial point of a running problem -- `valu.frac` counts a wave with three live lanes as fully useful, this does not
+            try:
+                ls = batch.lane_stats()
+                out["roofline"]["lanes"] = {"lane_efficiency": ls["lane_efficiency"], "wave_passes": ls["wave_passes"],
+                                            "by_class": {k: v["lane_efficiency"] for k, v in ls["by_class"].items()},
+                                            "wave_passes_by_class": {k: v["wave_passes"] for k, v in ls["by_class"].items()},
+                                            "by_spec": {k: v["lane_efficiency"] for k, v in ls["by_spec"].items()},
+                                            "what": "live lane-passes / (64 x wave passes) of ets_round_kernel, all rounds of one step"}
+            except (RuntimeError, AttributeError) as e:
+                out["roofline"]["lanes"] = {"error": str(e)}
         if final_pass_ms:
             out["roofline"]["final_pass"] = {"kernel": "ets_final_kernel<spec,period> alone", "kernel_ms": round(final_pass_ms, 4),
                                              "achieved": round(float(np.mean(alg_bytes)) / (final_pass_ms * 1e-3) / 1e9, 1),
@@ -332,6 +437,11 @@ def main():
                               "series_ok": e_ok,
                               "what": "anofox_ts_forecast_batch: NULL fill + pack to the pinned time-major block (all host threads) + H2D + "
                                       "fit + D2H + per-series malloc'd result arrays; PCIe-inclusive, never the headline value"}
+        # ---- the other BASELINE configurations, short loops (never `value`) ----------------------------
+        also_steps = args.also if args.also >= 0 else (3 if (world == 1 and not sim and args.workload == "autoets_m5_positive"
+                                                             and not args.n_series and not args.t) else 0)
+        if also_steps > 0 and world == 1:
+            out["also"] = also_pass(ALSO_WORKLOADS, also_steps, h, dev, lib, synth, DeviceBatch, pack_time_major, torch)
         # ---- CPU baseline: the oracle ("port") on a bounded sample of the same workload -------------
         sample = wl["cpu_sample"] if args.cpu_sample < 0 else args.cpu_sample
         if sample > 0:

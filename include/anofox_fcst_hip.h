@@ -194,6 +194,28 @@ typedef struct AnofoxHipStats {
                                    is one pass"), independent of which driver ran which round                                  */
 } AnofoxHipStats;
 
+/*
+ * Lane-level efficiency of the Nelder-Mead round kernels of the last run (round 5).  A wave streams a pass as long as ONE of its 64
+ * lanes still evaluates a trial point; a lane whose problem has converged, or that has used the round's budget, idles until the wave
+ * leaves.  wave_passes = passes streamed by waves, live_lane_passes = lane-passes that evaluated a point of a running problem (the
+ * four-lanes-per-problem and one-wave-per-problem drivers count every lane that evaluates a speculative point), so
+ * live_lane_passes / (64 * wave_passes) is the share of issued lanes that did work.  Classes: 0 additive-class specs, 1 general-class
+ * specs, 2 damped multiplicative-trend specs (b^phi every step).  Per slot: the spec id (error * 15 + trend * 3 + season; trend
+ * 0 N, 1 A, 2 Ad, 3 M, 4 Md) and its two counters.  Versioned by size: pass sizeof(AnofoxHipLaneStats) of the header you compiled
+ * against; the library writes min(struct_size, its own size) bytes and stores that number in `struct_size` (an older caller never
+ * sees bytes it did not allocate -- what anofox_hip_batch_stats, whose struct grew in round 4, cannot promise).
+ */
+typedef struct AnofoxHipLaneStats {
+    uint64_t struct_size;
+    uint64_t wave_passes[3];
+    uint64_t live_lane_passes[3];
+    uint32_t n_slots;
+    uint32_t reserved;
+    int32_t  slot_spec_id[30];
+    uint64_t slot_wave_passes[30];
+    uint64_t slot_live_lane_passes[30];
+} AnofoxHipLaneStats;
+
 /* Device selection; returns number of visible devices or -1. */
 int anofox_hip_device_count(void);
 int anofox_hip_set_device(int device);
@@ -251,6 +273,9 @@ bool anofox_hip_batch_set_device_block(AnofoxHipBatch *batch,
  * there is none), found by detect_period_kernel on the resident block.  False before a block is set.
  */
 bool anofox_hip_batch_periods(const AnofoxHipBatch *batch, int32_t *out_periods);
+
+/* Lane-level efficiency counters of the last run (waits for it); false before a run. */
+bool anofox_hip_batch_lane_stats(AnofoxHipBatch *batch, AnofoxHipLaneStats *out, size_t struct_size);
 
 /* Asynchronous fit + forecast on `stream` (a hipStream_t, may be NULL). */
 bool anofox_hip_batch_run(AnofoxHipBatch *batch, void *stream,

@@ -896,7 +896,7 @@ def test_host_entry_uploads_large_blocks_in_chunks(env):
     assert len(seen) > 20
 
 
-@pytest.mark.parametrize("scaling", ["default", "strong", "weak"])
+@pytest.mark.parametrize("scaling", ["default", "strong", "weak", "self-launch"])
 def test_bench_two_ranks_on_one_gpu(env, scaling):
     """bench.py's N > 1 path end to end -- two processes, torch.distributed rendezvous, sharded batches on the device, gather
     of the forecast chunks, max-over-ranks timing, one JSON line -- on this box's single GPU (ANOFOX_BENCH_ONE_GPU: both
@@ -907,6 +907,12 @@ def test_bench_two_ranks_on_one_gpu(env, scaling):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(29300 + os.getpid() % 400), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--workload", "autoets_m5", "--n-series", "1500", "--t", "200", "--cpu-sample", "0"]
+    if scaling == "self-launch":
+        # the UN-WRAPPED invocation, the shape of the command the driver runs for N = 1: bench.py starts its own ranks (a child
+        # torch.distributed.run, never an exec) and the line it prints says two ranks ran
+        cmd = [sys.executable] + cmd[cmd.index(os.path.join(root, "bench.py")):]
+        envv.pop("RANK", None); envv.pop("WORLD_SIZE", None)
+        scaling = "default"
     if scaling == "default":
         scaling = "strong"          # `bench.py --gpus N` without flags IS BASELINE config 3: ONE batch, series-sharded over the ranks
     else:
@@ -916,6 +922,7 @@ def test_bench_two_ranks_on_one_gpu(env, scaling):
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     j = json.loads(line)
     assert j["n_gpus"] == 2 and j["scaling"] == scaling and j["value"] > 0
+    assert "ranks seen: 2" in j["config"]["parallelism"]
     assert j["config"]["series_total"] == (1500 if scaling == "strong" else 3000)
     assert j["config"]["series_per_gpu"] == (750 if scaling == "strong" else 1500)
 
