@@ -217,6 +217,54 @@ __device__ __forceinline__ double dm_pow_step(double x, double y, const DmPowLan
     return __builtin_ldexp(ev, n >> 6);
 }
 
+// Round 5: b^phi for a growth rate near one (|b - 1| <= 1/16: 99.9 % of the steps of the M5-shape fits).  The binomial series
+// (1 + r)^y = sum_k C(y, k) r^k: the coefficients depend on the exponent only and are computed once per pass into registers
+// (dm_pow_near1_coef), the step is a Horner chain of DM_POW_NEAR1_DEG fused multiply-adds -- no table (no LDS round trip on the
+// recursion's critical path), no range reduction: 12 instructions against 36 + two lookups.  oracle/det_math.h (det_pow_near1_coef,
+// det_pow_near1) states the identical sequence; the branch is taken on the lane's own VALUE (ets_device.hpp), so a lane's result
+// does not depend on what shares its wave.
+constexpr int DM_POW_NEAR1_DEG = 11;
+constexpr double DM_POW_NEAR1_R = 0x1p-4;
+struct DmPowNear1 { double c[DM_POW_NEAR1_DEG + 1]; };
+__device__ __forceinline__ void dm_pow_near1_coef(double y, DmPowNear1 &o)
+{
+    constexpr double inv[DM_POW_NEAR1_DEG + 1] = { 0.0, 1.0, 1.0 / 2.0, 1.0 / 3.0, 1.0 / 4.0, 1.0 / 5.0, 1.0 / 6.0, 1.0 / 7.0,
+                                                   1.0 / 8.0, 1.0 / 9.0, 1.0 / 10.0, 1.0 / 11.0 };
+    o.c[0] = 1.0;
+    o.c[1] = y;
+#pragma unroll
+    for (int k = 2; k <= DM_POW_NEAR1_DEG; k++) o.c[k] = o.c[k - 1] * ((y - (double)(k - 1)) * inv[k]);
+}
+__device__ __forceinline__ double dm_pow_near1(double r, const DmPowNear1 &o)
+{
+    // Horner's rule (the oracle's order).  Estrin's scheme was measured slower (tools/ubench/fma_vgpr: 109 against 89 cycles per
+    // evaluation on one wave per SIMD, 156 against 128 on two): a dependent fp64 FMA completes every ~7.4 cycles and an independent one
+    // issues every ~5-6, so on this machine a step costs its instruction COUNT, not its dependent depth
+    double p = o.c[DM_POW_NEAR1_DEG];
+#pragma unroll
+    for (int k = DM_POW_NEAR1_DEG - 1; k >= 1; k--) p = fma(p, r, o.c[k]);
+    return fma(p, r, 1.0);
+}
+
+// Round 5: the one reciprocal of a general-class step, 1 / d for |d| in [2^-1000, 2^1000] (the caller rejects the trial point
+// otherwise, as oracle/ets.c does: det_recip_ok).  This is the compiler's own expansion of an fp64 division -- v_rcp_f64, two
+// Newton steps, quotient, residual, correction -- without the two v_div_scale, the v_div_fmas select and the v_div_fixup that only
+// matter for operands whose reciprocal or residual leaves the normal range: on this domain no operand is scaled (v_div_scale
+// returns it unchanged and leaves VCC clear, so v_div_fmas IS the fma below) and v_div_fixup returns its first operand, so the
+// result is bit for bit the hardware's correctly rounded quotient, which is the CPU's 1.0 / d.  7 instructions instead of 12.
+// (anofox_hip_selftest compares it with the compiled division on 2^28 operands per call.)
+__device__ __forceinline__ double dm_recip(double d)
+{
+    const double x0 = __builtin_amdgcn_rcp(d);
+    const double e0 = fma(-d, x0, 1.0);
+    const double x1 = fma(x0, e0, x0);
+    const double e1 = fma(-d, x1, 1.0);
+    const double x2 = fma(x1, e1, x1);          // (the numerator is one: the expansion's n * x2 is x2 itself)
+    const double e2 = fma(-d, x2, 1.0);
+    return fma(e2, x2, x2);
+}
+__device__ __forceinline__ bool dm_recip_ok(double d) { const double a = fabs(d); return a >= 0x1p-1000 && a <= 0x1p+1000; }
+
 // general x^y, x > 0 (forecast path: the exponent is a partial geometric sum and may exceed 1)
 __device__ __forceinline__ double dm_pow_pos(double x, double y) { return dm_exp(y * dm_log(x)); }
 

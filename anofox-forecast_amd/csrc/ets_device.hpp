@@ -16,6 +16,7 @@
 // Built with -ffp-contract=off; fma() only where written.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "det_math.hpp"
 #include "nm.hpp"
 
@@ -57,6 +58,15 @@ __device__ __forceinline__ int wave_min_i32(int v)
     return v;
 }
 
+#ifndef ANOFOX_TWO_BLOCK
+#define ANOFOX_TWO_BLOCK 1
+#endif
+#ifndef ANOFOX_S_DM
+#define ANOFOX_S_DM 8           // block length (rows in flight) of the damped multiplicative-trend pass
+#endif
+#ifndef ANOFOX_S_GEN
+#define ANOFOX_S_GEN 16         // ... of the other general-class passes
+#endif
 #ifndef ANOFOX_K4_S_SEAS
 #define ANOFOX_K4_S_SEAS 8      // block length of the four-candidates-per-lane pass with a seasonal ring in registers (4 x m more doubles of state)
 #endif
@@ -69,8 +79,12 @@ struct EtsCfg {
     static constexpr bool CLASSIC = false;      // (classic_device.hpp: the SES / Holt / Holt-Winters / SeasonalES family on the same round kernels)
 };
 
-struct EtsPar { double alpha, bstar, phi, beta, gamma; DmPowLane pl; };      // pl: this lane's copies of the b^phi tables (damped multiplicative trend only)
-struct EtsState { double l, b, sse, mant; int eacc; int bad; double f; };   // f: last one-step forecast (inspection only)
+struct EtsPar { double alpha, bstar, phi, beta, gamma; DmPowLane pl; DmPowNear1 pc; };      // pl: this lane's copies of the b^phi tables, pc: the binomial coefficients of phi (damped multiplicative trend only)
+// f: last one-step forecast (inspection only).  dlo / dhi: smallest / largest magnitude the step's reciprocal has been asked for, bmin: the
+// smallest undamped multiplicative growth rate seen -- the pass checks them ONCE at its end (ets_objective_value) instead of comparing in
+// every step: a comparison feeds a scalar mask that feeds a select, and with one or two waves per SIMD that round trip between the vector
+// and the scalar unit stalls the recursion (~30 cycles a step, profiles/r05_step_anatomy.txt); min / max stay on the vector unit, off the chain
+struct EtsState { double l, b, sse, mant; int eacc; int bad; double f; double dlo, dhi, bmin; };
 
 template <class Cfg>
 __device__ __forceinline__ void ets_unpack(const double (&x)[Cfg::DIM], EtsPar &p)
@@ -106,59 +120,93 @@ __device__ __forceinline__ void ets_step(const EtsPar &p, EtsState &st, double y
         if constexpr (Cfg::T == C_ADD) st.b = fma(p.beta, e, phib);
         if constexpr (Cfg::S == C_ADD) s = fma(p.gamma, e, s);
     } else {
+        // every other spec, in error-correction form (oracle/ets.c ets_lik states the same operations in the same order)
         double phib = 0.0, q = st.l;
         if constexpr (Cfg::T == C_ADD) {
             phib = Cfg::D ? p.phi * st.b : st.b;
             q = st.l + phib;
         } else if constexpr (Cfg::T == C_MUL) {
-            if (!(st.b > 0.0)) st.bad = 1;
             if constexpr (Cfg::D) {
-                // growth rates outside [2^-1000, 2^1000] reject the trial point (oracle/ets.c does the same), so the
-                // power below never meets a special case and runs without a branch
-                if (!(st.b >= 0x1p-1000 && st.b <= 0x1p+1000)) st.bad = 1;
-                phib = dm_pow_step(st.b, p.phi, p.pl);
-            } else phib = st.b;
+                // growth rates live next to one: the binomial series in r = b - 1 (round 5, det_math.hpp), for every lane; the rare
+                // lane outside |r| <= 1/16 takes the table-driven power (and the checks that only matter there: growth rates
+                // outside [2^-1000, 2^1000] or not positive reject the trial point, as oracle/ets.c does)
+                // (a per-lane branch: the block is skipped when no lane of the wave is far.  Measured alternatives, profiles/r05_step_anatomy.txt:
+                //  ANY branch in the step costs ~96 cycles of a one-wave-per-SIMD step, taken or not; a wave-uniform ballot branch with
+                //  the cold block out of line is 25-30 % slower over a whole fit -- the far case then pays two far jumps)
+                const double r = st.b - 1.0;
+                phib = dm_pow_near1(r, p.pc);
+                if (!(fabs(r) <= DM_POW_NEAR1_R)) {
+                    if (!(st.b >= 0x1p-1000 && st.b <= 0x1p+1000)) st.bad = 1;
+                    phib = dm_pow_step(st.b, p.phi, p.pl);
+                }
+            } else {
+                st.bmin = __builtin_fmin(st.bmin, st.b);          // (checked at the end of the pass: a growth rate <= 0 rejects the trial point)
+                phib = st.b;
+            }
             q = st.l * phib;
         }
         double f = q;
         if constexpr (Cfg::S == C_ADD) f = q + s;
         else if constexpr (Cfg::S == C_MUL) f = q * s;
-        // ONE reciprocal per step serves every quotient: 1/f (relative error; 1/s = q/f and 1/q = s/f
-        // for a multiplicative season) and 1/l (multiplicative growth) come from 1/(f l), 1/f or 1/l.
-        // An fp64 division is ~20 VALU instructions here, so this halves the general recursion.
-        constexpr bool need_f = (Cfg::E == C_MUL) || (Cfg::S == C_MUL);
-        double rf = 0.0, rl = 0.0;
-        if constexpr (need_f && Cfg::T == C_MUL) { double R = 1.0 / (f * st.l); rf = R * st.l; rl = R * f; }
-        else if constexpr (need_f) rf = 1.0 / f;
-        else if constexpr (Cfg::T == C_MUL) rl = 1.0 / st.l;
-        double e = y - f;
-        if constexpr (Cfg::E == C_MUL) {
-            e = e * rf;
-            int ex;
-            st.mant = frexp(st.mant * fabs(f), &ex);
-            st.eacc += ex;
-        }
-        st.sse = fma(e, e, st.sse);
-        double pp = y;
-        if constexpr (Cfg::S == C_ADD) pp = y - s;
-        else if constexpr (Cfg::S == C_MUL) pp = y * (rf * q);
-        double lnew = fma(p.alpha, pp - q, q);
-        if constexpr (Cfg::T == C_ADD) {
-            double r = lnew - st.l;
-            st.b = fma(p.bstar, r - phib, phib);
-        } else if constexpr (Cfg::T == C_MUL) {
-            double r = lnew * rl;
-            st.b = fma(p.bstar, r - phib, phib);
-        }
-        if constexpr (Cfg::S == C_ADD) {
-            double tt = y - q;
-            s = fma(p.gamma, tt - s, s);
-        } else if constexpr (Cfg::S == C_MUL) {
-            double tt = y * (rf * s);
-            s = fma(p.gamma, tt - s, s);
-        }
-        st.l = lnew;
         st.f = f;
+        // ONE reciprocal per step (dm_recip: the division's own instruction sequence without range scaling and fix-up); a denominator
+        // outside [2^-1000, 2^1000] rejects the trial point here and in oracle/ets.c -- tracked as a running min / max of its magnitude
+        auto recip = [&](const double d) __attribute__((always_inline)) {
+            const double ad = fabs(d);
+            st.dlo = __builtin_fmin(st.dlo, ad);
+            st.dhi = __builtin_fmax(st.dhi, ad);
+            return dm_recip(d);
+        };
+        if constexpr (Cfg::E == C_MUL) {
+            static_assert(Cfg::S != C_ADD, "multiplicative error with an additive season is not a valid spec");
+            const double rf = recip(f);
+            const double eps = (y - f) * rf;
+            st.mant = st.mant * fabs(f);                            // renormalised every fourth observation by the pass (ets_renorm)
+            st.sse = fma(eps, eps, st.sse);
+            const double qe = q * eps;
+            st.l = fma(p.alpha, qe, q);
+            if constexpr (Cfg::T == C_ADD) st.b = fma(p.beta, qe, phib);
+            else if constexpr (Cfg::T == C_MUL) st.b = fma(p.beta, phib * eps, phib);
+            if constexpr (Cfg::S == C_MUL) s = fma(p.gamma, s * eps, s);
+        } else {
+            const double e = y - f;
+            st.sse = fma(e, e, st.sse);
+            if constexpr (Cfg::S == C_MUL && Cfg::T == C_MUL) {
+                const double R = recip(f * st.l);                   // = 1 / (q s l): 1 / (s l) = R q, 1 / s = R q l, 1 / q = R (s l)
+                const double esl = e * (R * q);
+                const double es = esl * st.l;
+                const double sl = s * st.l;
+                st.l = fma(p.alpha, es, q);
+                st.b = fma(p.beta, esl, phib);
+                s = fma(p.gamma, e * (R * sl), s);
+            } else if constexpr (Cfg::S == C_MUL) {
+                const double R = recip(f);                          // 1 / s = R q, 1 / q = R s
+                const double es = e * (R * q);
+                st.l = fma(p.alpha, es, q);
+                if constexpr (Cfg::T == C_ADD) st.b = fma(p.beta, es, phib);
+                s = fma(p.gamma, e * (R * s), s);
+            } else {
+                static_assert(Cfg::T == C_MUL, "general class: a multiplicative component");
+                const double rl = recip(st.l);
+                st.l = fma(p.alpha, e, q);
+                st.b = fma(p.beta, e * rl, phib);
+                if constexpr (Cfg::S == C_ADD) s = fma(p.gamma, e, s);
+            }
+        }
+    }
+}
+
+// sum log|f| of a multiplicative-error pass is carried as mant * 2^eacc.  oracle/ets.c renormalises the product (frexp) at every
+// observation; here it happens after every fourth step of a block and at the block's end -- the same (mant, eacc) bit for bit, because
+// a multiplicative-error trial point is only admissible while every |f| lies in [2^-120, 2^120] (checked at the end of the pass through
+// dlo / dhi): up to four such factors times a mantissa in [1/2, 1) stay normal numbers, and scaling by a power of two is exact
+template <class Cfg>
+__device__ __forceinline__ void ets_renorm(EtsState &st)
+{
+    if constexpr (Cfg::E == C_MUL) {
+        int ex;
+        st.mant = frexp(st.mant, &ex);
+        st.eacc += ex;
     }
 }
 
@@ -166,6 +214,13 @@ template <class Cfg>
 __device__ __forceinline__ double ets_objective_value(const EtsState &st, int n)
 {
     if (st.bad || !(fabs(st.sse) <= 1.7976931348623157e308)) return __builtin_huge_val();
+    if constexpr (!Cfg::ADDITIVE) {
+        // the domain of the step's reciprocal and of an undamped multiplicative growth rate, checked once (EtsState).  n == 0: no step ran
+        // (multiplicative error: the denominator is the one-step forecast, whose domain is the narrower one of the log-likelihood product)
+        constexpr double D_LO = Cfg::E == C_MUL ? 0x1p-120 : 0x1p-1000, D_HI = Cfg::E == C_MUL ? 0x1p+120 : 0x1p+1000;
+        if (n > 0 && !(st.dlo >= D_LO && st.dhi <= D_HI)) return __builtin_huge_val();
+        if constexpr (Cfg::T == C_MUL && !Cfg::D) { if (n > 0 && !(st.bmin > 0.0)) return __builtin_huge_val(); }
+    }
     double lik = (double)n * dm_log(st.sse);
     if constexpr (Cfg::E == C_MUL) lik = lik + 2.0 * (dm_log(st.mant) + (double)st.eacc * ETS_LN2);
     if (lik != lik) return __builtin_huge_val();
@@ -207,8 +262,10 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
 #pragma unroll
     for (int k = 0; k < K; k++) {
         ets_unpack<Cfg>(cand[k], par[k]);
-        if constexpr (Cfg::T == C_MUL && Cfg::D) par[k].pl = dm_pow_lane();
+        if constexpr (Cfg::T == C_MUL && Cfg::D) { par[k].pl = dm_pow_lane(); dm_pow_near1_coef(par[k].phi, par[k].pc); }
         st[k].l = in.l0; st[k].b = in.b0; st[k].sse = 0.0; st[k].mant = 1.0; st[k].eacc = 0; st[k].bad = 0;
+        st[k].f = 0.0; st[k].dlo = __builtin_huge_val(); st[k].dhi = 0.0; st[k].bmin = __builtin_huge_val();
+
     }
     const double *yp = v.yb;            // wave-uniform base; the lane's column is added as a 32-bit offset
     const unsigned col_bytes = (unsigned)v.col * 8u;     // ld < 2^29 columns: the byte offset of a column fits 32 bits
@@ -227,7 +284,7 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
     // cover the latency with fewer rows in flight, and their own register needs leave less room for the buffers
     // (ring in HBM: the ring values stream through two more buffers of S -- half the block length, or the four buffers spill)
     //  (four candidates per lane, K = 4: half the block, the four recursions' states take the registers)
-    constexpr int S_FULL = Cfg::ADDITIVE ? (K == 4 ? (MS > 0 ? ANOFOX_K4_S_SEAS : 16) : 32) : ((Cfg::T == C_MUL && Cfg::D) ? 8 : 16);
+    constexpr int S_FULL = Cfg::ADDITIVE ? (K == 4 ? (MS > 0 ? ANOFOX_K4_S_SEAS : 16) : 32) : ((Cfg::T == C_MUL && Cfg::D) ? ANOFOX_S_DM : ANOFOX_S_GEN);
     //  and at most 8 -- the ring prefetch needs periods of two blocks, a merged batch keeps periods from 17 up in HBM)
     constexpr int S_TARGET = ((MS == -2 || MS == -4) && K == 1 && S_FULL > 8) ? 8 : S_FULL;
     constexpr int S = (MS > 0) ? ((S_TARGET / MS > 0 ? S_TARGET / MS : 1) * MS) : S_TARGET;
@@ -271,36 +328,39 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
 #pragma unroll
             for (int k = 0; k < K; k++) s[k][0] = 0.0;
         }
+        // Two blocks per iteration on alternating buffers (round 5: every class, it used to be the additive one only): the copy between
+        // the buffers -- one of a step's instructions -- disappears.  The main loop runs the blocks that every active lane of the wave covers without a predicate; the tail runs them predicated.
+        auto run_block = [&](const double (&buf)[S], const int base, auto pred_tag) __attribute__((always_inline)) {
+            constexpr bool PRED = decltype(pred_tag)::value;
+#pragma unroll
+            for (int j = 0; j < S; j++) {
+                if (!PRED || base + j < v.len) {
+#pragma unroll
+                    for (int k = 0; k < K; k++) {
+                        ets_step<Cfg>(par[k], st[k], buf[j], s[k][MS > 0 ? j % MR : 0]);
+                        if ((j & 3) == 3 || j == S - 1) ets_renorm<Cfg>(st[k]);     // (a constant once the loop is unrolled)
+                    }
+                    keep_fit(base + j);
+                }
+            }
+        };
         int base = 0;
-        if constexpr (Cfg::ADDITIVE) {
-            // cheap steps: two blocks per iteration on alternating buffers, so the copy between the buffers (one of the
-            // ~11 instructions of a step) disappears while every wave-uniform full block remains
+        // ANOFOX_TWO_BLOCK: 0 one block per iteration and a copy between the buffers (half the code: the unrolled blocks of the ~25
+        // round kernels that share a CU's instruction cache are what it holds), 1 two blocks for the additive class only (round 4),
+        // 2 for every class
+        constexpr bool TWO = ANOFOX_TWO_BLOCK == 2 || (ANOFOX_TWO_BLOCK == 1 && Cfg::ADDITIVE);
+        if constexpr (TWO) {
             for (; base + 2 * S <= wave_min_len; base += 2 * S) {
                 load_block(nxt, base + S);
-#pragma unroll
-                for (int j = 0; j < S; j++)
-                    { _Pragma("unroll") for (int k = 0; k < K; k++) ets_step<Cfg>(par[k], st[k], cur[j], s[k][MS > 0 ? j % MR : 0]); keep_fit(base + j); }
+                run_block(cur, base, std::false_type{});
                 load_block(cur, base + 2 * S);
-#pragma unroll
-                for (int j = 0; j < S; j++)
-                    { _Pragma("unroll") for (int k = 0; k < K; k++) ets_step<Cfg>(par[k], st[k], nxt[j], s[k][MS > 0 ? j % MR : 0]); keep_fit(base + S + j); }
+                run_block(nxt, base + S, std::false_type{});
             }
         }
         for (; base < wave_len; base += S) {
             load_block(nxt, base + S);
-            if (base + S <= wave_min_len) {
-#pragma unroll
-                for (int j = 0; j < S; j++)
-                    { _Pragma("unroll") for (int k = 0; k < K; k++) ets_step<Cfg>(par[k], st[k], cur[j], s[k][MS > 0 ? j % MR : 0]); keep_fit(base + j); }
-            } else {
-#pragma unroll
-                for (int j = 0; j < S; j++)
-                    if (base + j < v.len) {
-#pragma unroll
-                        for (int k = 0; k < K; k++) ets_step<Cfg>(par[k], st[k], cur[j], s[k][MS > 0 ? j % MR : 0]);
-                        keep_fit(base + j);
-                    }
-            }
+            if (base + S <= wave_min_len) run_block(cur, base, std::false_type{});
+            else run_block(cur, base, std::true_type{});
 #pragma unroll
             for (int j = 0; j < S; j++) cur[j] = nxt[j];
         }
@@ -369,6 +429,7 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
                     if (full || base + i < v.len) {
                         double sv = rc[i];
                         ets_step<Cfg>(par[0], st[0], cur[i], sv);
+                        if ((i & 3) == 3 || i == S - 1) ets_renorm<Cfg>(st[0]);
                         ring[(size_t)j * NM_BLOCK + lane] = sv;
                         keep_fit(base + i);
                     }
@@ -387,6 +448,7 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
                     for (int k = 0; k < K; k++) {
                         double sv = ring[(k * m + j) * NM_BLOCK + lane];
                         ets_step<Cfg>(par[k], st[k], cur[i], sv);
+                        if ((i & 3) == 3 || i == S - 1) ets_renorm<Cfg>(st[k]);
                         ring[(k * m + j) * NM_BLOCK + lane] = sv;
                     }
                     keep_fit(base + i);
@@ -421,7 +483,10 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
         }
     }
 #pragma unroll
-    for (int k = 0; k < K; k++) fout[k] = ets_objective_value<Cfg>(st[k], v.len);
+    for (int k = 0; k < K; k++) {
+        ets_renorm<Cfg>(st[k]);        // (a lane whose series ended inside a block: its last steps were not followed by a renormalisation)
+        fout[k] = ets_objective_value<Cfg>(st[k], v.len);
+    }
     if constexpr (FINAL) {
         if (fin->sse_out && v.len > 0) *fin->sse_out = st[0].sse;
         if (fin->states && v.len > 0) { fin->states[0] = st[0].l; fin->states[fin->states_ld] = st[0].b; }

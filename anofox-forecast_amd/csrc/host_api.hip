@@ -1802,6 +1802,19 @@ bool anofox_hip_batch_stats(AnofoxHipBatch *b, AnofoxHipStats *out)
     return true;
 }
 
+bool anofox_hip_selftest_recip(uint64_t n_operands, uint64_t seed, uint64_t *out_mismatches, double *out_first_bad)
+{
+    if (!out_mismatches) return false;
+    AnofoxError err;
+    if (!device_ready(&err)) return false;
+    double fb = 0.0;
+    const unsigned long long r = anofox::recip_selftest(n_operands, seed, &fb, nullptr);
+    if (r == ~0ull) return false;
+    *out_mismatches = r;
+    if (out_first_bad) *out_first_bad = fb;
+    return true;
+}
+
 bool anofox_hip_batch_lane_stats(AnofoxHipBatch *b, AnofoxHipLaneStats *out, size_t struct_size)
 {
     if (!b || !out || !b->ran || struct_size < sizeof(uint64_t)) return false;

@@ -395,4 +395,44 @@ void launch_detect_periods(const double *y, size_t ld, const int32_t *len, int n
     }
 }
 
+// ---- self test of dm_recip (det_math.hpp): the short division sequence against the compiled IEEE division -------------------------
+// operand i of `n`: a 64-bit mix of (seed, i) as the significand and sign, the exponent swept over the whole admissible domain
+// [2^-1000, 2^1000]; counts the operands where the two quotients differ in any bit
+__global__ __launch_bounds__(256) void recip_selftest_kernel(unsigned long long n, unsigned long long seed, unsigned long long *mismatches, double *first_bad)
+{
+    unsigned long long bad = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * blockDim.x) {
+        unsigned long long z = seed + 0x9e3779b97f4a7c15ull * (i + 1);
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+        z ^= z >> 31;
+        const long long e = (long long)((z >> 52) % 2001ull) - 1000;            // exponent in [-1000, 1000]
+        unsigned long long bits = (z & 0x800fffffffffffffull) | ((unsigned long long)(e + 1023) << 52);
+        if (e == 1000) bits &= 0xfff0000000000000ull;                           // |d| <= 2^1000 exactly
+        if ((i & 1023) == 0) bits |= 0x000fffffffffffffull * ((i >> 10) & 1);   // all-ones / all-zeros significands among them
+        if (e == 1000) bits &= 0xfff0000000000000ull;
+        const double d = dm_from_bits(bits);
+        if (!dm_recip_ok(d)) continue;
+        const double want = 1.0 / d, got = dm_recip(d);
+        if (dm_bits(want) != dm_bits(got)) { if (bad == 0 && atomicAdd(mismatches + 1, 1ull) == 0) *first_bad = d; bad++; }
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
+unsigned long long recip_selftest(unsigned long long n, unsigned long long seed, double *first_bad_out, hipStream_t stream)
+{
+    unsigned long long *d_cnt = nullptr; double *d_bad = nullptr;
+    if (hipMalloc(&d_cnt, 2 * sizeof(unsigned long long)) != hipSuccess || hipMalloc(&d_bad, sizeof(double)) != hipSuccess) return ~0ull;
+    (void)hipMemsetAsync(d_cnt, 0, 2 * sizeof(unsigned long long), stream);
+    (void)hipMemsetAsync(d_bad, 0, sizeof(double), stream);
+    hipLaunchKernelGGL(recip_selftest_kernel, dim3(4096), dim3(256), 0, stream, n, seed, d_cnt, d_bad);
+    unsigned long long h[2] = {~0ull, 0};
+    double hb = 0.0;
+    if (hipStreamSynchronize(stream) != hipSuccess || hipMemcpy(h, d_cnt, sizeof h, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(&hb, d_bad, sizeof hb, hipMemcpyDeviceToHost) != hipSuccess) h[0] = ~0ull;
+    (void)hipFree(d_cnt); (void)hipFree(d_bad);
+    if (first_bad_out) *first_bad_out = hb;
+    return h[0];
+}
+
 } // namespace anofox

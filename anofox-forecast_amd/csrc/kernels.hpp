@@ -207,6 +207,10 @@ size_t arima_long_scratch_doubles(int n_series, int m, int max_fit_waves);   // 
 int arima_max_fit_waves();                                                  // resident waves of the fit kernels (what the scratch is sized for)
 int launch_arima(const ArimaArgs &, hipStream_t);   // returns the number of kernel launches; synchronises the stream between sweeps
 
+// dm_recip (det_math.hpp) against the compiled division on `n` generated operands of the admissible domain: the number of operands
+// whose quotients differ (0 is the claim), ~0 when the device could not run it; *first_bad: one of them
+unsigned long long recip_selftest(unsigned long long n, unsigned long long seed, double *first_bad, hipStream_t stream);
+
 void launch_prep(const PrepArgs &, hipStream_t);
 void launch_select(const SelectArgs &, hipStream_t);
 void launch_classic(int kind, const ClassicArgs &, hipStream_t);

@@ -110,7 +110,7 @@ EXPORTED_SYMBOLS = [
     "anofox_hip_batch_n_series", "anofox_hip_batch_periods", "anofox_hip_batch_set_fixed_params",
     "anofox_hip_set_devices", "anofox_hip_get_devices", "anofox_hip_set_min_series_per_device", "anofox_hip_shard_range",
     "anofox_hip_set_default_arima_method", "anofox_hip_batch_set_arima_method", "anofox_hip_release_caches",
-    "anofox_hip_batch_run_many", "anofox_hip_batch_lane_stats",
+    "anofox_hip_batch_run_many", "anofox_hip_batch_lane_stats", "anofox_hip_selftest_recip",
 ]
 
 ARIMA_CSS, ARIMA_CSS_ML = 0, 1     # include/anofox_fcst_hip.h: ANOFOX_ARIMA_CSS / ANOFOX_ARIMA_CSS_ML
@@ -163,6 +163,8 @@ def load():
     L.anofox_hip_batch_run.argtypes = [C.c_void_p, C.c_void_p, P(AnofoxError)]
     L.anofox_hip_batch_stats.restype = C.c_bool
     L.anofox_hip_batch_stats.argtypes = [C.c_void_p, P(AnofoxHipStats)]
+    L.anofox_hip_selftest_recip.restype = C.c_bool
+    L.anofox_hip_selftest_recip.argtypes = [C.c_uint64, C.c_uint64, P(C.c_uint64), P(C.c_double)]
     L.anofox_hip_batch_lane_stats.restype = C.c_bool
     L.anofox_hip_batch_lane_stats.argtypes = [C.c_void_p, P(AnofoxHipLaneStats), C.c_size_t]
     L.anofox_hip_batch_device_results.restype = C.c_bool

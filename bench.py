@@ -64,6 +64,7 @@ def parse_args():
     ap.add_argument("--horizon", type=int, default=28)
     ap.add_argument("--cpu-sample", type=int, default=-1, help="series for the CPU baseline (-1 auto, 0 skip)")
     ap.add_argument("--e2e-steps", type=int, default=-1, help="timed passes of the host-buffer entry (-1 auto, 0 skip)")
+    ap.add_argument("--ets-model", default="", help="single-spec probes: override the workload's ETS spec (e.g. AMdA; implies model ETS on strictly positive series)")
     ap.add_argument("--also", type=int, default=-1,
                     help="timed steps of each of the other BASELINE configurations, reported under \"also\" (-1 auto: 3 on the default "
                          "single-GPU invocation, 0 otherwise; 0 skip)")
@@ -237,7 +238,9 @@ def main():
         dist.all_gather_object(seen, (rank, dev_index))
     ranks_seen = f"{'RCCL (nccl)' if backend == 'nccl' else backend} ranks seen: {len(seen)} on devices {sorted(set(d for _, d in seen))}"
 
-    wl = WORKLOADS[args.workload]
+    wl = dict(WORKLOADS[args.workload])
+    if args.ets_model:
+        wl.update(model="ETS", ets_model=args.ets_model, positive=True, fixed=None)
     model, ets_model, m, positive, seed = wl["model"], wl["ets_model"], wl["m"], wl["positive"], wl["seed"]
     n_arg = args.n_series or wl["n"]
     T = args.t or wl["T"]

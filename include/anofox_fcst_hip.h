@@ -274,6 +274,14 @@ bool anofox_hip_batch_set_device_block(AnofoxHipBatch *batch,
  */
 bool anofox_hip_batch_periods(const AnofoxHipBatch *batch, int32_t *out_periods);
 
+/*
+ * Self test of the kernels' reciprocal (csrc/det_math.hpp dm_recip: v_rcp_f64 + two Newton steps + one correction, the division
+ * expansion without range scaling and fix-up) against the compiled IEEE division on `n_operands` generated operands covering
+ * [2^-1000, 2^1000] in both signs: *out_mismatches = operands whose two quotients differ in any bit (the parity contract needs 0:
+ * oracle/ets.c divides), *out_first_bad (may be NULL) one such operand.  False when no device could run it.
+ */
+bool anofox_hip_selftest_recip(uint64_t n_operands, uint64_t seed, uint64_t *out_mismatches, double *out_first_bad);
+
 /* Lane-level efficiency counters of the last run (waits for it); false before a run. */
 bool anofox_hip_batch_lane_stats(AnofoxHipBatch *batch, AnofoxHipLaneStats *out, size_t struct_size);
 

@@ -188,4 +188,50 @@ static inline double det_pow_step(double x, double y)
     return ev * det_from_bits((uint64_t)(0x3ff + (n >> 6)) << 52);
 }
 
+/*
+ * Round 5: b^phi for a growth rate NEAR ONE, which is where growth rates live (|b - 1| <= 1/16 in 99.9 % of the steps of the M5-shape
+ * fits, tools/pow_hist).  The binomial series (1 + r)^y = sum_k C(y, k) r^k has coefficients that depend on the exponent only: they
+ * are computed ONCE per likelihood pass (det_pow_near1_coef, DET_POW_NEAR1_DEG - 1 multiplications), and the step is a Horner chain
+ * of DET_POW_NEAR1_DEG fused multiply-adds -- no table, no range reduction (12 operations against 36 + two table lookups of
+ * det_pow_step).  Truncation: |C(y, 12)| 16^-12 < 1e-17 for y in (0, 1]; total error < 1 ulp.  ets.c takes this branch iff
+ * |b - 1| <= DET_POW_NEAR1_R (a per-series, per-step decision on the VALUE, so it is the same in the kernels whatever else
+ * shares the wave) and det_pow_step otherwise.  csrc/det_math.hpp (dm_pow_near1_coef / dm_pow_near1) states the identical sequence.
+ */
+#define DET_POW_NEAR1_DEG 11
+#define DET_POW_NEAR1_R 0x1p-4
+static inline void det_pow_near1_coef(double y, double *c /* [DET_POW_NEAR1_DEG + 1], c[0] unused */)
+{
+    static const double inv[DET_POW_NEAR1_DEG + 1] = { 0.0, 1.0, 1.0 / 2.0, 1.0 / 3.0, 1.0 / 4.0, 1.0 / 5.0, 1.0 / 6.0, 1.0 / 7.0,
+                                                       1.0 / 8.0, 1.0 / 9.0, 1.0 / 10.0, 1.0 / 11.0 };
+    c[0] = 1.0;
+    c[1] = y;
+    for (int k = 2; k <= DET_POW_NEAR1_DEG; k++) c[k] = c[k - 1] * ((y - (double)(k - 1)) * inv[k]);
+}
+static inline double det_pow_near1(double r, const double *c)
+{
+    /* Horner's rule.  (Estrin's scheme -- depth 5 instead of 12 -- was built and measured SLOWER on the GPU, tools/ubench/fma_vgpr:
+     * 109 against 89 cycles per evaluation on one wave per SIMD: a dependent fp64 FMA completes every ~7.4 cycles, an independent
+     * one issues every ~5-6, so the three extra instructions cost more than the shorter chain saves.) */
+    double p = c[DET_POW_NEAR1_DEG];
+    for (int k = DET_POW_NEAR1_DEG - 1; k >= 1; k--) p = fma(p, r, c[k]);
+    return fma(p, r, 1.0);
+}
+
+/*
+ * Round 5: the ONE reciprocal of a general-class step.  Its value is the correctly rounded 1 / d (this division); what is new is
+ * the DOMAIN: a denominator outside [2^-1000, 2^1000] in magnitude (or not a number) makes the trial point inadmissible -- the
+ * kernels then compute the quotient with v_rcp_f64 + two Newton steps + one correction, the compiler's own division expansion
+ * without its range scaling and special-case fix-up (7 instructions instead of 12), which is the correctly rounded quotient
+ * exactly on that domain (csrc/det_math.hpp dm_recip; checked against the hardware division by anofox_hip_selftest).
+ */
+static inline int det_recip_ok(double d) { double a = fabs(d); return a >= 0x1p-1000 && a <= 0x1p+1000; }
+/*
+ * A multiplicative-error model divides by the one-step forecast f and accumulates sum log|f|: f must lie in [2^-120, 2^120] in
+ * magnitude (1e-36 .. 1e36), else the trial point is inadmissible.  Inside that domain the running product of up to eight factors
+ * times a mantissa in [1/2, 1) cannot leave the normal range, so WHERE the product is renormalised (frexp) does not change a bit of
+ * (mant, eacc) -- scaling by a power of two is exact and commutes with rounding -- and the kernels may renormalise once every four
+ * observations while ets.c below does it at every one.
+ */
+static inline int det_mulerr_f_ok(double f) { double a = fabs(f); return a >= 0x1p-120 && a <= 0x1p+120; }
+
 #endif /* ORACLE_DET_MATH_H */

@@ -296,6 +296,8 @@ double ets_lik(const EtsSpec *spec, const double *y, int n, const double *par,
     double l = l0, b = b0, sse = 0.0;
     double mant = 1.0; long eacc = 0;
     int bad = 0;
+    double powc[DET_POW_NEAR1_DEG + 1];
+    if (spec->trend == ETS_MUL && spec->damped) det_pow_near1_coef(phi, powc);
 
     if (ets_is_additive_class(spec)) {
         for (int t = 0; t < n; t++) {
@@ -314,7 +316,21 @@ double ets_lik(const EtsSpec *spec, const double *y, int n, const double *par,
             if (spec->trend == ETS_ADD) b = fma(beta, e, phib);
             if (spec->season == ETS_ADD) sbuf[j] = fma(gamma, e, sbuf[j]);
         }
+    } else if (spec->error == ETS_MUL && spec->season == ETS_ADD) {
+        bad = 1;        /* never fitted: ETSSpec::is_valid() rejects it (forecast.c spec_is_valid) */
     } else {
+        /*
+         * Every other spec, in ERROR-CORRECTION form (round 5; Hyndman, Koehler, Ord & Snyder 2008, tables 2.2 / 2.3): the updates are
+         * written on the one-step error instead of on y / s, y / q and l' / l.  Algebraically the general recursion of rounds 1-4
+         * (pp - q = e / s, r - phi b = alpha e / (s l), tt - s = e / q; with a relative error eps = e / f they become q eps,
+         * phib eps, s eps), but a third fewer operations and a shorter dependent chain:
+         *     multiplicative error  eps = (y - f) / f :  l' = q + alpha q eps ;  b' = phib + beta q eps  (additive trend)
+         *                                                b' = phib + beta phib eps (multiplicative trend) ;  s' = s + gamma s eps
+         *     additive error        e = y - f          :  l' = q + alpha e / s ;  b' = phib + beta e / s  or  phib + beta e / (s l) ;
+         *                                                s' = s + gamma e / q     (the quotients from ONE reciprocal of f, l or f l)
+         * with beta = alpha beta*, gamma = gamma* (1 - alpha) as in the additive class.  sum log|f| is accumulated as mant * 2^eacc.
+         */
+        const int need_f = (spec->error == ETS_MUL) || (spec->season == ETS_MUL);
         for (int t = 0; t < n; t++) {
             int j = (spec->season != ETS_NONE) ? t % m : 0;
             double s = (spec->season != ETS_NONE) ? sbuf[j] : 0.0;
@@ -323,53 +339,68 @@ double ets_lik(const EtsSpec *spec, const double *y, int n, const double *par,
                 phib = spec->damped ? phi * b : b;
                 q = l + phib;
             } else if (spec->trend == ETS_MUL) {
-                if (!(b > 0.0)) { bad = 1; break; }
-                /* a damped growth rate outside [2^-1000, 2^1000] is inadmissible (the trial point is rejected): keeps
-                 * phi * log(b) inside the range where exp needs no special cases, on the CPU and in the kernels alike */
-                if (spec->damped && !(b >= 0x1p-1000 && b <= 0x1p+1000)) { bad = 1; break; }
-                phib = spec->damped ? det_pow_step(b, phi) : b;
+                if (spec->damped) {
+                    /* growth rates live next to one: the binomial series in r = b - 1 (det_math.h, round 5); anything else takes
+                     * the table-driven power.  |r| <= 1/16 implies b > 0 and b in range, so the checks belong to the other branch */
+                    const double r = b - 1.0;
+                    if (fabs(r) <= DET_POW_NEAR1_R) phib = det_pow_near1(r, powc);
+                    else {
+                        /* a damped growth rate outside [2^-1000, 2^1000] (or not positive) is inadmissible: keeps phi * log(b)
+                         * inside the range where exp needs no special cases, on the CPU and in the kernels alike */
+                        if (!(b >= 0x1p-1000 && b <= 0x1p+1000)) { bad = 1; break; }
+                        phib = det_pow_step(b, phi);
+                    }
+                } else {
+                    if (!(b > 0.0)) { bad = 1; break; }
+                    phib = b;
+                }
                 q = l * phib;
             }
             double f = q;
             if (spec->season == ETS_ADD) f = q + s;
             else if (spec->season == ETS_MUL) f = q * s;
-            /* ONE reciprocal per step serves every quotient of the step: 1/f (relative error,
-             * and 1/s = q/f, 1/q = s/f for a multiplicative season) and 1/l (multiplicative growth)
-             * come from R = 1/(f l), 1/f or 1/l.  fp64 division is ~20 VALU instructions on gfx950,
-             * so this is the single largest saving of the general recursion; the quotients differ
-             * from y/s, y/q, l'/l by an ulp or two.  A zero denominator gives inf/NaN, the SSE
-             * becomes non-finite and the candidate is rejected (no HUGEN clamps needed). */
             if (ets_fitted_sink) ets_fitted_sink[t] = f;
-            const int need_f = (spec->error == ETS_MUL) || (spec->season == ETS_MUL);
-            double rf = 0.0, rl = 0.0;
-            if (need_f && spec->trend == ETS_MUL) { double R = 1.0 / (f * l); rf = R * l; rl = R * f; }
-            else if (need_f) rf = 1.0 / f;
-            else if (spec->trend == ETS_MUL) rl = 1.0 / l;
-            double e = y[t] - f;
+            /* ONE reciprocal per step; its denominator must lie in [2^-1000, 2^1000] in magnitude, else the trial point is
+             * inadmissible (det_math.h det_recip_ok: the domain on which the kernels' short division sequence is the correctly
+             * rounded quotient).  A zero or non-finite denominator is outside that domain. */
+            double lnew;
             if (spec->error == ETS_MUL) {
-                e = e * rf;
-                int ex;
-                mant = frexp(mant * fabs(f), &ex);
-                eacc += ex;
-            }
-            sse = fma(e, e, sse);
-            double p = y[t];
-            if (spec->season == ETS_ADD) p = y[t] - s;
-            else if (spec->season == ETS_MUL) p = y[t] * (rf * q);
-            double lnew = fma(alpha, p - q, q);
-            if (spec->trend == ETS_ADD) {
-                double r = lnew - l;
-                b = fma(bstar, r - phib, phib);
-            } else if (spec->trend == ETS_MUL) {
-                double r = lnew * rl;
-                b = fma(bstar, r - phib, phib);
-            }
-            if (spec->season == ETS_ADD) {
-                double tt = y[t] - q;
-                sbuf[j] = fma(gamma, tt - s, s);
-            } else if (spec->season == ETS_MUL) {
-                double tt = y[t] * (rf * s);
-                sbuf[j] = fma(gamma, tt - s, s);
+                if (!det_mulerr_f_ok(f)) { bad = 1; break; }      /* (det_math.h: the domain of the division AND of the log-likelihood product) */
+                const double rf = 1.0 / f;
+                const double eps = (y[t] - f) * rf;
+                { int ex; mant = frexp(mant * fabs(f), &ex); eacc += ex; }
+                sse = fma(eps, eps, sse);
+                const double qe = q * eps;
+                lnew = fma(alpha, qe, q);
+                if (spec->trend == ETS_ADD) b = fma(beta, qe, phib);
+                else if (spec->trend == ETS_MUL) b = fma(beta, phib * eps, phib);
+                if (spec->season == ETS_MUL) sbuf[j] = fma(gamma, s * eps, s);
+            } else {
+                const double e = y[t] - f;
+                sse = fma(e, e, sse);
+                if (spec->season == ETS_MUL && spec->trend == ETS_MUL) {
+                    const double d = f * l;                  /* = q s l : 1 / (s l) = R q, 1 / s = R q l, 1 / q = R (s l) */
+                    if (!det_recip_ok(d)) { bad = 1; break; }
+                    const double R = 1.0 / d;
+                    const double esl = e * (R * q);
+                    const double es = esl * l;
+                    lnew = fma(alpha, es, q);
+                    b = fma(beta, esl, phib);
+                    sbuf[j] = fma(gamma, e * (R * (s * l)), s);
+                } else if (need_f) {                         /* multiplicative season, trend none / additive: 1 / s = R q, 1 / q = R s */
+                    if (!det_recip_ok(f)) { bad = 1; break; }
+                    const double R = 1.0 / f;
+                    const double es = e * (R * q);
+                    lnew = fma(alpha, es, q);
+                    if (spec->trend == ETS_ADD) b = fma(beta, es, phib);
+                    sbuf[j] = fma(gamma, e * (R * s), s);
+                } else {                                     /* multiplicative trend, season none / additive */
+                    if (!det_recip_ok(l)) { bad = 1; break; }
+                    const double rl = 1.0 / l;
+                    lnew = fma(alpha, e, q);
+                    b = fma(beta, e * rl, phib);
+                    if (spec->season == ETS_ADD) sbuf[j] = fma(gamma, e, s);
+                }
             }
             l = lnew;
         }

@@ -63,6 +63,45 @@ KATS = {"SES": 18.943503, "SESOptimized": 19.537535, "SeasonalES": 14.451866, "H
         "HoltWinters": 19.953912, "Naive": 21.0, "SMA": 19.0, "RandomWalkDrift": 21.478261}
 
 
+def test_kernel_reciprocal_is_the_ieee_division(env):
+    """The general-class step divides once (oracle/ets.c: 1.0 / d); the kernels compute that quotient with the division's own
+    instruction sequence minus range scaling and fix-up (det_math.hpp dm_recip), exact on [2^-1000, 2^1000] -- the domain outside
+    which both sides reject the trial point.  2^28 generated operands per seed, every exponent of the domain, both signs."""
+    api, O, lib, synth = env
+    import ctypes as C
+    L = lib.load()
+    for seed in (1, 20260101, 0xDEADBEEF):
+        bad, first = C.c_uint64(123), C.c_double(0.0)
+        assert L.anofox_hip_selftest_recip(1 << 28, seed, C.byref(bad), C.byref(first))
+        assert bad.value == 0, (seed, bad.value, first.value.hex())
+
+
+def test_lane_stats_are_consistent(env):
+    """anofox_hip_batch_lane_stats: live lane-passes never exceed 64 x wave passes, every fitted spec reports, and the struct is
+    versioned by size (a caller compiled against a smaller struct gets only the bytes it allocated)."""
+    api, O, lib, synth = env
+    import ctypes as C
+    import torch
+    from anofox_forecast_amd.device import DeviceBatch, pack_time_major
+    n, T, m = 3000, 300, 7
+    Y = synth.gen_series(synth.SEED_M5, 0, n, T, m, positive=True)
+    b = DeviceBatch(n, T, lib.make_options("AutoETS", 7, seasonal_period=m), "cuda:0")
+    y = torch.from_numpy(pack_time_major(Y, b.ld)).to("cuda:0")
+    ln = torch.full((b.ld,), T, dtype=torch.int32, device="cuda:0"); ln[n:] = 0
+    b.set_block(y, ln)
+    b.run()
+    ls = b.lane_stats()
+    assert len(ls["by_spec"]) == 25 and all(v["wave_passes"] > 0 for v in ls["by_spec"].values())
+    assert 0.3 < ls["lane_efficiency"] <= 1.0
+    assert all(c["live_lane_passes"] <= 64 * c["wave_passes"] for c in ls["by_class"].values())
+    st = b.stats()
+    assert ls["live_lane_passes"] >= st["total_passes"] - 25 * n          # (every lane-pass of the one-lane drivers is a pass; the final passes are not counted here)
+    small = (C.c_uint64 * 4)(0, 0, 0, 0xABCDEF)
+    assert lib.load().anofox_hip_batch_lane_stats(b.handle, C.cast(small, C.POINTER(lib.AnofoxHipLaneStats)), 24)
+    assert small[0] == 24 and small[3] == 0xABCDEF                       # 24 bytes written, the fourth word untouched
+    b.close()
+
+
 def test_reference_kats_through_c_abi(env):
     """test/sql/ts_model_distinctness.test:116,141,180 via anofox_ts_forecast on the GPU."""
     api, O, lib, _ = env
