@@ -678,7 +678,10 @@ struct ArWs {
         // per (dimension, shape class) queue: six problems per series.  A sweep emits up to 17 per series (more with lookahead) over
         // 42 queues; a queue that is full drops the candidate (its `computed` bit is cleared) and the next sweep queues it again --
         // same results, one more sweep -- which the single-bucket queue order (tune arima_queue_sort = 3) does run into
-        cap = (size_t)n * 6;
+        // A floor of 512 (round 5): a call with one or a few series runs its sweeps with lookahead 1 or 2 -- up to
+        // 18 or 18 x 18 candidates per series, of which more than six can land in one bucket; with cap = 6 n they were dropped and
+        // re-queued, and every extra sweep is a host round trip of the latency-bound path the lookahead exists to shorten
+        cap = std::max<size_t>((size_t)n * 6, 512);
         size_t off = 0;
         auto take = [&](size_t bytes) { char *r = p ? p + off : nullptr; off += align(bytes); return r; };
         W = (double *)take(sizeof(double) * (size_t)n * tw);
@@ -2219,7 +2222,9 @@ int launch_arima(const ArimaArgs &a, hipStream_t stream)
     if (a.trace >= 2) AR_HIPCHECK(hipMemsetAsync(ws.counts + 96, 0, 32 * sizeof(int32_t), stream));
     // one lane per series, every loop a chain of dependent loads and adds: the kernel is as fast as the number of waves that hide each
     // other's latency.  64 series per wave are 477 waves on the M5 batch -- half the SIMDs idle, the others with one wave; with 16 series
-    // per wave it is 1,906 waves (20.5 -> PREP_MS ms).  (Long periods keep 64: their figure scratch is laid out per 64 series.)
+    // per wave it would be 1,906 waves -- measured in round 4 and NOT faster once the ring window and the eight-lag KPSS sweep had cut the
+    // kernel from 20.5 to 5.3 ms (profiles/r04_arima_experiments.txt), so Tunables::arima_prep_lanes defaults to 64; the knob stays for
+    // the schedule-variant test.  (Long periods keep 64: their figure scratch is laid out per 64 series.)
     const int prep_block = long_m ? NM_BLOCK : a.prep_lanes;
     AR_HIPCHECK(hipMemsetAsync(ws.counts_p, 0, 128 * sizeof(int32_t), stream));
     hipLaunchKernelGGL(arima_prep_kernel, dim3((a.n_series + prep_block - 1) / prep_block), dim3(prep_block), prep_lds, stream, a, ws);

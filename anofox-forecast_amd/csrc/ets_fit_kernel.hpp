@@ -23,7 +23,8 @@ namespace anofox {
 // Per-class residency policy of the round kernels (round 4).  PARK: the Nelder-Mead simplex of every lane rests in a global scratch
 // of the workgroup between passes instead of LDS (nm.hpp), so LDS holds only the b^phi tables and the kernel may be resident four
 // times per SIMD; WAVES: the residency the register allocation is asked to allow (caps VGPRs at 512 / WAVES).
-// -DANOFOX_PARK_CLASS: 0 none (round-3 behaviour), 1 damped multiplicative trend (default), 2 + every general-class spec, 3 all ETS specs.
+// -DANOFOX_PARK_CLASS: 0 none (the DEFAULT: every PARK variant measured slower, profiles/r04_ab_experiments.txt), 1 damped multiplicative
+// trend, 2 + every general-class spec, 3 all ETS specs.
 #ifndef ANOFOX_PARK_CLASS
 #define ANOFOX_PARK_CLASS 0
 #endif

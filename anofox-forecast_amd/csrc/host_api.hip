@@ -15,6 +15,7 @@
 #include <cmath>
 #include <condition_variable>
 #include <mutex>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -921,7 +922,14 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
         int64_t additive_live = 0;
         for (size_t oi = 0; oi < order.size(); oi++)
             if (!dead[oi] && !spec_has_mult(specs[order[oi]])) additive_live += b->live_all >= 0 ? (int64_t)b->live_all : (int64_t)n;
-        const bool on = b->tun.k4 > 0 || (b->tun.k4 < 0 && all_additive && additive_live >= 131072);
+        // ... or (round 5) the batch oversubscribes the chip whatever its mix: with the general-class steps a third shorter (error-correction
+        // form) the 25-spec batch of strictly positive series is no longer bound by fp64 issue alone, and the additive specs' ~41 % fewer
+        // passes are worth their arithmetic -- 477.6 -> 450.9 ms on the 30,490-series batch, same box (profiles/r05_tune_sweep.txt).  One
+        // lane per problem fills two waves per SIMD from 131,072 live problems on; below four times that the chains' latency decides
+        int64_t all_live = 0;
+        for (size_t oi = 0; oi < order.size(); oi++)
+            if (!dead[oi]) all_live += (spec_has_mult(specs[order[oi]]) && b->live_pos >= 0) ? (int64_t)b->live_pos : (b->live_all >= 0 ? (int64_t)b->live_all : (int64_t)n);
+        const bool on = b->tun.k4 > 0 || (b->tun.k4 < 0 && ((all_additive && additive_live >= 131072) || all_live >= 524288));
         for (size_t oi = 0; oi < order.size(); oi++)
             k4[oi] = on && !dead[oi] && !b->fixed_params && !spec_has_mult(specs[order[oi]]) && fns[oi].round_k4 && fns[oi].round_auto_k4;
     }

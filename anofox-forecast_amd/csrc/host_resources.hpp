@@ -52,7 +52,8 @@ struct Tunables {
     int k4_top = 1, k4_top_below = 20480;   // tune k4_top, k4_top_below: see host_api.hip run_fit (0 = like every other spec)
                                 //   pass (ets_fit_kernel.hpp K4) wherever one or four LANES per problem would run.  -1 (default): when the run is
                                 //   memory bound and fills the chip that way -- the general-class specs see under half of the series AND the
-                                //   additive specs have >= 131,072 live problems together (two K4 waves per SIMD); 0 never; 1 always.
+                                //   additive specs have >= 131,072 live problems together (two K4 waves per SIMD), or (round 5) the batch has
+                                //   >= 524,288 live problems over all its specs; 0 never; 1 always.
                                 //   Measured: intermittent M5 batch 86.3 -> 70.4 ms, 125k x 1,024 batch 181 -> 136-140 ms, 1M x 1,024 1,200 -> 853 ms;
                                 //   beside the 19 general-class specs of the strictly positive batch it is time-neutral (fewer passes, the step is
                                 //   bound by fp64 issue), and ONE additive spec on 30,490 series is slower with it (20.5 against 17.9 ms: 477 waves)
@@ -472,10 +473,31 @@ void stream_set_destroy(StreamSet *s)
     for (auto &e : s->ev_join) if (e) (void)hipEventDestroy(e);
     delete s;
 }
+// The candidate specs of a fit run on up to 25 streams side by side; the HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues
+// (default 4) and streams that share a queue serialise.  The variable is read when the runtime initialises, which may be long before
+// this library sees its first call (a host that links it: INTEGRATION.md section A), so the library cannot reliably set it:
+//   * a load-time constructor sets GPU_MAX_HW_QUEUES=16 when the host has not set anything (works whenever the runtime initialises
+//     lazily at its first call, after this library was loaded -- ctypes / dlopen hosts, and linked hosts whose first HIP call is ours);
+//   * the first stream set checks what the environment says and warns ONCE on stderr, independent of ANOFOX_HIP_TIMING, when the
+//     value is missing or below 16: results are unaffected, the 25-spec AutoETS batch is ~2x slower on 4 queues.
+__attribute__((constructor, used)) static void anofox_hip_default_hw_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+inline void warn_hw_queues_once()
+{
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *q = std::getenv("GPU_MAX_HW_QUEUES");
+        const int v = q ? std::atoi(q) : 0;
+        if (v < 16)
+            std::fprintf(stderr, "[anofox-hip] warning: GPU_MAX_HW_QUEUES is %s (< 16): the candidate ETS specs run on concurrent HIP streams and will share "
+                                 "hardware queues -- export GPU_MAX_HW_QUEUES=16 in the host's environment before its first HIP call (results are "
+                                 "unaffected; the 25-spec AutoETS batch is about twice as slow)\n", q ? q : "unset");
+    });
+}
 StreamSet *stream_set_take()
 {
     int dev = 0;
     HIPCHECK(hipGetDevice(&dev));
+    warn_hw_queues_once();
     StreamPool &p = stream_pool();
     // The first streams of a device's FIRST set carry the most expensive specs of a fit (launch_fit_slots orders the specs by
     // work) and get the highest priority: the command processor then dispatches their workgroups first whenever slots free up, the

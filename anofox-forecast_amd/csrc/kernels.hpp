@@ -188,13 +188,13 @@ struct ArimaArgs {
     int32_t *status, *evals, *passes, *models;
     double *yhat;                       // [n_series x h]
     int32_t *model_code;                // 1000000 + p*1e5 + d*1e4 + q*1e3 + P*100 + D*10 + Q
-    int trace;                          // debugging: the refit kernel prints per-wave timings (ANOFOX_HIP_ARIMA_TRACE)
+    int trace;                          // debugging: the refit kernel prints per-wave timings (ANOFOX_HIP_TUNE arima_trace=1|2)
     double lookahead, spec_factor;      // schedule knobs of the search (host_api.hip Tunables: lookahead once the queue fits the resident lanes
     int lookahead_depth;                //   this many times over; four lanes per problem below spec_factor x the resident groups)
     const std::atomic<int> *concurrent; // host only: AutoARIMA runs in flight in this process (the parts of a call with detected periods run side by side)
     double shared_chunk_rounds;         // ... with more than one, a fit launch takes at most this many rounds of the resident lanes (tune
                                         // arima_shared_chunk_rounds; 0 = whole queue): see launch_arima
-    int prep_lanes;                     // series per wave of arima_prep_kernel (tune arima_prep_lanes: 16; 64 = one full wave per 64 series)
+    int prep_lanes;                     // series per wave of arima_prep_kernel (tune arima_prep_lanes; default 64 = one full wave per 64 series)
     int queue_sort;                     // order of the fit queue (tune arima_queue_sort; arima.hip ar_bucket): 0 as emitted, 1..3 by series within a bucket
     int refit_budget;                   // exact-likelihood refit: evaluations per series in the sequential launch before the speculative one takes over (0: one launch)
     double *long_scratch;               // seasonal period above 24: HBM scratch of arima_long_scratch_doubles() doubles (rings, polynomials), else NULL

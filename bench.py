@@ -349,9 +349,10 @@ def main():
             "value": round(value, 1), "unit": "series/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            # what the results are checked against: the oracle restates the published algorithms and reproduces every known answer the
-            # reference's SQL tests hold (AutoARIMA since round 4: 18.0145125 against 18.014537, 1.3e-6 relative -- DESIGN.md section 3)
-            "parity": ("bit-identical to oracle/ (restatement pinned on the reference's known answers incl. AutoARIMA's within 1e-5; nothing with a seasonal period is pinned in the reference tree)" if model == "AutoARIMA"
+            # what the results are checked against: the oracle restates the published algorithms; the reference's known answers are met to six
+            # decimals (SES / Holt / HoltWinters family, baselines) or within 1e-5 relative (AutoETS, AutoARIMA: 18.0145125 against 18.014537,
+            # not SQL-equal; its box / root threshold / budget were selected on that single series -- DESIGN.md section 3)
+            "parity": ("bit-identical to oracle/ (restatement within 1e-5 relative of the reference's one AutoARIMA known answer, not SQL-equal; its three constants were selected on that single series; nothing with a seasonal period is pinned in the reference tree)" if model == "AutoARIMA"
                        else "bit-identical to oracle/ (restatement pinned on the reference's known answers; crate-internal arithmetic for m = 7 unpinned)"),
             "config": {"workload": args.workload, "model": model + (f"({ets_model})" if ets_model else ""),
                        "fixed_params": list(wl["fixed"]) if wl["fixed"] else None,

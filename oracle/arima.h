@@ -35,11 +35,19 @@ extern "C" {
 #define ARIMA_MAX_DIM 6            /* p+q+P+Q <= 5, plus the constant */
 #define ARIMA_MAX_LAG (ARIMA_MAX_P + ARIMA_MAX_SP * ARIMA_MAX_PERIOD)
 #define ARIMA_MAX_MODELS 94
-#define ARIMA_SEARCH_EVALS(dim) (30 + 15 * (dim))   /* Nelder-Mead evaluations / iterations of a candidate in the search stage: the smallest
+#ifndef ARIMA_SEARCH_BASE            /* (the three constants below can be overridden on the command line: tools/arima_kat_search/robustness.py) */
+#define ARIMA_SEARCH_BASE 30
+#endif
+#ifndef ARIMA_SEARCH_PER_DIM
+#define ARIMA_SEARCH_PER_DIM 15
+#endif
+#define ARIMA_SEARCH_EVALS(dim) (ARIMA_SEARCH_BASE + ARIMA_SEARCH_PER_DIM * (dim))   /* Nelder-Mead evaluations / iterations of a candidate in the search stage: the smallest
                                                      * round budget at which the root check sees converged-enough candidates on the known-answer
                                                      * series (20 + 10 dim, 40 + 10 dim: wrong model; 30 + 15, 20 + 20, 50 + 10 and up: right) */
 #define ARIMA_COEF_BOX 0.99        /* every AR / MA / seasonal coefficient is clipped to [-0.99, 0.99] where the recursion reads it */
+#ifndef ARIMA_ROOT_MIN
 #define ARIMA_ROOT_MIN 1.001       /* admissible models have every AR and MA root outside this radius (box corner: 1.00504) */
+#endif
 #ifndef ARIMA_POLISH_NM_CAP
 #define ARIMA_POLISH_NM_CAP 100     /* ... of the selected model's CSS estimates: 100 x dim, like the exact-likelihood refit (the run starts where
                                      * the search stopped: 4 % of the M5-like series need more than that, and on the device the longest

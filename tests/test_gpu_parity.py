@@ -1204,11 +1204,13 @@ def test_hostile_inputs_match_oracle(env, model, kw):
                 assert np.array_equal(np.asarray(r["lower"]), np.asarray(ref["lower"]), equal_nan=True), (name, h)
 
 
-def _run_device_batch(lib, Y, model, h, m, dev="cuda:0"):
+def _run_device_batch(lib, Y, model, h, m, dev="cuda:0", arima_method=None):
     import torch
     from anofox_forecast_amd.device import DeviceBatch, pack_time_major
     n, T = Y.shape
     b = DeviceBatch(n, T, lib.make_options(model, h, seasonal_period=m), dev)
+    if arima_method is not None:
+        b.set_arima_method(arima_method)
     y = torch.from_numpy(pack_time_major(Y, b.ld)).to(dev)
     ln = torch.full((b.ld,), T, dtype=torch.int32, device=dev)
     ln[n:] = 0
@@ -1240,7 +1242,7 @@ def test_auto_arima_other_periods(env, m):
     _compare(api, O, lib, series, "AutoARIMA", 2 * m + 1, seasonal_period=m)
 
 
-@pytest.mark.parametrize("model,positive", [("AutoETS", False), ("AutoETS", True), ("AutoARIMA", False)])
+@pytest.mark.parametrize("model,positive", [("AutoETS", False), ("AutoETS", True), ("AutoARIMA", False), ("AutoARIMA-ML", False)])
 def test_full_size_m5_properties(env, model, positive):
     """BASELINE.json's full M5 shape (30,490 series x 1,913 observations, h = 28, m = 7), checked through properties that
     do not need the oracle at that size: a second run over the resident block reproduces every bit; a series' result does
@@ -1250,7 +1252,23 @@ def test_full_size_m5_properties(env, model, positive):
     api, O, lib, synth = env
     n, T, h, m = 30490, 1913, 28, 7
     Y = synth.gen_series(synth.SEED_M5, 0, n, T, m, positive)
-    full, again, names = _run_device_batch(lib, Y, model, h, m)
+    # "AutoARIMA-ML": BASELINE config 4 as written -- "(Kalman kernel)": the selected models refitted on the exact Gaussian likelihood
+    # (ANOFOX_ARIMA_CSS_ML, arima_refit_kernel), the oracle switched to the same method
+    method = lib.ARIMA_CSS_ML if model == "AutoARIMA-ML" else None
+    model = "AutoARIMA" if method is not None else model
+    import ctypes as C
+    flag = C.c_int.in_dll(O.lib(), "oracle_arima_ml_refit")
+    flag.value = 1 if method is not None else 0
+    try:
+        _full_size_checks(api, O, lib, Y, model, positive, h, m, method)
+    finally:
+        flag.value = 0
+
+
+def _full_size_checks(api, O, lib, Y, model, positive, h, m, method):
+    n = Y.shape[0]
+    run = lambda YY: _run_device_batch(lib, YY, model, h, m, arima_method=method)
+    full, again, names = run(Y)
     for k in ("yhat", "lower", "upper", "model_code", "status"):
         assert np.array_equal(full[k], again[k], equal_nan=True), f"{k}: second run differs"
     assert np.all(full["status"][:n] == 0)
@@ -1258,7 +1276,7 @@ def test_full_size_m5_properties(env, model, positive):
     assert np.all(np.isfinite(yh)) and np.all(lo <= yh) and np.all(yh <= hi)
     assert all(nm.startswith(model + "(") or nm == model for nm in names)
     pick = np.random.default_rng(5).choice(n, 96, replace=False)          # arbitrary series, arbitrary order
-    sub, _, sub_names = _run_device_batch(lib, Y[pick], model, h, m)
+    sub, _, sub_names = run(Y[pick])
     for k in ("yhat", "lower", "upper", "model_code"):
         assert np.array_equal(sub[k][:96], full[k][pick], equal_nan=True), f"{k}: result depends on the batch"
     oo = O.make_options(model, h, seasonal_period=m)
