@@ -989,9 +989,8 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
     // a handful of series: one launch per spec, every problem on a wave of its own (two iterations per pass) to completion -- one
     // series through AutoETS was 12 rounds x 3 launches x 25 specs
     const bool tiny = (uint64_t)n * order.size() <= (uint64_t)TINY_BATCH_PROBLEMS;
-    for (int r = 0; r < (b->fixed_params ? 0 : (tiny ? 1 : n_rounds)); r++) {
-        for (size_t oi = 0; oi < order.size(); oi++) {
-            if (dead[oi]) continue;
+    auto enqueue_round = [&](const int r, const size_t oi) {
+            if (dead[oi]) return;
             const int q = (int)(oi % (size_t)n_lanes);
             auto &lane = b->lanes[q];
             hipStream_t sq = spec_stream(stream_of[oi]);
@@ -1005,7 +1004,7 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
                 a.budget = 1 << 30; a.budget_seq = a.budget;
                 fns[oi].round_spec2(a, sq);
                 b->fit_launches++;
-                continue;
+                return;
             }
             if (r == 0 && b->use_pos && a.need_positive) {
                 // mixed batch: this spec is admissible for the strictly positive series only -- its first round runs on
@@ -1073,6 +1072,29 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
                 fns[oi].round_auto(a, sq);
             }
             b->fit_launches++;
+    };
+    const int total_rounds = b->fixed_params ? 0 : (tiny ? 1 : n_rounds);
+    // Head start of the damped multiplicative-trend chains (tune dm_head_rounds, round 5): their fits are the step's critical path -- alone
+    // on the chip one of them takes 185-280 ms of a 450 ms step (profiles/r05_step_anatomy.txt) -- and while all 25 chains start together
+    // their early, full rounds share every SIMD with the cheap specs' waves.  With a head start their first rounds are enqueued alone,
+    // the other specs' streams wait for an event recorded behind them, and fill the chip once those chains thin out.
+    int head = 0;
+    if (!tiny && !inline_stream && total_rounds > 0 && b->tun.dm_head_rounds > 0) {
+        std::vector<size_t> dm, rest;
+        for (size_t oi = 0; oi < order.size(); oi++)
+            if (!dead[oi]) (spec_trend_idx(specs[order[oi]]) == 4 ? dm : rest).push_back(oi);
+        if (!dm.empty() && !rest.empty()) {
+            head = std::min(b->tun.dm_head_rounds, total_rounds);
+            for (int r = 0; r < head; r++) for (size_t oi : dm) enqueue_round(r, oi);
+            LAUNCHCHECK("ETS fit head rounds");
+            for (size_t oi : dm) HIPCHECK(hipEventRecord(b->ev_join[stream_of[oi]], spec_stream(stream_of[oi])));
+            for (size_t oi : rest) for (size_t od : dm) HIPCHECK(hipStreamWaitEvent(spec_stream(stream_of[oi]), b->ev_join[stream_of[od]], 0));
+        }
+    }
+    for (int r = 0; r < total_rounds; r++) {
+        for (size_t oi = 0; oi < order.size(); oi++) {
+            if (r < head && spec_trend_idx(specs[order[oi]]) == 4) continue;      // (already enqueued)
+            enqueue_round(r, oi);
         }
         LAUNCHCHECK("ETS fit round");
     }

@@ -57,6 +57,7 @@ struct Tunables {
                                 //   Measured: intermittent M5 batch 86.3 -> 70.4 ms, 125k x 1,024 batch 181 -> 136-140 ms, 1M x 1,024 1,200 -> 853 ms;
                                 //   beside the 19 general-class specs of the strictly positive batch it is time-neutral (fewer passes, the step is
                                 //   bound by fp64 issue), and ONE additive spec on 30,490 series is slower with it (20.5 against 17.9 ms: 477 waves)
+    int dm_head_rounds = 0;     // tune dm_head_rounds: rounds the damped multiplicative-trend chains run before the other specs' streams start (launch_fit_slots)
     bool merge_periods = true;  // tune merge_periods: auto-detected periods run as merged batches (0: one batch per period)
     int part_threads = 16;      // tune part_threads: host threads that run the small per-period parts of an auto-detected batch side by side
     int pack_threads = 0;       // ANOFOX_HIP_PACK_THREADS: host threads of the packer (0: all, at most 32)
@@ -115,7 +116,7 @@ struct Tunables {
         if (kv.count("spec_below")) t.spec_below = t.spec_below_md = std::atoi(kv.at("spec_below").c_str());
         geti("spec_below_md", t.spec_below_md);
         geti("gather_cols", t.gather_cols);
-        geti("k4", t.k4); geti("k4_top", t.k4_top); geti("k4_top_below", t.k4_top_below);
+        geti("k4", t.k4); geti("dm_head_rounds", t.dm_head_rounds); geti("k4_top", t.k4_top); geti("k4_top_below", t.k4_top_below);
         if (kv.count("spec2_below")) t.spec2_below = t.spec2_below_md = std::atoi(kv.at("spec2_below").c_str());
         geti("spec2_below_md", t.spec2_below_md);
         if (kv.count("merge_periods")) t.merge_periods = std::atoi(kv.at("merge_periods").c_str()) != 0;
