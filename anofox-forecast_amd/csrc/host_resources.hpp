@@ -475,13 +475,11 @@ void stream_set_destroy(StreamSet *s)
     delete s;
 }
 // The candidate specs of a fit run on up to 25 streams side by side; the HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues
-// (default 4) and streams that share a queue serialise.  The variable is read when the runtime initialises, which may be long before
-// this library sees its first call (a host that links it: INTEGRATION.md section A), so the library cannot reliably set it:
-//   * a load-time constructor sets GPU_MAX_HW_QUEUES=16 when the host has not set anything (works whenever the runtime initialises
-//     lazily at its first call, after this library was loaded -- ctypes / dlopen hosts, and linked hosts whose first HIP call is ours);
-//   * the first stream set checks what the environment says and warns ONCE on stderr, independent of ANOFOX_HIP_TIMING, when the
-//     value is missing or below 16: results are unaffected, the 25-spec AutoETS batch is ~2x slower on 4 queues.
-__attribute__((constructor, used)) static void anofox_hip_default_hw_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+// (default 4) and streams that share a queue serialise.  The variable is read when the runtime initialises, and the library does not
+// touch the process environment (a setenv at load time races with getenv in a multi-threaded host such as DuckDB and changes every
+// other HIP user of the process: INTEGRATION.md, Environment) -- the HOST exports it.  What the library does (round 5): the first
+// stream set looks at what the environment says and warns ONCE on stderr, independent of ANOFOX_HIP_TIMING, when the value is missing
+// or below 16: results are unaffected, the 25-spec AutoETS batch is 1.3-2x slower on 4 queues.
 inline void warn_hw_queues_once()
 {
     static std::once_flag once;

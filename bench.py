@@ -66,8 +66,8 @@ def parse_args():
     ap.add_argument("--e2e-steps", type=int, default=-1, help="timed passes of the host-buffer entry (-1 auto, 0 skip)")
     ap.add_argument("--ets-model", default="", help="single-spec probes: override the workload's ETS spec (e.g. AMdA; implies model ETS on strictly positive series)")
     ap.add_argument("--also", type=int, default=-1,
-                    help="timed steps of each of the other BASELINE configurations, reported under \"also\" (-1 auto: 3 on the default "
-                         "single-GPU invocation, 0 otherwise; 0 skip)")
+                    help="timed steps of each of the other BASELINE configurations, reported under \"also\" (-1 auto: 3 on the plain default "
+                         "single-GPU invocation -- no --workload / --n-series / --cpu-sample / --e2e-steps --, 0 otherwise; 0 skip)")
     ap.add_argument("--simulate-world", type=int, default=0,
                     help="ONE process, ONE GPU: run rank 0's share of an N-GPU job (strong: shard 0 of N; weak: one full batch) and report the "
                          "per-GPU figure an N-GPU run would start from -- what can be known about 8 GPUs on a 1-GPU box (no collective runs)")
@@ -442,8 +442,11 @@ def main():
                               "what": "anofox_ts_forecast_batch: NULL fill + pack to the pinned time-major block (all host threads) + H2D + "
                                       "fit + D2H + per-series malloc'd result arrays; PCIe-inclusive, never the headline value"}
         # ---- the other BASELINE configurations, short loops (never `value`) ----------------------------
+        # (auto: only the PLAIN default invocation -- the driver's line; a run that switches the CPU or host-buffer leg off is a
+        #  measurement script, whose kernel trace or counters must hold the headline workload alone)
         also_steps = args.also if args.also >= 0 else (3 if (world == 1 and not sim and args.workload == "autoets_m5_positive"
-                                                             and not args.n_series and not args.t) else 0)
+                                                             and not args.n_series and not args.t and not args.ets_model
+                                                             and args.cpu_sample < 0 and args.e2e_steps < 0) else 0)
         if also_steps > 0 and world == 1:
             out["also"] = also_pass(ALSO_WORKLOADS, also_steps, h, dev, lib, synth, DeviceBatch, pack_time_major, torch)
         # ---- CPU baseline: the oracle ("port") on a bounded sample of the same workload -------------

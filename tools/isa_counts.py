@@ -100,26 +100,37 @@ def analyse(path, want=lambda name: True):
                 continue
             merged.append((pend, ins))
             pend = None
-        # the unpredicated block of S steps is straight-line code (fully unrolled, branch-free): the basic block with the most fp64
-        # instructions inside a loop; the loop's own overhead (row prefetch, buffer copy, branch) sits in the same block
-        in_loop = [False] * len(merged)
-        for a, b in loops_of(merged):
-            for i in range(a, b + 1):
-                in_loop[i] = True
-        best, cur, n_cur = None, {}, 0
-        for i, (lab, ins) in enumerate(merged + [("end", "s_endpgm")]):
-            if lab is not None or i == len(merged):
-                if n_cur and (best is None or cur.get("valu_f64", 0) > best[0].get("valu_f64", 0)):
-                    best = (cur, n_cur)
-                cur, n_cur = {}, 0
-            if i < len(merged) and in_loop[i]:
-                c = classify(ins)
-                cur[c] = cur.get(c, 0) + 1
-                n_cur += 1
-                if ins.startswith(("s_cbranch", "s_branch")):
-                    if best is None or cur.get("valu_f64", 0) > best[0].get("valu_f64", 0):
-                        best = (cur, n_cur)
-                    cur, n_cur = {}, 0
+        # The unpredicated main loop of ets_pass: one iteration = one block of S steps (two blocks for the additive class).  Round 5: a damped
+        # multiplicative-trend step holds a branch over its rarely needed table path, so the iteration is no longer ONE basic block --
+        # count the whole loop body instead, leaving out what an s_cbranch_execz skips (the path a wave takes when no lane needs the block).
+        labels = {lab: i for i, (lab, _) in enumerate(merged) if lab}
+
+        def count(a, b):
+            c, n, i = {}, 0, a
+            while i <= b:
+                ins = merged[i][1]
+                k = classify(ins)
+                c[k] = c.get(k, 0) + 1
+                n += 1
+                m = re.match(r"s_cbranch_execz\s+(\S+)", ins)
+                if m and m.group(1) in labels and i < labels[m.group(1)] <= b:
+                    i = labels[m.group(1)]
+                    continue
+                i += 1
+            return c, n
+        cand = []
+        for a, b in sorted(set(loops_of(merged))):
+            if any(a <= a2 and b2 <= b and (a2, b2) != (a, b) for a2, b2 in loops_of(merged)):
+                continue                                    # not innermost
+            c, n = count(a, b)
+            cand.append((a, c, n))
+        best = None
+        if cand:
+            top = max(c.get("valu_f64", 0) for _, c, _ in cand)
+            for a, c, n in cand:                            # the first (main, unpredicated) of the loops that hold the recursion
+                if c.get("valu_f64", 0) >= 0.6 * top:
+                    best = (c, n)
+                    break
         if best:
             rows.append((nm, best[0], best[1]))
     return rows
@@ -132,7 +143,7 @@ def steps_of(name):
         return None
     e, t, d, s, ms, spec = int(m.group(1)), int(m.group(2)), m.group(3) == "true", int(m.group(4)), int(m.group(5)), int(m.group(6))
     additive = e == 1 and t != 2 and s != 2
-    target = 32 if additive else (8 if (t == 2 and d) else 16)
+    target = 32 if additive else (8 if (t == 2 and d) else 16)      # ANOFOX_S_DM / ANOFOX_S_GEN of ets_device.hpp
     S = (max(target // ms, 1) * ms) if ms > 0 else target
     if additive and ms >= 0:
         S *= 2          # two blocks per iteration on alternating buffers
