@@ -297,7 +297,7 @@ void free_batch_buffers(AnofoxHipBatch *b)
     if (b->owns_len) F(b->d_len);
     F(b->d_mean); F(b->d_sd); F(b->d_fig_add); F(b->d_fig_mul); F(b->d_l0); F(b->d_b0); F(b->d_flags);
     F(b->d_aicc); F(b->d_yhat_slots); F(b->d_status_slots); F(b->d_evals_slots); F(b->d_iters_slots);
-    F(b->d_passes_slots); F(b->d_slot_spec);
+    F(b->d_passes_slots); F(b->d_slot_spec); F(b->d_lane_stats);
     F(b->d_yhat); F(b->d_lo); F(b->d_hi); F(b->d_model_code); F(b->d_status); F(b->d_detail);
     F(b->classic_st.sim); F(b->classic_st.fs); F(b->classic_st.phase); F(b->classic_st.evals); F(b->classic_st.iters); F(b->classic_st.passes); F(b->classic_st.done);
     F(b->d_classic_ybuf); F(b->d_classic_status); F(b->classic_map[0]); F(b->classic_map[1]); F(b->classic_cnt);
