@@ -102,6 +102,23 @@ def test_lane_stats_are_consistent(env):
     b.close()
 
 
+@pytest.mark.parametrize("scale", [1.0e-150, 1.0e-40, 1.0e30, 1.0e40, 1.0e150, 1.0e290])
+def test_extreme_scales_hit_the_domain_rules_identically(env, scale):
+    """Round 5 gave the general-class recursion two DOMAIN rules that oracle and kernels must apply identically: the step's reciprocal
+    is defined for denominators in [2^-1000, 2^1000] (the kernels divide with the division's own sequence minus range scaling), and a
+    multiplicative-error model's one-step forecast must lie in [2^-120, 2^120] (where the log-likelihood product may be renormalised
+    every fourth step).  Ordinary data never meets either bound; these series do -- positive M5-shape counts scaled by 1e-150 ... 1e290:
+    specs become inadmissible (their objective is +inf), the selection moves to what is left, and GPU and oracle must agree on
+    every model name and every bit, whatever the scale did."""
+    api, O, lib, synth = env
+    Y = synth.gen_series(synth.SEED_M5, 7700, 48, 180, 7, positive=True) * scale
+    series = [Y[s, : 180 - (s % 4) * 10] for s in range(48)]
+    _compare(api, O, lib, series, "AutoETS", 10, seasonal_period=7)
+    _compare(api, O, lib, series[:16], "AutoETS", 10, seasonal_period=1)
+    for spec in ("MMdM", "AMdN", "MAdM", "AMM", "MNN"):
+        _compare(api, O, lib, series[:24], "ETS", 7, ets_model=spec, seasonal_period=7)
+
+
 def test_reference_kats_through_c_abi(env):
     """test/sql/ts_model_distinctness.test:116,141,180 via anofox_ts_forecast on the GPU."""
     api, O, lib, _ = env
