@@ -18,9 +18,11 @@ def _rel(a, b):
     a, b = np.asarray(a), np.asarray(b)
     if a.shape != b.shape:
         return np.inf
-    both_nan = np.isnan(a) & np.isnan(b)
-    d = np.abs(a - b) / np.maximum(1.0, np.abs(b))
-    d[both_nan] = 0.0
+    same = (np.isnan(a) & np.isnan(b)) | (a == b)           # both NaN, or equal (equal infinities included: inf - inf is NaN)
+    with np.errstate(invalid="ignore"):
+        d = np.abs(a - b) / np.maximum(1.0, np.abs(b))
+    d[same] = 0.0
+    d[np.isnan(d)] = np.inf                                  # anything else that is not a number is a mismatch, not a pass
     return float(np.max(d)) if d.size else 0.0
 
 
