@@ -459,3 +459,36 @@ def test_fast_recursion_equals_the_textbook_state_equations(oracle):
     assert n_cases >= 150, n_cases
     print("worst relative deviation", worst, "over", n_cases, "cases")
     assert worst < 1e-11, worst
+
+
+def test_how_often_the_selected_arima_sits_on_the_coefficient_box(oracle):
+    """the +-0.99 coefficient box of the AutoARIMA restatement was chosen because the reference's one known answer is a
+    box-corner estimate; how often does the SELECTED model of ordinary series end on that box?  200 M5-shape series (T = 400, m = 7):
+    26 of the 187 selected models that have coefficients carry at least one at +-0.99 (13.9 %) -- mostly MA terms of over-differenced
+    intermittent counts, where the unclipped CSS optimum is a unit root.  The assertion is a tripwire (a change of the estimator that
+    pushes a third of the models onto the box should be noticed), not a claim about the crate."""
+    import ctypes as C
+    from anofox_forecast_amd import synth
+    L = oracle.lib()
+
+    class ArimaOrder(C.Structure):
+        _fields_ = [(k, C.c_int) for k in ("p", "d", "q", "P", "D", "Q", "s", "with_constant")]
+
+    class ArimaFit(C.Structure):
+        _fields_ = [("ord", ArimaOrder), ("x", C.c_double * 6), ("css", C.c_double), ("sigma2", C.c_double), ("aicc", C.c_double),
+                    ("n_used", C.c_int), ("evals", C.c_int), ("iters", C.c_int)]
+    L.oracle_auto_arima_detail.restype = C.c_int
+    L.oracle_auto_arima_detail.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(ArimaFit), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    Y = synth.gen_series(synth.SEED_M5, 0, 200, 400, 7)
+    with_coef = on_box = 0
+    for s in range(Y.shape[0]):
+        fit, out, tried, evals = ArimaFit(), np.zeros(3), C.c_int(), C.c_int()
+        if not L.oracle_auto_arima_detail(Y[s].ctypes.data, Y.shape[1], 7, 3, out.ctypes.data, C.byref(fit), C.byref(tried), C.byref(evals)):
+            continue
+        k = fit.ord.p + fit.ord.q + fit.ord.P + fit.ord.Q
+        if k == 0:
+            continue
+        with_coef += 1
+        on_box += any(abs(fit.x[i]) >= 0.99 - 1e-12 for i in range(k))
+    assert with_coef >= 150
+    assert on_box <= 0.25 * with_coef, (on_box, with_coef)
