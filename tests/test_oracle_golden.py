@@ -464,8 +464,7 @@ def test_fast_recursion_equals_the_textbook_state_equations(oracle):
 def test_how_often_the_selected_arima_sits_on_the_coefficient_box(oracle):
     """the +-0.99 coefficient box of the AutoARIMA restatement was chosen because the reference's one known answer is a
     box-corner estimate; how often does the SELECTED model of ordinary series end on that box?  200 M5-shape series (T = 400, m = 7):
-    26 of the 187 selected models that have coefficients carry at least one at +-0.99 (13.9 %) -- mostly MA terms of over-differenced
-    intermittent counts, where the unclipped CSS optimum is a unit root.  The assertion is a tripwire (a change of the estimator that
+    26 of the 187 selected models that have coefficients carry at least one at +-0.99 (13.9 %).  The assertion is a tripwire (a change of the estimator that
     pushes a third of the models onto the box should be noticed), not a claim about the crate."""
     import ctypes as C
     from anofox_forecast_amd import synth
