@@ -192,3 +192,21 @@ def test_pow_tables_are_one_file_and_pow_step_is_accurate(oracle, tmp_path):
         worst = max(worst, float(abs(Decimal(got) - ref) / Decimal(math.ulp(float(ref)))))
     assert worst < 2.0, worst
     assert L.oracle_det_pow_step(1.0, 0.9) == 1.0 and L.oracle_det_pow_step(4.0, 0.5) == 2.0
+
+
+def test_bench_gpus_n_starts_its_own_ranks():
+    """`python bench.py --gpus 2`, un-wrapped (the shape of the command the driver runs for N = 1): the process starts two ranks itself
+    (a child `python -m torch.distributed.run`, never an exec) and hands their exit code on.  Without a GPU both ranks stop at the
+    library's "no CPU fallback" gate -- which is the proof, on this CPU-only machine, that two ranks were started and the parent did
+    not quietly run one rank with "n_gpus": 1 (missing item 1).  The GPU half of the same path:
+    tests/test_gpu_parity.py::test_bench_two_ranks_on_one_gpu[self-launch]."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["CUDA_VISIBLE_DEVICES"] = ""
+    env["HIP_VISIBLE_DEVICES"] = ""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0                                  # the ranks' failure is the parent's exit code
+    assert out.stderr.count("bench.py needs a GPU") == 2, out.stderr[-2000:]
+    assert '"n_gpus"' not in out.stdout
