@@ -451,7 +451,7 @@ def main():
             out["also"] = also_pass(ALSO_WORKLOADS, also_steps, h, dev, lib, synth, DeviceBatch, pack_time_major, torch)
         # ---- CPU baseline: the oracle ("port") on a bounded sample of the same workload -------------
         sample = wl["cpu_sample"] if args.cpu_sample < 0 else args.cpu_sample
-        if sample > 0:
+        if sample > 0 and world == 1:                  # (the contract: rank 0 at N = 1 only -- an N-GPU line carries no CPU leg)
             from oracle import oracle as O
 
             def cpu_run(k):
