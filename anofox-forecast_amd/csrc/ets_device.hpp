@@ -296,13 +296,30 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
     // The hardware range check returns zeros for rows past the allocation, so the prefetch of the block after the last
     // one needs no clamp (those values are never used).
     typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
-    const size_t row_bytes = ld * 8;
+    // The range arithmetic of the additive class runs in 32-bit ROW counts: gfx950 has no scalar 64-bit ordered compare, and byte
+    // offsets compared as 64-bit values go through the vector unit and back -- three v_cmp -> s_cselect round trips per block, 22
+    // instructions instead of 7; a block of the additive class is 5-10 instructions a step, so that is 7 % of a fitted ETS(A,A,A)
+    // (17.7-17.8 -> 16.6 ms, profiles/r05_step_anatomy.txt section 6).  The general class keeps the byte form: its steps are 3-6 times
+    // longer, the saving is under 1 %, and with the row form in every class the 25-spec batch measured 1.5-2.7 % SLOWER (443 / 442 ->
+    // 456 / 449 ms, same box, alternating runs; not explained) where the additive-only form is neutral (455 / 459 -> 451 / 461 ms).
+    const size_t row_bytes = ld * 8;                               // (ld < 2^29 columns: fits 32 bits)
     const size_t total_bytes = (size_t)(row_max + 1) * row_bytes;
+    const int rows_total = row_max + 1;
     auto load_block = [&](double (&buf)[S], const int row0) __attribute__((always_inline)) {
-        const size_t off = (size_t)row0 * row_bytes;
-        const size_t rem = off < total_bytes ? total_bytes - off : 0;
-        const unsigned nrec = rem > 0xffffffffull ? 0xffffffffu : (unsigned)rem;
-        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)yp + (rem ? off : 0)), 0, nrec, 0x00020000);
+        unsigned nrec;
+        size_t off;
+        if constexpr (Cfg::ADDITIVE) {
+            const unsigned rows_left = row0 < rows_total ? (unsigned)(rows_total - row0) : 0u;
+            const unsigned long long rem = (unsigned long long)rows_left * (unsigned long long)(unsigned)row_bytes;
+            nrec = (unsigned)(rem >> 32) != 0u ? 0xffffffffu : (unsigned)rem;
+            off = rows_left ? (size_t)((unsigned long long)(unsigned)row0 * (unsigned long long)(unsigned)row_bytes) : (size_t)0;
+        } else {
+            const size_t o = (size_t)row0 * row_bytes;
+            const size_t rem = o < total_bytes ? total_bytes - o : 0;
+            nrec = rem > 0xffffffffull ? 0xffffffffu : (unsigned)rem;
+            off = rem ? o : 0;
+        }
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)yp + off), 0, nrec, 0x00020000);
 #pragma unroll
         for (int j = 0; j < S; j++) {
             const u32x2_t w = __builtin_amdgcn_raw_buffer_load_b64(rsrc, col_bytes, (unsigned)(j * row_bytes), 0);

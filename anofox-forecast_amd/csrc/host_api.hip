@@ -21,6 +21,7 @@
 #include <map>
 #include <stdexcept>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -511,11 +512,8 @@ std::vector<int> detect_periods_host_series(const double *const *values, const u
             const unsigned thr = (unsigned)std::min<size_t>(n_thr, n_tiles);
             if (thr <= 1) do_tiles(0, n_tiles);
             else {
-                std::vector<std::thread> pool;
                 std::atomic<bool> failed{false};
-                for (unsigned k = 0; k < thr; k++)
-                    pool.emplace_back([&, k] { try { do_tiles(n_tiles * k / thr, n_tiles * (k + 1) / thr); } catch (...) { failed = true; } });
-                for (auto &th : pool) th.join();
+                parallel_shares(thr, [&](unsigned k) { try { do_tiles(n_tiles * k / thr, n_tiles * (k + 1) / thr); } catch (...) { failed = true; } });
                 if (failed) throw HipFail{"period detection: packer thread failed (out of host memory)", true};
             }
             HIPCHECK(hipMemcpyAsync(b.d, b.h, T * ld * sizeof(double), hipMemcpyHostToDevice, st));
@@ -1659,6 +1657,8 @@ bool anofox_hip_batch_pack_host(AnofoxHipBatch *b, const double *const *values, 
         const size_t chunk_cols = chunk_tiles * TILE;
         const size_t n_chunks = (n_tiles + chunk_tiles - 1) / chunk_tiles;
         const size_t n_bufs = n_chunks > 1 ? 2 : 1;
+        const auto tp0 = std::chrono::steady_clock::now();
+        double fill_ms = 0.0;
         if (b->h_stage_elems < n_bufs * T * chunk_cols) {
             pin_free(b->h_stage);
             b->h_stage = nullptr; b->h_stage_elems = 0;
@@ -1698,6 +1698,7 @@ bool anofox_hip_batch_pack_host(AnofoxHipBatch *b, const double *const *values, 
                 }
             }
         };
+        const auto tp1 = std::chrono::steady_clock::now();
         unsigned n_thr = std::thread::hardware_concurrency();
         if (tl_host_thread_share > 1) n_thr = std::max(1u, n_thr / tl_host_thread_share);     // one of several device shards packing side by side
         if (b->tun.pack_threads > 0) n_thr = (unsigned)b->tun.pack_threads;
@@ -1713,25 +1714,30 @@ bool anofox_hip_batch_pack_host(AnofoxHipBatch *b, const double *const *values, 
                 double *stage = b->h_stage + (ck % n_bufs) * T * chunk_cols;
                 if (ck >= n_bufs) HIPCHECK(hipEventSynchronize(copied[ck % n_bufs]));       // the copy that last read this buffer
                 const unsigned thr = (unsigned)std::min<size_t>(n_thr, tiles);
+                const auto tf0 = std::chrono::steady_clock::now();
                 if (thr <= 1 || tiles < 8) do_tiles(stage, cols, base, base, base + tiles);
                 else {
-                    std::vector<std::thread> pool;
                     std::vector<std::string> fails(thr);
-                    for (unsigned k = 0; k < thr; k++)
-                        pool.emplace_back([&, k] {
-                            try { do_tiles(stage, cols, base, base + tiles * k / thr, base + tiles * (k + 1) / thr); }
-                            catch (const std::exception &e) { fails[k] = e.what(); }
-                            catch (...) { fails[k] = "packer thread failed"; }
-                        });
-                    for (auto &th : pool) th.join();
+                    parallel_shares(thr, [&](unsigned k) {
+                        try { do_tiles(stage, cols, base, base + tiles * k / thr, base + tiles * (k + 1) / thr); }
+                        catch (const std::exception &e) { try { fails[k] = e.what(); } catch (...) { fails[k].assign(1, '?'); } }
+                        catch (...) { try { fails[k] = "packer thread failed"; } catch (...) { fails[k].assign(1, '?'); } }
+                    });
                     for (auto &f : fails) if (!f.empty()) throw HipFail{f};
                 }
+                fill_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tf0).count();
                 HIPCHECK(hipMemcpy2DAsync(b->d_y + base * TILE, ld * sizeof(double), stage, cols * sizeof(double), cols * sizeof(double), T,
                                           hipMemcpyHostToDevice, b->own_stream));
                 HIPCHECK(hipEventRecord(copied[ck % n_bufs], b->own_stream));
             }
             HIPCHECK(hipStreamSynchronize(b->own_stream));
         } catch (...) { (void)hipStreamSynchronize(b->own_stream); throw; }       // nothing may still read the staging buffers
+        if (b->tun.timing) {
+            const auto tp2 = std::chrono::steady_clock::now();
+            std::fprintf(stderr, "[anofox-hip] pack of %zu columns: staging + bookkeeping %.1f ms, %u threads filled %zu tiles in %.1f ms, device block + copies %.1f ms\n", ld,
+                         std::chrono::duration<double, std::milli>(tp1 - tp0).count(), n_thr, n_tiles, fill_ms,
+                         std::chrono::duration<double, std::milli>(tp2 - tp1).count() - fill_ms);
+        }
         finalize_lengths(b);
         if (detect) batch_detect_periods(b);
         b->has_block = true;
@@ -1989,11 +1995,8 @@ bool anofox_hip_batch_fetch(AnofoxHipBatch *b, ForecastResult *out_results, Anof
     if (tl_host_thread_share > 1) n_thr = std::max(1u, n_thr / tl_host_thread_share);
     if (n_thr <= 1) do_range(0, n);
     else {
-        std::vector<std::thread> pool;
         std::atomic<bool> failed{false};
-        for (unsigned k = 0; k < n_thr; k++)
-            pool.emplace_back([&, k] { try { do_range(n * k / n_thr, n * (k + 1) / n_thr); } catch (...) { failed = true; } });
-        for (auto &t : pool) t.join();
+        parallel_shares(n_thr, [&](unsigned k) { try { do_range(n * k / n_thr, n * (k + 1) / n_thr); } catch (...) { failed = true; } });
         if (failed) return false;
     }
     return true;
@@ -2373,11 +2376,16 @@ static bool forecast_batch_one_device(const double *const *values, const uint64_
             std::vector<std::thread> cls_threads;
             struct Joiner { std::vector<std::thread> &t; ~Joiner() { for (auto &x : t) if (x.joinable()) x.join(); } } cls_joiner{cls_threads};
             std::vector<std::vector<Part> *> grp_hbm;
+            // (a class whose thread cannot be created -- EAGAIN under the host's thread limit -- runs here, before the parts)
+            auto start_cls = [&](std::vector<std::vector<Part> *> group) {
+                try { cls_threads.emplace_back(run_cls, group); }
+                catch (const std::system_error &) { run_cls(group); }
+            };
             for (auto *cls : todo) {
-                if (cls->back().first <= ETS_MERGED_LDS_PERIOD) cls_threads.emplace_back(run_cls, std::vector<std::vector<Part> *>{cls});
+                if (cls->back().first <= ETS_MERGED_LDS_PERIOD) start_cls(std::vector<std::vector<Part> *>{cls});
                 else grp_hbm.push_back(cls);
             }
-            if (!grp_hbm.empty()) cls_threads.emplace_back(run_cls, grp_hbm);
+            if (!grp_hbm.empty()) start_cls(grp_hbm);
             parts = std::move(keep);
             std::sort(parts.begin(), parts.end(), [](const Part &x, const Part &y) { return x.second.size() > y.second.size(); });
         if (tun.timing) {
@@ -2479,7 +2487,10 @@ static bool forecast_batch_one_device(const double *const *values, const uint64_
         std::vector<std::thread> pool;
         struct PoolJoiner { std::vector<std::thread> &t; ~PoolJoiner() { for (auto &x : t) if (x.joinable()) x.join(); } } pool_joiner{pool};
         const bool have_big = first_small > 0;
-        for (unsigned i = have_big ? 0 : 1; i < n_thr; i++) pool.emplace_back(work);
+        // (workers pull parts from a shared counter: the ones that cannot be created are not missed, this thread takes what is left)
+        for (unsigned i = have_big ? 0 : 1; i < n_thr; i++) {
+            try { pool.emplace_back(work); } catch (const std::system_error &) { break; }
+        }
         if (have_big) {
             // the big parts: up to four side by side (one is throttled by whatever else runs; one after the other they were the
             // critical path of the call), each on its own thread, largest first
@@ -2496,8 +2507,11 @@ static bool forecast_batch_one_device(const double *const *values, const uint64_
                 }
             };
             const size_t n_big_thr = std::min<size_t>(first_small, 4);
-            for (size_t i = 1; i < n_big_thr; i++) pool.emplace_back(big_work);
+            for (size_t i = 1; i < n_big_thr; i++) {
+                try { pool.emplace_back(big_work); } catch (const std::system_error &) { break; }
+            }
             big_work();
+            work();                          // (nothing left unless the small parts' workers could not be started)
         } else work();
         for (auto &t : pool) t.join();
         for (auto &t : cls_threads) if (t.joinable()) t.join();
@@ -2587,7 +2601,6 @@ bool anofox_ts_forecast_batch(const double *const *values, const uint64_t *const
     // staging block of that device), its slice of the caller's arrays -- the shards share nothing but the option block
     std::vector<AnofoxError> berr(G);
     std::vector<char> ok(G, 1);
-    std::vector<std::thread> threads;
     const bool timing = std::getenv("ANOFOX_HIP_TIMING") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     const int method_in_force = arima_method_in_force();
@@ -2609,9 +2622,7 @@ bool anofox_ts_forecast_batch(const double *const *values, const uint64_t *const
     };
     int caller_dev = 0;
     (void)hipGetDevice(&caller_dev);
-    for (size_t g = 1; g < G; g++) threads.emplace_back(shard, g);
-    shard(0);
-    for (auto &t : threads) t.join();
+    parallel_shares((unsigned)G, [&](unsigned g) { shard((size_t)g); });       // (a shard that finds no thread runs after shard 0, on this one)
     (void)hipSetDevice(caller_dev);
     if (timing)
         std::fprintf(stderr, "[anofox-hip] batch of %zu over %zu device shards: %.1f ms\n", n_series, G,
@@ -2633,7 +2644,6 @@ bool anofox_hip_batch_run_many(AnofoxHipBatch *const *batches, size_t n_batches,
 {
     if (!batches && n_batches) return false;
     std::vector<char> ok(n_batches, 1);
-    std::vector<std::thread> threads;
     auto one = [&](size_t i) {
         AnofoxError e;
         e.code = SUCCESS; e.message[0] = 0;
@@ -2641,9 +2651,7 @@ bool anofox_hip_batch_run_many(AnofoxHipBatch *const *batches, size_t n_batches,
         catch (...) { ok[i] = 0; set_error(&e, INTERNAL_ERROR, "Internal error: batch run failed"); }
         if (out_errors) out_errors[i] = e;
     };
-    for (size_t i = 1; i < n_batches; i++) threads.emplace_back(one, i);
-    if (n_batches) one(0);
-    for (auto &t : threads) t.join();
+    parallel_shares((unsigned)n_batches, [&](unsigned i) { one((size_t)i); });
     for (size_t i = 0; i < n_batches; i++) if (!ok[i]) return false;
     return true;
 }

@@ -565,6 +565,36 @@ void stream_pool_release_all()
 }
 
 // ---------------------------------------------------------------------------------------------
+// shares of a host loop on threads: share(k), k = 0 .. n - 1, each exactly once.  Share 0 runs on the calling thread; a share whose
+// thread cannot be created (std::system_error: EAGAIN under the process's or the cgroup's thread limit -- DuckDB's own workers call
+// this library concurrently) runs on the calling thread too, and every thread that did start is joined on every way out: a
+// joinable std::thread destroyed by an exception on its way through the caller is std::terminate, i.e. the host process gone.
+// `share` does its own error reporting (it runs on other threads: nothing may leave it).
+// ---------------------------------------------------------------------------------------------
+#ifdef ANOFOX_TEST_HOOKS
+inline std::atomic<int> &parallel_shares_refuse_after() { static std::atomic<int> v{-1}; return v; }     // tests/c_abi/resources_mt.cpp: threads granted before EAGAIN
+#endif
+template <class F> void parallel_shares(unsigned n, F &&share)
+{
+    if (n <= 1) { if (n == 1) share(0u); return; }
+    std::vector<std::thread> pool;
+    struct Joiner { std::vector<std::thread> &t; ~Joiner() { for (auto &x : t) if (x.joinable()) x.join(); } } joiner{pool};
+    pool.reserve(n - 1);
+    unsigned next = 1;
+    for (; next < n; next++) {
+        try {
+#ifdef ANOFOX_TEST_HOOKS
+            if (parallel_shares_refuse_after() >= 0 && (int)pool.size() >= parallel_shares_refuse_after())
+                throw std::system_error(std::make_error_code(std::errc::resource_unavailable_try_again));
+#endif
+            pool.emplace_back([&share, next] { share(next); });
+        } catch (const std::system_error &) { break; }
+    }
+    share(0u);
+    for (; next < n; next++) share(next);          // the shares nobody could be started for
+}
+
+// ---------------------------------------------------------------------------------------------
 // the devices the batch entry shards over (anofox_hip_set_devices / ANOFOX_HIP_DEVICES)
 // ---------------------------------------------------------------------------------------------
 struct DeviceList { std::mutex mu; bool env_read = false; std::vector<int> devs; size_t min_series = 2048; };

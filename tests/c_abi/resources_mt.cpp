@@ -5,8 +5,11 @@
 //   * a second free of a cached block never reaches hipFree; an out-of-memory allocation empties the device's cache and retries,
 //     and a refused one is reported as HipFail{oom};
 //   * every device gets its own priority stream set, exactly once, also when eight threads ask at the same time;
-//   * ANOFOX_HIP_DEVICES parsing; nothing leaks after the release calls.
+//   * ANOFOX_HIP_DEVICES parsing; nothing leaks after the release calls;
+//   * parallel_shares runs every share exactly once and joins what it started -- also when the host refuses threads (EAGAIN after 0, 1,
+//     3 grants, injected through the ANOFOX_TEST_HOOKS switch of the header) and when the caller's own share throws.
 // Built by tests/test_abi_cpu.py with g++ -fsanitize=thread (and once with address,undefined); exit code 0 = all checks passed.
+#define ANOFOX_TEST_HOOKS 1
 #include "fake_hip.h"
 
 #include <algorithm>
@@ -20,6 +23,7 @@
 #include <random>
 #include <stdexcept>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <unordered_map>
 #include <vector>
@@ -231,6 +235,28 @@ int main()
         for (int d = 0; d < G && d < 8; d++) { if (prio_sets[d] != 1) std::fprintf(stderr, "device %d: %d priority sets\n", d, prio_sets[d]); CHECK(prio_sets[d] == 1); }
         for (StreamSet *s : got) stream_set_give(s);
     }
+
+    // ---- shares of a host loop on threads --------------------------------------------------------------------------
+    for (int refuse : {-1, 0, 1, 3}) {
+        parallel_shares_refuse_after() = refuse;
+        for (unsigned n : {0u, 1u, 2u, 8u, 33u}) {
+            std::vector<std::atomic<int>> hits(n ? n : 1);
+            for (auto &h : hits) h = 0;
+            std::atomic<int> off_thread{0};
+            const auto me = std::this_thread::get_id();
+            parallel_shares(n, [&](unsigned k) { hits[k]++; if (std::this_thread::get_id() != me) off_thread++; });
+            for (unsigned k = 0; k < n; k++) CHECK(hits[k] == 1);
+            if (refuse >= 0) CHECK(off_thread <= refuse);
+            if (refuse < 0 && n > 1) CHECK(off_thread == (int)n - 1);
+        }
+        // the caller's share throws: the started threads are joined (a joinable std::thread's destructor would end the process)
+        std::atomic<int> done{0};
+        bool caught = false;
+        try { parallel_shares(6, [&](unsigned k) { if (k == 0) throw std::runtime_error("share 0"); std::this_thread::sleep_for(std::chrono::milliseconds(5)); done++; }); }
+        catch (const std::runtime_error &) { caught = true; }
+        CHECK(caught && done == (refuse < 0 ? 5 : std::min(refuse, 5)));
+    }
+    parallel_shares_refuse_after() = -1;
 
     // ---- nothing leaks -------------------------------------------------------------------------------------------
     dev_cache_release_all();
