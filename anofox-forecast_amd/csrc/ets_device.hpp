@@ -242,6 +242,9 @@ struct EtsFinalOut {
     // inspection (NULL otherwise): one-step fitted values of this lane's series at fitted[t * fitted_ld], final states at
     // states[r * states_ld] with r = 0 level, 1 growth, 2 + j seasonal state of phase j
     double *fitted; size_t fitted_ld; double *states; size_t states_ld;
+    // the sweep also carries the second pass of the series' population variance (NULL: no): *var_out = sum over t < len of (y_t - mean)^2,
+    // the additions in time order as calculate_confidence_intervals has them (forecast.rs:2558-2591)
+    double mean; double *var_out;
 };
 
 // The pass.  MS > 0: compile-time period, ring in VGPRs.  MS == 0: no seasonality.
@@ -327,8 +330,15 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
         }
     };
     load_block(cur, 0);
-    auto keep_fit = [&](const int t) __attribute__((always_inline)) {
-        if constexpr (FINAL) { if (fin->fitted && t < v.len) fin->fitted[(size_t)t * fin->fitted_ld] = st[0].f; }
+    double var_acc = 0.0;
+    auto keep_fit = [&](const int t, const double yv) __attribute__((always_inline)) {
+        if constexpr (FINAL) {
+            if (fin->fitted && t < v.len) fin->fitted[(size_t)t * fin->fitted_ld] = st[0].f;
+            // (unconditional: two operations of a step; a test here would make every step of the unrolled block its own basic block.  Every
+            //  caller runs this under `t < len` of the lanes it writes for; with var_out == NULL the sum is never stored)
+            const double dv = yv - fin->mean;
+            var_acc += dv * dv;
+        }
     };
 
     if constexpr (MS >= 0) {
@@ -357,7 +367,7 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
                         ets_step<Cfg>(par[k], st[k], buf[j], s[k][MS > 0 ? j % MR : 0]);
                         if ((j & 3) == 3 || j == S - 1) ets_renorm<Cfg>(st[k]);     // (a constant once the loop is unrolled)
                     }
-                    keep_fit(base + j);
+                    keep_fit(base + j, buf[j]);
                 }
             }
         };
@@ -448,7 +458,7 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
                         ets_step<Cfg>(par[0], st[0], cur[i], sv);
                         if ((i & 3) == 3 || i == S - 1) ets_renorm<Cfg>(st[0]);
                         ring[(size_t)j * NM_BLOCK + lane] = sv;
-                        keep_fit(base + i);
+                        keep_fit(base + i, cur[i]);
                     }
                     j = (j + 1 == m) ? 0 : j + 1;
                 }
@@ -468,7 +478,7 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
                         if ((i & 3) == 3 || i == S - 1) ets_renorm<Cfg>(st[k]);
                         ring[(k * m + j) * NM_BLOCK + lane] = sv;
                     }
-                    keep_fit(base + i);
+                    keep_fit(base + i, cur[i]);
                 }
                 j = (j + 1 == m) ? 0 : j + 1;
             }
@@ -506,6 +516,7 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
     }
     if constexpr (FINAL) {
         if (fin->sse_out && v.len > 0) *fin->sse_out = st[0].sse;
+        if (fin->var_out) *fin->var_out = var_acc;
         if (fin->states && v.len > 0) { fin->states[0] = st[0].l; fin->states[fin->states_ld] = st[0].b; }
     }
 }

@@ -256,7 +256,10 @@ __global__ __launch_bounds__(NM_BLOCK) void ets_final_kernel(const FitArgs a)
     fin.yhat = a.yhat + (size_t)(valid ? s : 0) * a.h;
     fin.sse_out = nullptr;
     fin.fitted = nullptr; fin.states = nullptr; fin.fitted_ld = 0; fin.states_ld = 0;
-    double sse = 0.0;
+    double sse = 0.0, var = 0.0;
+    const bool want_sd = a.sd_out != nullptr && !inspect;       // one-spec batch: this pass is the second sweep of the intervals' sd
+    fin.var_out = want_sd ? &var : nullptr;
+    fin.mean = (want_sd && active) ? a.mean[s] : 0.0;
     if (inspect) {
         fin.fitted = a.insp_fitted + (valid ? s : 0); fin.fitted_ld = a.ld;
         fin.states = a.insp_states + (valid ? s : 0); fin.states_ld = a.ld;
@@ -282,6 +285,7 @@ __global__ __launch_bounds__(NM_BLOCK) void ets_final_kernel(const FitArgs a)
         return;
     }
 
+    if (want_sd && valid && len > 0) a.sd_out[s] = active ? sqrt(var / (double)len) : 0.0;      // (a series this spec does not fit has no forecast)
     if (valid && len > 0) {
         double aicc = __builtin_huge_val();
         if (active) {

@@ -158,6 +158,7 @@ struct AnofoxHipBatch {
     double gather_budget = 0.0;  // bytes the gather blocks of one run may take together (55 % of the device): a block holds ld columns, or
                                  // fewer when the live specs' blocks would not fit (the gather then starts once that few problems still
                                  // run; until then the rounds index y by series)
+    bool sd_in_final = false;        // this run's one-spec ETS batch: the final pass computes d_sd (prep_kernel ran one sweep)
     double *d_ring = nullptr;        // seasonal rings of periods above the LDS limit: one area per (candidate spec, workgroup)
     size_t ring_elems = 0;
     double *d_prep_scratch = nullptr;   // prep kernel's window ring + per-phase accumulators for such periods
@@ -688,13 +689,19 @@ __global__ void explicit_select_kernel(int n, int h, const int32_t *len, const i
                                        const int32_t *passes, const int32_t *evals, double *yhat, int32_t *detail,
                                        int32_t *passes_total, int32_t *evals_total)
 {
-    int s = blockIdx.x * 256 + threadIdx.x;
-    if (s >= n || len[s] <= 0) return;
-    detail[s] = fit_status[s];
-    passes_total[s] = passes[s];
-    evals_total[s] = evals[s];
-    if (fit_status[s] == FIT_OK)
-        for (int i = 0; i < h; i++) yhat[(size_t)s * h + i] = yhat_slot[(size_t)s * h + i];
+    // one thread per forecast value (a thread per series copied its h values 8 h bytes apart from its neighbour's: 14 us for the M5 batch)
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t hh = (size_t)(h > 0 ? h : 1);
+    const size_t s = idx / hh;
+    const int i = (int)(idx - s * hh);
+    if (s >= (size_t)n || len[s] <= 0) return;
+    const int32_t fs = fit_status[s];
+    if (i == 0) {
+        detail[s] = fs;
+        passes_total[s] = passes[s];
+        evals_total[s] = evals[s];
+    }
+    if (fs == FIT_OK && i < h) yhat[idx] = yhat_slot[idx];
 }
 
 // count[0] = usable strictly positive series, count[1] = usable series (one workgroup)
@@ -854,6 +861,7 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
         a.st = lane.st;
         a.ring_scratch = nullptr;
         a.m_col = b->d_m_col;
+        if (b->sd_in_final && order.size() == 1) { a.mean = b->d_mean; a.sd_out = b->d_sd; }
         a.lane_stats = b->d_lane_stats ? b->d_lane_stats + 2 * k : nullptr;
         fns[oi] = ets_fit_launcher(id, (merged && se != 0) ? (a.m > lds_limit ? ETS_PERLANE_HBM : ETS_PERLANE_LDS) : a.m);
         if (!fns[oi].round_seq || !fns[oi].round_spec || !fns[oi].round_auto || !fns[oi].final) throw HipFail{"no kernel for ETS spec id " + std::to_string(id)};
@@ -1119,8 +1127,13 @@ void run_group(AnofoxHipBatch *b, int period, const int32_t *d_len, hipStream_t 
     const Plan &p = b->plan;
     const size_t n = b->n, ld = b->ld;
     const int blocks256 = (int)((n + 255) / 256);
-    auto prep = [&](int m, bool states) {
+    // sd_in_final: the batch has ONE candidate spec, whose final pass carries the second sweep of the intervals' sd (FitArgs::sd_out)
+    b->sd_in_final = false;
+    auto prep = [&](int m, bool states, bool sd_in_final = false, int skip_types = 0) {
         PrepArgs a{};
+        a.skip_sd = sd_in_final ? 1 : 0;
+        a.skip_types = skip_types;
+        b->sd_in_final = sd_in_final;
         a.y = b->d_y; a.ld = ld; a.len = d_len; a.n_series = (int)n; a.m = m;
         a.m_col = (states && m >= 2) ? b->d_m_col : nullptr;
         a.mean = b->d_mean; a.sd = b->d_sd; a.flags = b->d_flags;
@@ -1129,7 +1142,7 @@ void run_group(AnofoxHipBatch *b, int period, const int32_t *d_len, hipStream_t 
             if (m >= 2) ensure_fig(b, m);
             a.fig_add = b->d_fig_add; a.fig_mul = b->d_fig_mul; a.l0 = b->d_l0; a.b0 = b->d_b0;
             a.t_rows = (int)std::max<size_t>(b->t_max, 1);
-            if (m > ETS_LDS_PERIOD) {
+            if (m >= 2 && m <= ETS_MAX_PERIOD && !(m == 7 && !a.m_col)) {       // season_figures_kernel: series longer than its LDS use a scratch
                 const size_t sc = season_scratch_doubles((int)n, a.t_rows, m);
                 if (sc) a.scratch = ensure_prep_scratch(b, sc);
             }
@@ -1193,7 +1206,8 @@ void run_group(AnofoxHipBatch *b, int period, const int32_t *d_len, hipStream_t 
             int m = 1;
             if (spec_season(id) != 0 && period > 1) m = period;
             else id = id - spec_season(id);             // forecast.rs:1347-1351: no usable period -> non-seasonal
-            prep(m, true);
+            // (one candidate spec: its final pass carries the intervals' sd, and only its own season type is prepared)
+            prep(m, true, !(spec_season(id) != 0 && m > ETS_MAX_PERIOD), spec_season(id) == 2 ? 0 : 2);
             if (spec_season(id) != 0 && m > ETS_MAX_PERIOD) {
                 HIPCHECK(hipMemsetAsync(b->d_detail, 0x04, ld * sizeof(int32_t), st));   // != FIT_OK: unsupported period
                 finish();
@@ -1201,7 +1215,7 @@ void run_group(AnofoxHipBatch *b, int period, const int32_t *d_len, hipStream_t 
             }
             std::vector<int> specs{id};
             launch_fit_slots(b, specs, d_len, m, false, st);
-            hipLaunchKernelGGL(explicit_select_kernel, dim3(blocks256), dim3(256), 0, st, (int)n, b->h, d_len, b->d_status_slots,
+            hipLaunchKernelGGL(explicit_select_kernel, dim3((unsigned)((n * (size_t)std::max(b->h, 1) + 255) / 256)), dim3(256), 0, st, (int)n, b->h, d_len, b->d_status_slots,
                                b->d_yhat_slots, b->d_passes_slots, b->d_evals_slots, b->d_yhat, b->d_detail, b->d_passes_total,
                                b->d_evals_total);
             finish();

@@ -34,8 +34,11 @@ struct PrepArgs {
     double *fig_add, *fig_mul;   // [m x ld] seasonal figures (additive / multiplicative)
     double *l0, *b0;       // [9 x ld]: index (season_type * 3 + trend_type)
     double *scratch;       // periods above ETS_LDS_PERIOD: season_figures scratch (season_scratch_doubles), else unused
-    int pre_fig;           // 1: fig_add / fig_mul already hold the figures (launch_season_figures): no decomposition in pass A
+    int pre_fig;           // 1: fig_add / fig_mul already hold the figures (launch_season_figures): no decomposition in the sweep
     int t_rows;            // rows of the block (the figures kernel sizes its LDS by it)
+    int skip_sd;           // 1: the batch's ONE final pass computes sd (FitArgs::sd_out): prep_kernel is a single sweep then
+    int skip_types;        // season types NO candidate spec of the batch has (bit 0 additive, bit 1 multiplicative): their figures and start
+                           // states are not computed (the multiplicative figure is an IEEE division per time step)
 };
 
 // seasonal figures of long periods, one workgroup per series (prep.hip season_figures_kernel); `scratch`: season_scratch_doubles
@@ -94,6 +97,10 @@ struct FitArgs {
     // that evaluated a trial point of a running problem -- live_lane_passes / (64 wave_passes) is the share of the issued lanes that
     // did work (a converged or parked lane idles until its wave leaves; a wave of the one-wave-per-problem driver counts 64 live lanes)
     unsigned long long *lane_stats;
+    // a batch with ONE candidate spec (explicit ETS, fitted or with given parameters): its final pass is the second sweep of the intervals'
+    // population sd (forecast.rs:2558-2591: sum of (y - mean)^2 in time order), so prep_kernel needs none (PrepArgs::skip_sd).  NULL otherwise.
+    const double *mean;          // [ld] series means (prep_kernel)
+    double *sd_out;              // [ld]
 };
 
 struct SelectArgs {

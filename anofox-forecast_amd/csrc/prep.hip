@@ -1,13 +1,17 @@
-// prep.hip -- per-series statistics and ETS initial states in TWO streamed passes over the time-major block.
+// prep.hip -- per-series statistics and ETS initial states in ONE streamed sweep over the time-major block (+ one more for the
+// intervals' sd wherever no final pass can carry it).
 //
-//   pass A: sum (-> mean), positivity / constancy flags, and the classical decomposition: a sliding window of
-//           the last L = 2*(m/2)+1 observations (LDS ring) gives the centred moving average of every interior
-//           point; the detrended value (y - trend, y / trend) is added to its phase's accumulator (LDS).
-//   pass B: sum of squared deviations (-> sd, forecast.rs:2558-2591) and, for the three season types at once,
-//           the sums of the full-sample least-squares line of the seasonally adjusted series and of its first
-//           K values (level-only start).
-// Same operations in the same order as oracle/ets.c (ets_init_states) and oracle/forecast.c (intervals), so the
-// results are bit-identical; only the number of times y is streamed changed (2 instead of ~22).
+//   the sweep: sum (-> mean), positivity / constancy flags; the classical decomposition -- a sliding window of the last
+//           L = 2*(m/2)+1 observations gives the centred moving average of every interior point, the detrended value (y - trend,
+//           y / trend) is added to its phase's accumulator; the sums of the full-sample least-squares line of the plain series and,
+//           per phase, of the seasonally adjusted one (the figure is applied once per phase when the sweep has ended); the level-only
+//           start from the first max(10, 2 m) values.  Period 7: everything in registers (prep_kernel<7>).  Any other period: the
+//           figures and the per-phase sums come from season_figures_kernel (a workgroup per series, the series in LDS), the sweep
+//           (prep_kernel<0>) reads them.
+//   sd:     sum of squared deviations from the mean (forecast.rs:2558-2591: a two-pass sum by definition) -- a second sweep here, or
+//           none when the batch's one final pass carries it (PrepArgs::skip_sd).
+// Same operations in the same order as oracle/ets.c (ets_init_states) and oracle/forecast.c (intervals), so the results are
+// bit-identical; only the number of times y is streamed changed (1-2 instead of ~22).
 #include <type_traits>
 #include "ets_device.hpp"
 #include "kernels.hpp"
@@ -35,14 +39,17 @@ struct RowLoader {
         }
     }
 };
-// block length of the streamed rows: 16, or four revolutions of a compile-time period MR (ring slots and phases of a block are
+// block length of the streamed rows: 16, or three revolutions of a compile-time period MR (ring slots and phases of a block are
 // compile-time constants then).  One wave per 64 series is all the parallelism this kernel has (477 waves for the M5 block: every
 // sum is sequential in time, and the mean / sd are the reference's own in-tree arithmetic, forecast.rs:2558-2591, so the time axis
-// is not split), which makes it a question of bytes in flight: with 14 rows (7 KB) per wave in flight the two passes ran at
-// 2.0-2.7 TB/s (249 + 182 us per 487 MB, rocprofv3), whatever the arithmetic per step -- dealing the accumulators of a step to
-// three waves changed nothing (431 us against 454: three waves read every row three times).  28 rows per block, two blocks
-// alternating without a copy, is what the one-pass ets_final_kernel streams the same block with at 5.5 TB/s.
-template <int MR> constexpr int prep_block() { return MR > 0 ? 4 * MR : 16; }
+// is not split).  Two buffers alternate without a copy.  What bounds the m = 7 sweep is the wave's own instruction stream and its
+// registers (26 instructions a step, 256 VGPRs + AGPR traffic for the unrolled block's accumulators), not bytes in flight -- measured
+// on the M5 block (one sweep of 487 MB, fixed-parameter ETS(A,A,A) step in brackets): blocks of 2 / 3 / 4 / 6 revolutions 0.295 / 0.288 /
+// 0.310 / 0.318 ms per step; THREE buffers of 28 rows (two blocks always in flight) 238 us for the sweep against 138, FOUR of 14 rows 212 us.
+#ifndef ANOFOX_PREP_REVS
+#define ANOFOX_PREP_REVS 3
+#endif
+template <int MR> constexpr int prep_block() { return MR > 0 ? ANOFOX_PREP_REVS * MR : 16; }
 
 // Long periods (above ETS_LDS_PERIOD): the classical decomposition costs T * (m + 1) multiply-adds per series (every centred
 // moving average is its own sequential sum, as the oracle writes it) -- 1.4 M for T = 1,913, m = 755 -- and with one wave per 64
@@ -78,7 +85,7 @@ __global__ __launch_bounds__(SEASON_THREADS) void season_figures_kernel(const Pr
             x[i] = v;
             if (!(v > 0.0)) pos = 0;
         }
-        const bool positive = __syncthreads_and(pos) != 0;
+        const bool positive = __syncthreads_and(pos) != 0 && !(a.skip_types & 2);     // (multiplicative figures: strictly positive series, and somebody to use them)
         const int c_last = n - 1 - half;                                         // centres half .. c_last
         for (int c = half + tid; c <= c_last; c += SEASON_THREADS) {
             const double *q = x + (c - half);
@@ -111,13 +118,46 @@ __global__ __launch_bounds__(SEASON_THREADS) void season_figures_kernel(const Pr
         }
         __syncthreads();
         const double mean_a = sh_fmean[0], mean_m = positive ? sh_fmean[1] : 1.0;
+        // normalised figures -> HBM (and kept in fa / fm), and the per-phase sums of the least-squares start (oracle/ets.c ets_init_states):
+        // one phase per thread, the additions of a phase in time order; `tr` is free by now
+        double *psy = tr, *psxy = tr + m;
         for (int p = tid; p < m; p += SEASON_THREADS) {
-            a.fig_add[(size_t)p * a.ld + s] = fa[p] - mean_a;
+            const double fja = fa[p] - mean_a;
+            fa[p] = fja;
+            a.fig_add[(size_t)p * a.ld + s] = fja;
             if (positive) {
                 double fj = fm[p] / mean_m;
                 if (!(fj >= 1.0e-2)) fj = 1.0e-2;
+                fm[p] = fj;
                 a.fig_mul[(size_t)p * a.ld + s] = fj;
             }
+            double sy = 0.0, sxy = 0.0;
+            for (int t = p; t < n; t += m) {
+                const double v = x[t];
+                sy = sy + v;
+                sxy = sxy + (double)(t + 1) * v;
+            }
+            psy[p] = sy; psxy[p] = sxy;
+        }
+        __syncthreads();
+        // sy = sum_p (Sy_p - n_p fig_p), sxy = sum_p (Sxy_p - Sx_p fig_p) (additive), sum_p Sy_p / fig_p (multiplicative), p ascending: left
+        // in the (season type, additive trend) slots of l0 / b0, which prep_kernel reads before it writes the states there
+        if (a.l0 && tid < 2 && (tid == 0 || positive)) {
+            double sy = 0.0, sxy = 0.0;
+            for (int j = 0; j < m; j++) {
+                if (tid == 0) {
+                    const long long cnt = ((long long)n - j + m - 1) / m;
+                    const long long sx = cnt * (long long)(j + 1) + (long long)m * (cnt * (cnt - 1) / 2);
+                    sy = sy + (psy[j] - (double)cnt * fa[j]);
+                    sxy = sxy + (psxy[j] - (double)sx * fa[j]);
+                } else {
+                    sy = sy + psy[j] / fm[j];
+                    sxy = sxy + psxy[j] / fm[j];
+                }
+            }
+            const size_t slot = (size_t)((tid == 0 ? 1 : 2) * 3 + 1) * a.ld + s;
+            a.l0[slot] = sy;
+            a.b0[slot] = sxy;
         }
         __syncthreads();                    // the next series overwrites x
     }
@@ -145,15 +185,22 @@ void launch_season_figures(const PrepArgs &a, hipStream_t stream)
     }
 }
 
-// MR > 0: compile-time odd period (7): the window ring and the per-phase accumulators are VGPR arrays with compile-time
-// indices (the block is two revolutions long) -- no LDS traffic at all; same operations in the same order as the generic path.
+// One sweep (round 5; two until then).  What the second sweep used to hold:
+//   * the least-squares start of the seasonally adjusted series needs the NORMALISED figures, known only at the end of a sweep -- it is
+//     taken over per-phase sums now (oracle/ets.c ets_init_states: Sy_p = sum of y_t, Sxy_p = sum of (t + 1) y_t over the t of phase p,
+//     in time order; sy = sum_p (Sy_p - n_p fig_p), sxy = sum_p (Sxy_p - Sx_p fig_p); a multiplicative figure divides the phase sums),
+//     which one sweep accumulates beside the decomposition;
+//   * the level-only start is the mean of the first max(10, 2 m) adjusted values: those rows are read again (a few KB per wave);
+//   * the intervals' population sd is a two-pass sum by definition (forecast.rs:2558-2591): a batch with one candidate spec lets its
+//     final pass carry it (skip_sd; ets_final_kernel), any other batch keeps a second sweep here that does nothing else.
+// MR > 0: compile-time odd period (7): the window ring and every per-phase accumulator are VGPR arrays with compile-time indices (the
+// block is three revolutions long) -- no LDS traffic at all.  MR == 0: any other period, the figures (and the per-phase sums of the
+// start) come from season_figures_kernel (pre_fig), the period is read per lane.
 template <int MR = 0>
 __global__ __launch_bounds__(NM_BLOCK) void prep_kernel(const PrepArgs a)
 {
     constexpr int PREP_S = prep_block<MR>();
     static_assert(MR == 0 || (MR % 2 == 1 && MR >= 3), "register variant: odd periods");
-    extern __shared__ double lds_dyn[];
-    double *lds = lds_dyn;
     const int lane = threadIdx.x;
     const int s = blockIdx.x * NM_BLOCK + lane;
     const bool valid = s < a.n_series;
@@ -167,40 +214,46 @@ __global__ __launch_bounds__(NM_BLOCK) void prep_kernel(const PrepArgs a)
     rows.col_bytes = (unsigned)(valid ? s : 0) * 8u;
     rows.row_bytes = ld * 8;
     rows.total_bytes = (size_t)wave_rows * rows.row_bytes;
-    double cur[PREP_S], nxt[PREP_S];
+    double buf0[PREP_S], buf1[PREP_S];
+    // fn(block, first row) over the series' rows on alternating buffers: the rows of the block after next are requested before a block is consumed
+    auto stream_rows = [&](auto &&fn) __attribute__((always_inline)) {
+        for (int base = 0; base < wave_rows; base += 2 * PREP_S) {
+            rows.load(buf1, base + PREP_S);
+            fn(buf0, base);
+            rows.load(buf0, base + 2 * PREP_S);
+            if (base + PREP_S < wave_rows) fn(buf1, base + PREP_S);
+        }
+    };
     const bool states = a.l0 != nullptr;
-    const int m = a.m_col ? a.m_col[(size_t)blockIdx.x * NM_BLOCK] : a.m;      // merged batch: this workgroup's own period (a.m bounds the sizes)
+    const int m = MR > 0 ? MR : (a.m_col ? (valid ? a.m_col[s] : 1) : a.m);       // (merged batch: the series' own period; a.m bounds the sizes)
     const bool want_season = states && m >= 2 && m <= ETS_MAX_PERIOD;
-    const int half = m / 2, L = 2 * half + 1;
-    // LDS (lane-minor): window ring [L], sumA [m], sumM [m], cnt [m]
-    double *ring = lds;
-    double *sumA = lds + (size_t)(want_season ? L : 0) * NM_BLOCK;
-    double *sumM = sumA + (size_t)(want_season ? m : 0) * NM_BLOCK;
-    double *cnt = sumM + (size_t)(want_season ? m : 0) * NM_BLOCK;
     constexpr int MRA = MR > 0 ? MR : 1;
-    double rR[MRA], sAR[MRA], sMR[MRA], cNR[MRA];
+    // window ring: the raw values (the centre is read from it) and their products with the weight 1 / m -- the window mean adds the SAME
+    // seven rounded products in the same order whether they are formed when the value arrives or when the window is summed (six
+    // multiplications a step fewer); per-phase accumulators of the figures (the counts are closed forms) and of the start's sums
+    double rR[MRA], rW[MRA], sAR[MRA], sMR[MRA], pSy[MRA], pSxy[MRA];
 #pragma unroll
-    for (int j = 0; j < MRA; j++) { rR[j] = 0.0; sAR[j] = 0.0; sMR[j] = 0.0; cNR[j] = 0.0; }
-    if (MR == 0 && want_season && !a.pre_fig)
-        for (int j = 0; j < m; j++) { sumA[j * NM_BLOCK + lane] = 0.0; sumM[j * NM_BLOCK + lane] = 0.0; cnt[j * NM_BLOCK + lane] = 0.0; }
+    for (int j = 0; j < MRA; j++) { rR[j] = 0.0; rW[j] = 0.0; sAR[j] = 0.0; sMR[j] = 0.0; pSy[j] = 0.0; pSxy[j] = 0.0; }
     const double w = want_season ? 1.0 / (double)m : 0.0;
-    const double wend = (want_season && m % 2 == 0) ? 0.5 / (double)m : w;
-    const bool seasonal = want_season && n >= 2 * m;
-    const bool pre_fig = a.pre_fig != 0;                        // figures already in fig_add / fig_mul (season_figures_kernel)
-    const bool decompose = seasonal && !pre_fig;
+    const bool seasonal = want_season && n >= 2 * m && (MR > 0 || a.pre_fig != 0);
+    const bool want_mul = !(a.skip_types & 2);          // some candidate spec has a multiplicative season
+    const int K0 = 10 > n ? n : 10;
+    int Km = 2 * m > 10 ? 2 * m : 10;
+    if (Km > n) Km = n;
+    const double *figA = (MR == 0 && seasonal) ? a.fig_add + s : nullptr;
+    const double *figM = (MR == 0 && seasonal) ? a.fig_mul + s : nullptr;
 
-    // ---- pass A ----------------------------------------------------------------------------------------
+    // ---- the sweep ----------------------------------------------------------------------------------------
     double sum = 0.0;
     bool positive = true, constant = true, has_nan = false;
-    rows.load(cur, 0);
-    const double y0 = n > 0 ? cur[0] : 0.0;
-    int slot = 0;                       // t % L
-    int ph = 0;                         // (t - half) % m, phase of the window centre
-    if (want_season) ph = ((-half) % m + m) % m;
-    auto pass_a_block = [&](const double (&buf)[PREP_S], const int base) __attribute__((always_inline)) {
+    double sy[3] = {0, 0, 0}, sxy[3] = {0, 0, 0}, sk[3] = {0, 0, 0}, ysa0[3] = {0, 0, 0}, ysa1[3] = {0, 0, 0};
+    rows.load(buf0, 0);
+    const double y0 = n > 0 ? buf0[0] : 0.0;
+    int jph = 0;                        // t % m (generic variant: per lane)
+    auto sweep_block = [&](const double (&buf)[PREP_S], const int base) __attribute__((always_inline)) {
       // the multiplicative figure (one IEEE division per step) only matters for strictly positive series: once every series of
       // the wave has shown a value <= 0 (intermittent demand: within the first blocks) the wave stops computing it
-      const bool wave_pos = __any(positive && base < n);
+      const bool wave_pos = want_mul && __any(positive && base < n);
 #pragma unroll
       for (int jj = 0; jj < PREP_S; jj++) {
         const int t = base + jj;
@@ -210,66 +263,65 @@ __global__ __launch_bounds__(NM_BLOCK) void prep_kernel(const PrepArgs a)
             if (!(v > 0.0)) positive = false;
             if (v != y0) constant = false;
             if (v != v) has_nan = true;
-            if constexpr (MR > 0) {
-                if (seasonal) {
-                    constexpr int HALF = MR / 2;
-                    const int sl = jj % MR;                                  // compile-time after unrolling: base is a multiple of MR
-#pragma unroll
-                    for (int q = 0; q < MR; q++) rR[q] = (q == sl) ? v : rR[q];
-                    if (t >= MR - 1) {
-                        double acc = 0.0;
-#pragma unroll
-                        for (int k = 0; k < MR; k++) acc = acc + w * rR[(sl + 1 + k) % MR];     // odd period: every weight is 1 / m
-                        const double yc = rR[(sl + 1 + HALF) % MR];
-                        const int phc = ((jj - HALF) % MR + MR) % MR;
+            if (states) {
+                const double tv = (double)(t + 1) * v;
+                sy[0] = sy[0] + v;
+                sxy[0] = sxy[0] + tv;
+                if (t < K0) sk[0] = sk[0] + v;
+                if (t == 0) ysa0[0] = v;
+                if (t == 1) ysa1[0] = v;
+                if constexpr (MR > 0) {
+                    if (seasonal) {
+                        constexpr int HALF = MR / 2;
+                        const int sl = jj % MR;                                  // compile-time after unrolling: base is a multiple of MR
+                        const double wv = w * v;
 #pragma unroll
                         for (int q = 0; q < MR; q++) {
-                            sAR[q] = (q == phc) ? sAR[q] + (yc - acc) : sAR[q];
-                            cNR[q] = (q == phc) ? cNR[q] + 1.0 : cNR[q];
+                            rR[q] = (q == sl) ? v : rR[q];
+                            rW[q] = (q == sl) ? wv : rW[q];
+                            pSy[q] = (q == sl) ? pSy[q] + v : pSy[q];
+                            pSxy[q] = (q == sl) ? pSxy[q] + tv : pSxy[q];
                         }
-                        if (wave_pos) {
-                            const double ratio = yc / acc;
+                        if (t >= MR - 1) {
+                            double acc = 0.0;
 #pragma unroll
-                            for (int q = 0; q < MR; q++) sMR[q] = (q == phc) ? sMR[q] + ratio : sMR[q];
+                            for (int k = 0; k < MR; k++) acc = acc + rW[(sl + 1 + k) % MR];         // odd period: every weight is 1 / m
+                            const double yc = rR[(sl + 1 + HALF) % MR];
+                            const int phc = ((jj - HALF) % MR + MR) % MR;
+#pragma unroll
+                            for (int q = 0; q < MR; q++) sAR[q] = (q == phc) ? sAR[q] + (yc - acc) : sAR[q];
+                            if (wave_pos) {
+                                const double ratio = yc / acc;
+#pragma unroll
+                                for (int q = 0; q < MR; q++) sMR[q] = (q == phc) ? sMR[q] + ratio : sMR[q];
+                            }
                         }
                     }
-                }
-            } else
-            if (decompose) {
-                ring[slot * NM_BLOCK + lane] = v;
-                if (t >= L - 1) {
-                    double acc = 0.0;
-                    int k0 = slot + 1 == L ? 0 : slot + 1;           // slot of t - L + 1
-                    int kc = 0;
-                    double yc = 0.0;
-                    for (int k = 0; k < L; k++) {
-                        const double wk = (k == 0 || k == L - 1) ? wend : w;
-                        const double yv = ring[k0 * NM_BLOCK + lane];
-                        acc = acc + wk * yv;
-                        if (kc == half) yc = yv;
-                        kc++;
-                        k0 = k0 + 1 == L ? 0 : k0 + 1;
+                } else {
+                    // figures known (season_figures_kernel): the level-only start and the first two adjusted values in passing
+                    if (seasonal && t < Km) {
+                        const double va = v - figA[(size_t)jph * ld];
+                        const double vm = v / figM[(size_t)jph * ld];       // (used for strictly positive series only: their figures exist)
+                        sk[1] = sk[1] + va;
+                        sk[2] = sk[2] + vm;
+                        if (t == 0) { ysa0[1] = va; ysa0[2] = vm; }
+                        if (t == 1) { ysa1[1] = va; ysa1[2] = vm; }
+                        jph = jph + 1 == m ? 0 : jph + 1;
                     }
-                    sumA[ph * NM_BLOCK + lane] = sumA[ph * NM_BLOCK + lane] + (yc - acc);
-                    if (wave_pos) sumM[ph * NM_BLOCK + lane] = sumM[ph * NM_BLOCK + lane] + (yc / acc);
-                    cnt[ph * NM_BLOCK + lane] += 1.0;
                 }
             }
         }
-        slot = slot + 1 == L ? 0 : slot + 1;
-        if (want_season) ph = ph + 1 == m ? 0 : ph + 1;
       }
     };
     // Full blocks of the register variant run as STRAIGHT-LINE code: once every series of the wave is inside its sample for the whole
     // block (and past the first one, so the window is full) no step needs a per-lane branch -- flags become mask operations, the
-    // per-phase updates have compile-time targets -- and the 28 steps of a block form ONE basic block.  The per-lane `if (t < n)` of
-    // the gated form made every step its own basic block, so the seven dependent additions of a step's window mean (same order as
-    // the oracle: the sum is sequential by definition) could not overlap with the neighbouring steps' chains: a wave alone on its
-    // SIMD then waits out every fp64 latency -- 283 cycles per step measured (453 us for the two passes of the M5 block, whatever
-    // the number of rows in flight).  Same operations on the same values: a lane without a series (padding) computes into
-    // registers nobody reads.
+    // per-phase updates have compile-time targets -- and the 21 steps of a block form ONE basic block.  The per-lane `if (t < n)` of
+    // the gated form makes every step its own basic block, so the seven dependent additions of a step's window mean (same order as
+    // the oracle: the sum is sequential by definition) cannot overlap with the neighbouring steps' chains: a wave alone on its
+    // SIMD then waits out every fp64 latency -- 283 cycles per step measured.  Same operations on the same values: a lane without a
+    // series (padding) computes into registers nobody reads.
     const int wave_min_n = __builtin_amdgcn_readfirstlane(wave_min_i32(n > 0 ? n : 0x7fffffff));
-    auto pass_a_fast = [&](const double (&buf)[PREP_S], auto pos_tag) __attribute__((always_inline)) {
+    auto sweep_fast = [&](const double (&buf)[PREP_S], const int base, auto pos_tag) __attribute__((always_inline)) {
         constexpr bool POS = decltype(pos_tag)::value;
         if constexpr (MR > 0) {
             constexpr int HALF = MR / 2;
@@ -280,47 +332,52 @@ __global__ __launch_bounds__(NM_BLOCK) void prep_kernel(const PrepArgs a)
                 positive = positive & (v > 0.0);
                 constant = constant & (v == y0);
                 has_nan = has_nan | (v != v);
+                const double tv = (double)(base + jj + 1) * v;
+                sy[0] = sy[0] + v;
+                sxy[0] = sxy[0] + tv;
                 const int sl = jj % MR;
                 rR[sl] = v;
+                rW[sl] = w * v;
+                pSy[sl] = pSy[sl] + v;
+                pSxy[sl] = pSxy[sl] + tv;
                 double acc = 0.0;
 #pragma unroll
-                for (int k = 0; k < MR; k++) acc = acc + w * rR[(sl + 1 + k) % MR];
+                for (int k = 0; k < MR; k++) acc = acc + rW[(sl + 1 + k) % MR];
                 const double yc = rR[(sl + 1 + HALF) % MR];
                 const int phc = ((jj - HALF) % MR + MR) % MR;
                 sAR[phc] = sAR[phc] + (yc - acc);
-                cNR[phc] = cNR[phc] + 1.0;
                 if constexpr (POS) sMR[phc] = sMR[phc] + yc / acc;
             }
         }
     };
-    auto pass_a_any = [&](const double (&buf)[PREP_S], const int base) __attribute__((always_inline)) {
-        if (MR > 0 && base >= PREP_S && base + PREP_S <= wave_min_n) {
-            if (__any(positive && base < n)) pass_a_fast(buf, std::true_type{});
-            else pass_a_fast(buf, std::false_type{});
-        } else pass_a_block(buf, base);
+    auto sweep_any = [&](const double (&buf)[PREP_S], const int base) __attribute__((always_inline)) {
+        // (every series of such a block is seasonal: n >= base + PREP_S >= 6 m; past the first block no step takes part in the level-only
+        //  start or is t = 0, 1)
+        if (MR > 0 && states && base >= PREP_S && base + PREP_S <= wave_min_n) {
+            if (want_mul && __any(positive && base < n)) sweep_fast(buf, base, std::true_type{});
+            else sweep_fast(buf, base, std::false_type{});
+        } else sweep_block(buf, base);
     };
-    // two blocks per iteration on alternating buffers: the rows of the block after next are requested before a block is consumed
-    for (int base = 0; base < wave_rows; base += 2 * PREP_S) {
-        rows.load(nxt, base + PREP_S);
-        pass_a_any(cur, base);
-        rows.load(cur, base + 2 * PREP_S);
-        if (base + PREP_S < wave_rows) pass_a_any(nxt, base + PREP_S);
-    }
+    stream_rows(sweep_any);
     if (n <= 0) return;
     const double mean = sum / (double)n;
     a.mean[s] = mean;
     a.flags[s] = (positive ? SF_POSITIVE : 0u) | (constant ? SF_CONSTANT : 0u) | (has_nan ? SF_HAS_NAN : 0u);
+    const bool useA = seasonal, useM = seasonal && positive && want_mul;
 
-    // seasonal figures (normalised), kept in LDS for pass B and written to HBM for the fit kernels
     if constexpr (MR > 0) {
         if (seasonal) {
+            // seasonal figures (normalised), written to HBM for the fit kernels
 #pragma unroll
             for (int type = 1; type <= 2; type++) {
-                if (type == 2 && !positive) break;
+                if (type == 2 && !useM) break;
                 double tot = 0.0;
 #pragma unroll
                 for (int j = 0; j < MR; j++) {
-                    const double fj = (type == 1 ? sAR[j] : sMR[j]) / cNR[j];
+                    // centres c = HALF .. n - 1 - HALF of phase j (c mod m == j): first = j (j >= HALF) or j + m
+                    const int c_first = j >= MR / 2 ? j : j + MR, c_last = n - 1 - MR / 2;
+                    const double cn = (double)(c_last >= c_first ? (c_last - c_first) / MR + 1 : 0);
+                    const double fj = (type == 1 ? sAR[j] : sMR[j]) / cn;
                     if (type == 1) sAR[j] = fj; else sMR[j] = fj;
                     tot = tot + fj;
                 }
@@ -338,115 +395,63 @@ __global__ __launch_bounds__(NM_BLOCK) void prep_kernel(const PrepArgs a)
                     fig[(size_t)j * ld] = fj;
                 }
             }
-        }
-    } else
-    if (decompose) {
-        for (int type = 1; type <= 2; type++) {
-            if (type == 2 && !positive) break;
-            double *acc = type == 1 ? sumA : sumM;
-            double tot = 0.0;
-            for (int j = 0; j < m; j++) {
-                const double fj = acc[j * NM_BLOCK + lane] / cnt[j * NM_BLOCK + lane];
-                acc[j * NM_BLOCK + lane] = fj;
-                tot = tot + fj;
-            }
-            const double fmean = tot / (double)m;
-            double *fig = (type == 1 ? a.fig_add : a.fig_mul) + s;
-            for (int j = 0; j < m; j++) {
-                double fj = acc[j * NM_BLOCK + lane];
-                if (type == 1) fj = fj - fmean;
-                else {
-                    fj = fj / fmean;
-                    if (!(fj >= 1.0e-2)) fj = 1.0e-2;
+            // the least-squares sums of the adjusted series from the per-phase sums (oracle/ets.c ets_init_states, same order) ...
+#pragma unroll
+            for (int j = 0; j < MR; j++) {
+                const long long cnt = ((long long)n - j + MR - 1) / MR;                       // t = j, j + m, ... < n
+                const long long sx = cnt * (long long)(j + 1) + (long long)MR * (cnt * (cnt - 1) / 2);
+                sy[1] = sy[1] + (pSy[j] - (double)cnt * sAR[j]);
+                sxy[1] = sxy[1] + (pSxy[j] - (double)sx * sAR[j]);
+                if (useM) {
+                    sy[2] = sy[2] + pSy[j] / sMR[j];
+                    sxy[2] = sxy[2] + pSxy[j] / sMR[j];
                 }
-                acc[j * NM_BLOCK + lane] = fj;
-                fig[(size_t)j * ld] = fj;
             }
+            // ... and the level-only start: the first rows again (Km <= 2 m = 14)
+            for (int t = 0; t < Km; t++) {
+                const double v = a.y[(size_t)t * ld + s];
+                const int p = t % MR;
+                double fa = sAR[0], fm = sMR[0];
+#pragma unroll
+                for (int q = 1; q < MR; q++) { fa = (q == p) ? sAR[q] : fa; fm = (q == p) ? sMR[q] : fm; }
+                const double va = v - fa;
+                sk[1] = sk[1] + va;
+                if (t == 0) ysa0[1] = va;
+                if (t == 1) ysa1[1] = va;
+                if (useM) {
+                    const double vm = v / fm;
+                    sk[2] = sk[2] + vm;
+                    if (t == 0) ysa0[2] = vm;
+                    if (t == 1) ysa1[2] = vm;
+                }
+            }
+        }
+    } else if (seasonal) {
+        // season_figures_kernel left the sums of the adjusted series in the slots this kernel is about to fill
+        sy[1] = a.l0[(size_t)(1 * 3 + 1) * ld + s];
+        sxy[1] = a.b0[(size_t)(1 * 3 + 1) * ld + s];
+        if (useM) {
+            sy[2] = a.l0[(size_t)(2 * 3 + 1) * ld + s];
+            sxy[2] = a.b0[(size_t)(2 * 3 + 1) * ld + s];
         }
     }
 
-    // ---- pass B ----------------------------------------------------------------------------------------
-    double var = 0.0;
-    double sy[3] = {0, 0, 0}, sxy[3] = {0, 0, 0}, sk[3] = {0, 0, 0}, ysa0[3] = {0, 0, 0}, ysa1[3] = {0, 0, 0};
-    const bool useA = seasonal, useM = seasonal && positive;
-    const bool wave_useM = __any(useM);            // no strictly positive series in the wave: no multiplicative states, no division per step
-    int K0 = 10 > n ? n : 10;
-    int Km = 2 * m > 10 ? 2 * m : 10;
-    if (Km > n) Km = n;
-    int j = 0;
-    const double *figA = pre_fig ? a.fig_add + (valid ? s : 0) : sumA + lane;
-    const double *figM = pre_fig ? a.fig_mul + (valid ? s : 0) : sumM + lane;
-    const size_t fig_stride = pre_fig ? ld : (size_t)NM_BLOCK;
-    rows.load(cur, 0);
-    auto pass_b_block = [&](const double (&buf)[PREP_S], const int base) __attribute__((always_inline)) {
-#pragma unroll
-      for (int jj = 0; jj < PREP_S; jj++) {
-        const int t = base + jj;
-        if (t >= n) continue;
-        const double v = buf[jj];
-        const double dv = v - mean;
-        var += dv * dv;
-        if (states) {
-            double vs[3];
-            vs[0] = v;
-            if constexpr (MR > 0) {
-                vs[1] = useA ? v - sAR[jj % MR] : 0.0;
-                vs[2] = 0.0;
-                if (wave_useM) vs[2] = useM ? v / sMR[jj % MR] : 0.0;
-            } else {
-                vs[1] = useA ? v - figA[(size_t)j * fig_stride] : 0.0;
-                vs[2] = 0.0;
-                if (wave_useM) vs[2] = useM ? v / figM[(size_t)j * fig_stride] : 0.0;
-            }
-#pragma unroll
-            for (int st = 0; st < 3; st++) {
-                sy[st] = sy[st] + vs[st];
-                sxy[st] = sxy[st] + (double)(t + 1) * vs[st];
-                if (t < (st == 0 ? K0 : Km)) sk[st] = sk[st] + vs[st];
-                if (t == 0) ysa0[st] = vs[st];
-                if (t == 1) ysa1[st] = vs[st];
-            }
-            if (want_season) j = j + 1 == m ? 0 : j + 1;
-        }
-      }
-    };
-    // ... and the same for pass B: past the first block no step takes part in the level-only start (t < K <= 2 m) or is t = 0, 1
-    auto pass_b_fast = [&](const double (&buf)[PREP_S], const int base, auto m_tag) __attribute__((always_inline)) {
-        constexpr bool USEM = decltype(m_tag)::value;
-        if constexpr (MR > 0) {
+    // ---- the intervals' sd: a second sweep unless the batch's final pass carries it -------------------------------
+    if (!a.skip_sd) {
+        double var = 0.0;
+        rows.load(buf0, 0);
+        auto var_block = [&](const double (&buf)[PREP_S], const int base) __attribute__((always_inline)) {
 #pragma unroll
             for (int jj = 0; jj < PREP_S; jj++) {
-                const double v = buf[jj];
-                const double dv = v - mean;
-                var += dv * dv;
-                const double tt = (double)(base + jj + 1);
-                double vs[3];
-                vs[0] = v;
-                vs[1] = v - sAR[jj % MR];
-                vs[2] = 0.0;
-                if constexpr (USEM) vs[2] = useM ? v / sMR[jj % MR] : 0.0;
-#pragma unroll
-                for (int st = 0; st < (USEM ? 3 : 2); st++) {
-                    sy[st] = sy[st] + vs[st];
-                    sxy[st] = sxy[st] + tt * vs[st];
+                if (base + jj < n) {
+                    const double dv = buf[jj] - mean;
+                    var += dv * dv;
                 }
             }
-        }
-    };
-    auto pass_b_any = [&](const double (&buf)[PREP_S], const int base) __attribute__((always_inline)) {
-        // (every series of such a block is seasonal: n >= base + PREP_S >= 8 m)
-        if (MR > 0 && states && base >= PREP_S && base + PREP_S <= wave_min_n && __all(n <= 0 || useA)) {
-            if (wave_useM) pass_b_fast(buf, base, std::true_type{});
-            else pass_b_fast(buf, base, std::false_type{});
-        } else pass_b_block(buf, base);
-    };
-    for (int base = 0; base < wave_rows; base += 2 * PREP_S) {
-        rows.load(nxt, base + PREP_S);
-        pass_b_any(cur, base);
-        rows.load(cur, base + 2 * PREP_S);
-        if (base + PREP_S < wave_rows) pass_b_any(nxt, base + PREP_S);
+        };
+        stream_rows(var_block);
+        a.sd[s] = sqrt(var / (double)n);
     }
-    a.sd[s] = sqrt(var / (double)n);
     if (!states) return;
     const double dn = (double)n;
     const double sx = dn * (dn + 1.0) / 2.0;
@@ -485,22 +490,18 @@ __global__ __launch_bounds__(NM_BLOCK) void prep_kernel(const PrepArgs a)
 void launch_prep(const PrepArgs &a, hipStream_t stream)
 {
     const int grid = (a.n_series + NM_BLOCK - 1) / NM_BLOCK;
-    size_t lds_bytes = 0;
-    if (a.l0 != nullptr && a.m > ETS_LDS_PERIOD && a.m <= ETS_MAX_PERIOD) {
-        // long periods: the figures from one workgroup per series, then the two streamed passes without the decomposition
-        PrepArgs b = a;
-        launch_season_figures(b, stream);
-        b.pre_fig = 1;
-        hipLaunchKernelGGL((prep_kernel<0>), dim3(grid), dim3(NM_BLOCK), 0, stream, b);
-        return;
-    }
-    if (a.l0 != nullptr && a.m == 7 && !a.m_col) {        // the M5 / weekly period: ring and accumulators in registers
+    const bool states = a.l0 != nullptr;
+    if (states && a.m == 7 && !a.m_col) {                 // the M5 / weekly period: ring and accumulators in registers
         hipLaunchKernelGGL((prep_kernel<7>), dim3(grid), dim3(NM_BLOCK), 0, stream, a);
         return;
     }
-    if (a.l0 != nullptr && a.m >= 2 && a.m <= ETS_LDS_PERIOD) lds_bytes = sizeof(double) * (size_t)((2 * (a.m / 2) + 1) + 3 * a.m) * NM_BLOCK;
-    if (lds_bytes > 48 * 1024) anofox_check_attr(hipFuncSetAttribute((const void *)prep_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    hipLaunchKernelGGL((prep_kernel<0>), dim3(grid), dim3(NM_BLOCK), lds_bytes, stream, a);
+    PrepArgs b = a;
+    if (states && a.m >= 2 && a.m <= ETS_MAX_PERIOD) {
+        // any other period: figures and per-phase sums from one workgroup per series, then the sweep
+        launch_season_figures(b, stream);
+        b.pre_fig = 1;
+    }
+    hipLaunchKernelGGL((prep_kernel<0>), dim3(grid), dim3(NM_BLOCK), 0, stream, b);
 }
 
 } // namespace anofox

@@ -225,11 +225,39 @@ int ets_init_states(const EtsSpec *spec, const double *y, int n,
         for (int i = 0; i < K; i++) s = s + YSA(i);
         l0 = s / (double)K;
     } else {
+        /* sums of the least-squares line: sy = sum ysa_i, sxy = sum (i + 1) ysa_i.  Without a seasonal component they are the two
+         * running sums.  With one, the adjusted value is y_i - fig[i mod m] (y_i / fig[i mod m]), and the sums are taken PER PHASE
+         * first -- Sy_p = sum of y_i, Sxy_p = sum of (i + 1) y_i over the i of phase p, in time order -- and the figure applied once
+         * per phase: sy = sum_p (Sy_p - n_p fig_p), sxy = sum_p (Sxy_p - Sx_p fig_p), n_p / Sx_p = the count / the sum of (i + 1) of
+         * the phase (exact integers); for a multiplicative figure sum_p Sy_p / fig_p.  The same numbers up to rounding (round 5:
+         * the figures are only known at the END of a sweep over the series, and this form needs no second one). */
         double sy = 0.0, sxy = 0.0;
-        for (int i = 0; i < n; i++) {
-            double v = YSA(i);
-            sy = sy + v;
-            sxy = sxy + (double)(i + 1) * v;
+        if (spec->season == ETS_NONE) {
+            for (int i = 0; i < n; i++) {
+                double v = y[i];
+                sy = sy + v;
+                sxy = sxy + (double)(i + 1) * v;
+            }
+        } else {
+            double psy[ETS_MAX_PERIOD], psxy[ETS_MAX_PERIOD];
+            for (int j = 0; j < m; j++) { psy[j] = 0.0; psxy[j] = 0.0; }
+            for (int i = 0; i < n; i++) {
+                int j = i % m;
+                psy[j] = psy[j] + y[i];
+                psxy[j] = psxy[j] + (double)(i + 1) * y[i];
+            }
+            for (int j = 0; j < m; j++) {
+                if (j >= n) break;
+                long long cnt = ((long long)n - j + m - 1) / m;                       /* i = j, j + m, ... < n */
+                long long sx = cnt * (long long)(j + 1) + (long long)m * (cnt * (cnt - 1) / 2);
+                if (spec->season == ETS_ADD) {
+                    sy = sy + (psy[j] - (double)cnt * fig[j]);
+                    sxy = sxy + (psxy[j] - (double)sx * fig[j]);
+                } else {
+                    sy = sy + psy[j] / fig[j];
+                    sxy = sxy + psxy[j] / fig[j];
+                }
+            }
         }
         double dn = (double)n;
         double sx = dn * (dn + 1.0) / 2.0;

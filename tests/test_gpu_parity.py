@@ -856,6 +856,26 @@ def test_fixed_parameter_aaa_full_size_m5(env):
     assert st["total_passes"] == n and st["algorithmic_bytes"] == n * (8 * T + 24 * h)
 
 
+def test_one_sweep_prep_paths(env):
+    """prep.hip streams the block once (round 5): the least-squares start of the seasonally adjusted series comes from per-phase sums
+    (oracle/ets.c ets_init_states), for m = 7 in registers, for every other period from season_figures_kernel -- whose series live in LDS,
+    or in an HBM scratch when 2 T + 2 m doubles do not fit (here: T = 6,500) -- and a batch with ONE candidate spec lets its final pass
+    carry the intervals' sd (lower / upper compared like the forecasts).  Ragged lengths, both season types, a spec the data refuses
+    (multiplicative season on a series with zeros: no forecast, and no sd needed), periods either side of the LDS ring limit."""
+    api, O, lib, synth = env
+    Yl = synth.gen_series(synth.SEED_M5, 9100, 6, 6500, 12, positive=True)
+    long_series = [Yl[s, : 6500 - 37 * s] for s in range(6)]
+    _compare(api, O, lib, long_series, "ETS", 7, ets_model="AAA", seasonal_period=12)
+    _compare(api, O, lib, long_series, "ETS", 7, ets_model="MAdM", seasonal_period=12)
+    _compare(api, O, lib, long_series[:3], "AutoETS", 7, seasonal_period=12, model_pool="reduced")
+    Y = synth.gen_series(synth.SEED_M5, 9200, 90, 300, 7, positive=True)
+    Yz = synth.gen_series(synth.SEED_M5, 9300, 90, 300, 7)
+    mixed = [(Y[s] if s % 2 else Yz[s])[: 300 - (s % 7) * 11] for s in range(90)]
+    for model in ("AAA", "ANA", "AAdA", "MNM", "MAM", "MMdM", "AAN", "MNN"):
+        for m in (7, 5, 52, 64, 65):
+            _compare(api, O, lib, mixed, "ETS", 9, ets_model=model, seasonal_period=m)
+
+
 def test_stress_shape_properties(env):
     """BASELINE.json configs[4], one GPU's share (125,000 series x 1,024 observations, AutoETS, h = 28, m = 7): every series
     gets a forecast, intervals bracket it, a second run reproduces every bit, an arbitrary shuffled sub-batch reproduces
