@@ -491,3 +491,47 @@ def test_how_often_the_selected_arima_sits_on_the_coefficient_box(oracle):
         on_box += any(abs(fit.x[i]) >= 0.99 - 1e-12 for i in range(k))
     assert with_coef >= 150
     assert on_box <= 0.25 * with_coef, (on_box, with_coef)
+
+
+def test_trend_start_over_phase_sums_is_the_textbook_line(oracle):
+    """Round 5 restated the least-squares start of a seasonal spec with a trend over per-phase sums (oracle/ets.c ets_init_states:
+    sy = sum_p (Sy_p - n_p fig_p), sxy = sum_p (Sxy_p - Sx_p fig_p); a multiplicative figure divides the phase sums) so that one sweep
+    over the series gives it.  It must be the SAME line as the plain statement -- adjust every value by its phase's figure, then sum
+    in time order -- up to rounding: level and growth of every (trend, season) pair, odd and even periods, lengths that are not a
+    multiple of the period, against that statement written out in numpy (figures taken from the oracle, which did not change)."""
+    import ctypes as C
+    from anofox_forecast_amd import synth
+    L = oracle.lib()
+
+    class EtsSpec(C.Structure):
+        _fields_ = [(k, C.c_int) for k in ("error", "trend", "damped", "season", "m")]
+    L.ets_init_states.restype = C.c_int
+    L.ets_init_states.argtypes = [C.POINTER(EtsSpec), C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_void_p]
+    worst = 0.0
+    for m in (2, 7, 12, 24, 53):
+        Y = synth.gen_series(synth.SEED_M5, 4000 + m, 12, 4 * m + 211, m, positive=True)
+        for s in range(Y.shape[0]):
+            y = np.ascontiguousarray(Y[s, : Y.shape[1] - s])              # ragged: n mod m takes every value
+            n = len(y)
+            for season in (1, 2):
+                for trend in (1, 2):
+                    spec = EtsSpec(1, trend, 0, season, m)
+                    l0, b0, s0 = C.c_double(), C.c_double(), np.zeros(m)
+                    assert L.ets_init_states(C.byref(spec), y.ctypes.data, n, C.byref(l0), C.byref(b0), s0.ctypes.data) == 0
+                    fig = s0[np.arange(n) % m]
+                    ysa = y - fig if season == 1 else y / fig
+                    t = np.arange(1, n + 1, dtype=np.float64)
+                    sy, sxy, dn = float(np.sum(ysa)), float(np.sum(t * ysa)), float(n)
+                    sx, sxx = dn * (dn + 1.0) / 2.0, dn * (dn + 1.0) * (2.0 * dn + 1.0) / 6.0
+                    slope = (dn * sxy - sx * sy) / (dn * sxx - sx * sx)
+                    icpt = (sy - slope * sx) / dn
+                    if trend == 1:
+                        el0, eb0 = icpt, slope
+                    else:
+                        el0 = icpt + slope
+                        eb0 = (icpt + 2.0 * slope) / el0
+                        el0 = el0 / eb0
+                    # (the guards for a start at zero / a negative growth rate do not fire on these series)
+                    assert abs(el0 + eb0) >= 1e-8 and el0 >= 1e-8 and (trend == 1 or eb0 >= 1e-8)
+                    worst = max(worst, abs(l0.value - el0) / abs(el0), abs(b0.value - eb0) / max(abs(eb0), 1e-300))
+    assert worst <= 1e-9, worst
