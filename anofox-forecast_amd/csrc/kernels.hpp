@@ -33,7 +33,7 @@ struct PrepArgs {
     uint32_t *flags;
     double *fig_add, *fig_mul;   // [m x ld] seasonal figures (additive / multiplicative)
     double *l0, *b0;       // [9 x ld]: index (season_type * 3 + trend_type)
-    double *scratch;       // periods above ETS_LDS_PERIOD: season_figures scratch (season_scratch_doubles), else unused
+    double *scratch;       // season_figures scratch for series too long for its LDS (season_scratch_doubles), else unused
     int pre_fig;           // 1: fig_add / fig_mul already hold the figures (launch_season_figures): no decomposition in the sweep
     int t_rows;            // rows of the block (the figures kernel sizes its LDS by it)
     int skip_sd;           // 1: the batch's ONE final pass computes sd (FitArgs::sd_out): prep_kernel is a single sweep then
@@ -41,7 +41,7 @@ struct PrepArgs {
                            // states are not computed (the multiplicative figure is an IEEE division per time step)
 };
 
-// seasonal figures of long periods, one workgroup per series (prep.hip season_figures_kernel); `scratch`: season_scratch_doubles
+// seasonal figures of every period but 7, one workgroup per series (prep.hip season_figures_kernel); `scratch`: season_scratch_doubles
 // doubles when the series and its trend do not fit LDS (else unused)
 size_t season_scratch_doubles(int n_series, int t_rows, int m_max);
 void launch_season_figures(const PrepArgs &a, hipStream_t stream);

@@ -51,13 +51,13 @@ struct RowLoader {
 #endif
 template <int MR> constexpr int prep_block() { return MR > 0 ? ANOFOX_PREP_REVS * MR : 16; }
 
-// Long periods (above ETS_LDS_PERIOD): the classical decomposition costs T * (m + 1) multiply-adds per series (every centred
-// moving average is its own sequential sum, as the oracle writes it) -- 1.4 M for T = 1,913, m = 755 -- and with one wave per 64
-// series, window ring in an HBM scratch, prep_kernel spent 206 ms on the 36,000 columns of a merged batch before its first fit
-// could start.  season_figures_kernel gives a series a WORKGROUP instead: the series in LDS, one centre per thread (its window
-// summed in the oracle's order: acc = acc + w_k y_k, k ascending), then one phase per thread (the detrended values of a phase added
-// in time order), then the normalisation -- every sum keeps the order of oracle/ets.c ets_init_states, so the figures are the same
-// bits.  prep_kernel then runs with pre_fig = 1: pass A without the window, pass B reading the figures from fig_add / fig_mul.
+// Every period but 7 (round 5; periods above the LDS ring limit only, until then): the classical decomposition costs T * (m + 1)
+// multiply-adds per series (every centred moving average is its own sequential sum, as the oracle writes it) -- 1.4 M for T = 1,913,
+// m = 755 -- and with one wave per 64 series, window ring in an HBM scratch, prep_kernel spent 206 ms on the 36,000 columns of a merged
+// batch before its first fit could start.  season_figures_kernel gives a series a WORKGROUP instead: the series in LDS, one centre per
+// thread (its window summed in the oracle's order: acc = acc + w_k y_k, k ascending), then one phase per thread (the detrended values of
+// a phase added in time order), then the normalisation and the per-phase sums of the trend start -- every sum keeps the order of
+// oracle/ets.c ets_init_states, so the results are the same bits.  prep_kernel then runs with pre_fig = 1: one sweep without a window.
 // The period is read PER SERIES (m_col), the block-of-64 grouping of a merged batch is not needed here.
 constexpr int SEASON_THREADS = 256;
 constexpr int SEASON_LDS_DOUBLES = 12288;        // 96 KB of the CU's 160

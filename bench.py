@@ -339,7 +339,7 @@ def main():
             kernel = ("arima_fit_kernel + arima_fit_spec_kernel (all sweeps of one step + the selected models' polish)" +
                       (" + arima_refit_kernel (exact-likelihood refit)" if wl["arima_method"] else ""))
         elif wl["fixed"]:
-            # the whole step is the unit here: prep_kernel (means, decomposition, initial states: two streamed passes) dominates it,
+            # the whole step is the unit here: prep_kernel (means, decomposition, initial states: one streamed sweep) dominates it,
             # the one-pass ets_final_kernel is reported beside it
             kernel = "prep_kernel + ets_fixed_setup_kernel + ets_final_kernel + interval_kernel (the whole one-pass step; prep_kernel dominant)"
         else:
