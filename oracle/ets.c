@@ -37,6 +37,12 @@ static double clipd(double v, double lo, double hi)
     return v;
 }
 
+/* test hook (tools/nm_outcomes.py): when set, every iteration adds one to nm_outcome_sink[6 * (n - 1) + kind], kind = 0 expansion kept,
+ * 1 reflection kept as the new best, 2 reflection kept elsewhere, 3 outside contraction, 4 inside contraction, 5 shrink; and to
+ * nm_outcome_sink[24 + 8 * (n - 1) + j] for the position j the new vertex is inserted at (shrinks excluded), and to the table of
+ * consecutive outcomes nm_outcome_sink[56 + 676 * (n - 1) + 26 * previous + current], outcome = 5 * kind + j (25 = shrink) */
+long long *nm_outcome_sink = NULL;
+
 void nm_minimize(nm_fn fn, void *ctx, int n, const double *x0,
                  const double *lo, const double *hi, NmResult *res)
 {
@@ -45,6 +51,7 @@ void nm_minimize(nm_fn fn, void *ctx, int n, const double *x0,
     double xb[ETS_MAX_DIM] = {0}, xt[ETS_MAX_DIM] = {0}, xr[ETS_MAX_DIM] = {0};
     const int maxiter = 200 * n, maxfun = 200 * n;
     int evals = 0, iters = 1;
+    int prev_outcome = -1;
 
     for (int i = 0; i < n; i++) sim[0][i] = clipd(x0[i], lo[i], hi[i]);
     for (int k = 0; k < n; k++) {
@@ -89,20 +96,21 @@ void nm_minimize(nm_fn fn, void *ctx, int n, const double *x0,
         int doshrink = 0;
         double fnew = 0.0; const double *xnew = NULL;
 
+        int kind = 5;
         if (fxr < fs[0]) {
             for (int i = 0; i < n; i++) xt[i] = clipd(3.0 * xb[i] - 2.0 * xw[i], lo[i], hi[i]);
             double fxe = fn(xt, ctx); evals++;
-            if (fxe < fxr) { xnew = xt; fnew = fxe; } else { xnew = xr; fnew = fxr; }
+            if (fxe < fxr) { xnew = xt; fnew = fxe; kind = 0; } else { xnew = xr; fnew = fxr; kind = 1; }
         } else if (fxr < fs[n - 1]) {
-            xnew = xr; fnew = fxr;
+            xnew = xr; fnew = fxr; kind = 2;
         } else if (fxr < fs[n]) {
             for (int i = 0; i < n; i++) xt[i] = clipd(1.5 * xb[i] - 0.5 * xw[i], lo[i], hi[i]);
             double fxc = fn(xt, ctx); evals++;
-            if (fxc <= fxr) { xnew = xt; fnew = fxc; } else doshrink = 1;
+            if (fxc <= fxr) { xnew = xt; fnew = fxc; kind = 3; } else doshrink = 1;
         } else {
             for (int i = 0; i < n; i++) xt[i] = clipd(0.5 * xb[i] + 0.5 * xw[i], lo[i], hi[i]);
             double fxcc = fn(xt, ctx); evals++;
-            if (fxcc < fs[n]) { xnew = xt; fnew = fxcc; } else doshrink = 1;
+            if (fxcc < fs[n]) { xnew = xt; fnew = fxcc; kind = 4; } else doshrink = 1;
         }
 
         if (!doshrink) {
@@ -117,7 +125,17 @@ void nm_minimize(nm_fn fn, void *ctx, int n, const double *x0,
             }
             fs[j] = fnew;
             for (int i = 0; i < n; i++) sim[j][i] = tmp[i];
+            if (nm_outcome_sink) {
+                __atomic_fetch_add(&nm_outcome_sink[24 + 8 * (n - 1) + j], 1, __ATOMIC_RELAXED);
+                const int outcome = 5 * kind + j;
+                if (prev_outcome >= 0) __atomic_fetch_add(&nm_outcome_sink[56 + 676 * (n - 1) + 26 * prev_outcome + outcome], 1, __ATOMIC_RELAXED);
+                prev_outcome = outcome;
+            }
         } else {
+            if (nm_outcome_sink) {
+                if (prev_outcome >= 0) __atomic_fetch_add(&nm_outcome_sink[56 + 676 * (n - 1) + 26 * prev_outcome + 25], 1, __ATOMIC_RELAXED);
+                prev_outcome = 25;
+            }
             for (int k = 1; k <= n; k++) {
                 for (int i = 0; i < n; i++)
                     sim[k][i] = clipd(sim[0][i] + 0.5 * (sim[k][i] - sim[0][i]), lo[i], hi[i]);
@@ -136,6 +154,7 @@ void nm_minimize(nm_fn fn, void *ctx, int n, const double *x0,
                 memcpy(sim[j], tmp, sizeof tmp);
             }
         }
+        if (nm_outcome_sink) __atomic_fetch_add(&nm_outcome_sink[6 * (n - 1) + (doshrink ? 5 : kind)], 1, __ATOMIC_RELAXED);
         iters++;
     }
     for (int i = 0; i < n; i++) res->x[i] = sim[0][i];
