@@ -190,7 +190,7 @@ void launch_season_figures(const PrepArgs &a, hipStream_t stream)
 //     taken over per-phase sums now (oracle/ets.c ets_init_states: Sy_p = sum of y_t, Sxy_p = sum of (t + 1) y_t over the t of phase p,
 //     in time order; sy = sum_p (Sy_p - n_p fig_p), sxy = sum_p (Sxy_p - Sx_p fig_p); a multiplicative figure divides the phase sums),
 //     which one sweep accumulates beside the decomposition;
-//   * the level-only start is the mean of the first max(10, 2 m) adjusted values: those rows are read again (a few KB per wave);
+//   * the level-only start is the mean of the first max(10, 2 m) adjusted values: m = 7 reads those rows again (a few KB per wave), the others know their figures in passing;
 //   * the intervals' population sd is a two-pass sum by definition (forecast.rs:2558-2591): a batch with one candidate spec lets its
 //     final pass carry it (skip_sd; ets_final_kernel), any other batch keeps a second sweep here that does nothing else.
 // MR > 0: compile-time odd period (7): the window ring and every per-phase accumulator are VGPR arrays with compile-time indices (the
