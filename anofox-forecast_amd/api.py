@@ -367,6 +367,152 @@ anofox_fcst_ts_forecast_by = ts_forecast_by  # alias registered by the reference
 
 
 # --------------------------------------------------------------------------------------------
+# route A: the scalar the SHIPPED macro text calls (round 6) -- one batch per DataChunk
+# --------------------------------------------------------------------------------------------
+CHUNK_GROUPS = 2048         # STANDARD_VECTOR_SIZE: the most rows DuckDB hands a scalar function at once
+
+
+def _row_options(method, params):
+    """One row's (method, params) as the option block WITHOUT the horizon: ts_forecast_scalar.cpp:405-468.  Route A validates the
+    keys only (`ValidateParams`, :121-158); the range / model / window checks exist in route B's bind alone."""
+    params = params or {}
+    unknown = [k for k in params if k not in VALID_PARAM_KEYS]
+    if unknown:
+        raise InvalidInputException(
+            "Unknown parameter(s): " + ", ".join(f"'{k}'" for k in unknown) +
+            ". Valid parameters are: model, seasonal_period, seasonal_periods, confidence_level, window, model_pool, "
+            "laplace_variant, laplace_seasonal_batch_init")
+
+    def num(key, default, kind):
+        v = params.get(key)
+        if v is None or str(v) == "":
+            return default
+        try:
+            return kind(str(v))
+        except ValueError:
+            return default
+    return dict(method="AutoETS" if method is None else str(method), ets_model=str(params.get("model") or ""),
+                seasonal_period=num("seasonal_period", 0, int), confidence_level=num("confidence_level", 0.90, float),
+                window=num("window", 0, int), seasonal_periods_str=str(params.get("seasonal_periods") or ""),
+                model_pool=str(params.get("model_pool") or ""))
+
+
+def ts_forecast_scalar(date_lists, value_lists, horizon, frequency, method, params, date_kind=None):
+    """_ts_forecast_scalar(dates LIST, values LIST(DOUBLE), horizon, frequency, method, params) over ONE chunk of rows, the way
+    binding/ts_forecast_scalar_hip.cpp executes it (the reference: ts_forecast_scalar.cpp:298-523, one anofox_ts_forecast call per
+    row): every row is decoded (dates to microseconds with NULL = 0, index order by date, values with 0.0 + a cleared validity bit
+    in NULL slots), rows are grouped by their option block, each distinct block is ONE anofox_ts_forecast_batch call with per-row
+    horizons, then the reference's error policy is applied in row order (:484-490).
+
+    `date_lists[r]` / `value_lists[r]`: arrays (values may be masked) or None for a NULL list; `horizon`, `frequency`, `method`,
+    `params`: one value for the chunk (what the macro passes) or a per-row list.  Returns one entry per row: None (the NULL row of a
+    NULL / empty list or of a failed series) or a dict of the STRUCT's fields as arrays."""
+    n_rows = len(value_lists)
+    if n_rows > CHUNK_GROUPS:
+        raise ValueError(f"a DataChunk holds at most {CHUNK_GROUPS} rows")
+
+    def per_row(x):
+        return list(x) if isinstance(x, (list, tuple)) else [x] * n_rows
+    horizon, frequency, method, params = per_row(horizon), per_row(frequency), per_row(method), per_row(params)
+    rows, blocks = [], []                       # blocks: [option dict, [row indices into `rows`]]
+    for r in range(n_rows):
+        if date_lists[r] is None or value_lists[r] is None or len(value_lists[r]) == 0:
+            continue
+        dates = np.asarray(date_lists[r])
+        kind = date_kind or _date_kind(dates)
+        us = _to_micros(dates, kind)
+        if np.issubdtype(dates.dtype, np.datetime64):
+            us = np.where(np.isnat(dates), 0, us)                  # a NULL date sorts as 0 (:356-357)
+        vals = value_lists[r]
+        mask = np.ma.getmaskarray(vals) if np.ma.isMaskedArray(vals) else np.zeros(len(vals), bool)
+        data = np.asarray(np.ma.getdata(vals), dtype=np.float64)
+        order = np.argsort(us, kind="stable")
+        opt = _row_options(method[r], params[r])
+        for b in blocks:
+            if b[0] == opt:
+                break
+        else:
+            b = [opt, []]
+            blocks.append(b)
+        b[1].append(len(rows))
+        rows.append(dict(at=r, values=np.where(mask[order], 0.0, data[order]), valid=~mask[order], last=int(us[order][-1]),
+                         horizon=7 if horizon[r] is None else int(horizon[r]),
+                         freq=parse_frequency("1d" if frequency[r] is None else frequency[r]), kind=kind, dtype=dates.dtype))
+    for opt, members in blocks:
+        hz = [rows[i]["horizon"] for i in members]
+        o = _lib.make_options(opt["method"], hz[0], ets_model=opt["ets_model"], seasonal_period=opt["seasonal_period"],
+                              confidence_level=opt["confidence_level"], window=opt["window"], model_pool=opt["model_pool"],
+                              seasonal_periods_str=opt["seasonal_periods_str"])
+        results, berr = forecast_batch([rows[i]["values"] for i in members], o, [rows[i]["valid"] for i in members], horizons=hz)
+        if not berr["ok"]:
+            raise InvalidInputException(berr["message"])
+        for i, res in zip(members, results):
+            rows[i]["result"] = res
+    out = [None] * n_rows
+    for row in rows:                                               # chunk order: the first failing row decides the exception
+        res = row["result"]
+        if not res["ok"]:
+            if res["code"] in (_lib.INVALID_MODEL, _lib.INVALID_INPUT):
+                raise InvalidInputException(res["message"])
+            continue
+        h = len(res["point"])
+        when = np.array([compute_forecast_date(row["last"], i + 1, row["freq"], row["kind"]) for i in range(h)], dtype=np.int64)
+        out[row["at"]] = {"forecast_step": np.arange(1, h + 1, dtype=np.int32), "ds": _from_micros(when, row["kind"], row["dtype"]),
+                          "yhat": res["point"], "yhat_lower": res["lower"], "yhat_upper": res["upper"],
+                          "model_name": [res["model_name"]] * h}
+    return out
+
+
+def ts_forecast_by_scalar_route(group, date, target, method, horizon, frequency, params=None, group_name="id",
+                                chunk_groups=CHUNK_GROUPS):
+    """The SHIPPED macro text (ts_macros.cpp:576-591) over numpy columns: GROUP BY group_col, LIST(date ORDER BY date),
+    LIST(target::DOUBLE ORDER BY date), `_ts_forecast_scalar` per chunk of <= 2,048 groups, unnest(recursive := true).  Output
+    columns as the macro names them: <group>, forecast_step, ds, yhat, yhat_lower, yhat_upper, model_name.  Groups come in
+    first-appearance order here (the hash aggregate's order is unspecified)."""
+    grp = np.asarray(group, dtype=object)
+    dates = np.asarray(date)
+    kind = _date_kind(dates)
+    us = _to_micros(dates, kind)
+    if np.issubdtype(dates.dtype, np.datetime64):
+        us = np.where(np.isnat(dates), np.iinfo(np.int64).min, us)     # ORDER BY puts NULL dates somewhere definite; the scalar re-sorts
+    tgt = np.asarray(target)
+    if tgt.dtype == object:
+        tgt = np.ma.masked_invalid(np.ma.array([np.nan if v is None else float(v) for v in tgt], dtype=np.float64))
+    elif not np.ma.isMaskedArray(target):
+        tgt = np.ma.array(tgt.astype(np.float64), mask=False)
+    else:
+        tgt = target
+    order, members = [], {}
+    for i in range(len(grp)):
+        k = "__NULL__" if grp[i] is None else grp[i]
+        if k not in members:
+            members[k] = []
+            order.append(k)
+        members[k].append(i)
+    out = {group_name: [], "forecast_step": [], "ds": [], "yhat": [], "yhat_lower": [], "yhat_upper": [], "model_name": []}
+    for lo in range(0, len(order), chunk_groups):
+        keys = order[lo:lo + chunk_groups]
+        date_lists, value_lists = [], []
+        for k in keys:
+            idx = np.array(members[k])
+            idx = idx[np.argsort(us[idx], kind="stable")]
+            date_lists.append(dates[idx])
+            value_lists.append(tgt[idx])
+        structs = ts_forecast_scalar(date_lists, value_lists, horizon, frequency, method, {} if params is None else params, kind)
+        for k, s in zip(keys, structs):
+            if s is None:
+                continue                                           # unnest of a NULL list: no rows
+            out[group_name] += [None if k == "__NULL__" else k] * len(s["yhat"])
+            for c in ("forecast_step", "ds", "yhat", "yhat_lower", "yhat_upper", "model_name"):
+                out[c].append(s[c])
+    for c, dt in (("forecast_step", np.int32), ("yhat", np.float64), ("yhat_lower", np.float64), ("yhat_upper", np.float64)):
+        out[c] = np.concatenate(out[c]) if out[c] else np.empty(0, dtype=dt)
+    out["ds"] = np.concatenate(out["ds"]) if out["ds"] else _from_micros(np.empty(0, np.int64), kind, dates.dtype)
+    out["model_name"] = [m for part in out["model_name"] for m in part]
+    return out
+
+
+# --------------------------------------------------------------------------------------------
 # ts_forecast_agg (SURVEY.md section 8f rank 3): the GROUP BY aggregate caller
 # --------------------------------------------------------------------------------------------
 def ts_forecast_agg(group, date, value, method="auto", horizon=12, params=None):

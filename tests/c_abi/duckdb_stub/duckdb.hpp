@@ -1,8 +1,8 @@
 // duckdb.hpp -- TEST INFRASTRUCTURE.  A minimal DECLARATION-ONLY stand-in for the DuckDB C++ API (v1.x), written from DuckDB's public
-// interface as binding/ts_forecast_native_hip.cpp uses it.  It exists for ONE purpose: `g++ -fsyntax-only` of that file
-// (tests/test_abi_cpu.py test_duckdb_binding_parses), because DuckDB's headers are not in this image.  Nothing here is built, linked
+// interface as binding/ts_forecast_native_hip.cpp, ts_forecast_scalar_hip.cpp and ts_macros_hip.cpp use it.  It exists for ONE purpose:
+// `g++ -fsyntax-only` of those files (tests/test_abi_cpu.py test_duckdb_binding_parses), because DuckDB's headers are not in this image.  Nothing here is built, linked
 // or shipped; no reference build is made with it; signatures follow duckdb/src/include (types.hpp, value.hpp, vector.hpp,
-// data_chunk.hpp, table_function.hpp, exception.hpp, string_util.hpp, config.hpp).  A type-check against this file says the binding is
+// data_chunk.hpp, table_function.hpp, scalar_function.hpp, parser.hpp, create_macro_info.hpp, exception.hpp, string_util.hpp, config.hpp).  A type-check against this file says the binding is
 // well-formed C++ against THESE declarations -- the real check is the extension build on the integration side.
 #pragma once
 #include <cstdint>
@@ -36,8 +36,13 @@ struct LogicalType {
     string ToString() const;
     bool operator==(const LogicalType &o) const;
     static const LogicalType INTEGER, BIGINT, DOUBLE, VARCHAR, DATE, TIMESTAMP, TIMESTAMP_TZ, TABLE, ANY;
+    static LogicalType LIST(const LogicalType &child);
+    static LogicalType STRUCT(child_list_t<LogicalType> children);
 };
 struct StructType { static const child_list_t<LogicalType> &GetChildTypes(const LogicalType &type); };
+struct ListType { static const LogicalType &GetChildType(const LogicalType &type); };
+struct list_entry_t { uint64_t offset; uint64_t length; };
+struct string_t { string GetString() const; };
 
 class Value {
 public:
@@ -73,6 +78,7 @@ public:
 struct StringUtil {
     static string Lower(const string &s);
     static vector<string> Split(const string &s, char delimiter);
+    template <class... A> static string Format(const string fmt, A... params);
 };
 
 struct SelectionVector { idx_t get_index(idx_t i) const; };
@@ -83,14 +89,31 @@ struct UnifiedVectorFormat {
     ValidityMask validity;
     template <class T> static const T *GetData(const UnifiedVectorFormat &f) { return reinterpret_cast<const T *>(f.data); }
 };
+enum class VectorType : uint8_t { FLAT_VECTOR, FSST_VECTOR, CONSTANT_VECTOR, DICTIONARY_VECTOR, SEQUENCE_VECTOR };
 class Vector {
 public:
     explicit Vector(LogicalType type);
     const LogicalType &GetType() const;
+    void SetVectorType(VectorType type);
     void ToUnifiedFormat(idx_t count, UnifiedVectorFormat &out);
     Value GetValue(idx_t index) const;
 };
 struct VectorOperations { static void Cast(Vector &source, Vector &result, idx_t count); };
+struct FlatVector {
+    template <class T> static T *GetData(Vector &v);
+    static void SetNull(Vector &v, idx_t idx, bool is_null);
+};
+struct ListVector {
+    static Vector &GetEntry(Vector &list);
+    static idx_t GetListSize(const Vector &list);
+    static void Reserve(Vector &list, idx_t required_capacity);
+    static void SetListSize(Vector &list, idx_t size);
+};
+struct StructVector { static vector<unique_ptr<Vector>> &GetEntries(Vector &v); };
+struct StringVector {
+    static string_t AddString(Vector &v, const char *data);
+    static string_t AddString(Vector &v, const string &data);
+};
 class DataChunk {
 public:
     vector<Vector> data;
@@ -109,6 +132,8 @@ class ExecutionContext;
 class DatabaseInstance;
 struct FunctionData {
     virtual ~FunctionData() = default;
+    virtual unique_ptr<FunctionData> Copy() const;
+    virtual bool Equals(const FunctionData &other) const;
     template <class T> T &Cast() { return reinterpret_cast<T &>(*this); }
     template <class T> const T &Cast() const { return reinterpret_cast<const T &>(*this); }
 };
@@ -149,10 +174,87 @@ public:
     table_in_out_function_t in_out_function;
     table_in_out_function_final_t in_out_function_final;
 };
+
+// ---- scalar functions (scalar_function.hpp, expression.hpp, bound_function_expression.hpp, expression_executor_state.hpp)
+class Expression {
+public:
+    virtual ~Expression() = default;
+    LogicalType return_type;
+    template <class T> T &Cast() { return reinterpret_cast<T &>(*this); }
+    template <class T> const T &Cast() const { return reinterpret_cast<const T &>(*this); }
+};
+class BoundFunctionExpression : public Expression {
+public:
+    unique_ptr<FunctionData> bind_info;
+};
+struct ExpressionState { const Expression &expr; };
+enum class FunctionNullHandling : uint8_t { DEFAULT_NULL_HANDLING, SPECIAL_HANDLING };
+class ScalarFunction;
+typedef void (*scalar_function_t)(DataChunk &, ExpressionState &, Vector &);
+typedef unique_ptr<FunctionData> (*bind_scalar_function_t)(ClientContext &, ScalarFunction &, vector<unique_ptr<Expression>> &);
+class ScalarFunction {
+public:
+    ScalarFunction(string name, vector<LogicalType> arguments, LogicalType return_type, scalar_function_t function,
+                   bind_scalar_function_t bind = nullptr);
+    LogicalType return_type;
+    FunctionNullHandling null_handling;
+};
+
+// ---- parser and macro catalog entries (parser.hpp, sql_statement.hpp, create_statement.hpp, create_info.hpp, create_macro_info.hpp)
+#define DEFAULT_SCHEMA "main"
+enum class StatementType : uint8_t { INVALID_STATEMENT, SELECT_STATEMENT, CREATE_STATEMENT };
+enum class CatalogType : uint8_t { INVALID, MACRO_ENTRY, TABLE_MACRO_ENTRY };
+enum class OnCreateConflict : uint8_t { ERROR_ON_CONFLICT, IGNORE_ON_CONFLICT, REPLACE_ON_CONFLICT, ALTER_ON_CONFLICT };
+struct FunctionDescription {
+    string description;
+    vector<string> examples;
+    vector<string> categories;
+};
+struct CreateInfo {
+    virtual ~CreateInfo() = default;
+    CatalogType type;
+    string schema;
+    OnCreateConflict on_conflict;
+    bool temporary;
+    bool internal;
+};
+struct CreateFunctionInfo : public CreateInfo {
+    string name;
+    string alias_of;
+    vector<FunctionDescription> descriptions;
+};
+struct CreateMacroInfo : public CreateFunctionInfo {};
+class SQLStatement {
+public:
+    virtual ~SQLStatement() = default;
+    StatementType type;
+    template <class T> T &Cast() { return reinterpret_cast<T &>(*this); }
+};
+class CreateStatement : public SQLStatement {
+public:
+    unique_ptr<CreateInfo> info;
+};
+class Parser {
+public:
+    Parser();
+    void ParseQuery(const string &query);
+    vector<unique_ptr<SQLStatement>> statements;
+};
+template <class S, class T> unique_ptr<T> unique_ptr_cast(unique_ptr<S> src) { return unique_ptr<T>(static_cast<T *>(src.release())); }
+
 class ExtensionLoader {
 public:
     void RegisterFunction(TableFunction function);
+    void RegisterFunction(ScalarFunction function);
+    void RegisterFunction(CreateMacroInfo &function);
     DatabaseInstance &GetDatabaseInstance();
+};
+class Extension {                                  // extension.hpp: what anofox_forecast_extension.hpp derives from
+public:
+    virtual ~Extension() = default;
+    virtual void Load(ExtensionLoader &loader) = 0;
+    virtual std::string Name() = 0;
+    virtual std::string Version() const { return ""; }
 };
 enum class SetScope : uint8_t { AUTOMATIC, LOCAL, SESSION, GLOBAL };
 typedef void (*set_option_callback_t)(ClientContext &context, SetScope scope, Value &parameter);

@@ -173,7 +173,7 @@ def test_device_keyed_caches_on_four_fake_devices(sanitizer):
 
 
 def test_duckdb_binding_parses():
-    """binding/ts_forecast_native_hip.cpp has never been through the extension's build (no DuckDB headers in this image).  This is the
+    """binding/*.cpp have never been through the extension's build (no DuckDB headers in this image).  This is the
     next best thing: `g++ -fsyntax-only` against the REFERENCE's own helper headers (src/include/ts_forecast_native.hpp,
     ts_fill_gaps_native.hpp, anofox_fcst_ffi.h -- read where they lie, in this container only) and a declaration-only stand-in for
     DuckDB's API (tests/c_abi/duckdb_stub/, test infrastructure, written from DuckDB's public interface).  It proves the file is
@@ -187,7 +187,9 @@ def test_duckdb_binding_parses():
         pytest.skip("the reference tree is not on this machine (GPU box): its helper headers are read in place, never copied")
     if shutil.which("g++") is None:
         pytest.skip("no g++")
-    cmd = ["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-I", os.path.join(ROOT, "tests", "c_abi", "duckdb_stub"), "-I", ref,
-           "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "binding", "ts_forecast_native_hip.cpp")]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0, out.stderr[-3000:]
+    # round 6: the scalar of route A (one batch per DataChunk) and the macro that sends ts_forecast_by to the batch route
+    for unit in ("ts_forecast_native_hip.cpp", "ts_forecast_scalar_hip.cpp", "ts_macros_hip.cpp"):
+        cmd = ["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-I", os.path.join(ROOT, "tests", "c_abi", "duckdb_stub"), "-I", ref,
+               "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "binding", unit)]
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, (unit, out.stderr[-3000:])

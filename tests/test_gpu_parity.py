@@ -1572,6 +1572,65 @@ def test_ts_forecast_by_sql_replay(env):
     assert len(api.ts_forecast_by(*G, "ETS", 5, "1d", {"model": "AAA"})["yhat"]) == 10
 
 
+def test_route_a_chunks_equal_route_b(env):
+    """Round 6: `ts_forecast_by` on the batch route.  The shipped macro text reaches the scalar `_ts_forecast_scalar`
+    (ts_macros.cpp:576-591); binding/ts_forecast_scalar_hip.cpp hands every chunk of <= 2,048 groups to ONE anofox_ts_forecast_batch,
+    binding/ts_macros_hip.cpp points the macro at `_ts_forecast_native` (one batch per statement).  Both mirrors
+    (api.ts_forecast_by_scalar_route / api.ts_forecast_by) run the data of test/sql/ts_forecast_by.test and a ragged 300-group table
+    through the C-ABI: the same rows, bit for bit, whatever the chunk size -- a forecast does not depend on its batch's company."""
+    api, O, lib, synth = env
+    i = np.arange(60)
+    g_grp = np.array(["A"] * 60 + ["B"] * 60, dtype=object)
+    g_ds = np.concatenate([np.datetime64("2024-01-01T00:00:00", "us") + i.astype("timedelta64[D]")] * 2)
+    g_y = np.concatenate([10.0 + i * 0.5 + np.sin(i * 3.14159 / 7) * 2, 20.0 + i * 0.3 + np.cos(i * 3.14159 / 7) * 3])
+    j = np.arange(84)
+    s_grp = np.array(["S1"] * 84 + ["S2"] * 84, dtype=object)
+    s_ds = np.concatenate([np.datetime64("2024-01-01T00:00:00", "us") + j.astype("timedelta64[D]")] * 2)
+    s_y = np.concatenate([100 + np.sin(j * 2 * 3.14159 / 7) * 20 + j * 0.1, 200 + np.cos(j * 2 * 3.14159 / 7) * 30 + j * 0.2])
+
+    def same(a, b, what):
+        assert list(a.keys())[1:] == ["forecast_step", "ds", "yhat", "yhat_lower", "yhat_upper", "model_name"], what
+        assert list(a["id"]) == list(b["id"]) and list(a["model_name"]) == list(b["model_name"]), what
+        assert np.array_equal(a["forecast_step"], b["forecast_step"]) and np.array_equal(a["ds"], b["ds"]), what
+        for c in ("yhat", "yhat_lower", "yhat_upper"):
+            assert np.array_equal(a[c], b[c], equal_nan=True), (what, c)
+
+    for table, model, h, params in (((g_grp, g_ds, g_y), "Naive", 5, {}), ((g_grp, g_ds, g_y), "AutoETS", 3, {}),
+                                    ((g_grp, g_ds, g_y), "AutoARIMA", 3, {}), ((g_grp, g_ds, g_y), "ETS", 5, {"model": "AAA"}),
+                                    ((s_grp, s_ds, s_y), "HoltWinters", 7, {"confidence_level": 0.95, "seasonal_period": 7}),
+                                    ((s_grp, s_ds, s_y), "AutoETS", 7, {"seasonal_period": "7"}),
+                                    ((s_grp, s_ds, s_y), "SeasonalNaive", 7, {"seasonal_period": 7})):
+        b_rows = api.ts_forecast_by(*table, model, h, "1d", params, date_name="ds")
+        for chunk in (2048, 1):
+            same(api.ts_forecast_by_scalar_route(*table, model, h, "1d", params, chunk_groups=chunk), b_rows, (model, chunk))
+    # a ragged table: 300 groups of 20..400 observations with NULL targets, shuffled rows, chunks of 2,048 / 128 / 7 groups
+    rng = np.random.default_rng(606)
+    lens = rng.integers(20, 400, 300)
+    Y = synth.gen_series(synth.SEED_M5, 606, 300, 400, 7, positive=True)
+    grp = np.concatenate([np.full(n, f"g{k:03d}", dtype=object) for k, n in enumerate(lens)])
+    ds = np.concatenate([np.datetime64("2023-01-01", "D") + np.arange(n) for n in lens])
+    y = np.ma.array(np.concatenate([Y[k, :n] for k, n in enumerate(lens)]), mask=rng.random(int(lens.sum())) < 0.02)
+    perm = rng.permutation(len(grp))
+    for model, params in (("AutoETS", {"seasonal_period": "7"}), ("Holt", {}), ("AutoETS", {})):
+        b_rows = api.ts_forecast_by(grp[perm], ds[perm], y[perm], model, 14, "1d", params, date_name="ds")
+        assert len(b_rows["yhat"]) == 300 * 14
+        for chunk in (2048, 128, 7):
+            same(api.ts_forecast_by_scalar_route(grp[perm], ds[perm], y[perm], model, 14, "1d", params, chunk_groups=chunk), b_rows,
+                 (model, chunk))
+    # per-row arguments inside one chunk (only the scalar can take them): every row equals its own single-series call
+    lists_d = [ds[grp == f"g{k:03d}"] for k in range(6)]
+    lists_v = [y[grp == f"g{k:03d}"] for k in range(6)]
+    methods = ["AutoETS", "Holt", "AutoETS", "Naive", "Holt", "AutoETS"]
+    hz = [3, 5, 7, 2, 4, 6]
+    prm = [{"seasonal_period": "7"}, {}, {"seasonal_period": "7"}, {}, {"confidence_level": "0.8"}, {"seasonal_period": "7"}]
+    got = api.ts_forecast_scalar(lists_d, lists_v, hz, "1d", methods, prm)
+    for k in range(6):
+        one = api.ts_forecast_scalar([lists_d[k]], [lists_v[k]], hz[k], "1d", methods[k], prm[k])[0]
+        assert len(got[k]["yhat"]) == hz[k] and got[k]["model_name"] == one["model_name"]
+        for c in ("yhat", "yhat_lower", "yhat_upper", "ds"):
+            assert np.array_equal(got[k][c], one[c]), (k, c)
+
+
 def test_ts_forecast_params_sql_replay(env):
     """test/sql/ts_forecast_params.test: interval shape, SeasonalNaive / auto aliases on the LIST form, parameter maps and
     every frequency spelling through ts_forecast_by on DATE columns, the aggregate with and without params, horizons 0 / 1 / 24,

@@ -210,3 +210,66 @@ def test_bench_gpus_n_starts_its_own_ranks():
     assert out.returncode != 0                                  # the ranks' failure is the parent's exit code
     assert out.stderr.count("bench.py needs a GPU") == 2, out.stderr[-2000:]
     assert '"n_gpus"' not in out.stdout
+
+
+def test_scalar_chunk_groups_rows_by_option_block(monkeypatch):
+    """Route A, round 6 (binding/ts_forecast_scalar_hip.cpp, mirrored by api.ts_forecast_scalar): a chunk's rows are grouped by their
+    option block and every distinct block is ONE batch call with per-row horizons; NULL / empty lists are NULL rows and never reach
+    the library; the reference's error policy (ts_forecast_scalar.cpp:484-490) is applied in chunk order.  The batch entry is replaced
+    by a recorder here: no GPU, no forecast is computed."""
+    calls = []
+
+    def fake_batch(series, opts, valids=None, horizons=None):
+        calls.append((opts.model.decode(), opts.seasonal_period, opts.confidence_level, bool(opts.auto_detect_seasonality),
+                      [list(s) for s in series], [list(v) for v in valids], list(horizons)))
+        res = []
+        for s, h in zip(series, horizons):
+            if len(s) < 3:
+                res.append({"ok": False, "code": 6, "message": "Insufficient data"})
+            elif opts.model == b"Naive" and opts.seasonal_period > 1:
+                res.append({"ok": False, "code": 2, "message": "Model 'Naive' does not use seasonal_period"})
+            else:
+                res.append({"ok": True, "code": 0, "message": "", "point": np.full(h, s[-1]), "lower": np.full(h, s[-1] - 1.0),
+                            "upper": np.full(h, s[-1] + 1.0), "model_name": opts.model.decode()})
+        return res, {"ok": True, "code": 0, "message": ""}
+    monkeypatch.setattr(api, "forecast_batch", fake_batch)
+    day = np.datetime64("2024-01-01", "D")
+    d5 = day + np.arange(5)
+    rows_d = [d5, d5[::-1].copy(), None, d5[:2], d5, d5[:0]]
+    rows_v = [np.arange(5.0), np.ma.array([4.0, 3.0, 2.0, 1.0, 0.0], mask=[0, 0, 1, 0, 0]), np.arange(5.0), np.arange(2.0),
+              np.arange(5.0) * 2, np.arange(0.0)]
+    out = api.ts_forecast_scalar(rows_d, rows_v, [3, 2, 3, 3, 4, 3], "1d", "Naive", {})
+    assert len(calls) == 1                                                      # one option block -> one batch call for the chunk
+    model, sp, conf, auto, series, valids, hz = calls[0]
+    assert (model, sp, conf, auto) == ("Naive", 0, 0.90, True) and hz == [3, 2, 3, 4]      # the NULL and the empty list never travel
+    assert series[1] == [0.0, 1.0, 0.0, 3.0, 4.0] and valids[1] == [True, True, False, True, True]     # re-ordered by date; NULL slot 0.0
+    assert out[2] is None and out[5] is None and out[3] is None                 # NULL list, empty list, failed series (code 6)
+    assert list(out[0]["forecast_step"]) == [1, 2, 3] and out[0]["ds"][0] == day + 5 and len(out[1]["yhat"]) == 2
+    assert out[4]["yhat"][0] == 8.0 and out[4]["model_name"] == ["Naive"] * 4
+    # per-row method / params: two option blocks, two calls; rows keep their places
+    calls.clear()
+    out = api.ts_forecast_scalar([d5] * 4, [np.arange(5.0)] * 4, 2, "1d", ["Naive", "SES", "Naive", "SES"],
+                                 [{}, {"confidence_level": "0.95"}, {}, {"confidence_level": 0.95}])
+    assert [c[0] for c in calls] == ["Naive", "SES"] and [len(c[4]) for c in calls] == [2, 2] and calls[1][2] == 0.95
+    assert [o["model_name"][0] for o in out] == ["Naive", "SES", "Naive", "SES"]
+    # INVALID_INPUT aborts the statement; an unknown key is rejected before any call
+    calls.clear()
+    with pytest.raises(api.InvalidInputException, match="does not use seasonal_period"):
+        api.ts_forecast_scalar([d5], [np.arange(5.0)], 2, "1d", "Naive", {"seasonal_period": "7"})
+    with pytest.raises(api.InvalidInputException, match="Unknown parameter"):
+        api.ts_forecast_scalar([d5], [np.arange(5.0)], 2, "1d", "Naive", {"sesonal_period": "7"})
+    with pytest.raises(ValueError):
+        api.ts_forecast_scalar([d5] * 2049, [np.arange(5.0)] * 2049, 2, "1d", "Naive", {})
+    # the shipped macro text over columns: 5 groups in chunks of 2 -> 3 scalar calls, rows in group order
+    calls.clear()
+    grp = np.repeat(np.array(["a", "b", "c", "d", "e"], dtype=object), 4)
+    ds = np.tile(day + np.arange(4), 5)
+    y = np.arange(20.0)
+    perm = np.random.default_rng(3).permutation(20)
+    out = api.ts_forecast_by_scalar_route(grp[perm], ds[perm], y[perm], "Naive", 2, "1d", None, chunk_groups=2)
+    assert len(calls) == 3 and list(out.keys()) == ["id", "forecast_step", "ds", "yhat", "yhat_lower", "yhat_upper", "model_name"]
+    first = {}
+    for g, v in zip(out["id"], out["yhat"]):
+        first.setdefault(g, v)
+    assert first == {"a": 3.0, "b": 7.0, "c": 11.0, "d": 15.0, "e": 19.0} and len(out["yhat"]) == 10
+    assert out["ds"].dtype == ds.dtype and out["ds"][0] == day + 4
