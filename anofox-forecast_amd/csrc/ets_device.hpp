@@ -41,7 +41,7 @@ struct SeriesView {
     int wave_len;      // max len over the wave (uniform)
     int wave_min_len;  // min len over the wave's active lanes (uniform)
     int rows;          // rows the block holds (row indices are clamped to rows - 1 by the streaming loads)
-    const double *yb;  // the block itself (wave-uniform) and this lane's column: y == yb + col.  The streaming loads
+    const double *yb;  // the block itself (wave-uniform; a compact block's elements are YT, the pass addresses it in bytes) and this lane's column: y == yb + col.  The streaming loads
     int col;           // address rows from the scalar base so the per-load address work stays on the scalar unit
 };
 
@@ -58,6 +58,17 @@ __device__ __forceinline__ int wave_min_i32(int v)
     return v;
 }
 
+// Storage type of the streamed block (round 6).  The arithmetic is fp64 whatever the block holds; a batch whose every observation
+// survives the round trip through a narrower type exactly -- counts: the M5 shape -- is streamed from a COMPACT copy of the block
+// (kernels.hip compact_block_kernel makes it and counts the observations that do not survive; one that does not keeps the batch on
+// the fp64 block).  float: every value with <= 24 significant bits; uint16_t: integers 0 .. 65,535.  Half / a quarter of the bytes per
+// pass and of the registers the staged rows take; the step widens the value (one conversion) and runs the same operations on the
+// same numbers: bit-identical (tests/test_gpu_parity.py test_compact_storage_is_bit_identical).
+enum { YT_F64 = 0, YT_F32 = 1, YT_U16 = 2 };
+template <class YT> struct YtCode;
+template <> struct YtCode<double> { static constexpr int value = YT_F64; };
+template <> struct YtCode<float> { static constexpr int value = YT_F32; };
+template <> struct YtCode<unsigned short> { static constexpr int value = YT_U16; };
 #ifndef ANOFOX_TWO_BLOCK
 #define ANOFOX_TWO_BLOCK 1
 #endif
@@ -253,7 +264,7 @@ struct EtsFinalOut {
 // the lanes of a wave may then hold series of different periods, which is what lets a merged batch use the ordinary round schedule
 // (compaction + dense re-gather pack survivors of different periods into one wave).  Costs a vector phase counter and its wrap
 // per step; the ring of a lane is still `ring[j * 64 + lane]`, sized by the largest period of the batch.
-template <class Cfg, int MS, int K, bool FINAL>
+template <class Cfg, int MS, int K, bool FINAL, class YT = double>
 __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
                                          const double (&cand)[K][Cfg::DIM], double (&fout)[K],
                                          double *ring, const EtsFinalOut *fin)
@@ -271,7 +282,7 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
 
     }
     const double *yp = v.yb;            // wave-uniform base; the lane's column is added as a 32-bit offset
-    const unsigned col_bytes = (unsigned)v.col * 8u;     // ld < 2^29 columns: the byte offset of a column fits 32 bits
+    const unsigned col_bytes = (unsigned)v.col * (unsigned)sizeof(YT);     // ld < 2^29 columns: the byte offset of a column fits 32 bits
     const size_t ld = v.ld;
 
     // y is streamed through two register buffers of S steps: the S rows of the NEXT block are requested before the S
@@ -291,7 +302,10 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
     //  and at most 8 -- the ring prefetch needs periods of two blocks, a merged batch keeps periods from 17 up in HBM)
     constexpr int S_TARGET = ((MS == -2 || MS == -4) && K == 1 && S_FULL > 8) ? 8 : S_FULL;
     constexpr int S = (MS > 0) ? ((S_TARGET / MS > 0 ? S_TARGET / MS : 1) * MS) : S_TARGET;
-    double cur[S], nxt[S];
+    // (a staged row rests in the storage type: a float takes one register, a double two; 16-bit values are zero-extended by the load)
+    typedef std::conditional_t<std::is_same_v<YT, unsigned short>, unsigned, YT> ybuf_t;
+    auto widen = [](const ybuf_t x) __attribute__((always_inline)) { return (double)x; };
+    ybuf_t cur[S], nxt[S];
     // One loader, no branch (a conditional load in the loop makes the compiler wait for every outstanding load at once)
     // and no per-load address arithmetic on the vector unit: the rows of a block are fetched with buffer loads whose
     // descriptor is rebuilt once per block from scalars (base = first row of the block, range = what is left of the
@@ -305,10 +319,10 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
     // (17.7-17.8 -> 16.6 ms, profiles/r05_step_anatomy.txt section 6).  The general class keeps the byte form: its steps are 3-6 times
     // longer, the saving is under 1 %, and with the row form in every class the 25-spec batch measured 1.5-2.7 % SLOWER (443 / 442 ->
     // 456 / 449 ms, same box, alternating runs; not explained) where the additive-only form is neutral (455 / 459 -> 451 / 461 ms).
-    const size_t row_bytes = ld * 8;                               // (ld < 2^29 columns: fits 32 bits)
+    const size_t row_bytes = ld * sizeof(YT);                      // (ld < 2^29 columns: fits 32 bits)
     const size_t total_bytes = (size_t)(row_max + 1) * row_bytes;
     const int rows_total = row_max + 1;
-    auto load_block = [&](double (&buf)[S], const int row0) __attribute__((always_inline)) {
+    auto load_block = [&](ybuf_t (&buf)[S], const int row0) __attribute__((always_inline)) {
         unsigned nrec;
         size_t off;
         if constexpr (Cfg::ADDITIVE) {
@@ -325,8 +339,15 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
         const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)((const char *)yp + off), 0, nrec, 0x00020000);
 #pragma unroll
         for (int j = 0; j < S; j++) {
-            const u32x2_t w = __builtin_amdgcn_raw_buffer_load_b64(rsrc, col_bytes, (unsigned)(j * row_bytes), 0);
-            buf[j] = __builtin_bit_cast(double, w);
+            if constexpr (std::is_same_v<YT, double>) {
+                const u32x2_t w = __builtin_amdgcn_raw_buffer_load_b64(rsrc, col_bytes, (unsigned)(j * row_bytes), 0);
+                buf[j] = __builtin_bit_cast(double, w);
+            } else if constexpr (std::is_same_v<YT, float>) {
+                const unsigned w = __builtin_amdgcn_raw_buffer_load_b32(rsrc, col_bytes, (unsigned)(j * row_bytes), 0);
+                buf[j] = __builtin_bit_cast(float, w);
+            } else {
+                buf[j] = (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rsrc, col_bytes, (unsigned)(j * row_bytes), 0);
+            }
         }
     };
     load_block(cur, 0);
@@ -357,17 +378,17 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
         }
         // Two blocks per iteration on alternating buffers (round 5: every class, it used to be the additive one only): the copy between
         // the buffers -- one of a step's instructions -- disappears.  The main loop runs the blocks that every active lane of the wave covers without a predicate; the tail runs them predicated.
-        auto run_block = [&](const double (&buf)[S], const int base, auto pred_tag) __attribute__((always_inline)) {
+        auto run_block = [&](const ybuf_t (&buf)[S], const int base, auto pred_tag) __attribute__((always_inline)) {
             constexpr bool PRED = decltype(pred_tag)::value;
 #pragma unroll
             for (int j = 0; j < S; j++) {
                 if (!PRED || base + j < v.len) {
 #pragma unroll
                     for (int k = 0; k < K; k++) {
-                        ets_step<Cfg>(par[k], st[k], buf[j], s[k][MS > 0 ? j % MR : 0]);
+                        ets_step<Cfg>(par[k], st[k], widen(buf[j]), s[k][MS > 0 ? j % MR : 0]);
                         if ((j & 3) == 3 || j == S - 1) ets_renorm<Cfg>(st[k]);     // (a constant once the loop is unrolled)
                     }
-                    keep_fit(base + j, buf[j]);
+                    keep_fit(base + j, widen(buf[j]));
                 }
             }
         };
@@ -455,10 +476,10 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
                 for (int i = 0; i < S; i++) {
                     if (full || base + i < v.len) {
                         double sv = rc[i];
-                        ets_step<Cfg>(par[0], st[0], cur[i], sv);
+                        ets_step<Cfg>(par[0], st[0], widen(cur[i]), sv);
                         if ((i & 3) == 3 || i == S - 1) ets_renorm<Cfg>(st[0]);
                         ring[(size_t)j * NM_BLOCK + lane] = sv;
-                        keep_fit(base + i, cur[i]);
+                        keep_fit(base + i, widen(cur[i]));
                     }
                     j = (j + 1 == m) ? 0 : j + 1;
                 }
@@ -474,11 +495,11 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
 #pragma unroll
                     for (int k = 0; k < K; k++) {
                         double sv = ring[(k * m + j) * NM_BLOCK + lane];
-                        ets_step<Cfg>(par[k], st[k], cur[i], sv);
+                        ets_step<Cfg>(par[k], st[k], widen(cur[i]), sv);
                         if ((i & 3) == 3 || i == S - 1) ets_renorm<Cfg>(st[k]);
                         ring[(k * m + j) * NM_BLOCK + lane] = sv;
                     }
-                    keep_fit(base + i, cur[i]);
+                    keep_fit(base + i, widen(cur[i]));
                 }
                 j = (j + 1 == m) ? 0 : j + 1;
             }
@@ -525,7 +546,7 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
 // of its problem (throughput form, one y load feeds four recursions); 1 -> the four trial points of a
 // problem sit in four adjacent lanes (latency form: a quarter of the per-pass latency and VGPRs, four
 // times the waves), results exchanged with wave shuffles.  Both give bit-identical objective values.
-template <class Cfg, int MS, int CPL>
+template <class Cfg, int MS, int CPL, class YT = double>
 struct EtsModel {
     static constexpr int DIM = Cfg::DIM;
     SeriesView v;
@@ -544,20 +565,20 @@ struct EtsModel {
         double c1[1][DIM], f1[1];
 #pragma unroll
         for (int i = 0; i < DIM; i++) c1[0][i] = x[i];
-        ets_pass<Cfg, MS, 1, false>(v, in, c1, f1, ring, nullptr);
+        ets_pass<Cfg, MS, 1, false, YT>(v, in, c1, f1, ring, nullptr);
         return f1[0];
     }
     __device__ void eval(const double (&cand)[NM_K][DIM], double (&f)[NM_K]) const
     {
         if constexpr (CPL == NM_K) {
-            ets_pass<Cfg, MS, NM_K, false>(v, in, cand, f, ring, nullptr);
+            ets_pass<Cfg, MS, NM_K, false, YT>(v, in, cand, f, ring, nullptr);
         } else {
             const int sub = threadIdx.x & 3;                 // (lane & 3: a wave is 64 consecutive threads)
             double mine[1][DIM], f1[1];
 #pragma unroll
             for (int i = 0; i < DIM; i++)
                 mine[0][i] = sub == 0 ? cand[0][i] : (sub == 1 ? cand[1][i] : (sub == 2 ? cand[2][i] : cand[3][i]));
-            ets_pass<Cfg, MS, 1, false>(v, in, mine, f1, ring, nullptr);
+            ets_pass<Cfg, MS, 1, false, YT>(v, in, mine, f1, ring, nullptr);
             const int base = (threadIdx.x & (NM_BLOCK - 1)) & ~3;
 #pragma unroll
             for (int k = 0; k < NM_K; k++) f[k] = __shfl(f1[0], base + k);

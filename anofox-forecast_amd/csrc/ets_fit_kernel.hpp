@@ -40,6 +40,11 @@ namespace anofox {
 #ifndef ANOFOX_DM_WPB
 #define ANOFOX_DM_WPB 1
 #endif
+// ANOFOX_SETPRIO (experiment switch, round 6): wave issue priority (s_setprio) of the round kernels by spec class -- 0 none (shipped),
+// 1 damped multiplicative trend 3, 2 damped-M 3 / other general class 1, 3 damped-M 3 / general 2 / additive-class K4 kernels stay 0
+#ifndef ANOFOX_SETPRIO
+#define ANOFOX_SETPRIO 0
+#endif
 template <class Cfg> struct RoundTraits {
     static constexpr bool DAMPED_MUL = !Cfg::CLASSIC && Cfg::T == C_MUL && Cfg::D;
     static constexpr bool PARK = !Cfg::CLASSIC && (ANOFOX_PARK_CLASS >= 3 || (ANOFOX_PARK_CLASS == 2 && !Cfg::ADDITIVE) || (ANOFOX_PARK_CLASS == 1 && DAMPED_MUL));
@@ -48,8 +53,8 @@ template <class Cfg> struct RoundTraits {
 };
 
 // the model behind a Cfg: an ETS spec, or one of the SES / Holt / Holt-Winters / SeasonalES family (SSE objective, own start values)
-template <class Cfg, int MS, bool CLASSIC = Cfg::CLASSIC> struct RoundModelOf { using type = EtsModel<Cfg, MS, 1>; };
-template <class Cfg, int MS> struct RoundModelOf<Cfg, MS, true> { using type = ClassicRoundModel<Cfg::KIND, MS>; };
+template <class Cfg, int MS, class YT = double, bool CLASSIC = Cfg::CLASSIC> struct RoundModelOf { using type = EtsModel<Cfg, MS, 1, YT>; };
+template <class Cfg, int MS, class YT> struct RoundModelOf<Cfg, MS, YT, true> { using type = ClassicRoundModel<Cfg::KIND, MS>; };      // (the classic family streams the fp64 block)
 
 // SPEC = 0: sequential Nelder-Mead, one lane per problem (64 problems per wave)
 // SPEC = 1: speculative, the four trial points of a problem in four adjacent lanes (16 problems per wave)
@@ -63,13 +68,16 @@ template <class Cfg, int MS> struct RoundModelOf<Cfg, MS, true> { using type = C
 //           memory bound, so on a batch whose live specs are all additive (intermittent counts: the real M5 shape) the passes
 //           ARE the cost and four times the arithmetic is free; in a mix with the general-class specs (VALU bound) it is not,
 //           and the sequential driver stays.  Same iterates, same evaluation counts (the speculative driver's bookkeeping).
-template <class Cfg, int MS, int SPEC, bool K4 = false>
+// YT: storage type of the block the round streams (ets_device.hpp: double, or float / uint16_t for a compact copy of a batch of counts)
+template <class Cfg, int MS, int SPEC, bool K4 = false, class YT = double>
 __global__ __launch_bounds__(NM_BLOCK * RoundTraits<Cfg>::WPB, (RoundTraits<Cfg>::WAVES + RoundTraits<Cfg>::WPB - 1) / RoundTraits<Cfg>::WPB) void ets_round_kernel(const FitArgs a)
 {
     extern __shared__ double lds_all[];
     constexpr int D = Cfg::DIM;
     constexpr bool PARK = RoundTraits<Cfg>::PARK;
     constexpr int WPB = RoundTraits<Cfg>::WPB;
+    if constexpr (ANOFOX_SETPRIO >= 1 && RoundTraits<Cfg>::DAMPED_MUL) __builtin_amdgcn_s_setprio(3);
+    else if constexpr (ANOFOX_SETPRIO >= 2 && !Cfg::CLASSIC && !Cfg::ADDITIVE) __builtin_amdgcn_s_setprio(ANOFOX_SETPRIO == 2 ? 1 : 2);
     if constexpr (Cfg::T == C_MUL && Cfg::D) dm_pow_tab_init();     // b^phi tables -> LDS, by every thread of the workgroup, before any wave leaves
     const int lane = threadIdx.x & (NM_BLOCK - 1);
     const int wave = WPB > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
@@ -79,6 +87,7 @@ __global__ __launch_bounds__(NM_BLOCK * RoundTraits<Cfg>::WPB, (RoundTraits<Cfg>
     double *const lds = lds_all + (size_t)wave * (size_t)lds_per_wave;
     double *const nmst = PARK ? a.nm_scratch + (size_t)vblock * (size_t)nm_lds_doubles<D>() : lds;
     double *const lds_ring = PARK ? lds : lds + nm_lds_doubles<D>();
+    const unsigned long long trace_t0 = a.wave_trace ? __builtin_amdgcn_s_memrealtime() : 0ull;
     const int n_act = a.n_active ? *a.n_active : a.n_series;
     int mode = SPEC;
     if constexpr (SPEC == 3) mode = n_act > a.spec_below ? 0 : ((a.spec2_below > 0 && n_act <= a.spec2_below && n_act <= vgrid) ? 2 : 1);
@@ -137,7 +146,7 @@ __global__ __launch_bounds__(NM_BLOCK * RoundTraits<Cfg>::WPB, (RoundTraits<Cfg>
     v.rows = a.t_rows;
     if (v.wave_len == 0) return;
 
-    typename RoundModelOf<Cfg, MS>::type mdl;
+    typename RoundModelOf<Cfg, MS, YT>::type mdl;
     mdl.v = v;
     mdl.in.l0 = (active && !Cfg::CLASSIC) ? a.l0[s] : 0.0;
     mdl.in.b0 = (active && !Cfg::CLASSIC && Cfg::T != C_NONE) ? a.b0[s] : 0.0;
@@ -171,7 +180,7 @@ __global__ __launch_bounds__(NM_BLOCK * RoundTraits<Cfg>::WPB, (RoundTraits<Cfg>
 #define ANOFOX_ADVANCE_LANE()                                                                          \
     do {                                                                                               \
         if constexpr (K4) {                                                                            \
-            EtsModel<Cfg, MS, NM_K> mdl4;                                                              \
+            EtsModel<Cfg, MS, NM_K, YT> mdl4;                                                          \
             mdl4.v = mdl.v; mdl4.in = mdl.in; mdl4.ring = mdl.ring;                                    \
             nm_advance_spec(mdl4, nmst, r, budget);                                                    \
         } else nm_advance_seq(mdl, nmst, r, budget);                                                   \
@@ -186,6 +195,16 @@ __global__ __launch_bounds__(NM_BLOCK * RoundTraits<Cfg>::WPB, (RoundTraits<Cfg>
 #undef ANOFOX_ADVANCE_LANE
     nm_fence();
 
+    if (a.wave_trace && lane == 0) {
+        const unsigned long long slot = atomicAdd(a.wave_trace, 1ull);
+        if (slot < a.wave_trace[1]) {
+            unsigned long long *rec = a.wave_trace + 4 + 4 * slot;
+            rec[0] = a.wave_trace_tag | ((unsigned long long)mode << 8) | (unsigned long long)(K4 ? 4 : 0);
+            rec[1] = trace_t0;
+            rec[2] = __builtin_amdgcn_s_memrealtime();
+            rec[3] = (unsigned long long)__builtin_amdgcn_s_getreg(0xF804) | ((unsigned long long)__builtin_amdgcn_s_getreg(0xF814) << 32);    // HW_ID, XCC_ID
+        }
+    }
     if (a.lane_stats) {
         // a lane's pass counter moves only while it evaluates (nm.hpp); the lane that parks last was live in every pass of the wave
         const int mine = r.passes - passes_in;
@@ -213,7 +232,7 @@ __global__ __launch_bounds__(NM_BLOCK * RoundTraits<Cfg>::WPB, (RoundTraits<Cfg>
     }
 }
 
-template <class Cfg, int MS>
+template <class Cfg, int MS, class YT = double>
 __global__ __launch_bounds__(NM_BLOCK) void ets_final_kernel(const FitArgs a)
 {
     extern __shared__ double lds[];
@@ -266,7 +285,7 @@ __global__ __launch_bounds__(NM_BLOCK) void ets_final_kernel(const FitArgs a)
         fin.sse_out = &sse;
         fin.h = 0;                                   // the forecasts of the run stay as they are
     }
-    ets_pass<Cfg, MS, 1, true>(v, in, cand, f, (MS == -2) ? a.ring_scratch + (size_t)blockIdx.x * (size_t)a.m * NM_BLOCK : lds, &fin);
+    ets_pass<Cfg, MS, 1, true, YT>(v, in, cand, f, (MS == -2) ? a.ring_scratch + (size_t)blockIdx.x * (size_t)a.m * NM_BLOCK : lds, &fin);
     if (inspect) {
         if (active && fabs(f[0]) <= 1.7976931348623157e308) {
             EtsPar par;
@@ -304,7 +323,7 @@ __global__ __launch_bounds__(NM_BLOCK) void ets_final_kernel(const FitArgs a)
     }
 }
 
-template <class Cfg, int MS, int SPEC, bool K4 = false>
+template <class Cfg, int MS, int SPEC, bool K4 = false, class YT = double>
 void ets_round_launch(const FitArgs &a, hipStream_t stream)
 {
     static_assert(!K4 || ((SPEC == 0 || SPEC == 3) && MS >= 0 && !Cfg::CLASSIC), "K4: the one-lane-per-problem driver of an ETS spec without a run-time ring");
@@ -332,16 +351,16 @@ void ets_round_launch(const FitArgs &a, hipStream_t stream)
     if (MS == -1 || MS == -3) lds_bytes += sizeof(double) * (size_t)a.m * NM_BLOCK;
     lds_bytes *= WPB;
     if (lds_bytes > 48 * 1024)
-        anofox_check_attr(hipFuncSetAttribute((const void *)ets_round_kernel<Cfg, MS, SPEC, K4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    hipLaunchKernelGGL((ets_round_kernel<Cfg, MS, SPEC, K4>), dim3(blocks), dim3(NM_BLOCK * WPB), lds_bytes, stream, a);
+        anofox_check_attr(hipFuncSetAttribute((const void *)ets_round_kernel<Cfg, MS, SPEC, K4, YT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    hipLaunchKernelGGL((ets_round_kernel<Cfg, MS, SPEC, K4, YT>), dim3(blocks), dim3(NM_BLOCK * WPB), lds_bytes, stream, a);
 }
 
-template <class Cfg, int MS>
+template <class Cfg, int MS, class YT = double>
 void ets_final_launch(const FitArgs &a, hipStream_t stream)
 {
     const int grid = (a.n_series + NM_BLOCK - 1) / NM_BLOCK;
     size_t lds_bytes = (MS == -1) ? sizeof(double) * (size_t)a.m * NM_BLOCK : 0;
-    hipLaunchKernelGGL((ets_final_kernel<Cfg, MS>), dim3(grid), dim3(NM_BLOCK), lds_bytes, stream, a);
+    hipLaunchKernelGGL((ets_final_kernel<Cfg, MS, YT>), dim3(grid), dim3(NM_BLOCK), lds_bytes, stream, a);
 }
 
 } // namespace anofox

@@ -16,25 +16,37 @@ template <int ID> struct SpecOf {
     using Cfg = EtsCfg<e, t, d, s>;
 };
 // the K4 forms exist for the additive class without a period or with the weekly one in registers (m = 12: four rings of 12 spill): ets_fit_kernel.hpp
-template <int ID, int MS, int SPEC> FitLaunchFn k4_launcher()
+template <int ID, int MS, int SPEC, class YT> FitLaunchFn k4_launcher()
 {
-    if constexpr (SpecOf<ID>::Cfg::ADDITIVE && (MS == 0 || MS == 7)) return &ets_round_launch<typename SpecOf<ID>::Cfg, MS, SPEC, true>;
+    if constexpr (SpecOf<ID>::Cfg::ADDITIVE && (MS == 0 || MS == 7)) return &ets_round_launch<typename SpecOf<ID>::Cfg, MS, SPEC, true, YT>;
     else return nullptr;
 }
-template <int ID, int MS> FitLaunchers launchers_of()
+// YT: what the streamed block holds (ets_device.hpp).  The compact types are instantiated for the period variants a uniform batch
+// uses (none, 7, 12, run-time ring in LDS or HBM); a merged batch of several periods (MS -3 / -4) streams the fp64 block.
+template <int ID, int MS, class YT = double> FitLaunchers launchers_of()
 {
+    if constexpr (!std::is_same_v<YT, double> && MS <= -3) return FitLaunchers{nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr};
+    else {
     // the final pass sweeps the columns in their original blocks of one period each: the per-lane period variants (-3 / -4) exist for
     // the round kernels only
     constexpr int MSF = MS == -3 ? -1 : (MS == -4 ? -2 : MS);
-    return FitLaunchers{&ets_round_launch<typename SpecOf<ID>::Cfg, MS, 0>, &ets_round_launch<typename SpecOf<ID>::Cfg, MS, 1>,
-                        &ets_round_launch<typename SpecOf<ID>::Cfg, MS, 2>, &ets_round_launch<typename SpecOf<ID>::Cfg, MS, 3>,
-                        &ets_final_launch<typename SpecOf<ID>::Cfg, MSF>,
+    return FitLaunchers{&ets_round_launch<typename SpecOf<ID>::Cfg, MS, 0, false, YT>, &ets_round_launch<typename SpecOf<ID>::Cfg, MS, 1, false, YT>,
+                        &ets_round_launch<typename SpecOf<ID>::Cfg, MS, 2, false, YT>, &ets_round_launch<typename SpecOf<ID>::Cfg, MS, 3, false, YT>,
+                        &ets_final_launch<typename SpecOf<ID>::Cfg, MSF, YT>,
                         RoundTraits<typename SpecOf<ID>::Cfg>::PARK ? (size_t)nm_lds_doubles<SpecOf<ID>::Cfg::DIM>() : 0,
-                        k4_launcher<ID, MS, 0>(), k4_launcher<ID, MS, 3>()};
+                        k4_launcher<ID, MS, 0, YT>(), k4_launcher<ID, MS, 3, YT>()};
+    }
+}
+// run-time storage type -> the instantiation (yt: YT_F64 / YT_F32 / YT_U16)
+template <int ID, int MS> FitLaunchers launchers_of_yt(int yt)
+{
+    if (yt == YT_F32) return launchers_of<ID, MS, float>();
+    if (yt == YT_U16) return launchers_of<ID, MS, unsigned short>();
+    return launchers_of<ID, MS, double>();
 }
 
-FitLaunchers fit_unit_nonseasonal(int spec_id, int m);
-FitLaunchers fit_unit_seasonal_add(int spec_id, int m);
-FitLaunchers fit_unit_seasonal_gen_a(int spec_id, int m);
-FitLaunchers fit_unit_seasonal_gen_m(int spec_id, int m);
+FitLaunchers fit_unit_nonseasonal(int spec_id, int m, int yt);
+FitLaunchers fit_unit_seasonal_add(int spec_id, int m, int yt);
+FitLaunchers fit_unit_seasonal_gen_a(int spec_id, int m, int yt);
+FitLaunchers fit_unit_seasonal_gen_m(int spec_id, int m, int yt);
 } // namespace anofox

@@ -91,6 +91,16 @@ struct AnofoxHipBatch {
     int n_slots_cap = 0;
     double *d_aicc = nullptr, *d_yhat_slots = nullptr;
     int32_t *d_status_slots = nullptr, *d_evals_slots = nullptr, *d_iters_slots = nullptr, *d_passes_slots = nullptr, *d_slot_spec = nullptr;
+    // compact copies of the series block for the ETS round / final kernels (round 6, ets_device.hpp YT_*): a float block and a uint16_t
+    // block of t_max x ld cells each, remade by every run that fits (the caller may have rewritten a resident block), and the count of
+    // observations that do not survive either round trip.  y_type: what THIS run's fit streams (YT_F64 unless a counter is zero).
+    float *d_yc32 = nullptr;
+    unsigned short *d_yc16 = nullptr;
+    size_t yc_cells = 0;
+    unsigned int *d_misfit = nullptr;
+    unsigned int h_misfit[2] = {1u, 1u};
+    int y_type = 0;
+    unsigned long long *d_wave_trace = nullptr;    // developer instrument (tune wave_trace): 4 + 4 x WAVE_TRACE_RECORDS words, see FitArgs::wave_trace
     unsigned long long *d_lane_stats = nullptr;    // [n_slots_cap x 2] wave passes / live lane passes of every spec's round kernels (zeroed per run)
     // outputs
     double *d_yhat = nullptr, *d_lo = nullptr, *d_hi = nullptr;
@@ -299,7 +309,7 @@ void free_batch_buffers(AnofoxHipBatch *b)
     if (b->owns_len) F(b->d_len);
     F(b->d_mean); F(b->d_sd); F(b->d_fig_add); F(b->d_fig_mul); F(b->d_l0); F(b->d_b0); F(b->d_flags);
     F(b->d_aicc); F(b->d_yhat_slots); F(b->d_status_slots); F(b->d_evals_slots); F(b->d_iters_slots);
-    F(b->d_passes_slots); F(b->d_slot_spec); F(b->d_lane_stats);
+    F(b->d_passes_slots); F(b->d_slot_spec); F(b->d_lane_stats); F(b->d_wave_trace); F(b->d_yc32); F(b->d_yc16); F(b->d_misfit);
     F(b->d_yhat); F(b->d_lo); F(b->d_hi); F(b->d_model_code); F(b->d_status); F(b->d_detail);
     F(b->classic_st.sim); F(b->classic_st.fs); F(b->classic_st.phase); F(b->classic_st.evals); F(b->classic_st.iters); F(b->classic_st.passes); F(b->classic_st.done);
     F(b->d_classic_ybuf); F(b->d_classic_status); F(b->classic_map[0]); F(b->classic_map[1]); F(b->classic_cnt);
@@ -784,6 +794,51 @@ __global__ void ets_fixed_setup_kernel(int n, size_t ld, const int32_t *len, con
     evals[s] = 0; iters[s] = 0; passes[s] = 0; done[s] = 1;
 }
 
+// Compact storage of the series block (round 6; ets_device.hpp YT_*, kernels.hip compact_block_kernel).  The optimiser streams every
+// series hundreds of times, so a batch of counts -- the M5 shape: integers, or anything else whose every observation survives the
+// round trip through float or uint16_t bit for bit -- is streamed from a 4- or 2-byte copy of the block: half / a quarter of the bytes
+// of a pass and of the registers the staged rows take (30,490 x 1,913, 25 specs: 450 -> 396 ms per step with the float copy, same
+// passes, same bits).  begin: one sweep of the block makes both copies and counts the observations that do NOT survive (+ 0.15 ms for
+// 467 MB); decide (after the host has synchronised the stream): a copy is used only when its counter is zero, so ONE inexact
+// observation anywhere keeps the whole batch on the fp64 block.  Not for given parameters (one pass: the sweep would cost more than
+// it saves), a merged batch of several periods (its per-lane-period kernels exist for fp64 only) or a handful of series.
+// tune compact: -1 auto (narrowest exact type; batches of at least 65,536 cells), 0 never, 1 float at most, 2 narrowest exact type (1 / 2: any size).
+bool compact_storage_begin(AnofoxHipBatch *b, const int32_t *d_len, hipStream_t st)
+{
+    b->y_type = YT_F64;
+    if (b->tun.compact == 0 || b->fixed_params || b->d_m_col != nullptr) return false;
+    if (b->tun.compact < 0 && b->n * (size_t)std::max<size_t>(b->t_max, 1) < (size_t)1 << 16) return false;      // (auto: not for a handful of short series)
+    const size_t cells = b->ld * std::max<size_t>(b->t_max, 1);
+    if (b->yc_cells < cells) {
+        if (b->d_yc32) b->retired.push_back(b->d_yc32);
+        if (b->d_yc16) b->retired.push_back(b->d_yc16);
+        b->d_yc32 = nullptr; b->d_yc16 = nullptr; b->yc_cells = 0;
+        try {
+            b->d_yc32 = dalloc<float>(cells);
+            b->d_yc16 = dalloc<unsigned short>(cells);
+        } catch (const HipFail &f) {
+            if (!f.oom) throw;
+            if (b->d_yc32) { dev_free(b->d_yc32, true); b->d_yc32 = nullptr; }      // no room beside a co-resident allocator: the fp64 block serves
+            return false;
+        }
+        b->yc_cells = cells;
+    }
+    if (!b->d_misfit) b->d_misfit = dalloc<unsigned int>(2);
+    HIPCHECK(hipMemsetAsync(b->d_misfit, 0, 2 * sizeof(unsigned int), st));
+    launch_compact_block(b->d_y, b->ld, d_len, (int)b->n, (int)std::max<size_t>(b->t_max, 1), b->d_yc32, b->d_yc16, b->d_misfit, st);
+    b->h_misfit[0] = b->h_misfit[1] = 1u;
+    HIPCHECK(hipMemcpyAsync(b->h_misfit, b->d_misfit, sizeof b->h_misfit, hipMemcpyDeviceToHost, st));
+    return true;
+}
+void compact_storage_decide(AnofoxHipBatch *b, bool pending, hipStream_t st)
+{
+    b->y_type = YT_F64;
+    if (!pending) return;
+    HIPCHECK(hipStreamSynchronize(st));          // (already drained when the caller has just read its own counters)
+    if (b->h_misfit[1] == 0u && b->tun.compact != 1) b->y_type = YT_U16;
+    else if (b->h_misfit[0] == 0u) b->y_type = YT_F32;
+}
+
 void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const int32_t *d_len, int m, bool skip_constant,
                       hipStream_t st)
 {
@@ -800,6 +855,10 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
     // batch runs the ordinary schedule -- compaction and the dense re-gather pack survivors of different periods into one wave;
     // the final pass sweeps the original blocks (one period each)
     const bool merged = b->d_m_col != nullptr;
+    // what the kernels stream: the fp64 block, or a compact copy of it (compact_storage_decide: every observation survives the narrower type)
+    const int yt = merged ? (int)YT_F64 : b->y_type;
+    const void *ybase = yt == YT_F32 ? (const void *)b->d_yc32 : (yt == YT_U16 ? (const void *)b->d_yc16 : (const void *)b->d_y);
+    const int ybytes = yt == YT_F32 ? 4 : (yt == YT_U16 ? 2 : 8);
     const int lds_limit = merged ? ETS_MERGED_LDS_PERIOD : ETS_LDS_PERIOD;      // largest period whose seasonal ring stays in LDS
     // ONE spec (ETS with an explicit model, fitted or with given parameters): its launches go on the run's own stream -- no fork, no
     // join.  A cross-stream event wait is cheap when the host has just synchronised and expensive inside a pipeline of runs: twenty
@@ -842,7 +901,7 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
         const int tt = ti == 0 ? 0 : (ti <= 2 ? 1 : 2);
         FitArgs &a = args[oi];
         a = FitArgs{};
-        a.y = b->d_y; a.ld = ld; a.len = d_len; a.n_series = (int)n; a.t_rows = (int)std::max<size_t>(b->t_max, 1);
+        a.y = (const double *)ybase; a.ld = ld; a.len = d_len; a.n_series = (int)n; a.t_rows = (int)std::max<size_t>(b->t_max, 1);
         a.m = se != 0 ? m : 1; a.h = b->h;
         a.l0 = b->d_l0 + (size_t)(se * 3 + tt) * ld;
         a.b0 = b->d_b0 + (size_t)(se * 3 + tt) * ld;
@@ -863,7 +922,8 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
         a.m_col = b->d_m_col;
         if (b->sd_in_final && order.size() == 1) { a.mean = b->d_mean; a.sd_out = b->d_sd; }
         a.lane_stats = b->d_lane_stats ? b->d_lane_stats + 2 * k : nullptr;
-        fns[oi] = ets_fit_launcher(id, (merged && se != 0) ? (a.m > lds_limit ? ETS_PERLANE_HBM : ETS_PERLANE_LDS) : a.m);
+        a.wave_trace = b->d_wave_trace;
+        fns[oi] = ets_fit_launcher(id, (merged && se != 0) ? (a.m > lds_limit ? ETS_PERLANE_HBM : ETS_PERLANE_LDS) : a.m, yt);
         if (!fns[oi].round_seq || !fns[oi].round_spec || !fns[oi].round_auto || !fns[oi].final) throw HipFail{"no kernel for ETS spec id " + std::to_string(id)};
     }
     // Periods above the LDS limit keep the seasonal ring of every lane in HBM: one area per (spec, workgroup of the widest
@@ -1003,6 +1063,7 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
             FitArgs &a = args[oi];
             const bool spec_mode = r >= b->seq_rounds;
             a.first_round = (r == 0);
+            a.wave_trace_tag = ((unsigned long long)specs[order[oi]] << 32) | ((unsigned long long)r << 16);
             a.spec_below = -1; a.spec2_below = -1;
             a.gathered = 0;
             if (tiny) {
@@ -1021,7 +1082,7 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
                 if (b->d_ypos) { a.y_round = b->d_ypos; a.ld_round = ld; a.gathered = 1; a.gather_cap = (int)ld; }
                 else { a.y_round = b->d_y; a.ld_round = ld; }
             } else if (r == 0) {
-                a.y_round = b->d_y; a.ld_round = ld; a.series_of = nullptr; a.n_active = nullptr;
+                a.y_round = a.y; a.ld_round = ld; a.series_of = nullptr; a.n_active = nullptr;
             } else {
                 const int32_t *prev_map = (r == 1) ? nullptr : lane.map[(r - 1) & 1];
                 const int32_t *prev_cnt = (r == 1) ? nullptr : lane.cnt + ((r - 1) % 3);
@@ -1029,11 +1090,11 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
                 launch_compact(prev_map, prev_cnt, (int)n, lane.st.done, lane.map[r & 1], lane.cnt + (r % 3), sq, lane.cnt + ((r + 1) % 3));
                 a.series_of = lane.map[r & 1]; a.n_active = lane.cnt + (r % 3);
                 if (b->use_gather && lane.ybuf) {
-                    launch_gather_columns(b->d_y, ld, lane.map[r & 1], lane.cnt + (r % 3), (int)n, (int)b->t_max, lane.ybuf, lane.ybuf_cols, sq,
-                                          (int)lane.ybuf_cols);
+                    launch_gather_columns(a.y, ld, lane.map[r & 1], lane.cnt + (r % 3), (int)n, (int)b->t_max, lane.ybuf, lane.ybuf_cols, sq,
+                                          (int)lane.ybuf_cols, ybytes);
                     a.y_round = lane.ybuf; a.ld_round = lane.ybuf_cols; a.gathered = 1; a.gather_cap = (int)lane.ybuf_cols;
                 } else {
-                    a.y_round = b->d_y; a.ld_round = ld;
+                    a.y_round = a.y; a.ld_round = ld;
                 }
             }
             const int s2 = (spec_trend_idx(specs[order[oi]]) == 4) ? b->spec2_below_md : b->spec2_below;
@@ -1214,6 +1275,7 @@ void run_group(AnofoxHipBatch *b, int period, const int32_t *d_len, hipStream_t 
                 break;
             }
             std::vector<int> specs{id};
+            compact_storage_decide(b, compact_storage_begin(b, d_len, st), st);
             launch_fit_slots(b, specs, d_len, m, false, st);
             hipLaunchKernelGGL(explicit_select_kernel, dim3((unsigned)((n * (size_t)std::max(b->h, 1) + 255) / 256)), dim3(256), 0, st, (int)n, b->h, d_len, b->d_status_slots,
                                b->d_yhat_slots, b->d_passes_slots, b->d_evals_slots, b->d_yhat, b->d_detail, b->d_passes_total,
@@ -1234,6 +1296,7 @@ void run_group(AnofoxHipBatch *b, int period, const int32_t *d_len, hipStream_t 
     case M_AutoETS: {
         int m = (period > 1 && period <= ETS_MAX_PERIOD) ? period : 1;
         prep(m, true);
+        const bool compact_pending = compact_storage_begin(b, d_len, st);
         std::vector<int> specs;
         for (int id = 0; id < 30; id++) {
             if (spec_season(id) != 0 && m <= 1) continue;
@@ -1249,7 +1312,7 @@ void run_group(AnofoxHipBatch *b, int period, const int32_t *d_len, hipStream_t 
             hipLaunchKernelGGL(count_positive_kernel, dim3(1), dim3(1024), 0, st, (int)n, d_len, b->d_flags, b->d_count);
             int32_t cnt[2] = {0, 0};
             HIPCHECK(hipMemcpyAsync(cnt, b->d_count, sizeof cnt, hipMemcpyDeviceToHost, st));
-            HIPCHECK(hipStreamSynchronize(st));
+            HIPCHECK(hipStreamSynchronize(st));             // (the compact copies' misfit counters have arrived too)
             size_t n_add = 0;
             for (int id : specs) if (!spec_has_mult(id)) n_add++;
             const double live = (double)cnt[0] * (double)specs.size() + (double)(cnt[1] - cnt[0]) * (double)n_add;
@@ -1260,6 +1323,7 @@ void run_group(AnofoxHipBatch *b, int period, const int32_t *d_len, hipStream_t 
             b->use_pos = false;
             b->live_pos = b->live_all = -1;
         }
+        compact_storage_decide(b, compact_pending, st);
         b->none_pos = b->live_all >= 0 && b->live_pos == 0;       // no strictly positive series at all: the 19 specs with a multiplicative component have nothing to fit
         if (b->use_pos || b->none_pos)
             hipLaunchKernelGGL(mark_nonpositive_kernel, dim3((unsigned)blocks256), dim3(256), 0, st, (int)n, d_len, b->d_flags, b->d_notpos);
@@ -1267,7 +1331,10 @@ void run_group(AnofoxHipBatch *b, int period, const int32_t *d_len, hipStream_t 
             launch_compact(nullptr, nullptr, (int)n, b->d_notpos, b->d_pos_map, b->d_pos_cnt, st);
             if (b->use_gather) {
                 if (!b->d_ypos) b->d_ypos = dalloc<double>(std::max<size_t>(b->t_max, 1) * ld);
-                launch_gather_columns(b->d_y, ld, b->d_pos_map, b->d_pos_cnt, (int)n, (int)b->t_max, b->d_ypos, ld, st, (int)ld);
+                // (the strictly positive columns, in the storage type the fit streams)
+                const int yt = b->d_m_col ? (int)YT_F64 : b->y_type;
+                launch_gather_columns(yt == YT_F32 ? (const void *)b->d_yc32 : (yt == YT_U16 ? (const void *)b->d_yc16 : (const void *)b->d_y), ld, b->d_pos_map,
+                                      b->d_pos_cnt, (int)n, (int)b->t_max, b->d_ypos, ld, st, (int)ld, yt == YT_F32 ? 4 : (yt == YT_U16 ? 2 : 8));
             }
         }
         launch_fit_slots(b, specs, d_len, m, true, st);
@@ -1331,6 +1398,13 @@ void run_batch(AnofoxHipBatch *b, hipStream_t st)
     b->last_stream = st;
     HIPCHECK(hipEventRecord(b->ev_start, st));
     if (b->d_lane_stats) HIPCHECK(hipMemsetAsync(b->d_lane_stats, 0, 2 * (size_t)b->n_slots_cap * sizeof(unsigned long long), st));
+    if (!b->tun.wave_trace.empty() && b->n_slots_cap > 0) {
+        constexpr size_t WAVE_TRACE_RECORDS = 4u << 20;
+        if (!b->d_wave_trace) b->d_wave_trace = dalloc<unsigned long long>(4 + 4 * WAVE_TRACE_RECORDS);
+        const unsigned long long head[4] = {0ull, (unsigned long long)WAVE_TRACE_RECORDS, 0ull, 0ull};
+        HIPCHECK(hipMemcpyAsync(b->d_wave_trace, head, sizeof head, hipMemcpyHostToDevice, st));
+        HIPCHECK(hipStreamSynchronize(st));        // (`head` is a stack array)
+    }
     {
         const size_t nh = n * (size_t)std::max(b->h, 0);
         const size_t cover = std::max<size_t>(std::max(nh, ld), 1);
@@ -1828,6 +1902,7 @@ bool anofox_hip_batch_stats(AnofoxHipBatch *b, AnofoxHipStats *out)
     out->t_max = b->t_max;
     out->n_problems = b->n_problems;
     out->fit_kernel_launches = b->fit_launches;
+    out->y_storage = (uint32_t)(b->insp_ok ? b->y_type : 0);
     for (size_t s = 0; s < b->n; s++) {
         uint64_t p = (uint64_t)std::max(passes[s], 0);
         out->total_passes += p;
@@ -1873,6 +1948,18 @@ bool anofox_hip_batch_lane_stats(AnofoxHipBatch *b, AnofoxHipLaneStats *out, siz
     std::memset(&r, 0, sizeof r);
     r.struct_size = sizeof r;
     if (hipEventSynchronize(b->ev_stop) != hipSuccess) return false;
+    if (b->d_wave_trace && !b->tun.wave_trace.empty()) {
+        unsigned long long head[4] = {0, 0, 0, 0};
+        if (hipMemcpy(head, b->d_wave_trace, sizeof head, hipMemcpyDeviceToHost) != hipSuccess) return false;
+        const size_t used = (size_t)std::min(head[0], head[1]);
+        std::vector<unsigned long long> rec(4 * used);
+        if (used && hipMemcpy(rec.data(), b->d_wave_trace + 4, rec.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return false;
+        if (FILE *f = std::fopen(b->tun.wave_trace.c_str(), "wb")) {
+            std::fwrite(head, sizeof head, 1, f);
+            if (used) std::fwrite(rec.data(), sizeof(unsigned long long), rec.size(), f);
+            std::fclose(f);
+        }
+    }
     if (b->insp_ok && b->d_lane_stats && !b->fixed_params) {
         std::vector<unsigned long long> c(2 * (size_t)b->n_slots_cap);
         if (hipMemcpy(c.data(), b->d_lane_stats, c.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return false;

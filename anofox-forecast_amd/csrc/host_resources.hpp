@@ -57,6 +57,8 @@ struct Tunables {
                                 //   Measured: intermittent M5 batch 86.3 -> 70.4 ms, 125k x 1,024 batch 181 -> 136-140 ms, 1M x 1,024 1,200 -> 853 ms;
                                 //   beside the 19 general-class specs of the strictly positive batch it is time-neutral (fewer passes, the step is
                                 //   bound by fp64 issue), and ONE additive spec on 30,490 series is slower with it (20.5 against 17.9 ms: 477 waves)
+    std::string wave_trace;     // tune wave_trace=<file>: developer instrument -- one record per wave of the ETS round kernels (FitArgs::wave_trace), written by anofox_hip_batch_lane_stats
+    int compact = -1;           // tune compact: compact storage of the streamed block (host_api.hip compact_storage_begin): -1 auto, 0 never, 1 float at most, 2 narrowest exact type whatever the batch size
     int dm_head_rounds = 0;     // tune dm_head_rounds: rounds the damped multiplicative-trend chains run before the other specs' streams start (launch_fit_slots)
     bool merge_periods = true;  // tune merge_periods: auto-detected periods run as merged batches (0: one batch per period)
     int part_threads = 16;      // tune part_threads: host threads that run the small per-period parts of an auto-detected batch side by side
@@ -111,6 +113,8 @@ struct Tunables {
             }
             if (!v.empty()) t.budgets = v;
         }
+        if (kv.count("wave_trace")) t.wave_trace = kv.at("wave_trace");
+        geti("compact", t.compact);
         geti("seq_rounds", t.seq_rounds);
         geti("gather", t.gather);
         if (kv.count("spec_below")) t.spec_below = t.spec_below_md = std::atoi(kv.at("spec_below").c_str());

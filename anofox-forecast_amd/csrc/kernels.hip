@@ -232,12 +232,12 @@ void launch_intervals(const IntervalArgs &a, hipStream_t stream)
 }
 
 // ------------------------------------------------------------------------------------------
-FitLaunchers ets_fit_launcher(int spec_id, int m)
+FitLaunchers ets_fit_launcher(int spec_id, int m, int yt)
 {
-    FitLaunchers f = fit_unit_nonseasonal(spec_id, m);
-    if (!f.final) f = fit_unit_seasonal_add(spec_id, m);
-    if (!f.final) f = fit_unit_seasonal_gen_a(spec_id, m);
-    if (!f.final) f = fit_unit_seasonal_gen_m(spec_id, m);
+    FitLaunchers f = fit_unit_nonseasonal(spec_id, m, yt);
+    if (!f.final) f = fit_unit_seasonal_add(spec_id, m, yt);
+    if (!f.final) f = fit_unit_seasonal_gen_a(spec_id, m, yt);
+    if (!f.final) f = fit_unit_seasonal_gen_m(spec_id, m, yt);
     return f;
 }
 
@@ -285,8 +285,9 @@ void launch_compact(const int32_t *series_prev, const int32_t *n_prev, int n_ser
 // still reads 512 contiguous bytes per wave and time step (reads here are the only uncoalesced ones)
 // ------------------------------------------------------------------------------------------
 constexpr int GATHER_TB = 32;
-__global__ __launch_bounds__(NM_BLOCK) void gather_columns_kernel(const double *y, size_t ld, const int32_t *series_of,
-                                                                  const int32_t *n_active, int t_max, double *out, size_t ld_out, int cap)
+template <class E>
+__global__ __launch_bounds__(NM_BLOCK) void gather_columns_kernel(const E *y, size_t ld, const int32_t *series_of,
+                                                                  const int32_t *n_active, int t_max, E *out, size_t ld_out, int cap)
 {
     const int n_act = *n_active;
     if ((int)blockIdx.x * NM_BLOCK >= n_act || n_act > cap) return;       // (more running problems than `out` holds: the round kernel indexes y by series)
@@ -297,14 +298,62 @@ __global__ __launch_bounds__(NM_BLOCK) void gather_columns_kernel(const double *
     for (int t = t0; t < t1; t++) out[(size_t)t * ld_out + p] = y[(size_t)t * ld + s];
 }
 
-void launch_gather_columns(const double *y, size_t ld, const int32_t *series_of, const int32_t *n_active, int n_series,
-                           int t_max, double *out, size_t ld_out, hipStream_t stream, int cap)
+void launch_gather_columns(const void *y, size_t ld, const int32_t *series_of, const int32_t *n_active, int n_series,
+                           int t_max, void *out, size_t ld_out, hipStream_t stream, int cap, int elem_bytes)
 {
     if (n_series <= 0 || t_max <= 0) return;          // a batch of empty series: nothing to copy (and no zero-sized grid)
     const int n_cols = std::min(n_series, cap);
     if (n_cols <= 0) return;
     dim3 grid((n_cols + NM_BLOCK - 1) / NM_BLOCK, (t_max + GATHER_TB - 1) / GATHER_TB);
-    hipLaunchKernelGGL(gather_columns_kernel, grid, dim3(NM_BLOCK), 0, stream, y, ld, series_of, n_active, t_max, out, ld_out, cap);
+    if (elem_bytes == 8)
+        hipLaunchKernelGGL(gather_columns_kernel<double>, grid, dim3(NM_BLOCK), 0, stream, (const double *)y, ld, series_of, n_active, t_max, (double *)out, ld_out, cap);
+    else if (elem_bytes == 4)
+        hipLaunchKernelGGL(gather_columns_kernel<float>, grid, dim3(NM_BLOCK), 0, stream, (const float *)y, ld, series_of, n_active, t_max, (float *)out, ld_out, cap);
+    else
+        hipLaunchKernelGGL(gather_columns_kernel<unsigned short>, grid, dim3(NM_BLOCK), 0, stream, (const unsigned short *)y, ld, series_of, n_active, t_max, (unsigned short *)out, ld_out, cap);
+}
+
+// ------------------------------------------------------------------------------------------
+// compact copies of the block (kernels.hpp launch_compact_block): one streamed sweep, a thread per column and 32 rows; the cells
+// beyond a series' length are copied too (never read as observations) but do not count as misfits
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NM_BLOCK) void compact_block_kernel(const double *y, size_t ld, const int32_t *len, int n_series, int t_rows, float *out32,
+                                                                 unsigned short *out16, unsigned int *misfit)
+{
+    const int s = blockIdx.x * NM_BLOCK + threadIdx.x;
+    const int t0 = blockIdx.y * GATHER_TB;
+    const int t1 = t0 + GATHER_TB < t_rows ? t0 + GATHER_TB : t_rows;
+    const int L = s < n_series ? len[s] : 0;
+    unsigned bad32 = 0, bad16 = 0;
+    if ((size_t)s < ld) {
+        for (int t = t0; t < t1; t++) {
+            const double v = y[(size_t)t * ld + s];
+            const float f = (float)v;
+            // (a value outside 0 .. 65,535, or not a number, converts to something that does not compare equal: counted below)
+            const unsigned short u = (v >= 0.0 && v <= 65535.0) ? (unsigned short)v : (unsigned short)0;
+            out32[(size_t)t * ld + s] = f;
+            if (out16) out16[(size_t)t * ld + s] = u;
+            if (t < L) {
+                // bit patterns, not values: -0.0 widens back from float as -0.0 but from an integer as +0.0
+                bad32 += (__double_as_longlong((double)f) == __double_as_longlong(v)) ? 0u : 1u;
+                bad16 += (__double_as_longlong((double)u) == __double_as_longlong(v)) ? 0u : 1u;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { bad32 += __shfl_xor(bad32, o); bad16 += __shfl_xor(bad16, o); }
+    if (threadIdx.x == 0) {
+        if (bad32) atomicAdd(misfit, bad32);
+        if (bad16) atomicAdd(misfit + 1, bad16);
+    }
+}
+
+void launch_compact_block(const double *y, size_t ld, const int32_t *len, int n_series, int t_rows, float *out32, unsigned short *out16,
+                          unsigned int *misfit, hipStream_t stream)
+{
+    if (ld == 0 || t_rows <= 0) return;
+    dim3 grid((unsigned)((ld + NM_BLOCK - 1) / NM_BLOCK), (unsigned)((t_rows + GATHER_TB - 1) / GATHER_TB));
+    hipLaunchKernelGGL(compact_block_kernel, grid, dim3(NM_BLOCK), 0, stream, y, ld, len, n_series, t_rows, out32, out16, misfit);
 }
 
 // ------------------------------------------------------------------------------------------

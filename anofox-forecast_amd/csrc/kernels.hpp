@@ -101,6 +101,11 @@ struct FitArgs {
     // population sd (forecast.rs:2558-2591: sum of (y - mean)^2 in time order), so prep_kernel needs none (PrepArgs::skip_sd).  NULL otherwise.
     const double *mean;          // [ld] series means (prep_kernel)
     double *sd_out;              // [ld]
+    // developer instrument (round 6; NULL = off: ANOFOX_HIP_TUNE wave_trace=<file>): every wave of a round kernel that streams at least one
+    // pass appends one record {tag, start, end (s_memrealtime ticks, 100 MHz), HW_ID | XCC_ID << 32} -- who is resident when, and how long a
+    // launch's waves wait for a SIMD with room.  wave_trace[0] = records used (atomic), [1] = capacity, records from [4] on.
+    unsigned long long *wave_trace;
+    unsigned long long wave_trace_tag;   // spec order index << 32 | round << 16 | workgroups of the launch are not needed: blockIdx goes in
 };
 
 struct SelectArgs {
@@ -160,7 +165,9 @@ struct FitLaunchers { FitLaunchFn round_seq, round_spec, round_spec2, round_auto
 // `m`: the period (7 and 12 have compile-time variants), or ETS_PERLANE_LDS / ETS_PERLANE_HBM for the round kernels of a merged
 // batch of several periods (per-lane period, ring in LDS / in HBM scratch sized by the batch's largest period)
 constexpr int ETS_PERLANE_LDS = -3, ETS_PERLANE_HBM = -4;
-FitLaunchers ets_fit_launcher(int spec_id, int m);
+// `yt`: storage type of the block the kernels stream (ets_device.hpp YT_F64 / YT_F32 / YT_U16); every entry is NULL when the
+// combination is not instantiated (compact types x per-lane period variants)
+FitLaunchers ets_fit_launcher(int spec_id, int m, int yt = 0);
 FitLaunchers classic_fit_launcher(int kind, int m);          // fit_classic.hip: the SES / Holt / Holt-Winters / SeasonalES family on the round kernels (final = NULL)
 struct ClassicArgs;
 void launch_classic_final(int kind, const FitArgs &a, const ClassicArgs &c, hipStream_t stream);
@@ -178,8 +185,14 @@ size_t detect_scratch_doubles(int n_series, int t_rows);
 void launch_detect_periods(const double *y, size_t ld, const int32_t *len, int n_series, int t_rows, double *scratch, int32_t *period,
                            double *best_acf, hipStream_t stream);
 // `cap`: columns `out` has room for -- the copy is skipped (the round kernel then indexes `y` by series) while more problems run
-void launch_gather_columns(const double *y, size_t ld, const int32_t *series_of, const int32_t *n_active, int n_series,
-                           int t_max, double *out, size_t ld_out, hipStream_t stream, int cap);
+// `elem_bytes`: 8 (fp64 block), 4 or 2 (compact copy: ld / ld_out still count columns)
+void launch_gather_columns(const void *y, size_t ld, const int32_t *series_of, const int32_t *n_active, int n_series,
+                           int t_max, void *out, size_t ld_out, hipStream_t stream, int cap, int elem_bytes = 8);
+// Compact copies of the time-major block for the round kernels (round 6): out32[t * ld + s] = (float)y, out16 = (uint16_t)y for every
+// cell of the block, and misfit[0] / misfit[1] += the OBSERVATIONS (t < len[s]) that do not survive the round trip through float /
+// uint16_t exactly.  A batch streams a compact copy only when its counter is zero (host_api.hip): bit-identical by construction.
+void launch_compact_block(const double *y, size_t ld, const int32_t *len, int n_series, int t_rows, float *out32, unsigned short *out16,
+                          unsigned int *misfit, hipStream_t stream);
 
 // AutoARIMA (arima.hip): prep (D, d, differenced block), stepwise CSS search (advance / fit sweeps), forecast + integration
 struct ArimaArgs {

@@ -70,7 +70,7 @@ class AnofoxHipStats(C.Structure):
         ("fit_kernel_ms", C.c_double),
         ("total_device_ms", C.c_double),
         ("fit_kernel_launches", C.c_uint32),
-        ("reserved", C.c_uint32),
+        ("y_storage", C.c_uint32),
         ("total_iters", C.c_uint64),
         ("min_pass_bytes", C.c_uint64),
     ]

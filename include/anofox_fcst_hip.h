@@ -186,7 +186,10 @@ typedef struct AnofoxHipStats {
     double   fit_kernel_ms;     /* HIP-event time of the dominant (fit) kernel(s) */
     double   total_device_ms;   /* HIP-event time of the whole run on its stream  */
     uint32_t fit_kernel_launches;
-    uint32_t reserved;
+    uint32_t y_storage;         /* what the ETS fit of the run streamed (round 6; the field was `reserved`, always 0): 0 the fp64 block,
+                                   1 / 2 a float / uint16_t copy of it -- made when EVERY observation of the batch survives that type
+                                   exactly (counts), so the fp64 arithmetic sees the same numbers; algorithmic_bytes keeps SURVEY.md's
+                                   unit (8 bytes per observation and pass) whatever was streamed */
     uint64_t total_iters;       /* Nelder-Mead iterations summed over the ETS problems (each problem counts from 1: the initial
                                    simplex) -- the passes a one-pass-per-iteration schedule needs; 0 for models without spec slots */
     uint64_t min_pass_bytes;    /* sum over problems of 8*T_s*(iterations + 1 final pass) + 24*h per series: the algorithmic bytes

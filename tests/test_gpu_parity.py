@@ -486,6 +486,100 @@ def test_schedule_variants_are_bit_identical(env, monkeypatch, seq_rounds, gathe
     _compare(api, O, lib, series, "ETS", 12, ets_model="MAdM", seasonal_period=7)
 
 
+def _device_run(lib, Y, lens, model, h, tune, monkeypatch, **kw):
+    """One device-resident run (block 3 of the header) under an ANOFOX_HIP_TUNE setting: forecasts, model codes, status, run statistics."""
+    import torch
+    from anofox_forecast_amd.device import DeviceBatch
+    monkeypatch.setenv("ANOFOX_HIP_TUNE", tune)
+    n, T = Y.shape
+    batch = DeviceBatch(n, T, lib.make_options(model, h, **kw), "cuda:0")
+    ld = batch.ld
+    block = torch.zeros((T, ld), dtype=torch.float64, device="cuda:0")
+    block[:, :n] = torch.from_numpy(np.ascontiguousarray(Y.T)).to("cuda:0")
+    batch.set_block(block, torch.from_numpy(np.asarray(lens, dtype=np.int32)).to("cuda:0"))
+    batch.run()
+    torch.cuda.synchronize()
+    r = batch.results()
+    out = {k: r[k].cpu().numpy().copy() for k in ("yhat", "lower", "upper", "model_code", "status")}
+    out["stats"] = batch.stats()
+    return out
+
+
+def test_compact_storage_is_bit_identical(env, monkeypatch):
+    """Round 6: a batch whose every observation survives the round trip through float / uint16_t exactly (counts: the M5 shape) is
+    streamed from a 4- / 2-byte copy of its block (ets_device.hpp YT_*, kernels.hip compact_block_kernel); the arithmetic stays
+    fp64 on the same numbers.  Whatever the storage -- forced off, float at most, narrowest -- forecasts, intervals, selected models
+    and pass counts are the same bits, for every period variant the compact kernels exist for (none, 7, 12, LDS ring, HBM ring), for a
+    mixed batch (the strictly positive columns are gathered in the storage type), ragged lengths, and a one-spec fit whose final
+    pass carries the intervals' sd.  ONE observation that does not survive (0.1; 70,000; -0.0 for the integer type) moves the whole
+    batch to the next wider type, and the results do not move."""
+    api, O, lib, synth = env
+    rng = np.random.default_rng(66)
+
+    def same(a, b, what):
+        for k in ("yhat", "lower", "upper"):
+            assert np.array_equal(a[k], b[k], equal_nan=True), (what, k)
+        assert np.array_equal(a["model_code"], b["model_code"]) and np.array_equal(a["status"], b["status"]), what
+        for k in ("total_passes", "total_evals", "total_iters"):
+            assert a["stats"][k] == b["stats"][k], (what, k)
+
+    cases = []
+    Yp = synth.gen_series(synth.SEED_M5, 6600, 150, 210, 7, positive=True)
+    Yi = synth.gen_series(synth.SEED_M5, 6800, 150, 210, 7)
+    ragged = [210 - (s % 7) * 11 for s in range(150)]
+    cases.append(("AutoETS m7 positive ragged", Yp, ragged, "AutoETS", dict(seasonal_period=7)))
+    cases.append(("AutoETS m7 mixed", np.concatenate([Yp[:60], Yi[:90]]), ragged, "AutoETS", dict(seasonal_period=7)))
+    cases.append(("AutoETS none", Yp, ragged, "AutoETS", dict(seasonal_period=1)))
+    cases.append(("AutoETS m12", synth.gen_series(synth.SEED_M5, 6900, 80, 200, 12, positive=True), [200] * 80, "AutoETS", dict(seasonal_period=12)))
+    cases.append(("AutoETS m24 (LDS ring)", synth.gen_series(synth.SEED_M5, 7000, 70, 260, 24, positive=True), [260] * 70, "AutoETS", dict(seasonal_period=24)))
+    cases.append(("ETS AAA m70 (HBM ring)", synth.gen_series(synth.SEED_STRESS, 7100, 40, 300, 70, positive=True), [300] * 40, "ETS", dict(ets_model="AAA", seasonal_period=70)))
+    cases.append(("ETS MAdM one spec", Yp, ragged, "ETS", dict(ets_model="MAdM", seasonal_period=7)))
+    for what, Y, lens, model, kw in cases:
+        base = _device_run(lib, Y, lens, model, 9, "compact=0", monkeypatch, **kw)
+        f32 = _device_run(lib, Y, lens, model, 9, "compact=1", monkeypatch, **kw)
+        u16 = _device_run(lib, Y, lens, model, 9, "compact=2", monkeypatch, **kw)
+        assert (base["stats"]["y_storage"], f32["stats"]["y_storage"], u16["stats"]["y_storage"]) == (0, 1, 2), what
+        same(f32, base, what + " float")
+        same(u16, base, what + " uint16")
+        # and the fp64 run is the oracle's (so all three are)
+        oo = O.make_options(model, 9, **kw)
+        for s in (0, len(Y) // 2, len(Y) - 1):
+            ref = O.forecast(Y[s, :lens[s]], oo)
+            assert ref["ok"] and _rel(base["yhat"][s], ref["point"]) <= REL_TOL, (what, s)
+    # observations that do not survive a type: the next wider one is used, the results stay
+    Y = Yp.copy()
+    lens = [210] * 150
+    want = _device_run(lib, Y, lens, "AutoETS", 9, "compact=0", monkeypatch, seasonal_period=7)
+    for value, storage in ((70000.0, 1), (2.5, 1), (16777217.0, 0), (0.1, 0)):
+        Z = Y.copy()
+        Z[77, 100] = value
+        got = _device_run(lib, Z, lens, "AutoETS", 9, "compact=2", monkeypatch, seasonal_period=7)
+        ref = _device_run(lib, Z, lens, "AutoETS", 9, "compact=0", monkeypatch, seasonal_period=7)
+        assert got["stats"]["y_storage"] == storage, (value, got["stats"]["y_storage"])
+        same(got, ref, f"misfit {value}")
+        assert np.array_equal(np.delete(got["yhat"], 77, 0), np.delete(want["yhat"], 77, 0))      # the other series never notice
+    Z = Yi.copy()
+    Z[5, 50] = -0.0                                  # equal to 0 as a number, a different bit pattern: not an integer cell
+    got = _device_run(lib, Z, lens, "AutoETS", 9, "compact=2", monkeypatch, seasonal_period=7)
+    assert got["stats"]["y_storage"] == 1
+    same(got, _device_run(lib, Z, lens, "AutoETS", 9, "compact=0", monkeypatch, seasonal_period=7), "negative zero")
+    # a misfit beyond a series' length is not an observation
+    Z = Yp.copy()
+    Z[3, 205] = 0.3
+    lens2 = list(ragged)
+    assert lens2[3] <= 205
+    got = _device_run(lib, Z, lens2, "AutoETS", 9, "compact=2", monkeypatch, seasonal_period=7)
+    assert got["stats"]["y_storage"] == 2
+    # automatic: a handful of short series stays on the fp64 block, the M5-size block does not (test_full_size_m5_properties)
+    assert _device_run(lib, Yp[:20], [210] * 20, "AutoETS", 9, "", monkeypatch, seasonal_period=7)["stats"]["y_storage"] == 0
+    assert _device_run(lib, np.tile(Yp, (3, 1)), [210] * 450, "AutoETS", 9, "", monkeypatch, seasonal_period=7)["stats"]["y_storage"] == 2
+    # given smoothing parameters: one pass, no copy; the host-buffer entry takes the same route as the resident block
+    monkeypatch.setenv("ANOFOX_HIP_TUNE", "compact=2")
+    _compare(api, O, lib, [Yp[s, :ragged[s]] for s in range(150)], "AutoETS", 9, seasonal_period=7)
+    _compare(api, O, lib, [Yi[s, :ragged[s]] for s in range(150)], "AutoETS", 9, seasonal_period=7,
+             valids=None)
+
+
 @pytest.mark.parametrize("k4", ["-1", "0", "1"])
 def test_four_candidates_per_lane_is_bit_identical(env, monkeypatch, k4):
     """ANOFOX_HIP_TUNE k4: the additive-class specs run one lane per problem with all four trial points of an iteration evaluated by
