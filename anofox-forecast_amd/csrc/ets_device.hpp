@@ -69,6 +69,16 @@ template <class YT> struct YtCode;
 template <> struct YtCode<double> { static constexpr int value = YT_F64; };
 template <> struct YtCode<float> { static constexpr int value = YT_F32; };
 template <> struct YtCode<unsigned short> { static constexpr int value = YT_U16; };
+// ANOFOX_DM_RETRY (round 6): the damped multiplicative-trend step WITHOUT its per-step branch.  A block of S steps first runs with
+// the near-one binomial b^phi for every lane (no branch: the steps of the unrolled block schedule across each other) while every
+// lane tracks the largest |b - 1| it met; one wave-uniform test after the block -- did ANY lane leave |b - 1| <= 1/16, or end with
+// a growth rate that is not a number -- and only then the block is run AGAIN from the state it started with, by the step with the
+// branch (the table-driven power and its domain checks for the far lanes): 3-5 % of the blocks of the M5-shape fits
+// (tools/far_blocks.py).  Same operations on the same numbers for every lane either way: the first run's results are used only
+// when no lane needed the other formula.  0: the per-step branch (rounds 4-5).
+#ifndef ANOFOX_DM_RETRY
+#define ANOFOX_DM_RETRY 1
+#endif
 #ifndef ANOFOX_TWO_BLOCK
 #define ANOFOX_TWO_BLOCK 1
 #endif
@@ -95,7 +105,7 @@ struct EtsPar { double alpha, bstar, phi, beta, gamma; DmPowLane pl; DmPowNear1 
 // smallest undamped multiplicative growth rate seen -- the pass checks them ONCE at its end (ets_objective_value) instead of comparing in
 // every step: a comparison feeds a scalar mask that feeds a select, and with one or two waves per SIMD that round trip between the vector
 // and the scalar unit stalls the recursion (~30 cycles a step, profiles/r05_step_anatomy.txt); min / max stay on the vector unit, off the chain
-struct EtsState { double l, b, sse, mant; int eacc; int bad; double f; double dlo, dhi, bmin; };
+struct EtsState { double l, b, sse, mant; int eacc; int bad; double f; double dlo, dhi, bmin; double rfar; };      // rfar: largest |b - 1| of the running block (ANOFOX_DM_RETRY)
 
 template <class Cfg>
 __device__ __forceinline__ void ets_unpack(const double (&x)[Cfg::DIM], EtsPar &p)
@@ -113,7 +123,9 @@ __device__ __forceinline__ void ets_unpack(const double (&x)[Cfg::DIM], EtsPar &
 }
 
 // One time step for one candidate.  `s` is the seasonal state of this phase (updated in place).
-template <class Cfg>
+// NEAR: the damped multiplicative-trend step with the near-one power for every lane and no branch (the caller checks st.rfar after
+// the block and re-runs it with NEAR = false when a lane was far: ANOFOX_DM_RETRY)
+template <class Cfg, bool NEAR = false>
 __device__ __forceinline__ void ets_step(const EtsPar &p, EtsState &st, double y, double &s)
 {
     if constexpr (Cfg::ADDITIVE) {
@@ -146,7 +158,8 @@ __device__ __forceinline__ void ets_step(const EtsPar &p, EtsState &st, double y
                 //  the cold block out of line is 25-30 % slower over a whole fit -- the far case then pays two far jumps)
                 const double r = st.b - 1.0;
                 phib = dm_pow_near1(r, p.pc);
-                if (!(fabs(r) <= DM_POW_NEAR1_R)) {
+                if constexpr (NEAR) st.rfar = __builtin_fmax(st.rfar, fabs(r));
+                else if (!(fabs(r) <= DM_POW_NEAR1_R)) {
                     if (!(st.b >= 0x1p-1000 && st.b <= 0x1p+1000)) st.bad = 1;
                     phib = dm_pow_step(st.b, p.phi, p.pl);
                 }
@@ -278,7 +291,7 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
         ets_unpack<Cfg>(cand[k], par[k]);
         if constexpr (Cfg::T == C_MUL && Cfg::D) { par[k].pl = dm_pow_lane(); dm_pow_near1_coef(par[k].phi, par[k].pc); }
         st[k].l = in.l0; st[k].b = in.b0; st[k].sse = 0.0; st[k].mant = 1.0; st[k].eacc = 0; st[k].bad = 0;
-        st[k].f = 0.0; st[k].dlo = __builtin_huge_val(); st[k].dhi = 0.0; st[k].bmin = __builtin_huge_val();
+        st[k].f = 0.0; st[k].dlo = __builtin_huge_val(); st[k].dhi = 0.0; st[k].bmin = __builtin_huge_val(); st[k].rfar = 0.0;
 
     }
     const double *yp = v.yb;            // wave-uniform base; the lane's column is added as a 32-bit offset
@@ -380,6 +393,26 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
         // the buffers -- one of a step's instructions -- disappears.  The main loop runs the blocks that every active lane of the wave covers without a predicate; the tail runs them predicated.
         auto run_block = [&](const ybuf_t (&buf)[S], const int base, auto pred_tag) __attribute__((always_inline)) {
             constexpr bool PRED = decltype(pred_tag)::value;
+            if constexpr (ANOFOX_DM_RETRY && Cfg::T == C_MUL && Cfg::D && K == 1 && !PRED && !FINAL) {
+                // (unpredicated blocks of the round kernels: the optimiser's passes; tail blocks and the final pass keep the per-step branch)
+                const EtsState st0 = st[0];
+                double s0[MR];
+#pragma unroll
+                for (int jj = 0; jj < MR; jj++) s0[jj] = s[0][jj];
+                st[0].rfar = 0.0;
+#pragma unroll
+                for (int j = 0; j < S; j++) {
+                    ets_step<Cfg, true>(par[0], st[0], widen(buf[j]), s[0][MS > 0 ? j % MR : 0]);
+                    if ((j & 3) == 3 || j == S - 1) ets_renorm<Cfg>(st[0]);
+                }
+                // any lane far (or with a growth rate that is not a number: the comparison in the other step sends it to the far side)?
+                // (a lane without a series -- the last wave of a launch -- runs on zeros: it has no say)
+                const bool again = v.len > 0 && (!(st[0].rfar <= DM_POW_NEAR1_R) || st[0].b != st[0].b);
+                if (__builtin_amdgcn_ballot_w64(again) == 0ull) return;
+                st[0] = st0;
+#pragma unroll
+                for (int jj = 0; jj < MR; jj++) s[0][jj] = s0[jj];
+            }
 #pragma unroll
             for (int j = 0; j < S; j++) {
                 if (!PRED || base + j < v.len) {

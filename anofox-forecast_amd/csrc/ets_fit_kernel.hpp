@@ -45,10 +45,14 @@ namespace anofox {
 #ifndef ANOFOX_SETPRIO
 #define ANOFOX_SETPRIO 0
 #endif
-template <class Cfg> struct RoundTraits {
+// ANOFOX_ROUND_WAVES_COMPACT: the same for the kernels that stream a compact copy of the block (a staged row takes one register instead of two)
+#ifndef ANOFOX_ROUND_WAVES_COMPACT
+#define ANOFOX_ROUND_WAVES_COMPACT ANOFOX_ROUND_WAVES
+#endif
+template <class Cfg, class YT = double> struct RoundTraits {
     static constexpr bool DAMPED_MUL = !Cfg::CLASSIC && Cfg::T == C_MUL && Cfg::D;
     static constexpr bool PARK = !Cfg::CLASSIC && (ANOFOX_PARK_CLASS >= 3 || (ANOFOX_PARK_CLASS == 2 && !Cfg::ADDITIVE) || (ANOFOX_PARK_CLASS == 1 && DAMPED_MUL));
-    static constexpr int WAVES = PARK ? ANOFOX_PARK_WAVES : ANOFOX_ROUND_WAVES;
+    static constexpr int WAVES = PARK ? ANOFOX_PARK_WAVES : (std::is_same_v<YT, double> ? ANOFOX_ROUND_WAVES : ANOFOX_ROUND_WAVES_COMPACT);
     static constexpr int WPB = DAMPED_MUL ? ANOFOX_DM_WPB : 1;
 };
 
@@ -70,7 +74,7 @@ template <class Cfg, int MS, class YT> struct RoundModelOf<Cfg, MS, YT, true> { 
 //           and the sequential driver stays.  Same iterates, same evaluation counts (the speculative driver's bookkeeping).
 // YT: storage type of the block the round streams (ets_device.hpp: double, or float / uint16_t for a compact copy of a batch of counts)
 template <class Cfg, int MS, int SPEC, bool K4 = false, class YT = double>
-__global__ __launch_bounds__(NM_BLOCK * RoundTraits<Cfg>::WPB, (RoundTraits<Cfg>::WAVES + RoundTraits<Cfg>::WPB - 1) / RoundTraits<Cfg>::WPB) void ets_round_kernel(const FitArgs a)
+__global__ __launch_bounds__(NM_BLOCK * RoundTraits<Cfg>::WPB, (RoundTraits<Cfg, YT>::WAVES + RoundTraits<Cfg>::WPB - 1) / RoundTraits<Cfg>::WPB) void ets_round_kernel(const FitArgs a)
 {
     extern __shared__ double lds_all[];
     constexpr int D = Cfg::DIM;
@@ -78,6 +82,10 @@ __global__ __launch_bounds__(NM_BLOCK * RoundTraits<Cfg>::WPB, (RoundTraits<Cfg>
     constexpr int WPB = RoundTraits<Cfg>::WPB;
     if constexpr (ANOFOX_SETPRIO >= 1 && RoundTraits<Cfg>::DAMPED_MUL) __builtin_amdgcn_s_setprio(3);
     else if constexpr (ANOFOX_SETPRIO >= 2 && !Cfg::CLASSIC && !Cfg::ADDITIVE) __builtin_amdgcn_s_setprio(ANOFOX_SETPRIO == 2 ? 1 : 2);
+    // per chain (host_api.hip launch_fit_slots, tune prio_top): the instruction takes an immediate
+    if (a.wave_prio == 3) __builtin_amdgcn_s_setprio(3);
+    else if (a.wave_prio == 2) __builtin_amdgcn_s_setprio(2);
+    else if (a.wave_prio == 1) __builtin_amdgcn_s_setprio(1);
     if constexpr (Cfg::T == C_MUL && Cfg::D) dm_pow_tab_init();     // b^phi tables -> LDS, by every thread of the workgroup, before any wave leaves
     const int lane = threadIdx.x & (NM_BLOCK - 1);
     const int wave = WPB > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;

@@ -871,14 +871,13 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
     // multiplicative / damped / seasonal fits start together instead of queueing behind each other
     std::vector<size_t> order(specs.size());
     for (size_t i = 0; i < order.size(); i++) order[i] = i;
+    // (relative wave-time of one fitted problem of each spec, measured on the M5 shape with the wave trace -- profiles/r06_wave_residency_base.txt:
+    //  resident wave-milliseconds per spec over a 30,490-series step, in thousands; the damped multiplicative-trend specs lead, and
+    //  among them the additive-season one needs the most iterations, not the one with the longest step)
     auto cost = [&](int id) {
-        int c = spec_dim(id) * 2 + (spec_season(id) ? 2 : 0);
-        const int ti = spec_trend_idx(id);
-        if (spec_error(id) == 1) c += 4;
-        if (spec_season(id) == 2) c += 6;
-        if (ti >= 3) c += 6;
-        if (ti == 4) c += 12;       // b^phi every step
-        return c;
+        static const int measured[30] = {/* A,N,* */ 3, 8, 14, /* A,A,* */ 7, 13, 27, /* A,Ad,* */ 17, 29, 41, /* A,M,* */ 14, 26, 22, /* A,Md,* */ 63, 92, 84,
+                                         /* M,N,* */ 7, 0, 15, /* M,A,* */ 18, 0, 29, /* M,Ad,* */ 33, 0, 48, /* M,M,* */ 16, 0, 28, /* M,Md,* */ 65, 0, 95};
+        return (id >= 0 && id < 30 && measured[id] > 0) ? measured[id] : 1;
     };
     // expected work of a spec on THIS batch: a spec with a multiplicative component only runs on the strictly positive series
     auto work = [&](int id) {
@@ -1064,6 +1063,7 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
             const bool spec_mode = r >= b->seq_rounds;
             a.first_round = (r == 0);
             a.wave_trace_tag = ((unsigned long long)specs[order[oi]] << 32) | ((unsigned long long)r << 16);
+            a.wave_prio = (int)oi < b->tun.prio_top ? std::max(1, 3 - (int)oi) : 0;
             a.spec_below = -1; a.spec2_below = -1;
             a.gathered = 0;
             if (tiny) {

@@ -59,6 +59,7 @@ struct Tunables {
                                 //   bound by fp64 issue), and ONE additive spec on 30,490 series is slower with it (20.5 against 17.9 ms: 477 waves)
     std::string wave_trace;     // tune wave_trace=<file>: developer instrument -- one record per wave of the ETS round kernels (FitArgs::wave_trace), written by anofox_hip_batch_lane_stats
     int compact = -1;           // tune compact: compact storage of the streamed block (host_api.hip compact_storage_begin): -1 auto, 0 never, 1 float at most, 2 narrowest exact type whatever the batch size
+    int prio_top = 0;           // tune prio_top: the N chains with the most expected work run their waves at raised issue priority (3, 2, 1, 1, ...: launch_fit_slots)
     int dm_head_rounds = 0;     // tune dm_head_rounds: rounds the damped multiplicative-trend chains run before the other specs' streams start (launch_fit_slots)
     bool merge_periods = true;  // tune merge_periods: auto-detected periods run as merged batches (0: one batch per period)
     int part_threads = 16;      // tune part_threads: host threads that run the small per-period parts of an auto-detected batch side by side
@@ -114,7 +115,7 @@ struct Tunables {
             if (!v.empty()) t.budgets = v;
         }
         if (kv.count("wave_trace")) t.wave_trace = kv.at("wave_trace");
-        geti("compact", t.compact);
+        geti("compact", t.compact); geti("prio_top", t.prio_top);
         geti("seq_rounds", t.seq_rounds);
         geti("gather", t.gather);
         if (kv.count("spec_below")) t.spec_below = t.spec_below_md = std::atoi(kv.at("spec_below").c_str());

@@ -104,6 +104,7 @@ struct FitArgs {
     // developer instrument (round 6; NULL = off: ANOFOX_HIP_TUNE wave_trace=<file>): every wave of a round kernel that streams at least one
     // pass appends one record {tag, start, end (s_memrealtime ticks, 100 MHz), HW_ID | XCC_ID << 32} -- who is resident when, and how long a
     // launch's waves wait for a SIMD with room.  wave_trace[0] = records used (atomic), [1] = capacity, records from [4] on.
+    int wave_prio;               // issue priority of the round kernel's waves (s_setprio 0..3): the chains that end the step run ahead of their SIMD's other wave
     unsigned long long *wave_trace;
     unsigned long long wave_trace_tag;   // spec order index << 32 | round << 16 | workgroups of the launch are not needed: blockIdx goes in
 };

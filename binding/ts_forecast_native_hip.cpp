@@ -1,9 +1,12 @@
 // ts_forecast_native_hip.cpp -- DuckDB table-in-out binding of the MI355X backend.
 //
 // Drop-in for src/table_functions/ts_forecast_native.cpp of DataZooDE/anofox-forecast: it registers the same internal function
-// `_ts_forecast_native(TABLE, horizon, frequency, method, params)` that the ts_forecast_by macro expands to
-// (src/macros/ts_macros.cpp:575-594), with the same output schema (ts_forecast_native.cpp:426-450) and the same bind-time
-// validations (:357-399), but
+// `_ts_forecast_native(TABLE, horizon, frequency, method, params)` (route B), with the same output schema
+// (ts_forecast_native.cpp:426-450) and the same bind-time validations (:357-399).  NOTE: the reference's SHIPPED ts_forecast_by
+// macro does not reach this function -- its text expands to GROUP BY + `_ts_forecast_scalar` (src/macros/ts_macros.cpp:576-591,
+// route A); binding/ts_macros_hip.cpp is the macro definition that sends ts_forecast_by (and its alias) here, and
+// binding/ts_forecast_scalar_hip.cpp batches route A per DataChunk for the unchanged macro text.  Against the reference's
+// `_ts_forecast_native`:
 //   * collection (:476-553) appends every DataChunk as plain columns to the library's columnar ingest
 //     (include/anofox_fcst_hip.h block 4) instead of boxing every row into a std::map<string, GroupData>;
 //   * finalize (:559-740) makes ONE call, anofox_ts_forecast_batch (block 2), for all groups -- the library shards the

@@ -328,6 +328,11 @@ static void ets_unpack(const EtsSpec *spec, const double *par,
  */
 /* test hook (oracle_ets_inspect): when set, every pass also stores its one-step forecasts here */
 double *ets_fitted_sink = NULL;
+/* test hook (tools/far_blocks.py): when set, every likelihood pass of a damped multiplicative-trend spec appends ets_far_blocks bytes
+ * to the sink -- byte k = 1 when a step of time block [8 k, 8 k + 8) took the table-driven power (|b - 1| > 1/16) -- as long as room is left */
+unsigned char *ets_far_sink = NULL;
+long ets_far_pos = 0, ets_far_cap = 0;
+int ets_far_blocks = 0;
 
 double ets_lik(const EtsSpec *spec, const double *y, int n, const double *par,
                double l0, double b0, const double *s0,
@@ -345,6 +350,12 @@ double ets_lik(const EtsSpec *spec, const double *y, int n, const double *par,
     int bad = 0;
     double powc[DET_POW_NEAR1_DEG + 1];
     if (spec->trend == ETS_MUL && spec->damped) det_pow_near1_coef(phi, powc);
+    unsigned char *far_row = NULL;
+    if (ets_far_sink && spec->trend == ETS_MUL && spec->damped && ets_far_pos + ets_far_blocks <= ets_far_cap) {
+        far_row = ets_far_sink + ets_far_pos;
+        ets_far_pos += ets_far_blocks;
+        for (int k = 0; k < ets_far_blocks; k++) far_row[k] = 0;
+    }
 
     if (ets_is_additive_class(spec)) {
         for (int t = 0; t < n; t++) {
@@ -395,6 +406,7 @@ double ets_lik(const EtsSpec *spec, const double *y, int n, const double *par,
                         /* a damped growth rate outside [2^-1000, 2^1000] (or not positive) is inadmissible: keeps phi * log(b)
                          * inside the range where exp needs no special cases, on the CPU and in the kernels alike */
                         if (!(b >= 0x1p-1000 && b <= 0x1p+1000)) { bad = 1; break; }
+                        if (far_row && t / 8 < ets_far_blocks) far_row[t / 8] = 1;
                         phib = det_pow_step(b, phi);
                     }
                 } else {
