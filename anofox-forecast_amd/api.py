@@ -23,6 +23,11 @@ relative; the reference's own check would print 18.014513 and fail).  The coeffi
 search budget (30 + 15 dim) of the AutoARIMA restatement were SELECTED ON THAT ONE 24-point series -- the only AutoARIMA number the
 reference tree holds -- and how wide the plateau around them is, is tabulated in tools/arima_kat_search/results/robustness.txt
 (DESIGN.md section 3).  Nothing with a seasonal period is pinned in the reference tree.
+
+Numerical domain (differs from the reference on extreme data only; DESIGN.md section 3, deviation table): a trial point whose recursion
+meets a denominator outside [2^-1000, 2^1000] is inadmissible, and for multiplicative-error specs so is a one-step forecast outside
+[2^-120, 2^120] -- on data scaled beyond ~1e36 or below ~1e-36 an explicit ETS(M,*,*) fails with "likelihood is not finite" (NULL row)
+and AutoETS selects among the additive-error specs.  Seasonal periods above 2,048 fail loudly.  Rescale such data before the call.
 """
 from __future__ import annotations
 

@@ -75,9 +75,13 @@ template <> struct YtCode<unsigned short> { static constexpr int value = YT_U16;
 // a growth rate that is not a number -- and only then the block is run AGAIN from the state it started with, by the step with the
 // branch (the table-driven power and its domain checks for the far lanes): 3-5 % of the blocks of the M5-shape fits
 // (tools/far_blocks.py).  Same operations on the same numbers for every lane either way: the first run's results are used only
-// when no lane needed the other formula.  0: the per-step branch (rounds 4-5).
+// when no lane needed the other formula.  0 (SHIPPED): the per-step branch (rounds 4-5).
+// MEASURED, round 6 (profiles/r06_ab_retry_prio.txt, same box, alternating): bit-identical (84 parity tests) and 17 % SLOWER on the
+// 25-spec batch (448-459 against 382-389 ms per step); no spills (183-248 registers), so it is not register pressure -- the block
+// is simply issued twice as code (two unrolled copies per loop body) and the first copy's results stay live across the test.
+// Together with round 5's wave-uniform ballot branch this closes the "step without its branch" line of attack on exact arithmetic.
 #ifndef ANOFOX_DM_RETRY
-#define ANOFOX_DM_RETRY 1
+#define ANOFOX_DM_RETRY 0
 #endif
 #ifndef ANOFOX_TWO_BLOCK
 #define ANOFOX_TWO_BLOCK 1
@@ -87,6 +91,12 @@ template <> struct YtCode<unsigned short> { static constexpr int value = YT_U16;
 #endif
 #ifndef ANOFOX_S_GEN
 #define ANOFOX_S_GEN 16         // ... of the other general-class passes
+#endif
+#ifndef ANOFOX_S_COMPACT_MUL
+#define ANOFOX_S_COMPACT_MUL 2      // block length factor of the general-class and damped-M passes over a compact (float / uint16) block
+#endif
+#ifndef ANOFOX_S_COMPACT_MUL_ADD
+#define ANOFOX_S_COMPACT_MUL_ADD 1  // ... of the additive-class passes
 #endif
 #ifndef ANOFOX_K4_S_SEAS
 #define ANOFOX_K4_S_SEAS 8      // block length of the four-candidates-per-lane pass with a seasonal ring in registers (4 x m more doubles of state)
@@ -311,7 +321,11 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
     // cover the latency with fewer rows in flight, and their own register needs leave less room for the buffers
     // (ring in HBM: the ring values stream through two more buffers of S -- half the block length, or the four buffers spill)
     //  (four candidates per lane, K = 4: half the block, the four recursions' states take the registers)
-    constexpr int S_FULL = Cfg::ADDITIVE ? (K == 4 ? (MS > 0 ? ANOFOX_K4_S_SEAS : 16) : 32) : ((Cfg::T == C_MUL && Cfg::D) ? ANOFOX_S_DM : ANOFOX_S_GEN);
+    //  (a compact block: a staged row takes ONE register, so twice the rows are in flight at the register cost of the fp64 block's
+    //   length -- measured, round 6, 25-spec batch on the uint16 copy: damped-M 8 -> 16 rows 388-392 -> 377-382 ms, general class
+    //   16 -> 32 rows 368-374 ms: profiles/r06_ab_block_len.txt)
+    constexpr int S_WIDE = std::is_same_v<YT, double> ? 1 : (Cfg::ADDITIVE ? ANOFOX_S_COMPACT_MUL_ADD : ANOFOX_S_COMPACT_MUL);
+    constexpr int S_FULL = (Cfg::ADDITIVE ? (K == 4 ? (MS > 0 ? ANOFOX_K4_S_SEAS : 16) : 32) : ((Cfg::T == C_MUL && Cfg::D) ? ANOFOX_S_DM : ANOFOX_S_GEN)) * S_WIDE;
     //  and at most 8 -- the ring prefetch needs periods of two blocks, a merged batch keeps periods from 17 up in HBM)
     constexpr int S_TARGET = ((MS == -2 || MS == -4) && K == 1 && S_FULL > 8) ? 8 : S_FULL;
     constexpr int S = (MS > 0) ? ((S_TARGET / MS > 0 ? S_TARGET / MS : 1) * MS) : S_TARGET;

@@ -998,6 +998,38 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
         for (size_t oi = 0; oi < order.size(); oi++)
             k4[oi] = on && !dead[oi] && !b->fixed_params && !spec_has_mult(specs[order[oi]]) && fns[oi].round_k4 && fns[oi].round_auto_k4;
     }
+    // Mid-size batches (round 6): fewer than 524,288 live problems (below that the first rounds run four lanes per problem for EVERY
+    // spec) but so many that four lanes for everybody oversubscribe the resident lanes more than eight times -- the 15,245-series
+    // shard of a 2-GPU M5 job: 381k problems, 1.5 M lanes on 131k.  There the first round's lanes are dealt by expected work: specs
+    // in cost order get four lanes per problem while the total stays under fill_target x the resident lanes, the rest start one
+    // lane per problem (the least arithmetic) and switch to four lanes when 1 / fill_late_div of their problems are left; one wave
+    // per problem at 1 / fill_s2_div.  Measured (profiles/r06_shard_policy.txt, shard of a 2-rank job alone on one GPU): 314 -> 280 ms.
+    // SMALLER batches keep four lanes for everybody: the 7,623- and 3,812-series shards (4 / 8 ranks) are bound by their longest
+    // chain from the first round, and dealing them fewer lanes makes it longer (204 -> 246-320 ms, 173 -> 187-215 ms) -- the chip
+    // absorbs three to six times its resident lanes of speculative work better than a chain absorbs 1.7 passes per iteration.
+    // Same trajectories whatever the driver (test_schedule_variants_are_bit_identical).
+    std::vector<char> fill_spec4(order.size(), 0);
+    bool fill_mode = false;
+    {
+        int64_t lanes = 0;
+        std::vector<int64_t> live_of(order.size(), 0);
+        for (size_t oi = 0; oi < order.size(); oi++) {
+            if (dead[oi]) continue;
+            live_of[oi] = (spec_has_mult(specs[order[oi]]) && b->live_pos >= 0) ? (int64_t)b->live_pos : (b->live_all >= 0 ? (int64_t)b->live_all : (int64_t)n);
+            lanes += live_of[oi];
+        }
+        const int64_t resident = 2 * 1024 * 64;
+        const bool tiny_batch = (uint64_t)n * order.size() <= (uint64_t)TINY_BATCH_PROBLEMS;
+        fill_mode = b->tun.fill_policy > 0 && !tiny_batch && !b->fixed_params && order.size() > 1 && b->seq_rounds_env < 0 && b->seq_rounds == 0 &&
+                    lanes * 4 > 8 * resident;
+        if (fill_mode) {
+            const int64_t target = resident * (int64_t)b->tun.fill_target / 100;
+            for (size_t oi = 0; oi < order.size(); oi++) {                  // `order` is by expected work, most first
+                if (dead[oi] || k4[oi]) continue;
+                if (lanes + 3 * live_of[oi] <= target) { fill_spec4[oi] = 1; lanes += 3 * live_of[oi]; }
+            }
+        }
+    }
     if (b->use_gather && !b->fixed_params) {
         // gather blocks of the specs that have something to fit: as many columns as the spec can ever have running (the strictly
         // positive series for a spec with a multiplicative component), scaled down together if that exceeds the budget
@@ -1098,6 +1130,21 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
                 }
             }
             const int s2 = (spec_trend_idx(specs[order[oi]]) == 4) ? b->spec2_below_md : b->spec2_below;
+            if (fill_mode && !k4[oi]) {
+                const int64_t live_i = (spec_has_mult(specs[order[oi]]) && b->live_pos >= 0) ? (int64_t)b->live_pos : (b->live_all >= 0 ? (int64_t)b->live_all : (int64_t)n);
+                const int s2v = (int)std::max<int64_t>(32, std::min<int64_t>(s2 > 0 ? s2 : 32, live_i / std::max(1, b->tun.fill_s2_div)));
+                a.budget = BUDGET[r]; a.budget_seq = (BUDGET[r] * 7) / 4;
+                if (r == 0) {
+                    if (fill_spec4[oi]) fns[oi].round_spec(a, sq);
+                    else { a.budget = a.budget_seq; fns[oi].round_seq(a, sq); }
+                } else {
+                    a.spec_below = fill_spec4[oi] ? 0x7fffffff : (int)std::max<int64_t>(64, live_i / std::max(1, b->tun.fill_late_div));
+                    a.spec2_below = s2v;
+                    fns[oi].round_auto(a, sq);
+                }
+                b->fit_launches++;
+                return;
+            }
             if (k4[oi]) {
                 // additive spec of a memory-bound run: one lane per problem with four trial points per pass wherever four LANES per
                 // problem would otherwise run -- the same bytes per iteration through a quarter of the load instructions (a wave of

@@ -59,6 +59,11 @@ struct Tunables {
                                 //   bound by fp64 issue), and ONE additive spec on 30,490 series is slower with it (20.5 against 17.9 ms: 477 waves)
     std::string wave_trace;     // tune wave_trace=<file>: developer instrument -- one record per wave of the ETS round kernels (FitArgs::wave_trace), written by anofox_hip_batch_lane_stats
     int compact = -1;           // tune compact: compact storage of the streamed block (host_api.hip compact_storage_begin): -1 auto, 0 never, 1 float at most, 2 narrowest exact type whatever the batch size
+    // batches that do NOT oversubscribe the chip one lane per problem (launch_fit_slots, round 6): speculation is dealt by expected work
+    int fill_policy = 1;        // tune fill_policy: 0 = rounds 1-5 (every spec four lanes per problem from the first round), 1 = by chip fill
+    int fill_target = 150;      // tune fill_target: lanes the first round may occupy, in percent of the resident lanes (2 waves x 1,024 SIMDs x 64)
+    int fill_late_div = 2;      // tune fill_late_div: a spec that started one lane per problem switches to four lanes at 1 / this of its problems
+    int fill_s2_div = 16;       // tune fill_s2_div: ... and any spec to one wave per problem at 1 / this of its problems (at most spec2_below)
     int prio_top = 0;           // tune prio_top: the N chains with the most expected work run their waves at raised issue priority (3, 2, 1, 1, ...: launch_fit_slots)
     int dm_head_rounds = 0;     // tune dm_head_rounds: rounds the damped multiplicative-trend chains run before the other specs' streams start (launch_fit_slots)
     bool merge_periods = true;  // tune merge_periods: auto-detected periods run as merged batches (0: one batch per period)
@@ -116,6 +121,7 @@ struct Tunables {
         }
         if (kv.count("wave_trace")) t.wave_trace = kv.at("wave_trace");
         geti("compact", t.compact); geti("prio_top", t.prio_top);
+        geti("fill_policy", t.fill_policy); geti("fill_target", t.fill_target); geti("fill_late_div", t.fill_late_div); geti("fill_s2_div", t.fill_s2_div);
         geti("seq_rounds", t.seq_rounds);
         geti("gather", t.gather);
         if (kv.count("spec_below")) t.spec_below = t.spec_below_md = std::atoi(kv.at("spec_below").c_str());

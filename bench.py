@@ -186,13 +186,10 @@ def self_launch(args):
     --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same arguments>` -- as a CHILD process (never an
     exec: this process must not be replaced once anything could have touched the GPU; here nothing has -- torch is not imported yet).
     The child's stdout / stderr are ours (inherited), and its exit code is returned."""
-    import socket
     import subprocess
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: the launcher picks its own rendezvous port (a port chosen here by bind / close can be taken before the child binds it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={args.gpus}", os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this driver
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // args.gpus)))
@@ -362,6 +359,10 @@ def main():
                        "series_ok": n_ok, "mean_passes_per_series": round(st["total_passes"] / max(n, 1), 1),
                        "max_passes_per_series": st["max_passes"], "mean_evals_per_series": round(st["total_evals"] / max(n, 1), 1),
                        "problems": st["n_problems"], "fit_kernel_launches": st["fit_kernel_launches"],
+                       # what the ETS fit streamed: the fp64 block, or a float / uint16 copy of it -- made only when EVERY observation of the batch
+                       # survives that type exactly (counts: this workload), so the fp64 arithmetic sees the same numbers (bit-identical results;
+                       # the algorithmic bytes below keep SURVEY.md's unit of 8 bytes per observation and pass, the PMC traffic shows what moved)
+                       "storage": {0: "f64 block", 1: "f32 copy of the block (exact for this batch)", 2: "u16 copy of the block (exact for this batch)"}.get(int(st.get("y_storage", 0)), "f64 block"),
                        "device_ms_per_step": round(float(np.mean(dev_ms)), 3), "datagen_s": round(gen_s, 1)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
@@ -429,6 +430,8 @@ def main():
                                  "note": "one rank of the job measured alone on one GPU; no RCCL gather in the timed region"}
         yhat_host = res["yhat"].cpu().numpy().copy()
         batch.close()       # the host-buffer entry below is what a binding calls on its own: no second resident batch (and its streams) beside it
+        del res, y_dev, len_dev       # ... and the headline block goes back to torch's allocator before the other workloads allocate theirs
+        torch.cuda.empty_cache()
         # ---- end to end: host buffers in, results on host (never `value`) -----------------------------
         e2e_steps = args.e2e_steps if args.e2e_steps >= 0 else (0 if world > 1 else (1 if ms_per_step > 400 else 2))
         if wl["fixed"]:

@@ -104,7 +104,12 @@ if traffic:
         "WRITE_SIZE_raw_bytes": {k: int(v) for k, v in write.items()},
         "hbm_bytes_corrected": {k: int(v) for k, v in corrected.items()},
         "ets_round_kernel_traffic_bytes_per_step": int(corrected.get("ets_round_kernel", 0)),
-        "fit_kernel_traffic_bytes_per_step": int(corrected.get("ets_round_kernel", 0) + corrected.get("ets_final_kernel", 0)),
+        # round 6: everything the fit phase moves -- the round and final kernels AND the kernels that only exist to feed them (the dense
+        # re-gather of the running problems' columns, the compaction, the compact copy of the block); round 5 quoted the first two only
+        "fit_kernel_traffic_bytes_per_step": int(sum(corrected.get(k, 0) for k in ("ets_round_kernel", "ets_final_kernel", "gather_columns_kernel",
+                                                                                   "compact_kernel", "compact_block_kernel"))),
+        "fit_kernel_traffic_parts": {k: int(corrected.get(k, 0)) for k in ("ets_round_kernel", "ets_final_kernel", "gather_columns_kernel",
+                                                                           "compact_kernel", "compact_block_kernel")},
     }
     # ---- SQ issue counters (separate passes): wave-level VALU instructions per step and how busy the SIMDs were ----
     sq = {}
