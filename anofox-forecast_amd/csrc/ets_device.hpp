@@ -403,8 +403,9 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
 #pragma unroll
             for (int k = 0; k < K; k++) s[k][0] = 0.0;
         }
-        // Two blocks per iteration on alternating buffers (round 5: every class, it used to be the additive one only): the copy between
-        // the buffers -- one of a step's instructions -- disappears.  The main loop runs the blocks that every active lane of the wave covers without a predicate; the tail runs them predicated.
+        // Two blocks per iteration on alternating buffers -- the copy between the buffers, one of a step's instructions, disappears: SHIPPED
+        // for the additive class only (ANOFOX_TWO_BLOCK = 1; for every class it measured slower in the 25-spec batch, round 5).  The main
+        // loop runs the blocks that every active lane of the wave covers without a predicate; the tail runs them predicated.
         auto run_block = [&](const ybuf_t (&buf)[S], const int base, auto pred_tag) __attribute__((always_inline)) {
             constexpr bool PRED = decltype(pred_tag)::value;
             if constexpr (ANOFOX_DM_RETRY && Cfg::T == C_MUL && Cfg::D && K == 1 && !PRED && !FINAL) {

@@ -263,7 +263,12 @@ __global__ __launch_bounds__(NM_BLOCK) void ets_final_kernel(const FitArgs a)
     v.wave_min_len = wave_min_i32(active ? len : 0x7fffffff);
     v.rows = a.t_rows;
     if (v.wave_len == 0) {
-        if (!inspect && valid && len > 0) { a.aicc[s] = __builtin_huge_val(); a.evals[s] = 0; a.iters[s] = 0; a.passes[s] = 0; }
+        if (!inspect && valid && len > 0) {
+            a.aicc[s] = __builtin_huge_val(); a.evals[s] = 0; a.iters[s] = 0; a.passes[s] = 0;
+            // one-spec batch: this pass is the only writer of the intervals' sd -- a wave without a fitted lane writes what an unfitted
+            // lane of a live wave gets (interval_kernel reads sd only where the status is 0, i.e. never here: defined all the same)
+            if (a.sd_out != nullptr) a.sd_out[s] = 0.0;
+        }
         return;
     }
     if constexpr (Cfg::T == C_MUL && Cfg::D) dm_pow_tab_init();

@@ -21,11 +21,13 @@ template <int ID, int MS, int SPEC, class YT> FitLaunchFn k4_launcher()
     if constexpr (SpecOf<ID>::Cfg::ADDITIVE && (MS == 0 || MS == 7)) return &ets_round_launch<typename SpecOf<ID>::Cfg, MS, SPEC, true, YT>;
     else return nullptr;
 }
-// YT: what the streamed block holds (ets_device.hpp).  The compact types are instantiated for the period variants a uniform batch
-// uses (none, 7, 12, run-time ring in LDS or HBM); a merged batch of several periods (MS -3 / -4) streams the fp64 block.
+// YT: what the streamed block holds (ets_device.hpp).  float exists for every period variant; uint16_t (a quarter of the bytes: worth
+// another 2-3 % on the weekly M5 batch) for the two the BASELINE configurations use, no period and the weekly ring in registers --
+// a batch of counts with any other period streams the float copy (host_api.hip compact_storage_decide).
+constexpr bool ets_u16_variant(int ms) { return ms == 0 || ms == 7; }
 template <int ID, int MS, class YT = double> FitLaunchers launchers_of()
 {
-    if constexpr (!std::is_same_v<YT, double> && MS <= -3) return FitLaunchers{nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr};
+    if constexpr (std::is_same_v<YT, unsigned short> && !ets_u16_variant(MS)) return FitLaunchers{nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr};
     else {
     // the final pass sweeps the columns in their original blocks of one period each: the per-lane period variants (-3 / -4) exist for
     // the round kernels only

@@ -801,12 +801,12 @@ __global__ void ets_fixed_setup_kernel(int n, size_t ld, const int32_t *len, con
 // passes, same bits).  begin: one sweep of the block makes both copies and counts the observations that do NOT survive (+ 0.15 ms for
 // 467 MB); decide (after the host has synchronised the stream): a copy is used only when its counter is zero, so ONE inexact
 // observation anywhere keeps the whole batch on the fp64 block.  Not for given parameters (one pass: the sweep would cost more than
-// it saves), a merged batch of several periods (its per-lane-period kernels exist for fp64 only) or a handful of series.
+// it saves) or a handful of series.
 // tune compact: -1 auto (narrowest exact type; batches of at least 65,536 cells), 0 never, 1 float at most, 2 narrowest exact type (1 / 2: any size).
 bool compact_storage_begin(AnofoxHipBatch *b, const int32_t *d_len, hipStream_t st)
 {
     b->y_type = YT_F64;
-    if (b->tun.compact == 0 || b->fixed_params || b->d_m_col != nullptr) return false;
+    if (b->tun.compact == 0 || b->fixed_params) return false;
     if (b->tun.compact < 0 && b->n * (size_t)std::max<size_t>(b->t_max, 1) < (size_t)1 << 16) return false;      // (auto: not for a handful of short series)
     const size_t cells = b->ld * std::max<size_t>(b->t_max, 1);
     if (b->yc_cells < cells) {
@@ -830,12 +830,15 @@ bool compact_storage_begin(AnofoxHipBatch *b, const int32_t *d_len, hipStream_t 
     HIPCHECK(hipMemcpyAsync(b->h_misfit, b->d_misfit, sizeof b->h_misfit, hipMemcpyDeviceToHost, st));
     return true;
 }
-void compact_storage_decide(AnofoxHipBatch *b, bool pending, hipStream_t st)
+// `m`: the batch's seasonal period (1: none).  The uint16_t kernels exist for the variants without a period and with the weekly ring
+// in registers (fit_units.hpp ets_u16_variant); any other period -- and a merged batch of several -- streams the float copy.
+void compact_storage_decide(AnofoxHipBatch *b, bool pending, hipStream_t st, int m)
 {
     b->y_type = YT_F64;
     if (!pending) return;
     HIPCHECK(hipStreamSynchronize(st));          // (already drained when the caller has just read its own counters)
-    if (b->h_misfit[1] == 0u && b->tun.compact != 1) b->y_type = YT_U16;
+    const bool u16_kernels = b->d_m_col == nullptr && (m <= 1 || m == 7);
+    if (b->h_misfit[1] == 0u && b->tun.compact != 1 && u16_kernels) b->y_type = YT_U16;
     else if (b->h_misfit[0] == 0u) b->y_type = YT_F32;
 }
 
@@ -856,7 +859,7 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
     // the final pass sweeps the original blocks (one period each)
     const bool merged = b->d_m_col != nullptr;
     // what the kernels stream: the fp64 block, or a compact copy of it (compact_storage_decide: every observation survives the narrower type)
-    const int yt = merged ? (int)YT_F64 : b->y_type;
+    const int yt = b->y_type;
     const void *ybase = yt == YT_F32 ? (const void *)b->d_yc32 : (yt == YT_U16 ? (const void *)b->d_yc16 : (const void *)b->d_y);
     const int ybytes = yt == YT_F32 ? 4 : (yt == YT_U16 ? 2 : 8);
     const int lds_limit = merged ? ETS_MERGED_LDS_PERIOD : ETS_LDS_PERIOD;      // largest period whose seasonal ring stays in LDS
@@ -1180,6 +1183,10 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
                 // speculative (one problem per wave, two iterations per pass)
                 a.spec_below = (spec_trend_idx(specs[order[oi]]) == 4) ? b->spec_below_md : b->spec_below;
                 a.spec2_below = s2 > 0 ? s2 : -1;
+                if ((int)oi < b->tun.top_boost_n) {         // (experiment: the chains that end the step get their parallelism earlier)
+                    a.spec_below = (int)std::min<int64_t>(0x7fffffff, (int64_t)a.spec_below * b->tun.top_boost_pct / 100);
+                    if (a.spec2_below > 0) a.spec2_below = (int)std::min<int64_t>(0x7fffffff, (int64_t)a.spec2_below * b->tun.top_boost_pct / 100);
+                }
                 // ONE launch: a launch whose workgroups only find out that another driver owns the round still has to be dispatched
                 a.budget_seq = (BUDGET[r] * 7) / 4;
                 a.budget = BUDGET[r];
@@ -1322,7 +1329,7 @@ void run_group(AnofoxHipBatch *b, int period, const int32_t *d_len, hipStream_t 
                 break;
             }
             std::vector<int> specs{id};
-            compact_storage_decide(b, compact_storage_begin(b, d_len, st), st);
+            compact_storage_decide(b, compact_storage_begin(b, d_len, st), st, m);
             launch_fit_slots(b, specs, d_len, m, false, st);
             hipLaunchKernelGGL(explicit_select_kernel, dim3((unsigned)((n * (size_t)std::max(b->h, 1) + 255) / 256)), dim3(256), 0, st, (int)n, b->h, d_len, b->d_status_slots,
                                b->d_yhat_slots, b->d_passes_slots, b->d_evals_slots, b->d_yhat, b->d_detail, b->d_passes_total,
@@ -1370,7 +1377,7 @@ void run_group(AnofoxHipBatch *b, int period, const int32_t *d_len, hipStream_t 
             b->use_pos = false;
             b->live_pos = b->live_all = -1;
         }
-        compact_storage_decide(b, compact_pending, st);
+        compact_storage_decide(b, compact_pending, st, m);
         b->none_pos = b->live_all >= 0 && b->live_pos == 0;       // no strictly positive series at all: the 19 specs with a multiplicative component have nothing to fit
         if (b->use_pos || b->none_pos)
             hipLaunchKernelGGL(mark_nonpositive_kernel, dim3((unsigned)blocks256), dim3(256), 0, st, (int)n, d_len, b->d_flags, b->d_notpos);
@@ -1379,7 +1386,7 @@ void run_group(AnofoxHipBatch *b, int period, const int32_t *d_len, hipStream_t 
             if (b->use_gather) {
                 if (!b->d_ypos) b->d_ypos = dalloc<double>(std::max<size_t>(b->t_max, 1) * ld);
                 // (the strictly positive columns, in the storage type the fit streams)
-                const int yt = b->d_m_col ? (int)YT_F64 : b->y_type;
+                const int yt = b->y_type;
                 launch_gather_columns(yt == YT_F32 ? (const void *)b->d_yc32 : (yt == YT_U16 ? (const void *)b->d_yc16 : (const void *)b->d_y), ld, b->d_pos_map,
                                       b->d_pos_cnt, (int)n, (int)b->t_max, b->d_ypos, ld, st, (int)ld, yt == YT_F32 ? 4 : (yt == YT_U16 ? 2 : 8));
             }

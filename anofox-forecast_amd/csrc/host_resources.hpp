@@ -64,6 +64,7 @@ struct Tunables {
     int fill_target = 150;      // tune fill_target: lanes the first round may occupy, in percent of the resident lanes (2 waves x 1,024 SIMDs x 64)
     int fill_late_div = 2;      // tune fill_late_div: a spec that started one lane per problem switches to four lanes at 1 / this of its problems
     int fill_s2_div = 16;       // tune fill_s2_div: ... and any spec to one wave per problem at 1 / this of its problems (at most spec2_below)
+    int top_boost_n = 0, top_boost_pct = 200;   // tune top_boost_n / top_boost_pct: the N heaviest chains switch to four lanes / one wave per problem at pct % of the class thresholds
     int prio_top = 0;           // tune prio_top: the N chains with the most expected work run their waves at raised issue priority (3, 2, 1, 1, ...: launch_fit_slots)
     int dm_head_rounds = 0;     // tune dm_head_rounds: rounds the damped multiplicative-trend chains run before the other specs' streams start (launch_fit_slots)
     bool merge_periods = true;  // tune merge_periods: auto-detected periods run as merged batches (0: one batch per period)
@@ -120,7 +121,7 @@ struct Tunables {
             if (!v.empty()) t.budgets = v;
         }
         if (kv.count("wave_trace")) t.wave_trace = kv.at("wave_trace");
-        geti("compact", t.compact); geti("prio_top", t.prio_top);
+        geti("compact", t.compact); geti("prio_top", t.prio_top); geti("top_boost_n", t.top_boost_n); geti("top_boost_pct", t.top_boost_pct);
         geti("fill_policy", t.fill_policy); geti("fill_target", t.fill_target); geti("fill_late_div", t.fill_late_div); geti("fill_s2_div", t.fill_s2_div);
         geti("seq_rounds", t.seq_rounds);
         geti("gather", t.gather);
@@ -488,16 +489,18 @@ void stream_set_destroy(StreamSet *s)
 // The candidate specs of a fit run on up to 25 streams side by side; the HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues
 // (default 4) and streams that share a queue serialise.  The variable is read when the runtime initialises, and the library does not
 // touch the process environment (a setenv at load time races with getenv in a multi-threaded host such as DuckDB and changes every
-// other HIP user of the process: INTEGRATION.md, Environment) -- the HOST exports it.  What the library does (round 5): the first
-// stream set looks at what the environment says and warns ONCE on stderr, independent of ANOFOX_HIP_TIMING, when the value is missing
-// or below 16: results are unaffected, the 25-spec AutoETS batch is 1.3-2x slower on 4 queues.
+// other HIP user of the process: INTEGRATION.md, Environment) -- the HOST exports it.  What the library does: the first stream set
+// looks at what the environment says and, when the value is missing or below 16, says so ONCE on stderr -- only when the host has
+// asked for the library's diagnostics (ANOFOX_HIP_TIMING; round 6: an embedding host such as DuckDB must not get library noise on its
+// stderr at every process start).  Results are unaffected, the 25-spec AutoETS batch is 1.3-2x slower on 4 queues;
+// INTEGRATION.md is the primary place that says so.
 inline void warn_hw_queues_once()
 {
     static std::once_flag once;
     std::call_once(once, [] {
         const char *q = std::getenv("GPU_MAX_HW_QUEUES");
         const int v = q ? std::atoi(q) : 0;
-        if (v < 16)
+        if (v < 16 && std::getenv("ANOFOX_HIP_TIMING") != nullptr)
             std::fprintf(stderr, "[anofox-hip] warning: GPU_MAX_HW_QUEUES is %s (< 16): the candidate ETS specs run on concurrent HIP streams and will share "
                                  "hardware queues -- export GPU_MAX_HW_QUEUES=16 in the host's environment before its first HIP call (results are "
                                  "unaffected; the 25-spec AutoETS batch is about twice as slow)\n", q ? q : "unset");

@@ -16,7 +16,31 @@ POOLS = ["", "complete", "no_multiplicative_trend", "damped_trend_only", "match_
 NO_PERIOD = {"Naive", "SES", "SESOptimized", "Holt", "RandomWalkDrift", "ARIMA"}
 
 
+# FUZZ_COUNTS=1 (round 6): every series is a count series (Poisson counts, constants, rounded trends; now and then a half-integer or
+# a value above 65,535) and the library is told to stream the narrowest exact copy of the block whatever the batch size
+# (ANOFOX_HIP_TUNE compact=2) -- the compact-storage kernels against the oracle.  NULLs are interpolated by the packer: a batch whose
+# interpolated values are not exact falls back to the wider type by itself, which is part of what is fuzzed.
+COUNTS = os.environ.get("FUZZ_COUNTS") == "1"
+if COUNTS:
+    os.environ["ANOFOX_HIP_TUNE"] = "compact=2"
+
+
 def make_series(n):
+    if COUNTS:
+        kind = rng.integers(0, 5)
+        t = np.arange(n)
+        m = int(rng.choice([1, 2, 4, 7, 12]))
+        if kind == 0:
+            y = rng.poisson(rng.lognormal(0, 1.2) * (1 + 0.3 * np.sin(2 * np.pi * t / max(m, 2))), n).astype(float) + float(rng.integers(0, 2))
+        elif kind == 1:
+            y = np.rint(20 + 0.1 * t + 5 * np.sin(2 * np.pi * t / max(m, 2)) + rng.normal(0, 1, n)) + 30.0
+        elif kind == 2:
+            y = np.full(n, float(rng.integers(0, 5)))
+        elif kind == 3:
+            y = np.rint(np.exp(0.01 * t + rng.normal(0, 0.05, n)) * (1 + 0.2 * np.sin(2 * np.pi * t / max(m, 2))) * 100.0) * (0.5 if rng.random() < 0.3 else 1.0)
+        else:
+            y = np.rint(np.abs(rng.normal(0, 1, n)) * 10.0 ** rng.integers(0, 6))
+        return y
     kind = rng.integers(0, 6)
     t = np.arange(n)
     m = int(rng.choice([1, 2, 4, 7, 12]))

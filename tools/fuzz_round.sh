@@ -8,4 +8,9 @@ for cmd in "tools/fuzz_long.py 1024 ${1:-11}" "tools/fuzz_parity.py 200 51" "too
   echo "## python $cmd" >> $OUT
   timeout 900 python $cmd 2>&1 | grep -v amdgpu.ids >> $OUT
 done
+# round 6: count series through the compact-storage kernels (float / uint16 copy of the block), two seeds
+for seed in 61 62; do
+  echo "## FUZZ_COUNTS=1 python tools/fuzz_parity.py 200 $seed" >> $OUT
+  FUZZ_COUNTS=1 timeout 900 python tools/fuzz_parity.py 200 $seed 2>&1 | grep -v amdgpu.ids >> $OUT
+done
 tail -40 $OUT
