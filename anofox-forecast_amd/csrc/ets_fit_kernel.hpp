@@ -49,6 +49,13 @@ namespace anofox {
 #ifndef ANOFOX_ROUND_WAVES_COMPACT
 #define ANOFOX_ROUND_WAVES_COMPACT ANOFOX_ROUND_WAVES
 #endif
+// ANOFOX_SEQ_WAVES_COMPACT (experiment, 0 = off): residency asked of the one-lane-per-problem-only kernels (the first round) over a
+// compact block.  Measured with 3 (profiles/r06_ab_three_waves_first_round.txt): 395 against 377 ms -- the kernels that fit 168
+// registers are no faster with a third wave per SIMD (9-10 ms per wave either way), the four that do not fit spill (a first round of
+// ETS(A,Md,M) 92 ms per wave): with two waves per SIMD the vector unit is already busy, residency is not the lever on this chip
+#ifndef ANOFOX_SEQ_WAVES_COMPACT
+#define ANOFOX_SEQ_WAVES_COMPACT 0
+#endif
 template <class Cfg, class YT = double> struct RoundTraits {
     static constexpr bool DAMPED_MUL = !Cfg::CLASSIC && Cfg::T == C_MUL && Cfg::D;
     static constexpr bool PARK = !Cfg::CLASSIC && (ANOFOX_PARK_CLASS >= 3 || (ANOFOX_PARK_CLASS == 2 && !Cfg::ADDITIVE) || (ANOFOX_PARK_CLASS == 1 && DAMPED_MUL));
@@ -74,7 +81,7 @@ template <class Cfg, int MS, class YT> struct RoundModelOf<Cfg, MS, YT, true> { 
 //           and the sequential driver stays.  Same iterates, same evaluation counts (the speculative driver's bookkeeping).
 // YT: storage type of the block the round streams (ets_device.hpp: double, or float / uint16_t for a compact copy of a batch of counts)
 template <class Cfg, int MS, int SPEC, bool K4 = false, class YT = double>
-__global__ __launch_bounds__(NM_BLOCK * RoundTraits<Cfg>::WPB, (RoundTraits<Cfg, YT>::WAVES + RoundTraits<Cfg>::WPB - 1) / RoundTraits<Cfg>::WPB) void ets_round_kernel(const FitArgs a)
+__global__ __launch_bounds__(NM_BLOCK * RoundTraits<Cfg>::WPB, ((ANOFOX_SEQ_WAVES_COMPACT > 0 && SPEC == 0 && !K4 && !std::is_same_v<YT, double> && !Cfg::CLASSIC ? ANOFOX_SEQ_WAVES_COMPACT : RoundTraits<Cfg, YT>::WAVES) + RoundTraits<Cfg>::WPB - 1) / RoundTraits<Cfg>::WPB) void ets_round_kernel(const FitArgs a)
 {
     extern __shared__ double lds_all[];
     constexpr int D = Cfg::DIM;

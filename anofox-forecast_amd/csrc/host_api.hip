@@ -997,7 +997,11 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
         int64_t all_live = 0;
         for (size_t oi = 0; oi < order.size(); oi++)
             if (!dead[oi]) all_live += (spec_has_mult(specs[order[oi]]) && b->live_pos >= 0) ? (int64_t)b->live_pos : (b->live_all >= 0 ? (int64_t)b->live_all : (int64_t)n);
-        const bool on = b->tun.k4 > 0 || (b->tun.k4 < 0 && ((all_additive && additive_live >= 131072) || all_live >= 524288));
+        // (round 6) ... as long as the run streams the fp64 block.  K4 buys 41 % fewer passes with four times the arithmetic: a trade for a
+        // pass bound by its BYTES.  Over a compact copy (2 or 4 bytes per observation) the additive pass is bound by its instructions like
+        // every other, and K4 loses: intermittent M5 batch 58.0 -> 53.8 ms, 125k x 1,024 99.9 -> 75.5 ms, 125k x 256 with all 25 specs
+        // 148-156 -> 141-142 ms, the 25-spec M5 batch unchanged (profiles/r06_k4_shapes.txt)
+        const bool on = b->tun.k4 > 0 || (b->tun.k4 < 0 && yt == YT_F64 && ((all_additive && additive_live >= 131072) || all_live >= 524288));
         for (size_t oi = 0; oi < order.size(); oi++)
             k4[oi] = on && !dead[oi] && !b->fixed_params && !spec_has_mult(specs[order[oi]]) && fns[oi].round_k4 && fns[oi].round_auto_k4;
     }

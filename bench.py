@@ -164,12 +164,14 @@ def also_pass(names, steps, h, dev, lib, synth, DeviceBatch, pack_time_major, to
         if wl["fixed"]:
             fit_ms.append(st["total_device_ms"]); dev_ms.append(st["total_device_ms"])       # the unit is the whole one-pass step
         kms = float(np.mean(fit_ms))
-        ach = st["algorithmic_bytes"] / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
-        minb = int(st.get("min_pass_bytes", 0))
+        ub = {0: 8, 1: 4, 2: 2}.get(int(st.get("y_storage", 0)), 8)      # bytes per observation of what the run streamed (see main)
+        ob = 24.0 * max(h, 0) * n
+        ach = ((st["algorithmic_bytes"] - ob) * ub / 8.0 + ob) / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+        minb = int((int(st.get("min_pass_bytes", 0)) - ob) * ub / 8.0 + ob) if st.get("min_pass_bytes", 0) else 0
         res = batch.results()
         out[name] = {"value": round(n / dt, 1), "unit": "series/s", "ms_per_step": round(dt * 1e3, 4), "steps": k,
                      "series": n, "T": T, "series_ok": int((res["status"] == 0).sum().item()),
-                     "roofline": {"frac": round(ach / HBM_PEAK_GBS, 4), "achieved": round(ach, 1), "kernel_ms": round(kms, 4),
+                     "roofline": {"frac": round(ach / HBM_PEAK_GBS, 4), "achieved": round(ach, 1), "kernel_ms": round(kms, 4), "bytes_per_observation": ub,
                                   "frac_min_passes": round(minb / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if (minb and kms > 0) else None}}
         if wl["model"] == "AutoARIMA":
             out[name]["arima_method"] = "CSS-ML (exact Gaussian likelihood refit: the Kalman kernel BASELINE config 4 names)" if wl["arima_method"] else "CSS (library default)"
@@ -326,11 +328,23 @@ def main():
         if wl["fixed"]:
             # config 2: the timed unit is the STEP (HIP events around everything the run enqueues), not the final pass alone
             final_pass_ms, fit_ms_avg = fit_ms_avg, float(np.mean(dev_ms))
+        # ALGORITHMIC bytes = what must move: one pass over one series reads T observations IN THE TYPE THE RUN STREAMS -- 8 bytes each
+        # from the fp64 block, 4 / 2 from the float / uint16 copy a batch of counts is streamed from (SURVEY.md 8(d) wrote the unit
+        # for fp64 storage; with the compact copy that unit would put `achieved` ABOVE the measured traffic and, on the all-additive
+        # batches, above the 8 TB/s peak).  The library's counter is in the fp64 unit: scale its pass part, keep the 24 h of results.
+        unit_bytes = {0: 8, 1: 4, 2: 2}.get(int(st.get("y_storage", 0)), 8)
+        out_bytes = 24.0 * max(h, 0) * n
+
+        def streamed(b):
+            return (float(b) - out_bytes) * unit_bytes / 8.0 + out_bytes if b else 0.0
+        alg_fp64_unit = float(np.mean(alg_bytes))
+        achieved_fp64_unit = alg_fp64_unit / (fit_ms_avg * 1e-3) / 1e9 if fit_ms_avg > 0 else 0.0
+        alg_bytes = [streamed(b) for b in alg_bytes]
         achieved = float(np.mean(alg_bytes)) / (fit_ms_avg * 1e-3) / 1e9 if fit_ms_avg > 0 else 0.0
         # the same time against the bytes of a one-pass-per-iteration schedule (Nelder-Mead iterations + one final pass per problem):
         # `frac` counts the passes the drivers actually executed (the sequential one runs ~1.7 per iteration), this one does not
         # depend on which driver ran which round
-        min_bytes = int(st.get("min_pass_bytes", 0))
+        min_bytes = int(streamed(int(st.get("min_pass_bytes", 0))))
         achieved_min = min_bytes / (fit_ms_avg * 1e-3) / 1e9 if (fit_ms_avg > 0 and min_bytes > 0) else None
         if model == "AutoARIMA":
             kernel = ("arima_fit_kernel + arima_fit_spec_kernel (all sweeps of one step + the selected models' polish)" +
@@ -361,7 +375,7 @@ def main():
                        "problems": st["n_problems"], "fit_kernel_launches": st["fit_kernel_launches"],
                        # what the ETS fit streamed: the fp64 block, or a float / uint16 copy of it -- made only when EVERY observation of the batch
                        # survives that type exactly (counts: this workload), so the fp64 arithmetic sees the same numbers (bit-identical results;
-                       # the algorithmic bytes below keep SURVEY.md's unit of 8 bytes per observation and pass, the PMC traffic shows what moved)
+                       # the roofline below counts the bytes of THIS type per observation and pass; `fp64_unit` keeps the 8-byte figure of earlier rounds)
                        "storage": {0: "f64 block", 1: "f32 copy of the block (exact for this batch)", 2: "u16 copy of the block (exact for this batch)"}.get(int(st.get("y_storage", 0)), "f64 block"),
                        "device_ms_per_step": round(float(np.mean(dev_ms)), 3), "datagen_s": round(gen_s, 1)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -369,7 +383,12 @@ def main():
                          "kernel": kernel, "kernel_ms": round(fit_ms_avg, 3), "algorithmic_bytes": int(np.mean(alg_bytes)),
                          "frac_min_passes": round(achieved_min / HBM_PEAK_GBS, 4) if achieved_min else None,
                          "min_pass_bytes": min_bytes or None,
-                         "mean_iterations_per_series": round(st.get("total_iters", 0) / max(n, 1), 1) if min_bytes else None},
+                         "mean_iterations_per_series": round(st.get("total_iters", 0) / max(n, 1), 1) if min_bytes else None,
+                         "bytes_per_observation": unit_bytes,
+                         # the same passes in SURVEY.md's fp64 unit (8 bytes per observation: what rounds 1-5 reported, and what the fp64 block
+                         # would have had to move) -- for comparison across rounds only; with a compact copy it exceeds what was moved
+                         "fp64_unit": {"achieved": round(achieved_fp64_unit, 1), "frac": round(achieved_fp64_unit / HBM_PEAK_GBS, 4),
+                                       "algorithmic_bytes": int(alg_fp64_unit)}},
         }
         if model != "AutoARIMA" and not wl["fixed"]:
             # lane-level efficiency of the round kernels (device counters of the LAST timed step): the share of issued lanes that

@@ -14,6 +14,10 @@ for w in autoets_m5_positive autoets_m5 autoarima_css_m5; do
   timeout 300 python bench.py --workload $w --scaling strong --simulate-world 8 --steps 5 --cpu-sample 0 --e2e-steps 0 2>>$OUT/strong.err | tail -1 > $OUT/bench_strong8_shard0_$w.json
 done
 timeout 300 python bench.py --workload autoets_stress --scaling strong --simulate-world 8 --n-series 1000000 --steps 3 --cpu-sample 0 --e2e-steps 0 2>>$OUT/strong.err | tail -1 > $OUT/bench_strong8_shard0_autoets_stress_1M.json
+for w in 2 4; do
+  timeout 300 python bench.py --workload autoets_m5_positive --scaling strong --simulate-world $w --steps 5 --cpu-sample 0 --e2e-steps 0 2>>$OUT/strong.err | tail -1 > $OUT/bench_strong${w}_shard0_autoets_m5_positive.json
+  timeout 300 python bench.py --workload autoets_stress --scaling strong --simulate-world $w --n-series 1000000 --steps 3 --cpu-sample 0 --e2e-steps 0 2>>$OUT/strong.err | tail -1 > $OUT/bench_strong${w}_shard0_autoets_stress_1M.json
+done
 # BASELINE config 5 whole on ONE GPU (1M x 1,024: 8.2 GB of series, per-spec gather blocks of 772k columns = 158 GB)
 timeout 900 python bench.py --workload autoets_stress --n-series 1000000 --steps 2 --cpu-sample 0 --e2e-steps 0 2>>$OUT/strong.err | tail -1 > $OUT/bench_autoets_stress_1M_one_gpu.json
 # the default call shape (periods detected per series), the single-call latencies and the concurrent C workers
