@@ -42,6 +42,11 @@ static double clipd(double v, double lo, double hi)
  * nm_outcome_sink[24 + 8 * (n - 1) + j] for the position j the new vertex is inserted at (shrinks excluded), and to the table of
  * consecutive outcomes nm_outcome_sink[56 + 676 * (n - 1) + 26 * previous + current], outcome = 5 * kind + j (25 = shrink) */
 long long *nm_outcome_sink = NULL;
+/* test hook (tools/nm_spread.py): when set, every iteration appends {iteration, largest |x_k - x_0| / xatol, largest |f_k - f_0| / fatol}
+ * of the sorted simplex it starts from, and the end of a run appends {-1, iterations, 0} -- how well the simplex's size predicts how many
+ * iterations a problem still needs (would sorting the running problems by it make the waves of a round finish together?) */
+double *nm_spread_sink = NULL;
+long nm_spread_pos = 0, nm_spread_cap = 0;
 
 void nm_minimize(nm_fn fn, void *ctx, int n, const double *x0,
                  const double *lo, const double *hi, NmResult *res)
@@ -82,6 +87,14 @@ void nm_minimize(nm_fn fn, void *ctx, int n, const double *x0,
             for (int i = 0; i < n; i++)
                 if (!(fabs(sim[k][i] - sim[0][i]) <= NM_XATOL)) small = 0;
             if (!(fabs(fs[0] - fs[k]) <= NM_FATOL)) small = 0;
+        }
+        if (nm_spread_sink && nm_spread_pos + 3 <= nm_spread_cap) {
+            double dx = 0.0, df = 0.0;
+            for (int k = 1; k <= n; k++) {
+                for (int i = 0; i < n; i++) { const double d = fabs(sim[k][i] - sim[0][i]); if (d > dx) dx = d; }
+                const double d = fabs(fs[0] - fs[k]); if (d > df) df = d;
+            }
+            nm_spread_sink[nm_spread_pos++] = (double)iters; nm_spread_sink[nm_spread_pos++] = dx / NM_XATOL; nm_spread_sink[nm_spread_pos++] = df / NM_FATOL;
         }
         if (small) break;
 
@@ -157,6 +170,7 @@ void nm_minimize(nm_fn fn, void *ctx, int n, const double *x0,
         if (nm_outcome_sink) __atomic_fetch_add(&nm_outcome_sink[6 * (n - 1) + (doshrink ? 5 : kind)], 1, __ATOMIC_RELAXED);
         iters++;
     }
+    if (nm_spread_sink && nm_spread_pos + 3 <= nm_spread_cap) { nm_spread_sink[nm_spread_pos++] = -1.0; nm_spread_sink[nm_spread_pos++] = (double)iters; nm_spread_sink[nm_spread_pos++] = 0.0; }
     for (int i = 0; i < n; i++) res->x[i] = sim[0][i];
     res->f = fs[0];
     res->iters = iters;
