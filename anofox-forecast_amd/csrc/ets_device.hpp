@@ -92,6 +92,9 @@ template <> struct YtCode<unsigned short> { static constexpr int value = YT_U16;
 #ifndef ANOFOX_S_GEN
 #define ANOFOX_S_GEN 16         // ... of the other general-class passes
 #endif
+#ifndef ANOFOX_S_HBM_RING_COMPACT
+#define ANOFOX_S_HBM_RING_COMPACT 16    // block length of the HBM-ring pass (one long period) over a compact block
+#endif
 #ifndef ANOFOX_S_COMPACT_MUL
 #define ANOFOX_S_COMPACT_MUL 2      // block length factor of the general-class and damped-M passes over a compact (float / uint16) block
 #endif
@@ -327,7 +330,11 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
     constexpr int S_WIDE = std::is_same_v<YT, double> ? 1 : (Cfg::ADDITIVE ? ANOFOX_S_COMPACT_MUL_ADD : ANOFOX_S_COMPACT_MUL);
     constexpr int S_FULL = (Cfg::ADDITIVE ? (K == 4 ? (MS > 0 ? ANOFOX_K4_S_SEAS : 16) : 32) : ((Cfg::T == C_MUL && Cfg::D) ? ANOFOX_S_DM : ANOFOX_S_GEN)) * S_WIDE;
     //  and at most 8 -- the ring prefetch needs periods of two blocks, a merged batch keeps periods from 17 up in HBM)
-    constexpr int S_TARGET = ((MS == -2 || MS == -4) && K == 1 && S_FULL > 8) ? 8 : S_FULL;
+    // (a uniform batch of ONE long period, MS == -2, has m > ETS_LDS_PERIOD = 64 >= 2 S for blocks up to 32 steps; over a compact block the
+    //  two y buffers leave the registers for two ring buffers of ANOFOX_S_HBM_RING_COMPACT steps)
+    //  (the ROUND kernels only: the final pass of a merged batch of several periods also runs MS == -2, block by block, with periods from 17 up)
+    constexpr int S_HBM_CAP = (MS == -2 && !FINAL && !std::is_same_v<YT, double>) ? ANOFOX_S_HBM_RING_COMPACT : 8;
+    constexpr int S_TARGET = ((MS == -2 || MS == -4) && K == 1 && S_FULL > S_HBM_CAP) ? S_HBM_CAP : S_FULL;
     constexpr int S = (MS > 0) ? ((S_TARGET / MS > 0 ? S_TARGET / MS : 1) * MS) : S_TARGET;
     // (a staged row rests in the storage type: a float takes one register, a double two; 16-bit values are zero-extended by the load)
     typedef std::conditional_t<std::is_same_v<YT, unsigned short>, unsigned, YT> ybuf_t;
@@ -504,7 +511,7 @@ __device__ __forceinline__ void ets_pass(const SeriesView &v, const EtsInit &in,
             // every step (the compiler cannot move it above the previous step's store to the same array).  The ring values of a block
             // are S DISTINCT phases and those of the next block S others (m > 16 >= 2 S), so they stream exactly like y: the next
             // block's S values are requested before the current block's steps run, the updated values go out as stores.
-            static_assert(2 * S <= ETS_MERGED_LDS_PERIOD, "the ring prefetch needs periods of at least two blocks");
+            static_assert(2 * S <= ((MS == -2 && !FINAL) ? ETS_LDS_PERIOD : ETS_MERGED_LDS_PERIOD), "the ring prefetch needs periods of at least two blocks");
             double rc[S], rn[S];
             auto ring_load = [&](double (&buf)[S], int j0) __attribute__((always_inline)) {
 #pragma unroll
