@@ -273,3 +273,28 @@ def test_scalar_chunk_groups_rows_by_option_block(monkeypatch):
         first.setdefault(g, v)
     assert first == {"a": 3.0, "b": 7.0, "c": 11.0, "d": 15.0, "e": 19.0} and len(out["yhat"]) == 10
     assert out["ds"].dtype == ds.dtype and out["ds"][0] == day + 4
+
+
+def test_gather_plan_layout():
+    """dist.GatherPlan (round 6): a rank's chunk is ONE buffer -- three [per x h] fp64 sections, then model codes and status as int32,
+    every section 8-byte aligned, sections disjoint, views typed and shaped without a copy; the root's receive buffer is world of
+    them.  (The collective itself: tests/test_dist_gloo.py.)"""
+    torch = pytest.importorskip("torch")
+    from anofox_forecast_amd.dist import GatherPlan
+    for n_total, h, world in ((30490, 28, 8), (7, 3, 2), (1000003, 1, 4), (5, 0, 2)):
+        plan = GatherPlan(n_total, h, rank=0, world=world, device="cpu", dst=0)
+        per = (n_total + world - 1) // world
+        assert plan.per == per and plan.recv.numel() == world * plan.chunk_bytes and len(plan._parts) == world
+        spans = sorted((off, off + nbytes) for off, nbytes, _, _ in plan.sections.values())
+        assert all(off % 8 == 0 for off, _ in spans)
+        assert all(a_end <= b_off for (_, a_end), (b_off, _) in zip(spans, spans[1:])) and spans[-1][1] <= plan.chunk_bytes
+        y = plan._view(plan.send, "yhat")
+        assert y.dtype == torch.float64 and tuple(y.shape) == (per, h) and (h == 0 or y.data_ptr() == plan.send.data_ptr())
+        code = plan._view(plan.send, "model_code")
+        assert code.dtype == torch.int32 and tuple(code.shape) == (per,)
+        code.fill_(7)
+        plan._view(plan.send, "status").fill_(-1)
+        if h:
+            plan._view(plan.send, "upper").fill_(2.5)
+            assert float(plan._view(plan.send, "lower").abs().sum()) == 0.0          # a neighbour's fill does not reach it
+        assert int(plan._view(plan.send, "model_code").sum()) == 7 * per
