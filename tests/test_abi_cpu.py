@@ -49,6 +49,27 @@ int main(void) {
     assert out[3] == "2 3 5 10"
 
 
+def test_additive_structs_match_their_ctypes_mirrors(hiplib):
+    """The backend's own structs (AnofoxHipStats -- round 6: `reserved` became `y_storage`, same place --, AnofoxHipLaneStats,
+    AnofoxHipInspection): size and the offsets that matter, as gcc lays out include/anofox_fcst_hip.h against lib.py's ctypes mirrors."""
+    src = r"""
+#include <stdio.h>
+#include <stddef.h>
+#include "anofox_fcst_hip.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu\n", sizeof(AnofoxHipStats), offsetof(AnofoxHipStats, fit_kernel_launches), offsetof(AnofoxHipStats, y_storage),
+         offsetof(AnofoxHipStats, total_iters), offsetof(AnofoxHipStats, min_pass_bytes));
+  printf("%zu %zu\n", sizeof(AnofoxHipLaneStats), sizeof(AnofoxHipInspection));
+  return 0; }"""
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), os.path.join(d, "t.c"), "-o", os.path.join(d, "t")])
+        out = subprocess.check_output([os.path.join(d, "t")]).decode().split("\n")
+    S = hiplib.AnofoxHipStats
+    assert out[0] == f"{C.sizeof(S)} {S.fit_kernel_launches.offset} {S.y_storage.offset} {S.total_iters.offset} {S.min_pass_bytes.offset}"
+    assert out[1] == f"{C.sizeof(hiplib.AnofoxHipLaneStats)} {C.sizeof(hiplib.AnofoxHipInspection)}"
+
+
 def test_no_gpu_fails_loudly(hiplib):
     import torch
     if torch.cuda.is_available():
