@@ -411,6 +411,8 @@ void BatchScalarExecute(DataChunk &args, ExpressionState &state, Vector &result)
     Vector &ds = *fields[1];
     idx_t at = 0;
     for (idx_t r = 0; r < count; r++) {
+        out_entries[r].offset = 0;                 // (a NULL row's entry is defined too: consumers may look at it before the validity bit)
+        out_entries[r].length = 0;
         if (is_null[r]) {
             FlatVector::SetNull(result, r, true);
         }
