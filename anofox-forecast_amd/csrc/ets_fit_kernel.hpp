@@ -367,6 +367,9 @@ void ets_round_launch(const FitArgs &a, hipStream_t stream)
     const int blocks = (grid + WPB - 1) / WPB;                  // `grid` counts one-wave workgroups; WPB of them share a real one
     if (RoundTraits<Cfg>::PARK && (a.nm_scratch == nullptr || (size_t)blocks * WPB * (size_t)nm_lds_doubles<Cfg::DIM>() > a.nm_scratch_doubles))
         throw std::runtime_error("ets_round_launch: the simplex scratch does not cover the launch");
+    // the HBM ring of a long period: one area of m * 64 doubles per one-wave workgroup of THIS launch
+    if ((MS == -2 || MS == -4) && (a.ring_scratch == nullptr || (size_t)blocks * WPB * (size_t)a.m * NM_BLOCK > a.ring_scratch_doubles))
+        throw std::runtime_error("ets_round_launch: the seasonal-ring scratch does not cover the launch");
     size_t lds_bytes = RoundTraits<Cfg>::PARK ? 0 : sizeof(double) * (size_t)nm_lds_doubles<Cfg::DIM>();
     if (MS == -1 || MS == -3) lds_bytes += sizeof(double) * (size_t)a.m * NM_BLOCK;
     lds_bytes *= WPB;
@@ -379,6 +382,8 @@ template <class Cfg, int MS, class YT = double>
 void ets_final_launch(const FitArgs &a, hipStream_t stream)
 {
     const int grid = (a.n_series + NM_BLOCK - 1) / NM_BLOCK;
+    if (MS == -2 && (a.ring_scratch == nullptr || (size_t)grid * (size_t)a.m * NM_BLOCK > a.ring_scratch_doubles))
+        throw std::runtime_error("ets_final_launch: the seasonal-ring scratch does not cover the launch");
     size_t lds_bytes = (MS == -1) ? sizeof(double) * (size_t)a.m * NM_BLOCK : 0;
     hipLaunchKernelGGL((ets_final_kernel<Cfg, MS, YT>), dim3(grid), dim3(NM_BLOCK), lds_bytes, stream, a);
 }

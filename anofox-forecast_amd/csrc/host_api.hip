@@ -619,6 +619,7 @@ void run_classic(AnofoxHipBatch *b, int kind, const int32_t *d_len, int m, int o
         if (f.m > ETS_LDS_PERIOD) {
             const size_t wg = merged ? n : std::max<size_t>((n + 15) / 16, std::min<size_t>(n, 1024));
             f.ring_scratch = ensure_ring(b, wg * (size_t)f.m * 64u);
+            f.ring_scratch_doubles = wg * (size_t)f.m * 64u;
         }
         static const int BUDGET[] = {24, 24, 24, 24, 48, 48, 96, 192, 1024};
         // a handful of series (one call per group from the scalar binding, the coalesced calls of a few workers): every problem
@@ -934,13 +935,18 @@ void launch_fit_slots(AnofoxHipBatch *b, const std::vector<int> &specs, const in
         size_t n_long = 0;
         for (size_t oi = 0; oi < order.size(); oi++) if (args[oi].m > lds_limit) n_long++;
         if (n_long) {
-            const size_t wg = std::max<size_t>((n + 15) / 16, std::min<size_t>(n, (size_t)std::max(b->spec2_below, b->spec2_below_md)));
+            // (a tiny batch runs EVERY problem on a wave of its own whatever the thresholds say: found in round 6 as the intermittent
+            //  "Memory access fault by GPU" of test_two_level_speculation_is_bit_identical[20] -- 24 series, spec2_below = 20: 24 one-wave
+            //  workgroups on a scratch sized for 20, four rings written past its end; never with the default thresholds, which are
+            //  larger than any tiny batch.  docs/history/r06_round_log.md section E)
+            const bool tiny_batch = (uint64_t)n * order.size() <= (uint64_t)TINY_BATCH_PROBLEMS;
+            const size_t wg = std::max<size_t>((n + 15) / 16, std::min<size_t>(n, tiny_batch ? n : (size_t)std::max(b->spec2_below, b->spec2_below_md)));
             const size_t per_spec = wg * (size_t)m * 64u;
             if ((double)n_long * (double)per_spec * 8.0 > 64.0 * 1073741824.0)
                 throw HipFail{"seasonal period " + std::to_string(m) + " on " + std::to_string(n) + " series needs more than 64 GiB of ring scratch: shard the batch"};
             double *base = ensure_ring(b, n_long * per_spec);
             size_t k = 0;
-            for (size_t oi = 0; oi < order.size(); oi++) if (args[oi].m > lds_limit) args[oi].ring_scratch = base + (k++) * per_spec;
+            for (size_t oi = 0; oi < order.size(); oi++) if (args[oi].m > lds_limit) { args[oi].ring_scratch = base + (k++) * per_spec; args[oi].ring_scratch_doubles = per_spec; }
         }
     }
     // Specs whose round kernels keep the Nelder-Mead simplex out of LDS: a global scratch per stream, one slice per workgroup of the

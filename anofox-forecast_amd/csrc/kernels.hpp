@@ -74,6 +74,8 @@ struct FitArgs {
     int gather_cap;              // columns y_round has room for: the gather (and this flag) only apply while n_active <= gather_cap
     NmStateBuf st;
     double *ring_scratch;        // periods above ETS_LDS_PERIOD: m * 64 doubles per workgroup of the launch (seasonal ring in HBM)
+    size_t ring_scratch_doubles; //   doubles it holds: every launch checks that its workgroups fit (ets_round_launch; round 6 -- a scratch sized for
+                                 //   fewer workgroups than a launch has is a stray device write, found as an intermittent memory fault)
     double *nm_scratch;          // PARK kernels (ets_fit_kernel.hpp RoundTraits): nm_lds_doubles<DIM>() doubles per workgroup of the launch,
     size_t nm_scratch_doubles;   //   where the lanes' simplices rest between passes (else they rest in LDS); doubles it holds
     int m, h;
