@@ -154,15 +154,12 @@ def also_pass(names, steps, h, dev, lib, synth, DeviceBatch, pack_time_major, to
         fit_ms, dev_ms = [], []
         t0 = time.perf_counter()
         for _ in range(k):
-            batch.run()
-            if not wl["fixed"]:
-                st = batch.stats()
-                fit_ms.append(st["fit_kernel_ms"]); dev_ms.append(st["total_device_ms"])
+            batch.run()                                     # (nothing but the step in the timed region: see main)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / k
-        st = batch.stats()
-        if wl["fixed"]:
-            fit_ms.append(st["total_device_ms"]); dev_ms.append(st["total_device_ms"])       # the unit is the whole one-pass step
+        st = batch.stats()                                  # events and counters of the last step
+        fit_ms.append(st["total_device_ms"] if wl["fixed"] else st["fit_kernel_ms"])      # (fixed: the unit is the whole one-pass step)
+        dev_ms.append(st["total_device_ms"])
         kms = float(np.mean(fit_ms))
         ub = {0: 8, 1: 4, 2: 2}.get(int(st.get("y_storage", 0)), 8)      # bytes per observation of what the run streamed (see main)
         ob = 24.0 * max(h, 0) * n
@@ -284,29 +281,25 @@ def main():
         step()
     barrier()
     fit_ms, dev_ms, alg_bytes, st = [], [], [], None
-    # The fixed-parameter step is half a millisecond of a dozen launches without any host synchronisation: reading the library's
-    # per-step events (a wait plus two small copies, ~90 us) after every step would be a fifth of what is being timed, so that
-    # workload's steps are enqueued back to back (K runs in flight on the batch's stream, each ordered behind the one before);
-    # `ms_per_step` is the wall time between the two barriers over K as always, the device time of the step and of its final pass
-    # come from the LAST step's own events (recorded on the stream the run is launched on), read once after the barrier.
-    per_step_stats = not wl["fixed"]
+    # Nothing but the step is inside the timed region: K runs enqueued one after the other on the batch's stream (a run's own round
+    # loop waits for its device counters, so the host never runs ahead by more than a step's closing kernels).  Rounds 1-6 read the
+    # library's statistics after every step -- a wait plus device-to-host copies of per-problem counters that grow with the batch
+    # (30,490 series: 1.5-3 ms per step; 125,000: 24 ms of an 80 ms step; 1,000,000: 79 ms of 423: `profiles/r06_bench_timing_overhead.txt`)
+    # -- instrumentation of this file, not work of the path.  Now the device time of the step, the kernel time of the fit phase and
+    # the pass counters all come from the library's own HIP events (recorded on the stream the run is launched on -- the batch's own
+    # stream when torch's current stream is the null stream, so torch events would not see it) and counters of the LAST timed step,
+    # read once after the closing barrier: every step is the same computation on the same block, the counters are equal step to
+    # step and the times within a percent.
     t_start = time.perf_counter()
     for _ in range(args.steps):
         step()
-        if per_step_stats:
-            # per-step kernel timing comes from HIP events recorded on the launch stream inside the library;
-            # reading them waits for that step only (steps are sequential on one stream anyway)
-            st = batch.stats()
-            fit_ms.append(st["fit_kernel_ms"])
-            dev_ms.append(st["total_device_ms"])
-            alg_bytes.append(st["algorithmic_bytes"])
     barrier()
     elapsed = time.perf_counter() - t_start
-    if not per_step_stats:
-        st = batch.stats()
-        fit_ms.append(st["fit_kernel_ms"])
-        dev_ms.append(st["total_device_ms"])
-        alg_bytes.append(st["algorithmic_bytes"])
+    st = batch.stats()
+    fit_ms.append(st["fit_kernel_ms"])
+    dev_ms.append(st["total_device_ms"])
+    dev_ms_last = float(st["total_device_ms"])
+    alg_bytes.append(st["algorithmic_bytes"])
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         if one_gpu:
@@ -327,7 +320,7 @@ def main():
         final_pass_ms = None
         if wl["fixed"]:
             # config 2: the timed unit is the STEP (HIP events around everything the run enqueues), not the final pass alone
-            final_pass_ms, fit_ms_avg = fit_ms_avg, float(np.mean(dev_ms))
+            final_pass_ms, fit_ms_avg = fit_ms_avg, dev_ms_last
         # ALGORITHMIC bytes = what must move: one pass over one series reads T observations IN THE TYPE THE RUN STREAMS -- 8 bytes each
         # from the fp64 block, 4 / 2 from the float / uint16 copy a batch of counts is streamed from (SURVEY.md 8(d) wrote the unit
         # for fp64 storage; with the compact copy that unit would put `achieved` ABOVE the measured traffic and, on the all-additive
@@ -377,10 +370,10 @@ def main():
                        # survives that type exactly (counts: this workload), so the fp64 arithmetic sees the same numbers (bit-identical results;
                        # the roofline below counts the bytes of THIS type per observation and pass; `fp64_unit` keeps the 8-byte figure of earlier rounds)
                        "storage": {0: "f64 block", 1: "f32 copy of the block (exact for this batch)", 2: "u16 copy of the block (exact for this batch)"}.get(int(st.get("y_storage", 0)), "f64 block"),
-                       "device_ms_per_step": round(float(np.mean(dev_ms)), 3), "datagen_s": round(gen_s, 1)},
+                       "device_ms_per_step": round(dev_ms_last, 3), "datagen_s": round(gen_s, 1)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": kernel, "kernel_ms": round(fit_ms_avg, 3), "algorithmic_bytes": int(np.mean(alg_bytes)),
+                         "kernel": kernel, "kernel_ms": round(fit_ms_avg, 3), "kernel_ms_of": "the library's HIP events of the last timed step (launch stream)", "algorithmic_bytes": int(np.mean(alg_bytes)),
                          "frac_min_passes": round(achieved_min / HBM_PEAK_GBS, 4) if achieved_min else None,
                          "min_pass_bytes": min_bytes or None,
                          "mean_iterations_per_series": round(st.get("total_iters", 0) / max(n, 1), 1) if min_bytes else None,
