@@ -44,6 +44,7 @@ class DeviceBatch:
         self.handle = handle
         self.ld = int(self.L.anofox_hip_batch_ld(handle))
         self._y = self._len = None
+        self._side = None            # launch stream of runs asked for on torch's null stream (run)
 
     def set_block(self, y_time_major: torch.Tensor, lengths: torch.Tensor):
         assert y_time_major.dtype == torch.float64 and y_time_major.is_cuda and y_time_major.is_contiguous()
@@ -74,9 +75,24 @@ class DeviceBatch:
         return out
 
     def run(self, stream: torch.cuda.Stream | None = None):
-        st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        """One fit + forecast of the block, asynchronous and ORDERED on `stream` (torch's current stream by default): what was
+        enqueued there before is visible to the run, what is enqueued there afterwards -- torch ops on results(), a collective -- sees
+        the run's results.  The null stream cannot carry the run itself (the C entry reads a null handle as "the batch's own stream", a
+        non-blocking one the null stream does not wait for: until the last day of round 6 a consumer on torch's default stream, the
+        multi-rank gather of bench.py among them, could read the result arrays while the closing kernels were still writing them),
+        so a run asked for on the null stream goes to a side stream of this batch, fenced against it on both ends."""
+        cur = stream if stream is not None else torch.cuda.current_stream(self.device)
+        st = cur
+        if cur.cuda_stream == 0:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.device)
+            self._side.wait_stream(cur)
+            st = self._side
         err = _lib.AnofoxError()
-        if not self.L.anofox_hip_batch_run(self.handle, C.c_void_p(st.cuda_stream), C.byref(err)):
+        ok = self.L.anofox_hip_batch_run(self.handle, C.c_void_p(st.cuda_stream), C.byref(err))
+        if st is not cur:
+            cur.wait_stream(st)
+        if not ok:
             raise RuntimeError(f"anofox_hip_batch_run failed: [{err.code}] {err.message.decode()}")
 
     def stats(self) -> dict:

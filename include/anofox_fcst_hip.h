@@ -288,7 +288,7 @@ bool anofox_hip_selftest_recip(uint64_t n_operands, uint64_t seed, uint64_t *out
 /* Lane-level efficiency counters of the last run (waits for it); false before a run. */
 bool anofox_hip_batch_lane_stats(AnofoxHipBatch *batch, AnofoxHipLaneStats *out, size_t struct_size);
 
-/* Asynchronous fit + forecast on `stream` (a hipStream_t, may be NULL). */
+/* Asynchronous fit + forecast, ordered on `stream` (a hipStream_t).  NULL is NOT the null stream: it means the batch's own non-blocking stream, which the null stream does not wait for -- wait for the batch (anofox_hip_batch_stats / _fetch, or a device-wide wait) before reading its results from another stream. */
 bool anofox_hip_batch_run(AnofoxHipBatch *batch, void *stream,
                           struct AnofoxError *out_error);
 

@@ -2131,3 +2131,42 @@ def test_default_chain_with_unsupported_detected_period(env):
         single = api.forecast_series(long_period, opts)
         ref = O.forecast(long_period, O.make_options(model, 6))
         assert single["ok"] == ref["ok"] and (single["ok"] or single["code"] == ref["code"])
+
+
+@pytest.mark.gpu
+def test_results_are_ordered_after_a_run_on_the_default_stream(env):
+    """`DeviceBatch.run` is asynchronous and ordered on torch's current stream: a torch op enqueued there right after the run, with no
+    host wait in between, reads the results of THAT run -- also when the current stream is the null stream, which cannot carry the
+    run itself (the C entry reads a null handle as the batch's own non-blocking stream; device.py fences a side stream instead).
+    The multi-rank step of bench.py relies on it: its gather follows the run on the default stream.  Two blocks, one batch: the
+    clone taken right after the second run must hold the second block's forecasts, not the first's."""
+    import torch
+    from anofox_forecast_amd.device import DeviceBatch, pack_time_major
+    api, O, lib, synth = env
+    n, T, h, m = 4096, 400, 14, 7
+    Y1 = synth.gen_series(synth.SEED_M5, 0, n, T, m, positive=True)
+    Y2 = synth.gen_series(synth.SEED_M5, n, n, T, m, positive=True)
+    dev = "cuda:0"
+    assert torch.cuda.current_stream(torch.device(dev)).cuda_stream == 0          # the case under test
+    b = DeviceBatch(n, T, lib.make_options("AutoETS", h, seasonal_period=m), dev)
+    ln = torch.full((b.ld,), T, dtype=torch.int32, device=dev)
+    ln[n:] = 0
+    blocks = [torch.from_numpy(pack_time_major(Y, b.ld)).to(dev) for Y in (Y1, Y2)]
+    seen = []
+    for y in blocks:
+        b.set_block(y, ln)
+        b.run()
+        seen.append({k: v.clone() for k, v in b.results().items()})        # enqueued behind the run: no host wait
+    torch.cuda.synchronize()
+    settled = {k: v.clone() for k, v in b.results().items()}               # the second block's results, after a device-wide wait
+    for k in settled:
+        assert torch.equal(seen[1][k], settled[k]), k
+    assert not torch.equal(seen[0]["yhat"], seen[1]["yhat"])
+    # and each is what a waited-for run of that block gives
+    b.set_block(blocks[0], ln)
+    b.run()
+    torch.cuda.synchronize()
+    first = b.results()
+    for k in first:
+        assert torch.equal(seen[0][k], first[k]), k
+    b.close()
